@@ -1,0 +1,128 @@
+"""ctypes binding of include/carl_amd.h (libcarl_amd.so).
+
+There is NO CPU fallback: if the HIP library is missing the import of the engine
+fails loudly.  ``torch`` is imported first so that the library binds to the HIP
+runtime PyTorch-ROCm already loaded (same ``libamdhip64.so.7``), which is what makes
+``tensor.data_ptr()`` and ``torch.cuda.current_stream().cuda_stream`` valid on the
+other side of the C ABI.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must precede the CDLL load, see module docstring)
+
+from carl_amd import build as _build
+
+CARL_ABI_VERSION = 1
+CARL_MAX_CTX_OBS = 32
+
+# carl_family_t
+CARTPOLE, PENDULUM, ACROBOT, MOUNTAINCAR, MOUNTAINCAR_CONT = range(5)
+# carl_selector_t
+SEL_STATIC, SEL_ROUND_ROBIN, SEL_RANDOM, SEL_HOST = range(4)
+FLAG_AUTORESET = 1
+FLAG_CARTPOLE_RECOMPUTE = 2
+FLAG_ACROBOT_FP32 = 4
+ACTION_I32, ACTION_I64, ACTION_F32 = range(3)
+
+_vp = C.c_void_p
+
+
+class FamilyInfo(C.Structure):
+    _fields_ = [
+        ("state_dim", C.c_int32), ("obs_dim", C.c_int32), ("n_features", C.c_int32),
+        ("action_dim", C.c_int32), ("action_is_discrete", C.c_int32), ("n_actions", C.c_int32),
+        ("max_episode_steps", C.c_int32), ("reserved", C.c_int32),
+        ("action_low", C.c_float), ("action_high", C.c_float),
+    ]
+
+
+class Batch(C.Structure):
+    _fields_ = [
+        ("family", C.c_int32), ("n_lanes", C.c_int32), ("n_contexts", C.c_int32),
+        ("ctx_stride", C.c_int32), ("max_episode_steps", C.c_int32), ("selector", C.c_int32),
+        ("selector_stride", C.c_int32), ("flags", C.c_int32),
+        ("lane_offset", C.c_int64), ("seed", C.c_uint64),
+        ("state", _vp), ("elapsed", _vp), ("ctx_idx", _vp), ("episode", _vp), ("n_calls", _vp),
+        ("ep_return", _vp),
+        ("ctx_table", _vp), ("ctx_obs", _vp),
+        ("n_ctx_obs", C.c_int32), ("ctx_obs_feat", C.c_int32 * CARL_MAX_CTX_OBS),
+        ("fin_capacity", C.c_int32),
+        ("last_return", _vp), ("last_length", _vp), ("episodes_done", _vp),
+        ("fin_count", _vp), ("fin_lane", _vp), ("fin_return", _vp), ("fin_length", _vp),
+    ]
+
+
+class StepIO(C.Structure):
+    _fields_ = [
+        ("action", _vp), ("action_dtype", C.c_int32), ("reserved", C.c_int32),
+        ("obs", _vp), ("reward", _vp), ("terminated", _vp), ("truncated", _vp), ("final_obs", _vp),
+    ]
+
+
+EXPORTS = {
+    "carl_abi_version": (C.c_int, []),
+    "carl_last_error": (C.c_char_p, []),
+    "carl_family_info": (C.c_int, [C.c_int, C.POINTER(FamilyInfo)]),
+    "carl_reset": (C.c_int, [C.POINTER(Batch), _vp, _vp, _vp]),
+    "carl_reset_indexed": (C.c_int, [C.POINTER(Batch), _vp, _vp, _vp, _vp]),
+    "carl_step": (C.c_int, [C.POINTER(Batch), C.POINTER(StepIO), _vp]),
+    "carl_rollout": (C.c_int, [C.POINTER(Batch), C.POINTER(StepIO), C.c_int32, _vp]),
+    "carl_done_compact": (C.c_int, [_vp, _vp, C.c_int32, _vp, _vp, _vp, _vp]),
+    "carl_done_compact_scratch_elems": (C.c_int32, [C.c_int32]),
+}
+
+
+class CarlHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib_path() -> str:
+    return _build.LIB_PATH
+
+
+def load() -> C.CDLL:
+    """Load libcarl_amd.so (building it in-tree first if hipcc is here and the
+    sources are newer).  Raises if the library cannot be produced or loaded."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB_PATH
+    if os.environ.get("CARL_AMD_NO_BUILD", "0") != "1":
+        try:
+            path = _build.build()
+        except Exception as e:  # hipcc absent / compile error
+            if not os.path.exists(path):
+                raise CarlHipError(
+                    f"libcarl_amd.so is missing and could not be built ({e}); the engine has "
+                    "no CPU fallback -- run `python -m carl_amd.build` on a machine with hipcc"
+                ) from e
+    if not os.path.exists(path):
+        raise CarlHipError(f"{path} not found; run `python -m carl_amd.build`")
+    lib = C.CDLL(path)
+    for name, (res, args) in EXPORTS.items():
+        fn = getattr(lib, name)  # AttributeError = ABI drift, fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    v = lib.carl_abi_version()
+    if v != CARL_ABI_VERSION:
+        raise CarlHipError(f"libcarl_amd ABI version {v} != binding {CARL_ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(code: int) -> None:
+    if code != 0:
+        msg = load().carl_last_error()
+        raise CarlHipError(f"libcarl_amd call failed ({code}): {msg.decode() if msg else ''}")
+
+
+def family_info(family: int) -> FamilyInfo:
+    info = FamilyInfo()
+    check(load().carl_family_info(family, C.byref(info)))
+    return info

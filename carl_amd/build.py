@@ -1,0 +1,64 @@
+"""Compile the HIP engine for gfx950 with hipcc (in-tree, no JIT cache).
+
+``python -m carl_amd.build`` -> carl_amd/lib/libcarl_amd.so.  hipcc cross-compiles
+without a GPU, so this also runs in the build container.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_DIR = os.path.join(_HERE, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libcarl_amd.so")
+ARCH = "gfx950"
+
+SOURCES = ["carl_amd.hip"]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (set HIPCC or install ROCm under /opt/rocm)")
+
+
+def _deps() -> list[str]:
+    out = []
+    for root in (CSRC, os.path.join(os.path.dirname(_HERE), "include")):
+        for f in sorted(os.listdir(root)):
+            if f.endswith((".hip", ".cuh", ".h")):
+                out.append(os.path.join(root, f))
+    return out
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    return any(os.path.getmtime(d) > t for d in _deps())
+
+
+def build(force: bool = False, verbose: bool = False, extra_flags: list[str] | None = None) -> str:
+    if not force and not needs_build():
+        return LIB_PATH
+    os.makedirs(LIB_DIR, exist_ok=True)
+    cmd = [
+        _hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
+        "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
+        *(extra_flags or []),
+        *[os.path.join(CSRC, s) for s in SOURCES],
+        "-o", LIB_PATH,
+    ]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    flags = [a for a in sys.argv[1:] if a.startswith("-") and a not in ("--force",)]
+    print(build(force=True, verbose=True, extra_flags=flags))

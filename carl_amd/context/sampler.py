@@ -1,0 +1,70 @@
+"""Seeded context sampler (API of the reference's carl/context/sampler.py:11-61).
+
+``sample_contexts(n)`` returns the reference's ``{i: {feature: value}}`` dict;
+``sample_context_table(n)`` returns the same draws as a dense ``ContextTable``
+without building n Python dicts -- the form the engine uploads.
+"""
+from __future__ import annotations
+
+from collections.abc import Mapping
+
+import numpy as np
+
+from carl_amd.context.context_space import ContextFeature, ContextSpace
+from carl_amd.context.features import ConfigurationSpace
+from carl_amd.context.search_space_encoding import search_space_to_config_space
+from carl_amd.context.table import ContextTable
+from carl_amd.utils.types import Context, Contexts
+
+
+class ContextSampler(ConfigurationSpace):
+    def __init__(self, context_distributions, context_space: ContextSpace, seed: int,
+                 name: str | None = None):
+        self.context_distributions = context_distributions
+        super().__init__(name=name, seed=seed)
+
+        if isinstance(context_distributions, list):
+            self.add_context_features(context_distributions)
+        elif isinstance(context_distributions, dict):
+            self.add_context_features(context_distributions.values())
+        elif isinstance(context_distributions, str) or (
+            isinstance(context_distributions, Mapping) and "hyperparameters" in context_distributions
+        ):
+            cs = search_space_to_config_space(context_distributions)
+            self.add_context_features(cs.get_hyperparameters())
+        else:
+            raise ValueError(
+                f"Unknown type `{type(context_distributions)}` for `context_distributions`."
+            )
+
+        self.context_feature_names = [cf.name for cf in self.get_context_features()]
+        self.context_space = context_space
+
+    def add_context_features(self, context_features) -> None:
+        self.add_hyperparameters(context_features)
+
+    def get_context_features(self) -> list[ContextFeature]:
+        return list(self.values())
+
+    def sample_contexts(self, n_contexts: int) -> Contexts:
+        contexts = self._sample_contexts(size=n_contexts)
+        return {i: C for i, C in enumerate(contexts)}
+
+    def _sample_contexts(self, size: int = 1) -> list[Context]:
+        contexts = self.sample_configuration(size=size)
+        default_context = self.context_space.get_default_context()
+        if size == 1:
+            contexts = [contexts]
+        return [dict(default_context | dict(C)) for C in contexts]
+
+    def sample_context_table(self, n_contexts: int) -> ContextTable:
+        """Same RNG consumption and values as ``sample_contexts`` (numeric features only)."""
+        cols = self.sample_vectors(n_contexts)
+        names = list(self.context_space.context_feature_names)
+        extra = [k for k in cols if k not in names]
+        names = names + extra  # reference: default_context | dict(C) appends unknown keys
+        base = self.context_space.get_default_context()
+        out = np.empty((n_contexts, len(names)), dtype=np.float64)
+        for j, n in enumerate(names):
+            out[:, j] = np.asarray(cols[n], dtype=np.float64) if n in cols else float(base[n])
+        return ContextTable(names, out)

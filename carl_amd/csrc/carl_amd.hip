@@ -1,0 +1,209 @@
+// carl_amd.hip -- C-ABI entry points (include/carl_amd.h) and kernel dispatch.
+// gfx950 only.  No persistent device allocations, no global mutable state.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/carl_amd.h"
+#include "classic_control.cuh"
+#include "engine_kernels.cuh"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+int check_launch(const char* what) {
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail((int)e, "%s: %s", what, hipGetErrorString(e));
+  return 0;
+}
+
+const carl_family_info_t kInfo[CARL_N_FAMILIES] = {
+    /* state obs feat adim disc nact max_steps rsv lo hi */
+    {4, 4, 8, 1, 1, 2, 500, 0, 0.0f, 1.0f},     // CartPole-v1
+    {2, 3, 7, 1, 0, 0, 200, 0, -2.0f, 2.0f},    // Pendulum-v1
+    {4, 6, 14, 1, 1, 3, 500, 0, 0.0f, 2.0f},    // Acrobot-v1
+    {2, 2, 11, 1, 1, 3, 200, 0, 0.0f, 2.0f},    // MountainCar-v0
+    {2, 2, 10, 1, 0, 0, 999, 0, -1.0f, 1.0f},   // MountainCarContinuous-v0
+};
+
+int validate_batch(const carl_batch_t* b, const char* who) {
+  if (b == nullptr) return fail(CARL_ERR_INVALID_ARGUMENT, "%s: batch is NULL", who);
+  if (b->family < 0 || b->family >= CARL_N_FAMILIES)
+    return fail(CARL_ERR_INVALID_ARGUMENT, "%s: unknown family %d", who, b->family);
+  if (b->n_lanes < 0) return fail(CARL_ERR_INVALID_ARGUMENT, "%s: n_lanes %d < 0", who, b->n_lanes);
+  if (b->n_contexts <= 0 || b->ctx_stride < b->n_contexts)
+    return fail(CARL_ERR_INVALID_ARGUMENT, "%s: n_contexts %d / ctx_stride %d invalid", who, b->n_contexts,
+                b->ctx_stride);
+  if (b->selector < CARL_SEL_STATIC || b->selector > CARL_SEL_HOST)
+    return fail(CARL_ERR_INVALID_ARGUMENT, "%s: unknown selector %d", who, b->selector);
+  if (!b->state || !b->elapsed || !b->ctx_idx || !b->episode || !b->n_calls || !b->ep_return || !b->ctx_table)
+    return fail(CARL_ERR_INVALID_ARGUMENT, "%s: a required batch pointer is NULL", who);
+  if (b->n_ctx_obs < 0 || b->n_ctx_obs > CARL_MAX_CTX_OBS)
+    return fail(CARL_ERR_INVALID_ARGUMENT, "%s: n_ctx_obs %d out of range", who, b->n_ctx_obs);
+  for (int k = 0; k < b->n_ctx_obs; ++k)
+    if (b->ctx_obs_feat[k] < 0 || b->ctx_obs_feat[k] >= kInfo[b->family].n_features)
+      return fail(CARL_ERR_INVALID_ARGUMENT, "%s: ctx_obs_feat[%d] = %d out of range", who, k, b->ctx_obs_feat[k]);
+  if (b->n_ctx_obs > 0 && b->ctx_obs == nullptr)
+    return fail(CARL_ERR_INVALID_ARGUMENT, "%s: n_ctx_obs > 0 but ctx_obs is NULL", who);
+  if (b->fin_count != nullptr && (b->fin_capacity <= 0 || !b->fin_lane || !b->fin_return || !b->fin_length))
+    return fail(CARL_ERR_INVALID_ARGUMENT, "%s: finished-episode log is incomplete", who);
+  return 0;
+}
+
+int validate_io(const carl_batch_t* b, const carl_step_io_t* io, const char* who) {
+  if (io == nullptr) return fail(CARL_ERR_INVALID_ARGUMENT, "%s: io is NULL", who);
+  if (!io->action || !io->obs || !io->reward || !io->terminated || !io->truncated)
+    return fail(CARL_ERR_INVALID_ARGUMENT, "%s: a required io pointer is NULL", who);
+  const bool discrete = kInfo[b->family].action_is_discrete != 0;
+  if (discrete && io->action_dtype != CARL_ACTION_I32 && io->action_dtype != CARL_ACTION_I64)
+    return fail(CARL_ERR_INVALID_ARGUMENT, "%s: discrete family needs int32/int64 actions", who);
+  if (!discrete && io->action_dtype != CARL_ACTION_F32)
+    return fail(CARL_ERR_INVALID_ARGUMENT, "%s: continuous family needs float32 actions", who);
+  return 0;
+}
+
+// Stage the whole [F][C] table in LDS when the context set is small relative to the
+// lanes (many lanes share a context, ids are not lane-ordered).
+template <class Fam>
+bool use_lds_ctx(const carl_batch_t* b) {
+  const size_t bytes = (size_t)Fam::F * b->n_contexts * sizeof(float);
+  return bytes <= 48 * 1024 && (int64_t)b->n_contexts * 8 <= (int64_t)b->n_lanes;
+}
+
+// 64-thread workgroups spread a small batch over all 256 CUs x 4 SIMDs (65 536
+// lanes = 1024 waves = one per SIMD); large batches use 256.
+int pick_block(int n, bool lds) { return (lds || n > 256 * 1024) ? 256 : 64; }
+
+template <class Fam>
+int launch_reset(const carl_batch_t* b, const uint8_t* mask, const int32_t* idx, const int32_t* count, float* obs,
+                 hipStream_t s) {
+  if (b->n_lanes == 0) return 0;
+  const bool lds = use_lds_ctx<Fam>(b);
+  const int block = 256;
+  int grid = (b->n_lanes + block - 1) / block;
+  if (grid > 4096) grid = 4096;
+  if (lds) {
+    const size_t sh = (size_t)Fam::F * b->n_contexts * sizeof(float);
+    hipLaunchKernelGGL((carl::reset_kernel<Fam, true>), dim3(grid), dim3(block), sh, s, *b, mask, idx, count, obs);
+  } else {
+    hipLaunchKernelGGL((carl::reset_kernel<Fam, false>), dim3(grid), dim3(block), 0, s, *b, mask, idx, count, obs);
+  }
+  return check_launch("carl_reset");
+}
+
+template <class Fam>
+int launch_step(const carl_batch_t* b, const carl_step_io_t* io, int n_steps, hipStream_t s) {
+  if (b->n_lanes == 0 || n_steps == 0) return 0;
+  const bool lds = use_lds_ctx<Fam>(b);
+  const int block = pick_block(b->n_lanes, lds);
+  const int grid = (b->n_lanes + block - 1) / block;
+  const size_t sh = lds ? (size_t)Fam::F * b->n_contexts * sizeof(float) : 0;
+  if (n_steps < 0) {  // per-call step
+    if (lds)
+      hipLaunchKernelGGL((carl::step_kernel<Fam, true>), dim3(grid), dim3(block), sh, s, *b, *io);
+    else
+      hipLaunchKernelGGL((carl::step_kernel<Fam, false>), dim3(grid), dim3(block), 0, s, *b, *io);
+    return check_launch("carl_step");
+  }
+  if (lds)
+    hipLaunchKernelGGL((carl::rollout_kernel<Fam, true>), dim3(grid), dim3(block), sh, s, *b, *io, n_steps);
+  else
+    hipLaunchKernelGGL((carl::rollout_kernel<Fam, false>), dim3(grid), dim3(block), 0, s, *b, *io, n_steps);
+  return check_launch("carl_rollout");
+}
+
+#define CARL_DISPATCH(family, CALL)                                   \
+  switch (family) {                                                   \
+    case CARL_CARTPOLE: return CALL(carl::CartPole);                  \
+    case CARL_PENDULUM: return CALL(carl::Pendulum);                  \
+    case CARL_ACROBOT:                                                \
+      return (batch->flags & CARL_FLAG_ACROBOT_FP32) ? CALL(carl::AcrobotFast) : CALL(carl::Acrobot); \
+    case CARL_MOUNTAINCAR: return CALL(carl::MountainCar);            \
+    case CARL_MOUNTAINCAR_CONT: return CALL(carl::MountainCarCont);   \
+    default: return fail(CARL_ERR_INVALID_ARGUMENT, "unknown family %d", family); \
+  }
+
+}  // namespace
+
+extern "C" {
+
+int carl_abi_version(void) { return CARL_ABI_VERSION; }
+
+const char* carl_last_error(void) { return g_err; }
+
+int carl_family_info(int family, carl_family_info_t* out) {
+  if (out == nullptr) return fail(CARL_ERR_INVALID_ARGUMENT, "carl_family_info: out is NULL");
+  if (family < 0 || family >= CARL_N_FAMILIES)
+    return fail(CARL_ERR_INVALID_ARGUMENT, "carl_family_info: unknown family %d", family);
+  *out = kInfo[family];
+  return 0;
+}
+
+int carl_reset(const carl_batch_t* batch, const uint8_t* mask, float* obs, void* stream) {
+  if (int e = validate_batch(batch, "carl_reset")) return e;
+#define CALL(F) launch_reset<F>(batch, mask, nullptr, nullptr, obs, (hipStream_t)stream)
+  CARL_DISPATCH(batch->family, CALL)
+#undef CALL
+}
+
+int carl_reset_indexed(const carl_batch_t* batch, const int32_t* idx, const int32_t* count, float* obs,
+                       void* stream) {
+  if (int e = validate_batch(batch, "carl_reset_indexed")) return e;
+  if (idx == nullptr || count == nullptr)
+    return fail(CARL_ERR_INVALID_ARGUMENT, "carl_reset_indexed: idx/count is NULL");
+#define CALL(F) launch_reset<F>(batch, nullptr, idx, count, obs, (hipStream_t)stream)
+  CARL_DISPATCH(batch->family, CALL)
+#undef CALL
+}
+
+int carl_step(const carl_batch_t* batch, const carl_step_io_t* io, void* stream) {
+  if (int e = validate_batch(batch, "carl_step")) return e;
+  if (int e = validate_io(batch, io, "carl_step")) return e;
+#define CALL(F) launch_step<F>(batch, io, -1, (hipStream_t)stream)
+  CARL_DISPATCH(batch->family, CALL)
+#undef CALL
+}
+
+int carl_rollout(const carl_batch_t* batch, const carl_step_io_t* io, int32_t n_steps, void* stream) {
+  if (int e = validate_batch(batch, "carl_rollout")) return e;
+  if (int e = validate_io(batch, io, "carl_rollout")) return e;
+  if (n_steps < 0) return fail(CARL_ERR_INVALID_ARGUMENT, "carl_rollout: n_steps %d < 0", n_steps);
+#define CALL(F) launch_step<F>(batch, io, n_steps, (hipStream_t)stream)
+  CARL_DISPATCH(batch->family, CALL)
+#undef CALL
+}
+
+int32_t carl_done_compact_scratch_elems(int32_t n) {
+  return n <= 0 ? 1 : (n + carl::kCompactBlock - 1) / carl::kCompactBlock;
+}
+
+int carl_done_compact(const uint8_t* terminated, const uint8_t* truncated, int32_t n, int32_t* idx_out,
+                      int32_t* count_out, int32_t* scratch, void* stream) {
+  if (n < 0) return fail(CARL_ERR_INVALID_ARGUMENT, "carl_done_compact: n %d < 0", n);
+  if (!terminated || !truncated || !idx_out || !count_out || !scratch)
+    return fail(CARL_ERR_INVALID_ARGUMENT, "carl_done_compact: NULL pointer");
+  hipStream_t s = (hipStream_t)stream;
+  if (n == 0) {
+    const hipError_t e = hipMemsetAsync(count_out, 0, sizeof(int32_t), s);
+    return e == hipSuccess ? 0 : fail((int)e, "carl_done_compact: %s", hipGetErrorString(e));
+  }
+  const int nb = carl_done_compact_scratch_elems(n);
+  hipLaunchKernelGGL(carl::done_count_kernel, dim3(nb), dim3(carl::kCompactBlock), 0, s, terminated, truncated, n,
+                     scratch);
+  hipLaunchKernelGGL(carl::done_write_kernel, dim3(nb), dim3(carl::kCompactBlock), 0, s, terminated, truncated, n,
+                     scratch, idx_out, count_out);
+  return check_launch("carl_done_compact");
+}
+
+}  // extern "C"

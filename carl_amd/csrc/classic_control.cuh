@@ -1,0 +1,381 @@
+// classic_control.cuh -- per-lane physics of CARL's classic-control families in fp32.
+//
+// Each family is a traits struct the generic engine kernels (engine_kernels.cuh) are
+// instantiated with:
+//   S, D, F           state columns, observation length, context-table rows
+//   Action            int (Discrete) or float (Box)
+//   Params            the context features the physics reads, gathered per lane
+//   load(ctx, c, ..)  gather Params of context id c (feature rows in the order of the
+//                     reference class's get_context_features())
+//   step(...)         one transition: the arithmetic of gymnasium 0.29.1's env.step
+//                     [upstream; equations E-CP .. E-MCC of SURVEY.md section 8a]
+//   observe(...)      what env.step / CARL's reset returns as "obs"
+//   reset(...)        CARL's init-state distribution from 4 Philox words
+//
+// The reference computes in float64 on float32-representable state; this engine
+// keeps fp32 state and computes in fp32 (north_star: transitions within 1e-5).
+#pragma once
+
+#include "carl_device.cuh"
+
+namespace carl {
+
+constexpr float kPi = 3.14159265358979323846f;
+
+// ================================ CartPole ========================================
+// features: carl/envs/gymnasium/classic_control/carl_cartpole.py:15-42
+struct CartPole {
+  static constexpr int S = 4, D = 4, F = 8;
+  using Action = int;
+  enum { GRAVITY, MASSCART, MASSPOLE, LENGTH, FORCE_MAG, TAU, INIT_LO, INIT_HI };
+  static constexpr bool kNeedsStepNoise = false;
+
+  struct Params {
+    float gravity, masspole, length, force_mag, tau, total_mass, polemass_length;
+  };
+
+  template <class Ctx>
+  __device__ static __forceinline__ Params load(const Ctx& ctx, int c, int flags) {
+    Params p;
+    p.gravity = ctx.get(GRAVITY, c);
+    p.masspole = ctx.get(MASSPOLE, c);
+    p.length = ctx.get(LENGTH, c);
+    p.force_mag = ctx.get(FORCE_MAG, c);
+    p.tau = ctx.get(TAU, c);
+    if (flags & CARL_FLAG_CARTPOLE_RECOMPUTE) {
+      p.total_mass = p.masspole + ctx.get(MASSCART, c);
+      p.polemass_length = p.masspole * p.length;
+    } else {
+      // Quirk C1: gymnasium derives these once in __init__ from ITS
+      // defaults (masspole 0.1 + masscart 1.0, masspole 0.1 * length 0.5); CARL's
+      // setattr (carl_gymnasium_env.py:75-77) never refreshes them.
+      p.total_mass = 0.1f + 1.0f;
+      p.polemass_length = 0.1f * 0.5f;
+    }
+    return p;
+  }
+
+  __device__ static __forceinline__ bool out_of_bounds(float x, float theta) {
+    const float x_thr = 2.4f;
+    const float th_thr = (float)(12.0 * 2.0 * 3.14159265358979323846 / 360.0);
+    return (x < -x_thr) | (x > x_thr) | (theta < -th_thr) | (theta > th_thr);
+  }
+
+  // CartPoleEnv.step, kinematics_integrator == "euler"
+  __device__ static __forceinline__ bool step(const Params& p, float (&s)[S], int action,
+                                              float /*noise*/, float& reward) {
+    const float x = s[0], x_dot = s[1], theta = s[2], theta_dot = s[3];
+    // steps_beyond_terminated: a lane stepped again after terminating (only
+    // reachable with auto-reset off) earns 0; inferred from the pre-step state.
+    const bool was_terminated = out_of_bounds(x, theta);
+    const float force = (action == 1) ? p.force_mag : -p.force_mag;
+    float sintheta, costheta;
+    sincosf(theta, &sintheta, &costheta);
+    const float temp = (force + p.polemass_length * (theta_dot * theta_dot) * sintheta) / p.total_mass;
+    const float thetaacc = (p.gravity * sintheta - costheta * temp) /
+                           (p.length * (4.0f / 3.0f - p.masspole * (costheta * costheta) / p.total_mass));
+    const float xacc = temp - p.polemass_length * thetaacc * costheta / p.total_mass;
+    s[0] = x + p.tau * x_dot;
+    s[1] = x_dot + p.tau * xacc;
+    s[2] = theta + p.tau * theta_dot;
+    s[3] = theta_dot + p.tau * thetaacc;
+    const bool terminated = out_of_bounds(s[0], s[2]);
+    reward = (terminated && was_terminated) ? 0.0f : 1.0f;
+    return terminated;
+  }
+
+  __device__ static __forceinline__ void observe(const float (&s)[S], float (&o)[D]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = s[i];
+  }
+
+  // carl_cartpole.py:51-61: state = U(initial_state_lower, initial_state_upper, 4)
+  template <class Ctx>
+  __device__ static __forceinline__ void reset(const Ctx& ctx, int c, const u32x4& w, float (&s)[S]) {
+    const float lo = ctx.get(INIT_LO, c), hi = ctx.get(INIT_HI, c);
+    s[0] = uniform_between(lo, hi, w.x);
+    s[1] = uniform_between(lo, hi, w.y);
+    s[2] = uniform_between(lo, hi, w.z);
+    s[3] = uniform_between(lo, hi, w.w);
+  }
+};
+
+// ================================ Pendulum ========================================
+// features: carl_pendulum.py:15-39.  Quirk P1: row 0 ("gravity", default 8.0) is never
+// read by the physics; real gravity is "g".
+struct Pendulum {
+  static constexpr int S = 2, D = 3, F = 7;
+  using Action = float;
+  enum { GRAVITY_DEAD, DT, G, M, L, INIT_ANGLE_MAX, INIT_VEL_MAX };
+  static constexpr bool kNeedsStepNoise = false;
+
+  struct Params {
+    float g, m, l, dt;
+  };
+
+  template <class Ctx>
+  __device__ static __forceinline__ Params load(const Ctx& ctx, int c, int) {
+    return Params{ctx.get(G, c), ctx.get(M, c), ctx.get(L, c), ctx.get(DT, c)};
+  }
+
+  // PendulumEnv.step; reward from the OLD (th, thdot); never terminates
+  __device__ static __forceinline__ bool step(const Params& p, float (&s)[S], float action,
+                                              float /*noise*/, float& reward) {
+    const float max_speed = 8.0f, max_torque = 2.0f;
+    const float th = s[0], thdot = s[1];
+    const float u = fminf(fmaxf(action, -max_torque), max_torque);
+    // angle_normalize(x) = ((x + pi) % (2 pi)) - pi with Python's floor-mod
+    const float two_pi = 2.0f * kPi;
+    const float y = th + kPi;
+    float r = y - floorf(y / two_pi) * two_pi;
+    r = (r < 0.0f) ? r + two_pi : r;
+    r = (r >= two_pi) ? r - two_pi : r;
+    const float an = r - kPi;
+    const float costs = an * an + 0.1f * (thdot * thdot) + 0.001f * (u * u);
+    float newthdot = thdot + (3.0f * p.g / (2.0f * p.l) * sinf(th) + 3.0f / (p.m * (p.l * p.l)) * u) * p.dt;
+    newthdot = fminf(fmaxf(newthdot, -max_speed), max_speed);
+    s[0] = th + newthdot * p.dt;
+    s[1] = newthdot;
+    reward = -costs;
+    return false;
+  }
+
+  // _get_obs / carl_pendulum.py:61
+  __device__ static __forceinline__ void observe(const float (&s)[S], float (&o)[D]) {
+    float sn, cs;
+    sincosf(s[0], &sn, &cs);
+    o[0] = cs;
+    o[1] = sn;
+    o[2] = s[1];
+  }
+
+  // carl_pendulum.py:44-60: theta = U(0, initial_angle_max), thdot = U(0, initial_velocity_max)
+  // (one-sided: `low` defaults to 0 -- Quirk P2)
+  template <class Ctx>
+  __device__ static __forceinline__ void reset(const Ctx& ctx, int c, const u32x4& w, float (&s)[S]) {
+    s[0] = uniform_between(0.0f, ctx.get(INIT_ANGLE_MAX, c), w.x);
+    s[1] = uniform_between(0.0f, ctx.get(INIT_VEL_MAX, c), w.y);
+  }
+};
+
+// ================================ Acrobot =========================================
+// features: carl_acrobot.py:15-69
+//
+// Arithmetic type: RK4 at dt = 0.2 from |w2| near MAX_VEL_2 = 9 pi runs through stage
+// accelerations ~1e3 and stage velocities ~1e2, whose squares cancel in phi1 / ddtheta2;
+// plain fp32 loses up to 1e-3 relative on ~1 % of such states (measured with the CPU
+// oracle's fp32 variant).  So _dsdt/rk4 are evaluated in Real = double by default
+// (fp32 state in HBM, 1e-5 parity on every row) and in Real = float when the caller
+// sets CARL_FLAG_ACROBOT_FP32 (about the error above, several times the throughput).
+template <class Real>
+struct AcrobotT {
+  static constexpr int S = 4, D = 6, F = 14;
+  using Action = int;
+  enum { L1, L2, M1, M2, C1, C2, MOI, MAXV1, MAXV2, NOISE, IA_LO, IA_HI, IV_LO, IV_HI };
+  static constexpr bool kNeedsStepNoise = true;
+
+  struct Params {
+    float m1, m2, l1, lc1, lc2, moi, max_vel_1, max_vel_2, noise_max;
+  };
+
+  template <class Ctx>
+  __device__ static __forceinline__ Params load(const Ctx& ctx, int c, int) {
+    return Params{ctx.get(M1, c),  ctx.get(M2, c),    ctx.get(L1, c),    ctx.get(C1, c),   ctx.get(C2, c),
+                  ctx.get(MOI, c), ctx.get(MAXV1, c), ctx.get(MAXV2, c), ctx.get(NOISE, c)};
+  }
+
+  struct Deriv {
+    Real d0, d1, d2, d3;
+  };
+
+  __device__ static __forceinline__ void sincos_r(float x, float* s, float* c) { sincosf(x, s, c); }
+  __device__ static __forceinline__ void sincos_r(double x, double* s, double* c) { sincos(x, s, c); }
+  __device__ static __forceinline__ float cos_r(float x) { return cosf(x); }
+  __device__ static __forceinline__ double cos_r(double x) { return cos(x); }
+
+  // AcrobotEnv._dsdt, book_or_nips == "book", g = 9.8 literal
+  __device__ static __forceinline__ Deriv dsdt(const Params& p, Real theta1, Real theta2, Real dtheta1,
+                                               Real dtheta2, Real a) {
+    const Real m1 = p.m1, m2 = p.m2, l1 = p.l1, lc1 = p.lc1, lc2 = p.lc2, I1 = p.moi, I2 = p.moi;
+    const Real g = (Real)9.8;
+    const Real half_pi = (Real)(3.14159265358979323846 / 2.0);
+    Real s2, c2;
+    sincos_r(theta2, &s2, &c2);
+    const Real d1 = m1 * (lc1 * lc1) + m2 * (l1 * l1 + lc2 * lc2 + (Real)2.0 * l1 * lc2 * c2) + I1 + I2;
+    const Real d2 = m2 * (lc2 * lc2 + l1 * lc2 * c2) + I2;
+    const Real phi2 = m2 * lc2 * g * cos_r(theta1 + theta2 - half_pi);
+    const Real phi1 = -m2 * l1 * lc2 * (dtheta2 * dtheta2) * s2 -
+                      (Real)2.0 * m2 * l1 * lc2 * dtheta2 * dtheta1 * s2 +
+                      (m1 * lc1 + m2 * l1) * g * cos_r(theta1 - half_pi) + phi2;
+    const Real ddtheta2 = (a + d2 / d1 * phi1 - m2 * l1 * lc2 * (dtheta1 * dtheta1) * s2 - phi2) /
+                          (m2 * (lc2 * lc2) + I2 - (d2 * d2) / d1);
+    const Real ddtheta1 = -(d2 * ddtheta2 + phi1) / d1;
+    return Deriv{dtheta1, dtheta2, ddtheta1, ddtheta2};
+  }
+
+  // wrap(x, -pi, pi): while x > M: x -= 2pi; while x < m: x += 2pi (strict compares)
+  __device__ static __forceinline__ Real wrap_pi(Real x) {
+    const Real pi = (Real)3.14159265358979323846;
+    const Real diff = pi - (-pi);
+    while (x > pi) x = x - diff;
+    while (x < -pi) x = x + diff;
+    return x;
+  }
+
+  // AcrobotEnv.step: rk4 over [0, dt = 0.2] on (state, torque), wrap, bound, _terminal
+  __device__ static __forceinline__ bool step(const Params& p, float (&s)[S], int action, float noise,
+                                              float& reward) {
+    const Real dt = (Real)0.2, dt2 = dt / (Real)2.0;
+    const Real a = (Real)((float)(action - 1) + noise);
+    const Real y0 = s[0], y1 = s[1], y2 = s[2], y3 = s[3];
+    const Deriv k1 = dsdt(p, y0, y1, y2, y3, a);
+    const Deriv k2 = dsdt(p, y0 + dt2 * k1.d0, y1 + dt2 * k1.d1, y2 + dt2 * k1.d2, y3 + dt2 * k1.d3, a);
+    const Deriv k3 = dsdt(p, y0 + dt2 * k2.d0, y1 + dt2 * k2.d1, y2 + dt2 * k2.d2, y3 + dt2 * k2.d3, a);
+    const Deriv k4 = dsdt(p, y0 + dt * k3.d0, y1 + dt * k3.d1, y2 + dt * k3.d2, y3 + dt * k3.d3, a);
+    const Real two = (Real)2.0, six = (Real)6.0;
+    Real n0 = y0 + dt / six * (k1.d0 + two * k2.d0 + two * k3.d0 + k4.d0);
+    Real n1 = y1 + dt / six * (k1.d1 + two * k2.d1 + two * k3.d1 + k4.d1);
+    Real n2 = y2 + dt / six * (k1.d2 + two * k2.d2 + two * k3.d2 + k4.d2);
+    Real n3 = y3 + dt / six * (k1.d3 + two * k2.d3 + two * k3.d3 + k4.d3);
+    n0 = wrap_pi(n0);
+    n1 = wrap_pi(n1);
+    const Real mv1 = p.max_vel_1, mv2 = p.max_vel_2;
+    n2 = n2 < -mv1 ? -mv1 : (n2 > mv1 ? mv1 : n2);
+    n3 = n3 < -mv2 ? -mv2 : (n3 > mv2 ? mv2 : n3);
+    s[0] = (float)n0;
+    s[1] = (float)n1;
+    s[2] = (float)n2;
+    s[3] = (float)n3;
+    // _terminal on the unrounded state, like the reference's float64 state
+    const bool terminated = (-cos_r(n0) - cos_r(n1 + n0)) > (Real)1.0;
+    reward = terminated ? 0.0f : -1.0f;
+    return terminated;
+  }
+
+  // torque noise: only when torque_noise_max > 0 (AcrobotEnv.step)
+  __device__ static __forceinline__ float step_noise(const Params& p, const carl_batch_t& b, uint64_t glane,
+                                                     uint32_t episode, int elapsed) {
+    if (!(p.noise_max > 0.0f)) return 0.0f;
+    const u32x4 w = lane_words(b.seed, glane, episode, kSubStep0 + (uint32_t)elapsed);
+    return uniform_between(-p.noise_max, p.noise_max, w.x);
+  }
+
+  // carl_acrobot.py:101-111
+  __device__ static __forceinline__ void observe(const float (&s)[S], float (&o)[D]) {
+    sincosf(s[0], &o[1], &o[0]);
+    sincosf(s[1], &o[3], &o[2]);
+    o[4] = s[2];
+    o[5] = s[3];
+  }
+
+  // carl_acrobot.py:78-100
+  template <class Ctx>
+  __device__ static __forceinline__ void reset(const Ctx& ctx, int c, const u32x4& w, float (&s)[S]) {
+    const float alo = ctx.get(IA_LO, c), ahi = ctx.get(IA_HI, c);
+    const float vlo = ctx.get(IV_LO, c), vhi = ctx.get(IV_HI, c);
+    s[0] = uniform_between(alo, ahi, w.x);
+    s[1] = uniform_between(alo, ahi, w.y);
+    s[2] = uniform_between(vlo, vhi, w.z);
+    s[3] = uniform_between(vlo, vhi, w.w);
+  }
+};
+using Acrobot = AcrobotT<double>;
+using AcrobotFast = AcrobotT<float>;
+
+// ================================ MountainCar =====================================
+// features: carl_mountaincar.py:15-51 (Quirk M1: CARL's goal_position default 0.45)
+struct MountainCar {
+  static constexpr int S = 2, D = 2, F = 11;
+  using Action = int;
+  enum { MIN_POS, MAX_POS, MAX_SPEED, GOAL_POS, GOAL_VEL, FORCE, GRAVITY, MINP_START, MAXP_START, MINV_START, MAXV_START };
+  static constexpr bool kNeedsStepNoise = false;
+
+  struct Params {
+    float min_position, max_position, max_speed, goal_position, goal_velocity, force, gravity;
+  };
+
+  template <class Ctx>
+  __device__ static __forceinline__ Params load(const Ctx& ctx, int c, int) {
+    return Params{ctx.get(MIN_POS, c),  ctx.get(MAX_POS, c), ctx.get(MAX_SPEED, c), ctx.get(GOAL_POS, c),
+                  ctx.get(GOAL_VEL, c), ctx.get(FORCE, c),   ctx.get(GRAVITY, c)};
+  }
+
+  // MountainCarEnv.step
+  __device__ static __forceinline__ bool step(const Params& p, float (&s)[S], int action, float /*noise*/,
+                                              float& reward) {
+    float position = s[0], velocity = s[1];
+    velocity += (float)(action - 1) * p.force + cosf(3.0f * position) * (-p.gravity);
+    velocity = fminf(fmaxf(velocity, -p.max_speed), p.max_speed);
+    position += velocity;
+    position = fminf(fmaxf(position, p.min_position), p.max_position);
+    if (position == p.min_position && velocity < 0.0f) velocity = 0.0f;
+    s[0] = position;
+    s[1] = velocity;
+    reward = -1.0f;
+    return (position >= p.goal_position) && (velocity >= p.goal_velocity);
+  }
+
+  __device__ static __forceinline__ void observe(const float (&s)[S], float (&o)[D]) {
+    o[0] = s[0];
+    o[1] = s[1];
+  }
+
+  // carl_mountaincar.py:60-80
+  template <class Ctx>
+  __device__ static __forceinline__ void reset(const Ctx& ctx, int c, const u32x4& w, float (&s)[S]) {
+    s[0] = uniform_between(ctx.get(MINP_START, c), ctx.get(MAXP_START, c), w.x);
+    s[1] = uniform_between(ctx.get(MINV_START, c), ctx.get(MAXV_START, c), w.y);
+  }
+};
+
+// ============================ MountainCarContinuous ===============================
+// features: carl_mountaincarcontinuous.py:15-48 (goal_position default 0.5)
+struct MountainCarCont {
+  static constexpr int S = 2, D = 2, F = 10;
+  using Action = float;
+  enum { MIN_POS, MAX_POS, MAX_SPEED, GOAL_POS, GOAL_VEL, POWER, MINP_START, MAXP_START, MINV_START, MAXV_START };
+  static constexpr bool kNeedsStepNoise = false;
+
+  struct Params {
+    float min_position, max_position, max_speed, goal_position, goal_velocity, power;
+  };
+
+  template <class Ctx>
+  __device__ static __forceinline__ Params load(const Ctx& ctx, int c, int) {
+    return Params{ctx.get(MIN_POS, c),  ctx.get(MAX_POS, c),  ctx.get(MAX_SPEED, c),
+                  ctx.get(GOAL_POS, c), ctx.get(GOAL_VEL, c), ctx.get(POWER, c)};
+  }
+
+  // Continuous_MountainCarEnv.step (gravity literal 0.0025; penalty on the UNclipped action)
+  __device__ static __forceinline__ bool step(const Params& p, float (&s)[S], float action, float /*noise*/,
+                                              float& reward) {
+    float position = s[0], velocity = s[1];
+    const float force = fminf(fmaxf(action, -1.0f), 1.0f);
+    velocity += force * p.power - 0.0025f * cosf(3.0f * position);
+    velocity = (velocity > p.max_speed) ? p.max_speed : velocity;
+    velocity = (velocity < -p.max_speed) ? -p.max_speed : velocity;
+    position += velocity;
+    position = (position > p.max_position) ? p.max_position : position;
+    position = (position < p.min_position) ? p.min_position : position;
+    if (position == p.min_position && velocity < 0.0f) velocity = 0.0f;
+    const bool terminated = (position >= p.goal_position) && (velocity >= p.goal_velocity);
+    reward = (terminated ? 100.0f : 0.0f) - (action * action) * 0.1f;
+    s[0] = position;
+    s[1] = velocity;
+    return terminated;
+  }
+
+  __device__ static __forceinline__ void observe(const float (&s)[S], float (&o)[D]) {
+    o[0] = s[0];
+    o[1] = s[1];
+  }
+
+  // carl_mountaincarcontinuous.py:57-77
+  template <class Ctx>
+  __device__ static __forceinline__ void reset(const Ctx& ctx, int c, const u32x4& w, float (&s)[S]) {
+    s[0] = uniform_between(ctx.get(MINP_START, c), ctx.get(MAXP_START, c), w.x);
+    s[1] = uniform_between(ctx.get(MINV_START, c), ctx.get(MAXV_START, c), w.y);
+  }
+};
+
+}  // namespace carl

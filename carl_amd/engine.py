@@ -1,0 +1,302 @@
+"""Device-resident batch of env lanes: buffers (PyTorch-ROCm tensors) + C-ABI calls.
+
+``VecEngine`` is the object the CARL-shaped envs wrap -- the replacement for the
+gymnasium env (+ TimeLimit) that ``CARLGymnasiumEnv`` builds with ``gymnasium.make``
+(reference: carl/envs/gymnasium/carl_gymnasium_env.py:63-64) -- for N lanes at once.
+PyTorch only provides device memory and streams here; all arithmetic runs in the HIP
+library behind include/carl_amd.h.  No CPU fallback exists.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Sequence
+
+import numpy as np
+import torch
+
+from carl_amd import _lib
+
+_FAMILY_BY_NAME = {
+    "cartpole": _lib.CARTPOLE, "pendulum": _lib.PENDULUM, "acrobot": _lib.ACROBOT,
+    "mountaincar": _lib.MOUNTAINCAR, "mountaincar_cont": _lib.MOUNTAINCAR_CONT,
+}
+
+
+def _ptr(t: torch.Tensor | None) -> int | None:
+    return None if t is None else t.data_ptr()
+
+
+class VecEngine:
+    """N lanes of one env family on one device.
+
+    Parameters
+    ----------
+    family : int | str
+        ``carl_family_t`` (or its lower-case name).
+    ctx_table : array [C, F]
+        Context set in the family's feature order (defaults already filled).
+    n_lanes : int
+    device : torch.device | str
+    selector : int
+        ``carl_selector_t`` rule applied on every lane reset.
+    ctx_idx0 : array [n_lanes] | None
+        Context id each lane holds BEFORE its first reset.  Default: round robin
+        ``(g - stride) mod C`` (so the first reset lands on ``g mod C``; with one lane
+        this is the reference's 0, 1, 2, ...), otherwise ``g mod C`` (g = global lane id).
+    lane_offset : int
+        Global id of lane 0: lanes sharded over GPUs keep their global ids, so RNG
+        streams and initial context assignment do not depend on the GPU count.
+    """
+
+    def __init__(self, family, ctx_table, n_lanes: int, device="cuda", *, selector: int = _lib.SEL_ROUND_ROBIN,
+                 selector_stride: int = 1, auto_reset: bool = True, max_episode_steps: int | None = None,
+                 seed: int = 0, lane_offset: int = 0, cartpole_recompute: bool = False,
+                 ctx_obs_rows: Sequence[int] | None = None, ctx_idx0=None, fin_capacity: int = 0,
+                 acrobot_fp32: bool = False):
+        self.lib = _lib.load()
+        if isinstance(family, str):
+            family = _FAMILY_BY_NAME[family]
+        self.family = int(family)
+        self.info = _lib.family_info(self.family)
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.CarlHipError(
+                f"VecEngine needs a ROCm device (got {self.device}); there is no CPU path")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self.n = int(n_lanes)
+        S, D, F = self.info.state_dim, self.info.obs_dim, self.info.n_features
+        self.S, self.D, self.F = S, D, F
+        dev = self.device
+        i32, f32 = torch.int32, torch.float32
+
+        self.state = torch.zeros((S, self.n), dtype=f32, device=dev)
+        self.elapsed = torch.zeros(self.n, dtype=i32, device=dev)
+        self.episode = torch.zeros(self.n, dtype=i32, device=dev)  # uint32 bits
+        self.n_calls = torch.zeros(self.n, dtype=i32, device=dev)
+        self.ep_return = torch.zeros(self.n, dtype=f32, device=dev)
+        self.last_return = torch.zeros(self.n, dtype=f32, device=dev)
+        self.last_length = torch.zeros(self.n, dtype=i32, device=dev)
+        self.episodes_done = torch.zeros(self.n, dtype=i32, device=dev)
+        # step outputs (reused every call: returned tensors alias these buffers)
+        self.obs = torch.zeros((self.n, D), dtype=f32, device=dev)
+        self.reward = torch.zeros(self.n, dtype=f32, device=dev)
+        self.terminated = torch.zeros(self.n, dtype=torch.uint8, device=dev)
+        self.truncated = torch.zeros(self.n, dtype=torch.uint8, device=dev)
+        self.final_obs = torch.zeros((self.n, D), dtype=f32, device=dev)
+        # done-mask compaction buffers
+        self.done_idx = torch.zeros(max(self.n, 1), dtype=i32, device=dev)
+        self.done_count = torch.zeros(1, dtype=i32, device=dev)
+        self._scratch = torch.zeros(int(self.lib.carl_done_compact_scratch_elems(self.n)), dtype=i32, device=dev)
+        # finished-episode log
+        self.fin_capacity = int(fin_capacity)
+        if self.fin_capacity > 0:
+            self.fin_count = torch.zeros(1, dtype=i32, device=dev)
+            self.fin_lane = torch.zeros(self.fin_capacity, dtype=torch.int64, device=dev)
+            self.fin_return = torch.zeros(self.fin_capacity, dtype=f32, device=dev)
+            self.fin_length = torch.zeros(self.fin_capacity, dtype=i32, device=dev)
+        else:
+            self.fin_count = self.fin_lane = self.fin_return = self.fin_length = None
+
+        self.b = _lib.Batch()
+        self.b.family = self.family
+        self.b.n_lanes = self.n
+        self.b.max_episode_steps = self.info.max_episode_steps if max_episode_steps is None else int(max_episode_steps)
+        self.b.selector = int(selector)
+        self.b.selector_stride = int(selector_stride)
+        self.b.flags = (_lib.FLAG_AUTORESET if auto_reset else 0) | (
+            _lib.FLAG_CARTPOLE_RECOMPUTE if cartpole_recompute else 0) | (
+            _lib.FLAG_ACROBOT_FP32 if acrobot_fp32 else 0)
+        self.b.lane_offset = int(lane_offset)
+        self.b.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+
+        self.ctx_obs_rows = list(range(F)) if ctx_obs_rows is None else [int(r) for r in ctx_obs_rows]
+        if len(self.ctx_obs_rows) > _lib.CARL_MAX_CTX_OBS:
+            raise ValueError(f"at most {_lib.CARL_MAX_CTX_OBS} observed context features")
+        self.ctx_obs = torch.zeros((len(self.ctx_obs_rows), self.n), dtype=f32, device=dev)
+        self.ctx_table = None
+        self.ctx_idx = None
+        self.set_contexts(ctx_table, ctx_idx0)
+        self._io = _lib.StepIO()
+        self._sync_pointers()
+
+    # ------------------------------------------------------------------ contexts
+    def default_ctx_idx(self, n_contexts: int) -> torch.Tensor:
+        g = torch.arange(self.n, dtype=torch.int64) + int(self.b.lane_offset)
+        if self.b.selector == _lib.SEL_ROUND_ROBIN:
+            g = g - int(self.b.selector_stride)
+        return (g % n_contexts).to(torch.int32)
+
+    def set_contexts(self, ctx_table, ctx_idx0=None) -> None:
+        """Upload a context set ([C, F], reference feature order) and (re)assign lanes.
+
+        Batched counterpart of the ``contexts`` setter (carl_env.py:122-137) plus
+        ``_update_context`` (carl_gymnasium_env.py:75-77)."""
+        t = torch.as_tensor(np.asarray(ctx_table, dtype=np.float64) if not torch.is_tensor(ctx_table) else ctx_table)
+        if t.ndim != 2 or t.shape[1] != self.F:
+            raise ValueError(f"ctx_table must be [C, {self.F}], got {tuple(t.shape)}")
+        C_ = int(t.shape[0])
+        if C_ < 1:
+            raise ValueError("empty context set")
+        # feature-major [F, C] fp32 on device
+        self.ctx_table = t.to(torch.float32).t().contiguous().to(self.device)
+        self.b.n_contexts = C_
+        self.b.ctx_stride = C_
+        if ctx_idx0 is None:
+            idx = self.default_ctx_idx(C_)
+        else:
+            idx = torch.as_tensor(ctx_idx0).to(torch.int32).reshape(self.n)
+            if idx.numel() and (int(idx.min()) < 0 or int(idx.max()) >= C_):
+                raise ValueError("ctx_idx0 out of range")
+        self.ctx_idx = idx.to(self.device).contiguous()
+        if hasattr(self, "_io"):
+            self._sync_pointers()
+
+    def set_ctx_idx(self, idx) -> None:
+        """Host-driven context switch (``context_id`` setter, carl_env.py:139-157)."""
+        idx = torch.as_tensor(idx).to(torch.int32).reshape(self.n)
+        self.ctx_idx.copy_(idx.to(self.device))
+
+    def refresh_ctx_obs(self) -> None:
+        """ctx_obs[k, lane] = table[row_k, ctx_idx[lane]] for all lanes (the kernels only
+        touch lanes they reset)."""
+        if self.ctx_obs.shape[0]:
+            rows = torch.as_tensor(self.ctx_obs_rows, device=self.device)
+            self.ctx_obs.copy_(self.ctx_table[rows][:, self.ctx_idx.long()])
+
+    # ------------------------------------------------------------------ plumbing
+    def _sync_pointers(self) -> None:
+        b = self.b
+        b.state, b.elapsed, b.ctx_idx = _ptr(self.state), _ptr(self.elapsed), _ptr(self.ctx_idx)
+        b.episode, b.n_calls, b.ep_return = _ptr(self.episode), _ptr(self.n_calls), _ptr(self.ep_return)
+        b.ctx_table = _ptr(self.ctx_table)
+        b.n_ctx_obs = len(self.ctx_obs_rows)
+        b.ctx_obs = _ptr(self.ctx_obs) if self.ctx_obs_rows else None
+        for k, r in enumerate(self.ctx_obs_rows):
+            b.ctx_obs_feat[k] = r
+        b.last_return, b.last_length = _ptr(self.last_return), _ptr(self.last_length)
+        b.episodes_done = _ptr(self.episodes_done)
+        b.fin_capacity = self.fin_capacity
+        b.fin_count, b.fin_lane = _ptr(self.fin_count), _ptr(self.fin_lane)
+        b.fin_return, b.fin_length = _ptr(self.fin_return), _ptr(self.fin_length)
+
+    def _stream(self) -> int:
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    @property
+    def auto_reset(self) -> bool:
+        return bool(self.b.flags & _lib.FLAG_AUTORESET)
+
+    @auto_reset.setter
+    def auto_reset(self, on: bool) -> None:
+        self.b.flags = (self.b.flags | _lib.FLAG_AUTORESET) if on else (self.b.flags & ~_lib.FLAG_AUTORESET)
+
+    @property
+    def n_contexts(self) -> int:
+        return int(self.b.n_contexts)
+
+    def _action_tensor(self, action, lead: tuple[int, ...]) -> tuple[torch.Tensor, int]:
+        a = action if torch.is_tensor(action) else torch.as_tensor(np.asarray(action))
+        if self.info.action_is_discrete:
+            if a.dtype not in (torch.int32, torch.int64):
+                a = a.to(torch.int64)
+            dt = _lib.ACTION_I32 if a.dtype == torch.int32 else _lib.ACTION_I64
+        else:
+            if a.dtype != torch.float32:
+                a = a.to(torch.float32)
+            dt = _lib.ACTION_F32
+        if a.device != self.device:
+            a = a.to(self.device)
+        n_expected = int(np.prod(lead)) * self.n
+        if a.numel() != n_expected:
+            raise ValueError(f"action has {a.numel()} elements, expected {n_expected} ({lead} x {self.n} lanes)")
+        return a.contiguous(), dt
+
+    # ------------------------------------------------------------------ API
+    def seed(self, seed: int) -> None:
+        """``reset(seed=s)`` semantics: new RNG key, per-lane episode counters back to 0."""
+        self.b.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        self.episode.zero_()
+
+    def reset(self, mask: torch.Tensor | None = None) -> torch.Tensor:
+        """Reset all lanes (or those with ``mask != 0``); returns the obs buffer."""
+        m = None
+        if mask is not None:
+            m = mask.to(device=self.device, dtype=torch.uint8).contiguous()
+            if m.numel() != self.n:
+                raise ValueError("mask must have one entry per lane")
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.carl_reset(C.byref(self.b), _ptr(m), _ptr(self.obs), self._stream()))
+        return self.obs
+
+    def done_compact(self) -> tuple[torch.Tensor, torch.Tensor]:
+        """Ascending ids of lanes whose last step ended their episode -> (idx[n], count[1])."""
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.carl_done_compact(
+                _ptr(self.terminated), _ptr(self.truncated), self.n, _ptr(self.done_idx),
+                _ptr(self.done_count), _ptr(self._scratch), self._stream()))
+        return self.done_idx, self.done_count
+
+    def reset_indexed(self, idx: torch.Tensor, count: torch.Tensor) -> torch.Tensor:
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.carl_reset_indexed(C.byref(self.b), _ptr(idx), _ptr(count), _ptr(self.obs),
+                                                   self._stream()))
+        return self.obs
+
+    def reset_done(self) -> torch.Tensor:
+        """Explicit-reset path: compact the done mask, reset exactly those lanes."""
+        idx, count = self.done_compact()
+        return self.reset_indexed(idx, count)
+
+    def step(self, action):
+        """One step of every lane -> (obs[N,D], reward[N], terminated[N] u8, truncated[N] u8)."""
+        a, dt = self._action_tensor(action, ())
+        io = self._io
+        io.action, io.action_dtype = a.data_ptr(), dt
+        io.obs, io.reward = _ptr(self.obs), _ptr(self.reward)
+        io.terminated, io.truncated = _ptr(self.terminated), _ptr(self.truncated)
+        io.final_obs = _ptr(self.final_obs)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.carl_step(C.byref(self.b), C.byref(io), self._stream()))
+        return self.obs, self.reward, self.terminated, self.truncated
+
+    def alloc_rollout(self, n_steps: int, final_obs: bool = False) -> dict:
+        dev, n, D = self.device, self.n, self.D
+        out = {
+            "obs": torch.empty((n_steps, n, D), dtype=torch.float32, device=dev),
+            "reward": torch.empty((n_steps, n), dtype=torch.float32, device=dev),
+            "terminated": torch.empty((n_steps, n), dtype=torch.uint8, device=dev),
+            "truncated": torch.empty((n_steps, n), dtype=torch.uint8, device=dev),
+        }
+        if final_obs:
+            out["final_obs"] = torch.zeros((n_steps, n, D), dtype=torch.float32, device=dev)
+        return out
+
+    def rollout(self, actions, out: dict | None = None) -> dict:
+        """T steps in one launch; ``actions`` is [T, N] (or [T, N, 1]).  Every step's full
+        transition is written to ``out`` (see ``alloc_rollout``)."""
+        T = int(actions.shape[0])
+        a, dt = self._action_tensor(actions, (T,))
+        if out is None:
+            out = self.alloc_rollout(T)
+        if out["reward"].shape[0] < T:
+            raise ValueError("rollout output buffers are shorter than the action sequence")
+        io = _lib.StepIO()
+        io.action, io.action_dtype = a.data_ptr(), dt
+        io.obs, io.reward = _ptr(out["obs"]), _ptr(out["reward"])
+        io.terminated, io.truncated = _ptr(out["terminated"]), _ptr(out["truncated"])
+        io.final_obs = _ptr(out.get("final_obs"))
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.carl_rollout(C.byref(self.b), C.byref(io), T, self._stream()))
+        return out
+
+    def drain_finished(self):
+        """Finished-episode log since the last drain -> (global lane ids, returns, lengths,
+        n_dropped); resets the counter.  Synchronises."""
+        if self.fin_count is None:
+            raise RuntimeError("engine was built with fin_capacity=0")
+        n = int(self.fin_count.item())
+        k = min(n, self.fin_capacity)
+        out = (self.fin_lane[:k].clone(), self.fin_return[:k].clone(), self.fin_length[:k].clone(), n - k)
+        self.fin_count.zero_()
+        return out

@@ -1,0 +1,6 @@
+# flake8: noqa: F401
+from carl_amd.envs.carl_env import CARLEnv
+from carl_amd.envs.gymnasium import *  # noqa: F403
+from carl_amd.envs.gymnasium import __all__ as _gym_all
+
+__all__ = ["CARLEnv", *_gym_all]

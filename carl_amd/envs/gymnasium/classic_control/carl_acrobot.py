@@ -1,0 +1,49 @@
+"""CARLAcrobot: context-feature table of the reference (carl/envs/gymnasium/classic_control/carl_acrobot.py:11-115).
+
+Only the feature table lives here.  The reset distribution the reference implements as a
+Python ``reset()`` override -- angles = U(INITIAL_ANGLE_LOWER, INITIAL_ANGLE_UPPER, 2), velocities likewise;
+    obs = (cos t1, sin t1, cos t2, sin t2, w1, w2) (:71-115) --
+and the step physics run in the HIP kernels of the ``Acrobot-v1`` family
+(carl_amd/csrc/classic_control.cuh).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from carl_amd import spaces
+from carl_amd.context.context_space import ContextFeature, UniformFloatContextFeature
+from carl_amd.envs.gymnasium.carl_gymnasium_env import CARLGymnasiumEnv
+
+# (name, lower, upper, default) in the reference's order = row order of the device table
+_FEATURES = (
+    ("LINK_LENGTH_1", 0.1, 10, 1),
+    ("LINK_LENGTH_2", 0.1, 10, 1),
+    ("LINK_MASS_1", 0.1, 10, 1),
+    ("LINK_MASS_2", 0.1, 10, 1),
+    ("LINK_COM_POS_1", 0, 1, 0.5),
+    ("LINK_COM_POS_2", 0, 1, 0.5),
+    ("LINK_MOI", 0.1, 10, 1),
+    ("MAX_VEL_1", 0.4 * np.pi, 40 * np.pi, 4 * np.pi),
+    ("MAX_VEL_2", 0.9 * np.pi, 90 * np.pi, 9 * np.pi),
+    ("torque_noise_max", -1, 1, 0),
+    ("INITIAL_ANGLE_LOWER", -np.inf, np.inf, -0.1),
+    ("INITIAL_ANGLE_UPPER", -np.inf, np.inf, 0.1),
+    ("INITIAL_VELOCITY_LOWER", -np.inf, np.inf, -0.1),
+    ("INITIAL_VELOCITY_UPPER", -np.inf, np.inf, 0.1),
+)
+
+
+class CARLAcrobot(CARLGymnasiumEnv):
+    env_name: str = "Acrobot-v1"
+    metadata = {"render_modes": []}
+
+    @staticmethod
+    def get_context_features() -> dict[str, ContextFeature]:
+        return {
+            name: UniformFloatContextFeature(name, lower=lo, upper=hi, default_value=default)
+            for name, lo, hi, default in _FEATURES
+        }
+
+    def _base_observation_space(self) -> spaces.Space:
+        high = np.array([1.0, 1.0, 1.0, 1.0, 4 * np.pi, 9 * np.pi], dtype=np.float32)
+        return spaces.Box(-high, high, dtype=np.float32)

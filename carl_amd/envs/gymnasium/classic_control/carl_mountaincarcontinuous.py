@@ -1,0 +1,45 @@
+"""CARLMountainCarContinuous: context-feature table of the reference (carl/envs/gymnasium/classic_control/carl_mountaincarcontinuous.py:11-82).
+
+Only the feature table lives here.  The reset distribution the reference implements as a
+Python ``reset()`` override -- same start distribution as CARLMountainCar (:50-82) --
+and the step physics run in the HIP kernels of the ``MountainCarContinuous-v0`` family
+(carl_amd/csrc/classic_control.cuh).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from carl_amd import spaces
+from carl_amd.context.context_space import ContextFeature, UniformFloatContextFeature
+from carl_amd.envs.gymnasium.carl_gymnasium_env import CARLGymnasiumEnv
+
+# (name, lower, upper, default) in the reference's order = row order of the device table
+_FEATURES = (
+    ("min_position", -np.inf, np.inf, -1.2),
+    ("max_position", -np.inf, np.inf, 0.6),
+    ("max_speed", 0, np.inf, 0.07),
+    ("goal_position", -np.inf, np.inf, 0.5),
+    ("goal_velocity", -np.inf, np.inf, 0),
+    ("power", -np.inf, np.inf, 0.0015),
+    ("min_position_start", -np.inf, np.inf, -0.6),
+    ("max_position_start", -np.inf, np.inf, -0.4),
+    ("min_velocity_start", -np.inf, np.inf, 0),
+    ("max_velocity_start", -np.inf, np.inf, 0),
+)
+
+
+class CARLMountainCarContinuous(CARLGymnasiumEnv):
+    env_name: str = "MountainCarContinuous-v0"
+    metadata = {"render_modes": []}
+
+    @staticmethod
+    def get_context_features() -> dict[str, ContextFeature]:
+        return {
+            name: UniformFloatContextFeature(name, lower=lo, upper=hi, default_value=default)
+            for name, lo, hi, default in _FEATURES
+        }
+
+    def _base_observation_space(self) -> spaces.Space:
+        low = np.array([-1.2, -0.07], dtype=np.float32)
+        high = np.array([0.6, 0.07], dtype=np.float32)
+        return spaces.Box(low, high, dtype=np.float32)

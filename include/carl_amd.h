@@ -1,0 +1,200 @@
+/* carl_amd.h -- C ABI of the MI355X batched step/reset engine for CARL's
+ * contextual classic-control (and Brax-locomotion) families.
+ *
+ * The reference (automl/CARL v1.1.1) has NO FFI on this path: its boundary is a
+ * Python protocol, "the object CARLEnv wraps" (SURVEY.md section 8b).  This header
+ * is what a ctypes binding on the reference side would load (INTEGRATION.md shows
+ * the stub).  Every entry point cites the reference interface it replaces.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes, no torch/HIP types in signatures:
+ *    `stream` is a hipStream_t passed as void* (0 = the null stream).
+ *  - All array pointers are DEVICE pointers owned by the caller (the Python shim
+ *    allocates them as PyTorch-ROCm tensors and passes tensor.data_ptr()).  The
+ *    library never allocates persistent device memory and never frees caller
+ *    memory; scratch is caller-provided.
+ *  - Calls enqueue on `stream` and return without synchronising; no global mutable
+ *    state; one carl_batch_t per device, caller serialises calls per batch.
+ *  - Return value: 0 on success, otherwise a hipError_t value or CARL_ERR_*;
+ *    carl_last_error() returns a thread-local message.  Nothing throws or exits.
+ *  - Layouts: per-lane state is struct-of-arrays  state[s * n_lanes + lane];
+ *    the context table is feature-major  ctx_table[f * ctx_stride + c]  with
+ *    features in the order of the reference class's get_context_features();
+ *    observations are lane-major  obs[lane * obs_dim + d]  (what a VectorEnv
+ *    returns: carl/envs/brax/wrappers.py:111-118).
+ */
+#ifndef CARL_AMD_H_
+#define CARL_AMD_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CARL_ABI_VERSION 1
+#define CARL_MAX_CTX_OBS 32
+
+#define CARL_ERR_INVALID_ARGUMENT (-1)
+#define CARL_ERR_UNSUPPORTED (-2)
+
+/* env families.  Context-feature order per family = get_context_features():
+ *  CARTPOLE          carl/envs/gymnasium/classic_control/carl_cartpole.py:15-42
+ *  PENDULUM          carl/envs/gymnasium/classic_control/carl_pendulum.py:15-39
+ *  ACROBOT           carl/envs/gymnasium/classic_control/carl_acrobot.py:15-69
+ *  MOUNTAINCAR       carl/envs/gymnasium/classic_control/carl_mountaincar.py:15-51
+ *  MOUNTAINCAR_CONT  carl/envs/gymnasium/classic_control/carl_mountaincarcontinuous.py:15-48 */
+typedef enum carl_family {
+  CARL_CARTPOLE = 0,
+  CARL_PENDULUM = 1,
+  CARL_ACROBOT = 2,
+  CARL_MOUNTAINCAR = 3,
+  CARL_MOUNTAINCAR_CONT = 4,
+  CARL_N_FAMILIES = 5
+} carl_family_t;
+
+/* per-lane context selection rule applied on every reset of a lane
+ * (carl/context/selection.py: StaticSelector :125-136, RoundRobinSelector
+ * :110-122, RandomSelector :98-107).  HOST = ids are written by the caller
+ * (CustomSelector :139-180); the device leaves ctx_idx alone. */
+typedef enum carl_selector {
+  CARL_SEL_STATIC = 0,
+  CARL_SEL_ROUND_ROBIN = 1,
+  CARL_SEL_RANDOM = 2,
+  CARL_SEL_HOST = 3
+} carl_selector_t;
+
+enum {
+  CARL_FLAG_AUTORESET = 1,          /* reset done lanes inside step */
+  CARL_FLAG_CARTPOLE_RECOMPUTE = 2, /* recompute total_mass / polemass_length from
+                                       the context (NOT reference behaviour; the
+                                       default replicates Quirk C1) */
+  CARL_FLAG_ACROBOT_FP32 = 4        /* evaluate Acrobot's _dsdt/rk4 in fp32 instead of
+                                       fp64 (faster; up to ~1e-3 relative error on
+                                       states near the velocity bounds) */
+};
+
+enum { CARL_ACTION_I32 = 0, CARL_ACTION_I64 = 1, CARL_ACTION_F32 = 2 };
+
+typedef struct carl_family_info {
+  int32_t state_dim;          /* S: columns of `state` */
+  int32_t obs_dim;            /* D */
+  int32_t n_features;         /* F: rows of ctx_table */
+  int32_t action_dim;         /* 1 */
+  int32_t action_is_discrete; /* 1: Discrete(n_actions); 0: Box */
+  int32_t n_actions;          /* discrete: 2 or 3 */
+  int32_t max_episode_steps;  /* gymnasium registry TimeLimit default */
+  int32_t reserved;
+  float action_low, action_high; /* Box bounds when continuous */
+} carl_family_info_t;
+
+/* One batch of lanes (env instances) resident on one device.  Replaces the
+ * attribute state of N x {CARLEnv + TimeLimit + gymnasium env} objects:
+ *   state      <- env.unwrapped.state              (carl_cartpole.py:51 ...)
+ *   elapsed    <- TimeLimit._elapsed_steps         (gymnasium.make, carl_gymnasium_env.py:64)
+ *   ctx_idx    <- context_selector.context_id      (carl_env.py:118-120)
+ *   n_calls    <- context_selector.n_calls         (selection.py:45,75)
+ *   ctx_table  <- env.contexts after insert_defaults (carl_env.py:122-137) and the
+ *                 setattr loop of CARLGymnasiumEnv._update_context
+ *                 (carl_gymnasium_env.py:75-77)
+ *   ctx_obs    <- the "context" half of the observation dict (carl_env.py:276-305)
+ * RNG: Philox4x32-10, key = seed, counter = (global lane id lo, hi, episode, sub);
+ * global lane id = lane_offset + lane, so results do not depend on how lanes are
+ * split across devices. */
+typedef struct carl_batch {
+  int32_t family;            /* carl_family_t */
+  int32_t n_lanes;
+  int32_t n_contexts;        /* C: valid columns of ctx_table */
+  int32_t ctx_stride;        /* elements between feature rows, >= n_contexts */
+  int32_t max_episode_steps; /* TimeLimit; <= 0 -> never truncate */
+  int32_t selector;          /* carl_selector_t */
+  int32_t selector_stride;   /* round robin: id = (id + stride) mod C */
+  int32_t flags;             /* CARL_FLAG_* */
+  int64_t lane_offset;
+  uint64_t seed;
+  /* persistent per-lane state */
+  float* state;              /* [S][n_lanes] */
+  int32_t* elapsed;          /* [n_lanes] */
+  int32_t* ctx_idx;          /* [n_lanes] in [0, C) */
+  uint32_t* episode;         /* [n_lanes] resets so far under this seed (RNG counter) */
+  int32_t* n_calls;          /* [n_lanes] selector calls so far */
+  float* ep_return;          /* [n_lanes] running return of the current episode */
+  /* contexts */
+  const float* ctx_table;    /* [F][ctx_stride] */
+  float* ctx_obs;            /* [n_ctx_obs][n_lanes] or NULL */
+  int32_t n_ctx_obs;
+  int32_t ctx_obs_feat[CARL_MAX_CTX_OBS]; /* table row of each observed feature */
+  int32_t fin_capacity;      /* entries in the finished-episode log */
+  /* episode statistics, all nullable */
+  float* last_return;        /* [n_lanes] return of the lane's last finished episode */
+  int32_t* last_length;      /* [n_lanes] */
+  int32_t* episodes_done;    /* [n_lanes] finished-episode count */
+  /* finished-episode log (wave-ballot compaction, one atomic per wavefront):
+   * entry k < min(*fin_count, fin_capacity) = one finished episode.  Entry order
+   * is unspecified; the multiset of entries is deterministic. */
+  int32_t* fin_count;        /* [1] or NULL */
+  int64_t* fin_lane;         /* [fin_capacity] global lane id */
+  float* fin_return;         /* [fin_capacity] */
+  int32_t* fin_length;       /* [fin_capacity] */
+} carl_batch_t;
+
+/* Inputs/outputs of one step (or, for carl_rollout, of T steps: every array gains
+ * a leading [T] dimension).  Replaces the return tuple of CARLEnv.step
+ * (carl/envs/carl_env.py:321-342) minus the context half (see carl_batch.ctx_obs). */
+typedef struct carl_step_io {
+  const void* action;   /* [n_lanes * action_dim], dtype per action_dtype */
+  int32_t action_dtype; /* CARL_ACTION_* ; discrete families take I32/I64, Box F32 */
+  int32_t reserved;
+  float* obs;           /* [n_lanes][D]; with AUTORESET the post-reset observation
+                           for done lanes (gymnasium vector-env convention) */
+  float* reward;        /* [n_lanes] */
+  uint8_t* terminated;  /* [n_lanes] */
+  uint8_t* truncated;   /* [n_lanes] TimeLimit */
+  float* final_obs;     /* [n_lanes][D] or NULL; written for done lanes only */
+} carl_step_io_t;
+
+int carl_abi_version(void);
+const char* carl_last_error(void);
+
+/* static facts about a family: replaces reading env.observation_space /
+ * env.action_space / spec.max_episode_steps of the gymnasium env the reference
+ * builds with gymnasium.make (carl_gymnasium_env.py:63-64). */
+int carl_family_info(int family, carl_family_info_t* out);
+
+/* CARLEnv.reset for the lanes selected by `mask` (device u8 [n_lanes]; NULL = all):
+ * selector advance -> (context switch) -> CARL init-state draw -> elapsed = 0 -> obs.
+ * Replaces carl/envs/carl_env.py:245-274 + the per-family reset overrides
+ * (carl_cartpole.py:44-66, carl_pendulum.py:41-65, carl_acrobot.py:71-115,
+ * carl_mountaincar.py:53-85, carl_mountaincarcontinuous.py:50-82).
+ * `obs` [n_lanes][D] receives the initial observation of reset lanes only. */
+int carl_reset(const carl_batch_t* batch, const uint8_t* mask, float* obs, void* stream);
+
+/* Same, for the compact list idx[0 .. *count) produced by carl_done_compact
+ * ("reset_masked over the compacted done list"). */
+int carl_reset_indexed(const carl_batch_t* batch, const int32_t* idx, const int32_t* count,
+                       float* obs, void* stream);
+
+/* CARLEnv.step over all lanes: env physics + TimeLimit + episodic-return
+ * bookkeeping + (AUTORESET) in-kernel reset of done lanes.  Replaces
+ * carl/envs/carl_env.py:321-342 -> gymnasium TimeLimit.step -> <Env>.step. */
+int carl_step(const carl_batch_t* batch, const carl_step_io_t* io, void* stream);
+
+/* T consecutive steps in ONE launch, state held in registers between steps; every
+ * step still emits its full transition (obs/reward/terminated/truncated at
+ * [t][lane]).  action is [T][n_lanes].  No reference counterpart (the reference
+ * steps one env object per Python call); exists because a single step of 65 536
+ * lanes is shorter than a kernel launch. */
+int carl_rollout(const carl_batch_t* batch, const carl_step_io_t* io, int32_t n_steps, void* stream);
+
+/* done-mask compaction: ascending lane ids with terminated|truncated set.
+ * idx_out [n], count_out [1], scratch >= carl_done_compact_scratch_elems(n) int32.
+ * No reference counterpart (the gymnasium path has no auto-reset; the user calls
+ * reset() per env, carl_env.py:245). */
+int carl_done_compact(const uint8_t* terminated, const uint8_t* truncated, int32_t n,
+                      int32_t* idx_out, int32_t* count_out, int32_t* scratch, void* stream);
+int32_t carl_done_compact_scratch_elems(int32_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CARL_AMD_H_ */
