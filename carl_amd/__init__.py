@@ -24,3 +24,22 @@ def __getattr__(name):
 
         return getattr(importlib.import_module(_LAZY[name]), name)
     raise AttributeError(name)
+
+
+# ---- registry: the ids the reference registers with gymnasium ("carl/<Cls>-v0",
+# carl/__init__.py:31-35), resolvable without gymnasium -------------------------------
+registry = {
+    f"carl/{name}-v0": (module, name)
+    for name, module in _LAZY.items()
+    if name.startswith("CARL") and name != "CARLEnv"
+}
+
+
+def make(env_id: str, **kwargs):
+    """``gymnasium.make("carl/CARLCartPole-v0", contexts=...)`` equivalent."""
+    if env_id not in registry:
+        raise KeyError(f"unknown env id {env_id!r}; known: {sorted(registry)}")
+    import importlib
+
+    module, name = registry[env_id]
+    return getattr(importlib.import_module(module), name)(**kwargs)

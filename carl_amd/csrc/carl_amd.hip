@@ -191,10 +191,11 @@ int32_t carl_done_compact_scratch_elems(int32_t n) {
 int carl_done_compact(const uint8_t* terminated, const uint8_t* truncated, int32_t n, int32_t* idx_out,
                       int32_t* count_out, int32_t* scratch, void* stream) {
   if (n < 0) return fail(CARL_ERR_INVALID_ARGUMENT, "carl_done_compact: n %d < 0", n);
-  if (!terminated || !truncated || !idx_out || !count_out || !scratch)
+  if (!count_out) return fail(CARL_ERR_INVALID_ARGUMENT, "carl_done_compact: count_out is NULL");
+  if (n > 0 && (!terminated || !truncated || !idx_out || !scratch))
     return fail(CARL_ERR_INVALID_ARGUMENT, "carl_done_compact: NULL pointer");
   hipStream_t s = (hipStream_t)stream;
-  if (n == 0) {
+  if (n == 0) {  // empty batch: nothing to read, the count is 0
     const hipError_t e = hipMemsetAsync(count_out, 0, sizeof(int32_t), s);
     return e == hipSuccess ? 0 : fail((int)e, "carl_done_compact: %s", hipGetErrorString(e));
   }

@@ -63,11 +63,14 @@ struct CartPole {
 
   // CartPoleEnv.step, kinematics_integrator == "euler"
   __device__ static __forceinline__ bool step(const Params& p, float (&s)[S], int action,
-                                              float /*noise*/, float& reward) {
+                                              float /*noise*/, int elapsed, float& reward) {
     const float x = s[0], x_dot = s[1], theta = s[2], theta_dot = s[3];
-    // steps_beyond_terminated: a lane stepped again after terminating (only
-    // reachable with auto-reset off) earns 0; inferred from the pre-step state.
-    const bool was_terminated = out_of_bounds(x, theta);
+    // steps_beyond_terminated: a lane stepped again after terminating (only reachable
+    // with auto-reset off) earns 0.  Inferred instead of stored: the pre-step state is
+    // out of bounds and this is not the first step since reset (a reset may legally
+    // start out of bounds when the context widens initial_state_lower/upper; that
+    // first terminating step still earns 1.0).
+    const bool was_terminated = (elapsed > 0) && out_of_bounds(x, theta);
     const float force = (action == 1) ? p.force_mag : -p.force_mag;
     float sintheta, costheta;
     sincosf(theta, &sintheta, &costheta);
@@ -120,7 +123,7 @@ struct Pendulum {
 
   // PendulumEnv.step; reward from the OLD (th, thdot); never terminates
   __device__ static __forceinline__ bool step(const Params& p, float (&s)[S], float action,
-                                              float /*noise*/, float& reward) {
+                                              float /*noise*/, int /*elapsed*/, float& reward) {
     const float max_speed = 8.0f, max_torque = 2.0f;
     const float th = s[0], thdot = s[1];
     const float u = fminf(fmaxf(action, -max_torque), max_torque);
@@ -224,7 +227,7 @@ struct AcrobotT {
 
   // AcrobotEnv.step: rk4 over [0, dt = 0.2] on (state, torque), wrap, bound, _terminal
   __device__ static __forceinline__ bool step(const Params& p, float (&s)[S], int action, float noise,
-                                              float& reward) {
+                                              int /*elapsed*/, float& reward) {
     const Real dt = (Real)0.2, dt2 = dt / (Real)2.0;
     const Real a = (Real)((float)(action - 1) + noise);
     const Real y0 = s[0], y1 = s[1], y2 = s[2], y3 = s[3];
@@ -302,7 +305,7 @@ struct MountainCar {
 
   // MountainCarEnv.step
   __device__ static __forceinline__ bool step(const Params& p, float (&s)[S], int action, float /*noise*/,
-                                              float& reward) {
+                                              int /*elapsed*/, float& reward) {
     float position = s[0], velocity = s[1];
     velocity += (float)(action - 1) * p.force + cosf(3.0f * position) * (-p.gravity);
     velocity = fminf(fmaxf(velocity, -p.max_speed), p.max_speed);
@@ -348,7 +351,7 @@ struct MountainCarCont {
 
   // Continuous_MountainCarEnv.step (gravity literal 0.0025; penalty on the UNclipped action)
   __device__ static __forceinline__ bool step(const Params& p, float (&s)[S], float action, float /*noise*/,
-                                              float& reward) {
+                                              int /*elapsed*/, float& reward) {
     float position = s[0], velocity = s[1];
     const float force = fminf(fmaxf(action, -1.0f), 1.0f);
     velocity += force * p.power - 0.0025f * cosf(3.0f * position);

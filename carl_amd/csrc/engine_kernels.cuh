@@ -102,7 +102,7 @@ __device__ __forceinline__ void step_lane(const carl_batch_t& b, const Ctx& ctx,
     float noise = 0.0f;
     if constexpr (Fam::kNeedsStepNoise) noise = Fam::step_noise(r.p, b, glane, r.episode - 1u, r.elapsed);
     float reward;
-    const bool terminated = Fam::step(r.p, r.s, action, noise, reward);
+    const bool terminated = Fam::step(r.p, r.s, action, noise, r.elapsed, reward);
     r.elapsed += 1;
     // gymnasium TimeLimit.step: truncated = elapsed >= max_episode_steps
     const bool truncated = (b.max_episode_steps > 0) && (r.elapsed >= b.max_episode_steps);

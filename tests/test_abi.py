@@ -1,0 +1,109 @@
+"""C-ABI library: loads, exports every symbol include/carl_amd.h declares, and the ctypes
+structs have the C layout.  CPU-only: nothing here launches a kernel."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "carl_amd.h")
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(carl_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from carl_amd import _lib
+
+    lib = _lib.load()
+    names = declared_functions()
+    assert "carl_step" in names and "carl_rollout" in names and len(names) >= 9
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/carl_amd.h but not exported"
+    assert sorted(_lib.EXPORTS) == names, "ctypes binding and header disagree"
+    assert lib.carl_abi_version() == _lib.CARL_ABI_VERSION
+
+
+def test_family_info_is_host_side():
+    from carl_amd import _lib
+
+    want = {0: (4, 4, 8, 1, 2, 500), 1: (2, 3, 7, 0, 0, 200), 2: (4, 6, 14, 1, 3, 500), 3: (2, 2, 11, 1, 3, 200),
+            4: (2, 2, 10, 0, 0, 999)}
+    for fam, w in want.items():
+        i = _lib.family_info(fam)
+        assert (i.state_dim, i.obs_dim, i.n_features, i.action_is_discrete, i.n_actions, i.max_episode_steps) == w
+    with pytest.raises(_lib.CarlHipError):
+        _lib.family_info(99)
+    assert b"unknown family" in _lib.load().carl_last_error()
+
+
+def test_invalid_arguments_are_reported_not_crashed():
+    from carl_amd import _lib
+
+    lib = _lib.load()
+    assert lib.carl_reset(None, None, None, None) == -1
+    b = _lib.Batch()
+    b.family = 1
+    b.n_lanes = 4
+    assert lib.carl_step(C.byref(b), None, None) == -1  # n_contexts == 0
+    assert b"n_contexts" in lib.carl_last_error()
+    assert lib.carl_done_compact(None, None, -1, None, None, None, None) == -1
+    assert lib.carl_done_compact_scratch_elems(0) == 1 and lib.carl_done_compact_scratch_elems(1025) == 2
+
+
+def test_ctypes_struct_layout_matches_c(tmp_path):
+    """compile a tiny C program against the header and compare sizeof/offsetof"""
+    from carl_amd import _lib
+
+    prog = tmp_path / "layout.c"
+    fields_b = [f[0] for f in _lib.Batch._fields_]
+    fields_io = [f[0] for f in _lib.StepIO._fields_]
+    fields_fi = [f[0] for f in _lib.FamilyInfo._fields_]
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', "int main(void){",
+             'printf("%zu %zu %zu\\n", sizeof(carl_batch_t), sizeof(carl_step_io_t), sizeof(carl_family_info_t));']
+    for f in fields_b:
+        lines.append(f'printf("%zu\\n", offsetof(carl_batch_t, {f}));')
+    for f in fields_io:
+        lines.append(f'printf("%zu\\n", offsetof(carl_step_io_t, {f}));')
+    for f in fields_fi:
+        lines.append(f'printf("%zu\\n", offsetof(carl_family_info_t, {f}));')
+    lines.append("return 0;}")
+    prog.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c11", "-o", str(exe), str(prog)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    sizes, offs = list(map(int, out[:3])), list(map(int, out[3:]))
+    assert sizes == [C.sizeof(_lib.Batch), C.sizeof(_lib.StepIO), C.sizeof(_lib.FamilyInfo)]
+    want = ([getattr(_lib.Batch, f).offset for f in fields_b] + [getattr(_lib.StepIO, f).offset for f in fields_io]
+            + [getattr(_lib.FamilyInfo, f).offset for f in fields_fi])
+    assert offs == want
+
+
+def test_engine_refuses_cpu():
+    """no CPU fallback: asking for a CPU device is an error, not a silent slow path"""
+    from carl_amd import _lib
+    from carl_amd.engine import VecEngine
+
+    with pytest.raises(_lib.CarlHipError):
+        VecEngine(1, [[8.0, 0.05, 10, 1, 1, 3.14, 1]], 4, device="cpu")
+
+
+def test_product_never_imports_the_oracle():
+    """oracle/ is test infrastructure: no module under carl_amd/ may reference it"""
+    bad = []
+    for root, _, files in os.walk(os.path.join(ROOT, "carl_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cuh", ".h")):
+                txt = open(os.path.join(root, f)).read()
+                if re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M) or "oracle/" in txt and f.endswith(".py"):
+                    bad.append(f)
+    assert not bad, bad
+    code = "import sys; import carl_amd.envs, carl_amd.engine, carl_amd.distributed; " \
+           "assert not [m for m in sys.modules if m == 'oracle' or m.startswith('oracle.')]"
+    subprocess.run([sys.executable, "-c", code], check=True, cwd=ROOT)

@@ -1,0 +1,229 @@
+"""The CARLEnv API on the lane engine: the reference's own API-shape tests
+(test/test_CARLEnv.py:9-28, test/test_context_selector.py:19-60,
+test/test_gymnasium_envs.py:11-39, test/test_all_envs.py:9-22) plus the scalar-mode
+parity of BASELINE configs[0] (CARLCartPole, one default context) against the
+reference-style Python loop.  Needs an MI355X: the envs have no CPU path."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import carl_amd
+from carl_amd import envs as E
+from carl_amd.context.context_space import NormalFloatContextFeature, UniformFloatContextFeature
+from carl_amd.context.sampler import ContextSampler
+from carl_amd.context.selection import (
+    CustomSelector,
+    RandomSelector,
+    RoundRobinSelector,
+    StaticSelector,
+)
+from oracle import oracle as O
+from oracle import ref_style as R
+
+pytestmark = pytest.mark.gpu
+
+ALL = [E.CARLCartPole, E.CARLPendulum, E.CARLAcrobot, E.CARLMountainCar, E.CARLMountainCarContinuous]
+
+
+def generate_contexts():
+    context = {"dt": 0.03, "gravity": 10.0, "m": 1.0, "l": 1.8}
+    return {k: context for k in "abc"}
+
+
+# ---- test/test_CARLEnv.py ---------------------------------------------------------
+def test_observation(device):
+    env = E.CARLPendulum()
+    context = E.CARLPendulum.get_default_context()
+    obs, info = env.reset()
+    assert type(obs) is dict and "obs" in obs and "context" in obs
+    assert len(obs["context"]) == len(context)
+    assert obs["obs"].dtype == np.float32 and obs["obs"].shape == (3,)
+    assert info == {"context_id": 0}
+
+
+def test_observation_emptycontext(device):
+    env = E.CARLPendulum(obs_context_features=[])
+    state, info = env.reset()
+    assert len(state["context"]) == 0
+
+
+def test_observation_reducedcontext(device):
+    n = 3
+    keys = list(E.CARLPendulum.get_default_context().keys())[:n]
+    env = E.CARLPendulum(obs_context_features=keys)
+    state, info = env.reset()
+    assert len(state["context"]) == n
+
+
+def test_observation_vector_mode_order(device):
+    env = E.CARLPendulum(obs_context_features=["l", "g"], obs_context_as_dict=False, contexts={0: {"l": 1.5}})
+    state, _ = env.reset()
+    assert state["context"] == [1.5, 10.0]  # caller order (Quirk S5)
+    assert env.observation_space["context"].shape == (2,)
+
+
+# ---- test/test_context_selector.py --------------------------------------------------
+def test_default_selector(device):
+    env = E.CARLPendulum(contexts=generate_contexts())
+    env.reset()
+    assert type(env.context_selector) is RoundRobinSelector and env.context_selector.n_calls == 1
+    env.reset()
+    assert env.context_selector.n_calls == 2
+
+
+def test_selector_init_forms(device):
+    contexts = generate_contexts()
+    env = E.CARLPendulum(contexts=contexts, context_selector=RoundRobinSelector(contexts=contexts))
+    assert type(env.context_selector) is RoundRobinSelector
+    env = E.CARLPendulum(contexts=contexts, context_selector=RandomSelector(contexts=contexts))
+    assert type(env.context_selector) is RandomSelector
+    env = E.CARLPendulum(contexts=contexts, context_selector=RandomSelector)
+    assert type(env.context_selector) is RandomSelector
+    with pytest.raises(ValueError):
+        E.CARLPendulum(contexts=contexts, context_selector="bork")
+
+
+def test_round_robin_ids_and_context_switch(device, golden_dir):
+    """examples/sample_contexts_with_brax.ipynb cells 7-11: first reset id 0, second id 1,
+    `env.context_id = 4` switches immediately; ids follow the reference's selector run"""
+    gold = json.load(open(os.path.join(golden_dir, "selector_sequences.json")))["round_robin_5"]
+    s = ContextSampler([NormalFloatContextFeature("g", mu=9.8, sigma=1, upper=50, lower=0)],
+                       E.CARLPendulum.get_context_space(), seed=0)
+    contexts = s.sample_contexts(5)
+    env = E.CARLPendulum(contexts=contexts)
+    ids = []
+    for _ in range(12):
+        obs, info = env.reset()
+        ids.append(info["context_id"])
+        assert obs["context"]["g"] == contexts[info["context_id"]]["g"]
+        assert env.unwrapped.g == pytest.approx(contexts[info["context_id"]]["g"], rel=1e-6)
+    assert ids == gold["context_id"]
+    env.context_id = 4
+    assert env.context_id == 4 and env.context == env.contexts[4]
+    assert int(env.env.ctx_idx[0]) == 4
+    with pytest.raises(AssertionError):
+        env.context_id = 17
+
+
+def test_custom_selector_scalar_mode(device):
+    def fn(inst):
+        cid = 1 if inst.n_calls == 0 else 0
+        return inst.contexts[inst.contexts_keys[cid]], cid
+
+    env = E.CARLPendulum(contexts=generate_contexts(), context_selector=CustomSelector,
+                         context_selector_kwargs={"selector_function": fn})
+    assert [env.reset()[1]["context_id"] for _ in range(3)] == [1, 0, 0]
+    with pytest.raises(ValueError):
+        E.CARLPendulum(contexts=generate_contexts(), num_envs=8, context_selector=CustomSelector,
+                       context_selector_kwargs={"selector_function": fn})
+
+
+# ---- test/test_gymnasium_envs.py, test/test_all_envs.py -------------------------------
+@pytest.mark.parametrize("cls", ALL, ids=lambda c: c.__name__)
+def test_envs_construct_progress_update_reset(cls, device):
+    cls.get_context_features()
+    env = cls()
+    env._progress_instance()
+    env._update_context()
+    obs, info = env.reset()
+    assert env.observation_space["obs"].contains(obs["obs"])
+    a = env.action_space.sample()
+    obs, r, term, trunc, info = env.step(a)
+    assert isinstance(r, float) and isinstance(term, bool) and isinstance(trunc, bool)
+    assert info["context_id"] == env.context_id
+
+
+def test_registration_and_make(device):
+    for cls in ALL:
+        env_id = f"carl/{cls.__name__}-v0"
+        assert env_id in carl_amd.registry
+        assert isinstance(carl_amd.make(env_id), cls)
+    with pytest.raises(KeyError):
+        carl_amd.make("carl/Nope-v0")
+
+
+def test_contexts_are_filled_with_defaults_and_validated(device):
+    env = E.CARLCartPole(contexts={"x": {"gravity": 5.0}, "y": {}})
+    assert env.contexts["x"]["gravity"] == 5.0 and env.contexts["x"]["tau"] == 0.02
+    assert env.contexts["y"] == E.CARLCartPole.get_default_context()
+    new = {0: {"length": 0.7}}
+    env.contexts = new
+    assert env.contexts[0]["length"] == 0.7 and env.env.n_contexts == 1
+
+
+# ---- BASELINE configs[0]: CARLCartPole, 1 default context, scalar API vs ref-style loop ---
+@pytest.mark.parametrize("fam,cls", list(zip(range(5), [E.CARLCartPole, E.CARLPendulum, E.CARLAcrobot,
+                                                        E.CARLMountainCar, E.CARLMountainCarContinuous])),
+                         ids=O.FAMILY_NAMES)
+def test_scalar_api_matches_reference_style_loop(fam, cls, device):
+    """same seeds -> same trajectory as the reference-style scalar Python stack (fp64),
+    step by step through the public API; the loop is re-synchronised to the engine's fp32
+    state each step so that 1e-5 is a per-transition statement"""
+    rng = np.random.default_rng(fam)
+    env = cls(seed=3)
+    ref = R.RefStyleEnv(fam)
+    for episode in range(2):
+        obs, info = env.reset(seed=3 if episode == 0 else None)
+        u = [O.u01(w) for w in O.lane_words(3, 0, episode, 0)]
+        robs, rinfo = ref.reset(u=u)
+        assert info == rinfo
+        np.testing.assert_allclose(obs["obs"], robs["obs"], rtol=1e-6, atol=1e-7)
+        assert obs["context"] == robs["context"]
+        for t in range(60):
+            s = env.unwrapped.state
+            ref.env.unwrapped.state = tuple(s) if fam in (O.CARTPOLE, O.MOUNTAINCAR) else np.array(s)
+            a = R.random_action(fam, rng)
+            o1, r1, te1, tr1, i1 = env.step(a)
+            o2, r2, te2, tr2, i2 = ref.step(a)
+            np.testing.assert_allclose(o1["obs"], o2["obs"], rtol=1e-5, atol=1e-5)
+            assert r1 == pytest.approx(r2, rel=1e-5, abs=1e-5)
+            assert (te1, tr1, i1) == (te2, tr2, i2)
+            if te1 or tr1:
+                break
+
+
+# ---- batched mode --------------------------------------------------------------------
+def test_batched_api_shapes_and_semantics(device):
+    n = 1000
+    s = ContextSampler([UniformFloatContextFeature("g", 1, 20), UniformFloatContextFeature("l", 0.5, 2.0)],
+                       E.CARLPendulum.get_context_space(), seed=0)
+    table = s.sample_context_table(n)
+    env = E.CARLPendulum(contexts=table, num_envs=n, context_selector=StaticSelector, seed=1, max_episode_steps=7)
+    obs, info = env.reset(seed=1)
+    assert obs["obs"].shape == (n, 3) and obs["obs"].is_cuda
+    assert set(obs["context"]) == set(E.CARLPendulum.get_default_context())
+    np.testing.assert_array_equal(obs["context"]["g"].cpu().numpy(), table.column("g").astype(np.float32))
+    np.testing.assert_array_equal(info["context_id"].cpu().numpy(), np.arange(n))
+    assert env.observation_space["obs"].shape == (n, 3) and env.action_space.shape == (n, 1)
+    for t in range(1, 15):
+        a = torch.rand(n, 1, device=device) * 4 - 2
+        obs, rew, term, trunc, info = env.step(a)
+        assert rew.shape == (n,) and term.dtype == torch.bool and trunc.dtype == torch.bool
+        assert bool(trunc.all()) == (t % 7 == 0)
+        if t % 7 == 0:
+            assert bool(info["_final_observation"].all())
+            assert torch.isfinite(info["final_observation"]).all()
+    # vector-mode context
+    env2 = E.CARLPendulum(contexts=table, num_envs=n, context_selector=StaticSelector, obs_context_as_dict=False,
+                          obs_context_features=["l", "g"])
+    obs, _ = env2.reset()
+    assert obs["context"].shape == (n, 2)
+    np.testing.assert_array_equal(obs["context"][:, 0].cpu().numpy(), table.column("l").astype(np.float32))
+
+
+def test_batched_round_robin_lanes_advance_on_their_own_resets(device):
+    n, n_ctx = 64, 5
+    contexts = {i: {"g": float(5 + i)} for i in range(n_ctx)}
+    env = E.CARLPendulum(contexts=contexts, num_envs=n, max_episode_steps=4)
+    obs, info = env.reset()
+    ids = info["context_id"].cpu().numpy().copy()
+    np.testing.assert_array_equal(ids, np.arange(n) % n_ctx)
+    for t in range(1, 9):
+        obs, _, _, trunc, info = env.step(torch.zeros(n, 1, device=device))
+        if t % 4 == 0:
+            ids = (ids + 1) % n_ctx
+        np.testing.assert_array_equal(info["context_id"].cpu().numpy(), ids)
+        np.testing.assert_array_equal(obs["context"]["g"].cpu().numpy(), 5.0 + ids)
