@@ -200,14 +200,17 @@ def main():
     torch.cuda.synchronize()
 
     # ---- timed region: exactly K env steps of every lane -------------------------
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in chunks]
+    # one HIP-event pair around the whole launch train, on the stream the kernels run on
+    # (torch's current stream): launches are back-to-back, so (elapsed / launches) is the
+    # kernel's average duration plus the ~1-2 us kernel boundary
+    e_first, e_last = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for (e0, e1), t in zip(ev, chunks):
-        e0.record()
+    e_first.record()
+    for t in chunks:
         eng.rollout(actions[:t], out)
-        e1.record()
+    e_last.record()
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -215,9 +218,8 @@ def main():
         tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    kern_ms = [e0.elapsed_time(e1) for e0, e1 in ev]
-    full = [ms for ms, t in zip(kern_ms, chunks) if t == T]
-    avg_launch_s = (sum(full) / len(full)) * 1e-3
+    # average duration of a full-length launch (a shorter tail launch is pro-rated)
+    avg_launch_s = e_first.elapsed_time(e_last) * 1e-3 * T / K
     bytes_per_step = IO_PER_STEP[args.env] + PER_LAUNCH[args.env] / T
     achieved = bytes_per_step * n * T / avg_launch_s / 1e9
     roofline = {
@@ -227,6 +229,17 @@ def main():
         "achieved_with_survey_8d_bytes": BYTES_8D[args.env] * n * T / avg_launch_s / 1e9,
         "avg_launch_ms": avg_launch_s * 1e3, "units_per_launch": n * T,
     }
+    # HBM traffic per launch from the PMC passes of tools/profile_gpu.sh (FETCH_SIZE x 2
+    # per the gfx950 correction + WRITE_SIZE), recorded under profiles/; a bench run cannot
+    # collect counters itself, so this is the committed measurement for this exact workload
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            rec = json.load(f).get(f"{args.env}:{n}:{T}")
+        if rec:
+            roofline["traffic"] = rec["hbm_bytes_per_launch"]
+            roofline["traffic_source"] = rec["source"]
+    except OSError:
+        pass
 
     # ---- reporting collective: episodic returns all-gathered over RCCL ------------
     gather_ms = None

@@ -93,7 +93,10 @@ def load() -> C.CDLL:
     if _lib is not None:
         return _lib
     path = _build.LIB_PATH
-    if os.environ.get("CARL_AMD_NO_BUILD", "0") != "1":
+    override = os.environ.get("CARL_AMD_LIB_PATH")  # kernel experiments: load another build
+    if override:
+        path = override
+    elif os.environ.get("CARL_AMD_NO_BUILD", "0") != "1":
         try:
             path = _build.build()
         except Exception as e:  # hipcc absent / compile error

@@ -78,7 +78,7 @@ int validate_io(const carl_batch_t* b, const carl_step_io_t* io, const char* who
 template <class Fam>
 bool use_lds_ctx(const carl_batch_t* b) {
   const size_t bytes = (size_t)Fam::F * b->n_contexts * sizeof(float);
-  return bytes <= 48 * 1024 && (int64_t)b->n_contexts * 8 <= (int64_t)b->n_lanes;
+  return bytes <= 32 * 1024 && (int64_t)b->n_contexts * 8 <= (int64_t)b->n_lanes;
 }
 
 // 64-thread workgroups spread a small batch over all 256 CUs x 4 SIMDs (65 536
@@ -106,20 +106,29 @@ template <class Fam>
 int launch_step(const carl_batch_t* b, const carl_step_io_t* io, int n_steps, hipStream_t s) {
   if (b->n_lanes == 0 || n_steps == 0) return 0;
   const bool lds = use_lds_ctx<Fam>(b);
-  const int block = pick_block(b->n_lanes, lds);
-  const int grid = (b->n_lanes + block - 1) / block;
-  const size_t sh = lds ? (size_t)Fam::F * b->n_contexts * sizeof(float) : 0;
+  const bool rollout = n_steps >= 0;
+  // rollout: 256 compute lanes + one loader wave per workgroup, actions double-buffered
+  // in LDS; per-call step: plain lane-per-thread workgroups
+  const int block = rollout ? carl::kRolloutThreads : pick_block(b->n_lanes, lds);
+  const int lanes_per_block = rollout ? carl::kRolloutLanes : block;
+  const int grid = (b->n_lanes + lanes_per_block - 1) / lanes_per_block;
+  const size_t sh = (lds ? (size_t)Fam::F * b->n_contexts * sizeof(float) : 0) +
+                    (rollout ? carl::rollout_action_lds_bytes() : 0);
+  const bool a64 = io->action_dtype == CARL_ACTION_I64;
+  const dim3 g(grid), t(block);
+#define CARL_LAUNCH(KERNEL, ...)                                                                    \
+  do {                                                                                              \
+    if (lds && a64) hipLaunchKernelGGL((carl::KERNEL<Fam, true, true>), g, t, sh, s, __VA_ARGS__);   \
+    else if (lds) hipLaunchKernelGGL((carl::KERNEL<Fam, true, false>), g, t, sh, s, __VA_ARGS__);    \
+    else if (a64) hipLaunchKernelGGL((carl::KERNEL<Fam, false, true>), g, t, sh, s, __VA_ARGS__);    \
+    else hipLaunchKernelGGL((carl::KERNEL<Fam, false, false>), g, t, sh, s, __VA_ARGS__);            \
+  } while (0)
   if (n_steps < 0) {  // per-call step
-    if (lds)
-      hipLaunchKernelGGL((carl::step_kernel<Fam, true>), dim3(grid), dim3(block), sh, s, *b, *io);
-    else
-      hipLaunchKernelGGL((carl::step_kernel<Fam, false>), dim3(grid), dim3(block), 0, s, *b, *io);
+    CARL_LAUNCH(step_kernel, *b, *io);
     return check_launch("carl_step");
   }
-  if (lds)
-    hipLaunchKernelGGL((carl::rollout_kernel<Fam, true>), dim3(grid), dim3(block), sh, s, *b, *io, n_steps);
-  else
-    hipLaunchKernelGGL((carl::rollout_kernel<Fam, false>), dim3(grid), dim3(block), 0, s, *b, *io, n_steps);
+  CARL_LAUNCH(rollout_kernel, *b, *io, n_steps);
+#undef CARL_LAUNCH
   return check_launch("carl_rollout");
 }
 

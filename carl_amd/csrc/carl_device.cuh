@@ -128,6 +128,21 @@ __device__ __forceinline__ void log_finished(const carl_batch_t& b, bool done, u
   }
 }
 
+// Make every 32-bit word of `v` an operand of an (empty) asm statement: the compiler
+// must have the value in a register HERE, i.e. it has to wait for any load feeding it at
+// this point instead of at a later first use.
+template <class T>
+__device__ __forceinline__ void settle(T& v) {
+  if constexpr (sizeof(T) >= 4) {
+    static_assert(sizeof(T) % 4 == 0, "settle() works on 32-bit words");
+    uint32_t w[sizeof(T) / 4];
+    __builtin_memcpy(w, &v, sizeof(T));
+#pragma unroll
+    for (size_t i = 0; i < sizeof(T) / 4; ++i) asm volatile("" : "+v"(w[i]));
+    __builtin_memcpy(&v, w, sizeof(T));
+  }
+}
+
 // ---- vector stores of one lane's observation -------------------------------------
 // obs is lane-major [n][D]; consecutive lanes write consecutive D*4-byte records, so
 // one wide store per lane keeps the wavefront's store contiguous in HBM.

@@ -1,37 +1,48 @@
-// classic_control.cuh -- per-lane physics of CARL's classic-control families in fp32.
+// classic_control.cuh -- per-lane physics of CARL's classic-control families.
 //
 // Each family is a traits struct the generic engine kernels (engine_kernels.cuh) are
 // instantiated with:
-//   S, D, F           state columns, observation length, context-table rows
-//   Action            int (Discrete) or float (Box)
-//   Params            the context features the physics reads, gathered per lane
-//   load(ctx, c, ..)  gather Params of context id c (feature rows in the order of the
-//                     reference class's get_context_features())
-//   step(...)         one transition: the arithmetic of gymnasium 0.29.1's env.step
-//                     [upstream; equations E-CP .. E-MCC of SURVEY.md section 8a]
-//   observe(...)      what env.step / CARL's reset returns as "obs"
-//   reset(...)        CARL's init-state distribution from 4 Philox words
+//   S, D, F            state columns, observation length, context-table rows
+//   Action             int (Discrete) or float (Box)
+//   Params             what the physics reads of a context, gathered (and pre-combined
+//                      where the reference's own evaluation order allows) per lane
+//   Aux                values derived from the CURRENT state that the next step and the
+//                      observation share (e.g. sin/cos of the pendulum angle), kept in
+//                      registers across the steps of a fused rollout
+//   load(ctx, c, ..)   gather Params of context id c (feature rows in the order of the
+//                      reference class's get_context_features())
+//   prepare(s, aux)    aux of a freshly loaded / reset state
+//   step(...)          one transition: the arithmetic of gymnasium 0.29.1's env.step
+//                      [upstream; equations E-CP .. E-MCC of SURVEY.md section 8a];
+//                      leaves aux describing the NEW state
+//   observe(...)       what env.step / CARL's reset returns as "obs"
+//   reset(...)         CARL's init-state distribution from 4 Philox words
 //
-// The reference computes in float64 on float32-representable state; this engine
-// keeps fp32 state and computes in fp32 (north_star: transitions within 1e-5).
+// The reference computes in float64 on float32-representable state; this engine keeps
+// fp32 state in HBM and computes in fp32 (north_star: transitions within 1e-5), except
+// Acrobot's RK4, which is fp64 by default (see AcrobotT).
 #pragma once
 
 #include "carl_device.cuh"
+#include "fast_math.cuh"
 
 namespace carl {
 
 constexpr float kPi = 3.14159265358979323846f;
+
+struct NoAux {};
 
 // ================================ CartPole ========================================
 // features: carl/envs/gymnasium/classic_control/carl_cartpole.py:15-42
 struct CartPole {
   static constexpr int S = 4, D = 4, F = 8;
   using Action = int;
+  using Aux = NoAux;
   enum { GRAVITY, MASSCART, MASSPOLE, LENGTH, FORCE_MAG, TAU, INIT_LO, INIT_HI };
   static constexpr bool kNeedsStepNoise = false;
 
   struct Params {
-    float gravity, masspole, length, force_mag, tau, total_mass, polemass_length;
+    float gravity, masspole, length, force_mag, tau, inv_total_mass, polemass_length;
   };
 
   template <class Ctx>
@@ -42,18 +53,22 @@ struct CartPole {
     p.length = ctx.get(LENGTH, c);
     p.force_mag = ctx.get(FORCE_MAG, c);
     p.tau = ctx.get(TAU, c);
+    float total_mass;
     if (flags & CARL_FLAG_CARTPOLE_RECOMPUTE) {
-      p.total_mass = p.masspole + ctx.get(MASSCART, c);
+      total_mass = p.masspole + ctx.get(MASSCART, c);
       p.polemass_length = p.masspole * p.length;
     } else {
       // Quirk C1: gymnasium derives these once in __init__ from ITS
       // defaults (masspole 0.1 + masscart 1.0, masspole 0.1 * length 0.5); CARL's
       // setattr (carl_gymnasium_env.py:75-77) never refreshes them.
-      p.total_mass = 0.1f + 1.0f;
+      total_mass = 0.1f + 1.0f;
       p.polemass_length = 0.1f * 0.5f;
     }
+    p.inv_total_mass = 1.0f / total_mass;
     return p;
   }
+
+  __device__ static __forceinline__ void prepare(const float (&)[S], Aux&) {}
 
   __device__ static __forceinline__ bool out_of_bounds(float x, float theta) {
     const float x_thr = 2.4f;
@@ -62,8 +77,8 @@ struct CartPole {
   }
 
   // CartPoleEnv.step, kinematics_integrator == "euler"
-  __device__ static __forceinline__ bool step(const Params& p, float (&s)[S], int action,
-                                              float /*noise*/, int elapsed, float& reward) {
+  __device__ static __forceinline__ bool step(const Params& p, float (&s)[S], Aux&, int action, float /*noise*/,
+                                              int elapsed, float& reward) {
     const float x = s[0], x_dot = s[1], theta = s[2], theta_dot = s[3];
     // steps_beyond_terminated: a lane stepped again after terminating (only reachable
     // with auto-reset off) earns 0.  Inferred instead of stored: the pre-step state is
@@ -73,11 +88,12 @@ struct CartPole {
     const bool was_terminated = (elapsed > 0) && out_of_bounds(x, theta);
     const float force = (action == 1) ? p.force_mag : -p.force_mag;
     float sintheta, costheta;
-    sincosf(theta, &sintheta, &costheta);
-    const float temp = (force + p.polemass_length * (theta_dot * theta_dot) * sintheta) / p.total_mass;
-    const float thetaacc = (p.gravity * sintheta - costheta * temp) /
-                           (p.length * (4.0f / 3.0f - p.masspole * (costheta * costheta) / p.total_mass));
-    const float xacc = temp - p.polemass_length * thetaacc * costheta / p.total_mass;
+    sincos_fast(theta, sintheta, costheta);
+    const float temp = (force + p.polemass_length * (theta_dot * theta_dot) * sintheta) * p.inv_total_mass;
+    const float thetaacc =
+        div_fast(p.gravity * sintheta - costheta * temp,
+                 p.length * (4.0f / 3.0f - p.masspole * (costheta * costheta) * p.inv_total_mass));
+    const float xacc = temp - p.polemass_length * thetaacc * costheta * p.inv_total_mass;
     s[0] = x + p.tau * x_dot;
     s[1] = x_dot + p.tau * xacc;
     s[2] = theta + p.tau * theta_dot;
@@ -87,7 +103,7 @@ struct CartPole {
     return terminated;
   }
 
-  __device__ static __forceinline__ void observe(const float (&s)[S], float (&o)[D]) {
+  __device__ static __forceinline__ void observe(const float (&s)[S], const Aux&, float (&o)[D]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) o[i] = s[i];
   }
@@ -112,43 +128,54 @@ struct Pendulum {
   enum { GRAVITY_DEAD, DT, G, M, L, INIT_ANGLE_MAX, INIT_VEL_MAX };
   static constexpr bool kNeedsStepNoise = false;
 
+  // `3*g/(2*l)*sin(th)` and `3.0/(m*l**2)*u` evaluate left to right, so the two
+  // quotients are per-context constants with the reference's own rounding order
   struct Params {
-    float g, m, l, dt;
+    float c_sin;  // 3 g / (2 l)
+    float c_u;    // 3 / (m l^2)
+    float dt;
+  };
+  // sin/cos of the current angle: the observation of step t and the torque term of
+  // step t+1 need the same pair, so one sincos per step serves both
+  struct Aux {
+    float sn, cs;
   };
 
   template <class Ctx>
   __device__ static __forceinline__ Params load(const Ctx& ctx, int c, int) {
-    return Params{ctx.get(G, c), ctx.get(M, c), ctx.get(L, c), ctx.get(DT, c)};
+    const float g = ctx.get(G, c), m = ctx.get(M, c), l = ctx.get(L, c);
+    return Params{3.0f * g / (2.0f * l), 3.0f / (m * (l * l)), ctx.get(DT, c)};
   }
 
+  __device__ static __forceinline__ void prepare(const float (&s)[S], Aux& a) { sincos_fast(s[0], a.sn, a.cs); }
+
   // PendulumEnv.step; reward from the OLD (th, thdot); never terminates
-  __device__ static __forceinline__ bool step(const Params& p, float (&s)[S], float action,
+  __device__ static __forceinline__ bool step(const Params& p, float (&s)[S], Aux& aux, float action,
                                               float /*noise*/, int /*elapsed*/, float& reward) {
     const float max_speed = 8.0f, max_torque = 2.0f;
     const float th = s[0], thdot = s[1];
     const float u = fminf(fmaxf(action, -max_torque), max_torque);
     // angle_normalize(x) = ((x + pi) % (2 pi)) - pi with Python's floor-mod
-    const float two_pi = 2.0f * kPi;
+    const float two_pi = 2.0f * kPi, inv_two_pi = 1.0f / (2.0f * kPi);
     const float y = th + kPi;
-    float r = y - floorf(y / two_pi) * two_pi;
+    float r = __fmaf_rn(-floorf(y * inv_two_pi), two_pi, y);
     r = (r < 0.0f) ? r + two_pi : r;
     r = (r >= two_pi) ? r - two_pi : r;
     const float an = r - kPi;
     const float costs = an * an + 0.1f * (thdot * thdot) + 0.001f * (u * u);
-    float newthdot = thdot + (3.0f * p.g / (2.0f * p.l) * sinf(th) + 3.0f / (p.m * (p.l * p.l)) * u) * p.dt;
+    float newthdot = thdot + (p.c_sin * aux.sn + p.c_u * u) * p.dt;
     newthdot = fminf(fmaxf(newthdot, -max_speed), max_speed);
     s[0] = th + newthdot * p.dt;
     s[1] = newthdot;
+    sincos_fast(s[0], aux.sn, aux.cs);
     reward = -costs;
     return false;
   }
 
   // _get_obs / carl_pendulum.py:61
-  __device__ static __forceinline__ void observe(const float (&s)[S], float (&o)[D]) {
-    float sn, cs;
-    sincosf(s[0], &sn, &cs);
-    o[0] = cs;
-    o[1] = sn;
+  __device__ static __forceinline__ void observe(const float (&s)[S], const Aux& a, float (&o)[D]) {
+    o[0] = a.cs;
+    o[1] = a.sn;
     o[2] = s[1];
   }
 
@@ -178,41 +205,62 @@ struct AcrobotT {
   static constexpr bool kNeedsStepNoise = true;
 
   struct Params {
-    float m1, m2, l1, lc1, lc2, moi, max_vel_1, max_vel_2, noise_max;
+    Real m1lc1sq;  // m1 * lc1^2, the context-only leading term of d1
+    Real m1, m2, l1, lc1, lc2, moi;
+    Real max_vel_1, max_vel_2;
+    float noise_max;
+  };
+  struct Aux {  // cos/sin of theta1, theta2 of the current state (for the observation)
+    float c0, s0, c1, s1;
   };
 
   template <class Ctx>
   __device__ static __forceinline__ Params load(const Ctx& ctx, int c, int) {
-    return Params{ctx.get(M1, c),  ctx.get(M2, c),    ctx.get(L1, c),    ctx.get(C1, c),   ctx.get(C2, c),
-                  ctx.get(MOI, c), ctx.get(MAXV1, c), ctx.get(MAXV2, c), ctx.get(NOISE, c)};
+    Params p;
+    p.m1 = ctx.get(M1, c);
+    p.m2 = ctx.get(M2, c);
+    p.l1 = ctx.get(L1, c);
+    p.lc1 = ctx.get(C1, c);
+    p.lc2 = ctx.get(C2, c);
+    p.moi = ctx.get(MOI, c);
+    p.m1lc1sq = p.m1 * (p.lc1 * p.lc1);
+    p.max_vel_1 = ctx.get(MAXV1, c);
+    p.max_vel_2 = ctx.get(MAXV2, c);
+    p.noise_max = ctx.get(NOISE, c);
+    return p;
+  }
+
+  __device__ static __forceinline__ void prepare(const float (&s)[S], Aux& a) {
+    sincos_fast(s[0], a.s0, a.c0);
+    sincos_fast(s[1], a.s1, a.c1);
   }
 
   struct Deriv {
     Real d0, d1, d2, d3;
   };
 
-  __device__ static __forceinline__ void sincos_r(float x, float* s, float* c) { sincosf(x, s, c); }
-  __device__ static __forceinline__ void sincos_r(double x, double* s, double* c) { sincos(x, s, c); }
-  __device__ static __forceinline__ float cos_r(float x) { return cosf(x); }
-  __device__ static __forceinline__ double cos_r(double x) { return cos(x); }
-
-  // AcrobotEnv._dsdt, book_or_nips == "book", g = 9.8 literal
+  // AcrobotEnv._dsdt, book_or_nips == "book", g = 9.8 literal.
+  // cos(theta1 + theta2 - pi/2) and cos(theta1 - pi/2) are sin(theta1 + theta2) and
+  // sin(theta1) (differences ~ulp(pi/2)); with sin/cos of both angles in hand,
+  // sin(theta1 + theta2) = s1 c2 + c1 s2, so a derivative costs two sincos instead of
+  // one sincos + two cos.
   __device__ static __forceinline__ Deriv dsdt(const Params& p, Real theta1, Real theta2, Real dtheta1,
                                                Real dtheta2, Real a) {
     const Real m1 = p.m1, m2 = p.m2, l1 = p.l1, lc1 = p.lc1, lc2 = p.lc2, I1 = p.moi, I2 = p.moi;
     const Real g = (Real)9.8;
-    const Real half_pi = (Real)(3.14159265358979323846 / 2.0);
-    Real s2, c2;
-    sincos_r(theta2, &s2, &c2);
-    const Real d1 = m1 * (lc1 * lc1) + m2 * (l1 * l1 + lc2 * lc2 + (Real)2.0 * l1 * lc2 * c2) + I1 + I2;
+    Real s1, c1, s2, c2;
+    sincos_fast(theta1, s1, c1);
+    sincos_fast(theta2, s2, c2);
+    const Real s12 = s1 * c2 + c1 * s2;
+    const Real d1 = p.m1lc1sq + m2 * (l1 * l1 + lc2 * lc2 + (Real)2.0 * l1 * lc2 * c2) + I1 + I2;
     const Real d2 = m2 * (lc2 * lc2 + l1 * lc2 * c2) + I2;
-    const Real phi2 = m2 * lc2 * g * cos_r(theta1 + theta2 - half_pi);
+    const Real phi2 = m2 * lc2 * g * s12;
     const Real phi1 = -m2 * l1 * lc2 * (dtheta2 * dtheta2) * s2 -
-                      (Real)2.0 * m2 * l1 * lc2 * dtheta2 * dtheta1 * s2 +
-                      (m1 * lc1 + m2 * l1) * g * cos_r(theta1 - half_pi) + phi2;
-    const Real ddtheta2 = (a + d2 / d1 * phi1 - m2 * l1 * lc2 * (dtheta1 * dtheta1) * s2 - phi2) /
-                          (m2 * (lc2 * lc2) + I2 - (d2 * d2) / d1);
-    const Real ddtheta1 = -(d2 * ddtheta2 + phi1) / d1;
+                      (Real)2.0 * m2 * l1 * lc2 * dtheta2 * dtheta1 * s2 + (m1 * lc1 + m2 * l1) * g * s1 + phi2;
+    const Real inv_d1 = (Real)1.0 / d1;
+    const Real ddtheta2 = (a + d2 * inv_d1 * phi1 - m2 * l1 * lc2 * (dtheta1 * dtheta1) * s2 - phi2) /
+                          (m2 * (lc2 * lc2) + I2 - (d2 * d2) * inv_d1);
+    const Real ddtheta1 = -(d2 * ddtheta2 + phi1) * inv_d1;
     return Deriv{dtheta1, dtheta2, ddtheta1, ddtheta2};
   }
 
@@ -226,7 +274,7 @@ struct AcrobotT {
   }
 
   // AcrobotEnv.step: rk4 over [0, dt = 0.2] on (state, torque), wrap, bound, _terminal
-  __device__ static __forceinline__ bool step(const Params& p, float (&s)[S], int action, float noise,
+  __device__ static __forceinline__ bool step(const Params& p, float (&s)[S], Aux& aux, int action, float noise,
                                               int /*elapsed*/, float& reward) {
     const Real dt = (Real)0.2, dt2 = dt / (Real)2.0;
     const Real a = (Real)((float)(action - 1) + noise);
@@ -242,15 +290,19 @@ struct AcrobotT {
     Real n3 = y3 + dt / six * (k1.d3 + two * k2.d3 + two * k3.d3 + k4.d3);
     n0 = wrap_pi(n0);
     n1 = wrap_pi(n1);
-    const Real mv1 = p.max_vel_1, mv2 = p.max_vel_2;
-    n2 = n2 < -mv1 ? -mv1 : (n2 > mv1 ? mv1 : n2);
-    n3 = n3 < -mv2 ? -mv2 : (n3 > mv2 ? mv2 : n3);
+    n2 = n2 < -p.max_vel_1 ? -p.max_vel_1 : (n2 > p.max_vel_1 ? p.max_vel_1 : n2);
+    n3 = n3 < -p.max_vel_2 ? -p.max_vel_2 : (n3 > p.max_vel_2 ? p.max_vel_2 : n3);
     s[0] = (float)n0;
     s[1] = (float)n1;
     s[2] = (float)n2;
     s[3] = (float)n3;
-    // _terminal on the unrounded state, like the reference's float64 state
-    const bool terminated = (-cos_r(n0) - cos_r(n1 + n0)) > (Real)1.0;
+    // _terminal and the observation's trig on the unrounded angles, like the reference's
+    // float64 state: -cos t1 - cos(t1 + t2) > 1, cos(t1 + t2) = c0 c1 - s0 s1
+    Real s0r, c0r, s1r, c1r;
+    sincos_fast(n0, s0r, c0r);
+    sincos_fast(n1, s1r, c1r);
+    const bool terminated = (-c0r - (c0r * c1r - s0r * s1r)) > (Real)1.0;
+    aux = Aux{(float)c0r, (float)s0r, (float)c1r, (float)s1r};
     reward = terminated ? 0.0f : -1.0f;
     return terminated;
   }
@@ -264,9 +316,11 @@ struct AcrobotT {
   }
 
   // carl_acrobot.py:101-111
-  __device__ static __forceinline__ void observe(const float (&s)[S], float (&o)[D]) {
-    sincosf(s[0], &o[1], &o[0]);
-    sincosf(s[1], &o[3], &o[2]);
+  __device__ static __forceinline__ void observe(const float (&s)[S], const Aux& a, float (&o)[D]) {
+    o[0] = a.c0;
+    o[1] = a.s0;
+    o[2] = a.c1;
+    o[3] = a.s1;
     o[4] = s[2];
     o[5] = s[3];
   }
@@ -290,6 +344,7 @@ using AcrobotFast = AcrobotT<float>;
 struct MountainCar {
   static constexpr int S = 2, D = 2, F = 11;
   using Action = int;
+  using Aux = NoAux;
   enum { MIN_POS, MAX_POS, MAX_SPEED, GOAL_POS, GOAL_VEL, FORCE, GRAVITY, MINP_START, MAXP_START, MINV_START, MAXV_START };
   static constexpr bool kNeedsStepNoise = false;
 
@@ -303,11 +358,13 @@ struct MountainCar {
                   ctx.get(GOAL_VEL, c), ctx.get(FORCE, c),   ctx.get(GRAVITY, c)};
   }
 
+  __device__ static __forceinline__ void prepare(const float (&)[S], Aux&) {}
+
   // MountainCarEnv.step
-  __device__ static __forceinline__ bool step(const Params& p, float (&s)[S], int action, float /*noise*/,
+  __device__ static __forceinline__ bool step(const Params& p, float (&s)[S], Aux&, int action, float /*noise*/,
                                               int /*elapsed*/, float& reward) {
     float position = s[0], velocity = s[1];
-    velocity += (float)(action - 1) * p.force + cosf(3.0f * position) * (-p.gravity);
+    velocity += (float)(action - 1) * p.force + cos_fast(3.0f * position) * (-p.gravity);
     velocity = fminf(fmaxf(velocity, -p.max_speed), p.max_speed);
     position += velocity;
     position = fminf(fmaxf(position, p.min_position), p.max_position);
@@ -318,7 +375,7 @@ struct MountainCar {
     return (position >= p.goal_position) && (velocity >= p.goal_velocity);
   }
 
-  __device__ static __forceinline__ void observe(const float (&s)[S], float (&o)[D]) {
+  __device__ static __forceinline__ void observe(const float (&s)[S], const Aux&, float (&o)[D]) {
     o[0] = s[0];
     o[1] = s[1];
   }
@@ -336,6 +393,7 @@ struct MountainCar {
 struct MountainCarCont {
   static constexpr int S = 2, D = 2, F = 10;
   using Action = float;
+  using Aux = NoAux;
   enum { MIN_POS, MAX_POS, MAX_SPEED, GOAL_POS, GOAL_VEL, POWER, MINP_START, MAXP_START, MINV_START, MAXV_START };
   static constexpr bool kNeedsStepNoise = false;
 
@@ -349,12 +407,14 @@ struct MountainCarCont {
                   ctx.get(GOAL_POS, c), ctx.get(GOAL_VEL, c), ctx.get(POWER, c)};
   }
 
+  __device__ static __forceinline__ void prepare(const float (&)[S], Aux&) {}
+
   // Continuous_MountainCarEnv.step (gravity literal 0.0025; penalty on the UNclipped action)
-  __device__ static __forceinline__ bool step(const Params& p, float (&s)[S], float action, float /*noise*/,
+  __device__ static __forceinline__ bool step(const Params& p, float (&s)[S], Aux&, float action, float /*noise*/,
                                               int /*elapsed*/, float& reward) {
     float position = s[0], velocity = s[1];
     const float force = fminf(fmaxf(action, -1.0f), 1.0f);
-    velocity += force * p.power - 0.0025f * cosf(3.0f * position);
+    velocity += force * p.power - 0.0025f * cos_fast(3.0f * position);
     velocity = (velocity > p.max_speed) ? p.max_speed : velocity;
     velocity = (velocity < -p.max_speed) ? -p.max_speed : velocity;
     position += velocity;
@@ -368,7 +428,7 @@ struct MountainCarCont {
     return terminated;
   }
 
-  __device__ static __forceinline__ void observe(const float (&s)[S], float (&o)[D]) {
+  __device__ static __forceinline__ void observe(const float (&s)[S], const Aux&, float (&o)[D]) {
     o[0] = s[0];
     o[1] = s[1];
   }

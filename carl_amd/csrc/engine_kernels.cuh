@@ -3,8 +3,9 @@
 // One lane (thread) = one env instance.  All traffic is coalesced: SoA state
 // columns, feature-major context rows, lane-major observation records written with
 // one wide store per lane.  The arithmetic intensity is a few flop/byte, so these
-// kernels are HBM- (large N) or launch-latency- (N ~ 65 536) bound, never MFMA
-// material; the levers are bytes moved per step, wave count and launch count.
+// kernels are HBM- (large N) or latency- (N ~ 65 536: one wavefront per SIMD) bound,
+// never MFMA material; the levers are bytes moved per step, the length of a single
+// wave's instruction stream, and never making that wave wait on its own stores.
 #pragma once
 
 #include <type_traits>
@@ -69,77 +70,125 @@ __global__ void __launch_bounds__(256) reset_kernel(const carl_batch_t b, const 
     b.n_calls[lane] += 1;
     if (obs != nullptr) {
       float o[Fam::D];
-      Fam::observe(s, o);
+      typename Fam::Aux aux;
+      Fam::prepare(s, aux);
+      Fam::observe(s, aux, o);
       store_obs<Fam::D>(obs, (size_t)lane, o);
     }
   }
 }
 
 // ---------------------------- per-lane step body ------------------------------------
-// Shared by the per-call kernel (T = 1) and the fused rollout kernel.  Everything a
-// lane carries between steps lives in this struct (registers).
+// Everything a lane carries between steps lives in registers.
 template <class Fam>
 struct LaneRegs {
   float s[Fam::S];
   float ep_return;
   int elapsed;
   int cidx;
-  uint32_t episode;    // lazily loaded: only the reset path (and step noise) reads it
+  uint32_t episode;     // lazily loaded: only the reset path (and step noise) reads it
   bool episode_valid;
-  int n_new_calls;     // resets performed in this launch
+  int n_new_calls;      // resets performed in this launch
+  int n_new_episodes;   // episodes finished in this launch
   typename Fam::Params p;
+  typename Fam::Aux aux;  // derived from s: shared by this step's obs and the next step
 };
 
+// Per-lane output cursors, advanced by one step's stride after every step.  Keeping them
+// as lane-private addresses (VGPRs) keeps kernarg reloads (s_load + lgkmcnt waits) out
+// of the step loop.
+template <class Fam>
+struct Cursors {
+  float* obs;        // += n * D
+  float* reward;     // += n
+  uint8_t* term;     // += n
+  uint8_t* trunc;    // += n
+  float* final_obs;  // += n * D (nullable)
+  __device__ __forceinline__ void advance(size_t n) {
+    obs += n * Fam::D;
+    reward += n;
+    term += n;
+    trunc += n;
+    if (final_obs != nullptr) final_obs += n * Fam::D;
+  }
+};
+
+// The rarely-taken part of a step, entered only by wavefronts in which some lane just
+// finished an episode (wave-uniform branch on a ballot): episode statistics, the compact
+// finished-episode log (ballot + one atomic per wave), and the in-kernel auto-reset
+// (Philox draws, selector advance, context re-gather).
 template <class Fam, class Ctx>
-__device__ __forceinline__ void step_lane(const carl_batch_t& b, const Ctx& ctx, const carl_step_io_t& io,
-                                          bool active, int lane, uint64_t glane, size_t out, /* t*n + lane */
+__device__ __forceinline__ void finish_episodes(const carl_batch_t& b, const Ctx& ctx, bool done, int lane,
+                                                uint64_t glane, float* final_obs, float (&o)[Fam::D],
+                                                LaneRegs<Fam>& r) {
+  const float fin_ret = r.ep_return;
+  const int fin_len = r.elapsed;
+  if (done) {
+    if (b.last_return) b.last_return[lane] = fin_ret;
+    if (b.last_length) b.last_length[lane] = fin_len;
+    r.n_new_episodes += 1;
+  }
+  log_finished(b, done, glane, fin_ret, fin_len);
+  if ((b.flags & CARL_FLAG_AUTORESET) && done) {
+    if (final_obs != nullptr) store_obs<Fam::D>(final_obs, 0, o);
+    if (!r.episode_valid) {
+      r.episode = b.episode[lane];
+      r.episode_valid = true;
+    }
+    reset_lane<Fam>(b, ctx, lane, glane, r.cidx, r.episode, r.s);
+    r.p = Fam::load(ctx, r.cidx, b.flags);
+    r.elapsed = 0;
+    r.ep_return = 0.0f;
+    r.n_new_calls += 1;
+    Fam::prepare(r.s, r.aux);
+    Fam::observe(r.s, r.aux, o);
+    // Every value this path loaded from memory must have ARRIVED before control returns
+    // to the step loop: otherwise the compiler parks the matching `s_waitcnt vmcnt(0)`
+    // at the loop head, where it also drains the previous step's stores on EVERY
+    // iteration (one wave per SIMD => a full store round trip per step).
+    settle(r.p);
+    settle(r.s);
+    settle(r.aux);
+    settle(r.cidx);
+    settle(r.episode);
+  }
+}
+
+// One step of one lane.  `cur` points at this step's output records for this lane.
+template <class Fam, class Ctx>
+__device__ __forceinline__ void step_lane(const carl_batch_t& b, const Ctx& ctx, const Cursors<Fam>& cur,
+                                          int max_steps, bool active, int lane, uint64_t glane,
                                           typename Fam::Action action, LaneRegs<Fam>& r) {
   bool done = false;
   float o[Fam::D];
-  float fin_ret = 0.0f;
-  int fin_len = 0;
   if (active) {
     float noise = 0.0f;
     if constexpr (Fam::kNeedsStepNoise) noise = Fam::step_noise(r.p, b, glane, r.episode - 1u, r.elapsed);
     float reward;
-    const bool terminated = Fam::step(r.p, r.s, action, noise, r.elapsed, reward);
+    const bool terminated = Fam::step(r.p, r.s, r.aux, action, noise, r.elapsed, reward);
     r.elapsed += 1;
     // gymnasium TimeLimit.step: truncated = elapsed >= max_episode_steps
-    const bool truncated = (b.max_episode_steps > 0) && (r.elapsed >= b.max_episode_steps);
+    const bool truncated = (max_steps > 0) && (r.elapsed >= max_steps);
     r.ep_return += reward;
-    Fam::observe(r.s, o);
-    io.reward[out] = reward;
-    io.terminated[out] = (uint8_t)terminated;
-    io.truncated[out] = (uint8_t)truncated;
+    Fam::observe(r.s, r.aux, o);
+#ifndef CARL_EXP_NO_REWARD_STORE  // CARL_EXP_*: ablation builds for profiling only
+    *cur.reward = reward;
+#else
+    asm volatile("" ::"v"(reward));
+#endif
+#ifndef CARL_EXP_NO_FLAG_STORES
+    *cur.term = (uint8_t)terminated;
+    *cur.trunc = (uint8_t)truncated;
+#endif
     done = terminated | truncated;
-    fin_ret = r.ep_return;
-    fin_len = r.elapsed;
-    if (done) {
-      if (b.last_return) b.last_return[lane] = fin_ret;
-      if (b.last_length) b.last_length[lane] = fin_len;
-      if (b.episodes_done) b.episodes_done[lane] += 1;
-    }
   }
-  // finished-episode log: wave ballot + one atomic per wavefront
-  log_finished(b, done, glane, fin_ret, fin_len);
-  // auto-reset: the branch is wave-uniform (skipped unless some lane of the wave is
-  // done), so the Philox rounds cost nothing on the common path
-  if ((b.flags & CARL_FLAG_AUTORESET) && __ballot(done) != 0ull) {
-    if (done) {
-      if (io.final_obs != nullptr) store_obs<Fam::D>(io.final_obs, out, o);
-      if (!r.episode_valid) {
-        r.episode = b.episode[lane];
-        r.episode_valid = true;
-      }
-      reset_lane<Fam>(b, ctx, lane, glane, r.cidx, r.episode, r.s);
-      r.p = Fam::load(ctx, r.cidx, b.flags);
-      r.elapsed = 0;
-      r.ep_return = 0.0f;
-      r.n_new_calls += 1;
-      Fam::observe(r.s, o);
-    }
-  }
-  if (active) store_obs<Fam::D>(io.obs, out, o);
+  if (__builtin_expect(__ballot(done) != 0ull, 0)) finish_episodes<Fam>(b, ctx, done, lane, glane, cur.final_obs, o, r);
+#ifndef CARL_EXP_NO_OBS_STORE
+  if (active) store_obs<Fam::D>(cur.obs, 0, o);
+#else
+#pragma unroll
+  for (int d = 0; d < Fam::D; ++d) asm volatile("" ::"v"(o[d]));
+#endif
 }
 
 template <class Fam, class Ctx>
@@ -152,7 +201,18 @@ __device__ __forceinline__ void load_lane(const carl_batch_t& b, const Ctx& ctx,
   r.episode_valid = Fam::kNeedsStepNoise;
   if constexpr (Fam::kNeedsStepNoise) r.episode = b.episode[lane];
   r.n_new_calls = 0;
+  r.n_new_episodes = 0;
   r.p = Fam::load(ctx, r.cidx, b.flags);
+  Fam::prepare(r.s, r.aux);
+  // have all of it in registers NOW (see finish_episodes): the first use must not leave
+  // a vmcnt(0) wait inside the step loop
+  settle(r.p);
+  settle(r.s);
+  settle(r.aux);
+  settle(r.elapsed);
+  settle(r.ep_return);
+  settle(r.cidx);
+  if constexpr (Fam::kNeedsStepNoise) settle(r.episode);
 }
 
 template <class Fam>
@@ -161,15 +221,32 @@ __device__ __forceinline__ void store_lane(const carl_batch_t& b, int lane, cons
   for (int j = 0; j < Fam::S; ++j) b.state[(size_t)j * b.n_lanes + lane] = r.s[j];
   b.elapsed[lane] = r.elapsed;
   b.ep_return[lane] = r.ep_return;
-  if (r.n_new_calls != 0) {  // rare: only lanes that were reset in this launch
+  if (r.n_new_episodes != 0 && b.episodes_done != nullptr) b.episodes_done[lane] += r.n_new_episodes;
+  if (r.n_new_calls != 0) {  // only lanes that were reset in this launch
     b.ctx_idx[lane] = r.cidx;
     b.episode[lane] = r.episode;
     b.n_calls[lane] += r.n_new_calls;
   }
 }
 
+template <class Fam>
+__device__ __forceinline__ Cursors<Fam> make_cursors(const carl_step_io_t& io, int lane) {
+  Cursors<Fam> c;
+  c.obs = io.obs + (size_t)lane * Fam::D;
+  c.reward = io.reward + lane;
+  c.term = io.terminated + lane;
+  c.trunc = io.truncated + lane;
+  c.final_obs = io.final_obs ? io.final_obs + (size_t)lane * Fam::D : nullptr;
+  return c;
+}
+
+// action element type as stored by the caller: discrete families accept int32 or int64
+template <class Fam, bool A64>
+using action_store_t = std::conditional_t<std::is_same_v<typename Fam::Action, float>, float,
+                                          std::conditional_t<A64, long long, int>>;
+
 // -------------------------------- step (per call) -----------------------------------
-template <class Fam, bool LDS>
+template <class Fam, bool LDS, bool A64>
 __global__ void __launch_bounds__(256) step_kernel(const carl_batch_t b, const carl_step_io_t io) {
   extern __shared__ float lds_ctx[];
   const ctx_t<LDS> ctx = make_ctx<LDS, Fam::F>(b, lds_ctx);
@@ -180,36 +257,118 @@ __global__ void __launch_bounds__(256) step_kernel(const carl_batch_t b, const c
   typename Fam::Action action{};
   if (active) {
     load_lane<Fam>(b, ctx, lane, r);
-    action = load_action<typename Fam::Action>(io.action, io.action_dtype, (size_t)lane);
+    action = (typename Fam::Action) static_cast<const action_store_t<Fam, A64>*>(io.action)[lane];
   }
-  step_lane<Fam>(b, ctx, io, active, lane, glane, (size_t)lane, action, r);
+  const Cursors<Fam> cur = make_cursors<Fam>(io, active ? lane : 0);
+  step_lane<Fam>(b, ctx, cur, b.max_episode_steps, active, lane, glane, action, r);
   if (active) store_lane<Fam>(b, lane, r);
 }
 
 // -------------------------------- rollout (T steps fused) ---------------------------
 // State, context parameters and counters stay in registers for T steps; per step the
-// lane reads one action and writes one full transition.  The next action is fetched
-// before the current step's dependent arithmetic so its latency is hidden.
-template <class Fam, bool LDS>
-__global__ void __launch_bounds__(256) rollout_kernel(const carl_batch_t b, const carl_step_io_t io,
-                                                      const int n_steps) {
-  extern __shared__ float lds_ctx[];
+// lane reads one action and writes one full transition.
+//
+// Where the actions come from matters more than the arithmetic: on gfx9-family hardware
+// a wave's loads and stores retire through ONE in-order counter (vmcnt), so an action
+// load issued in the step loop drags a wait for every older store of that wave; with
+// one wave per SIMD (65 536 lanes) that serialised each step behind the previous
+// step's store round trip (~1500 cycles/step measured, profiles/r01a).  So the step
+// loop of a compute wave issues NO global loads: each workgroup has one extra LOADER
+// wave that streams the next chunk of actions HBM -> LDS (its vmcnt only ever covers
+// its own loads) while the compute waves consume the current chunk from LDS (lgkmcnt)
+// and only ever issue stores.  Double-buffered, one __syncthreads() per chunk.
+constexpr int kRolloutLanes = 256;                 // compute lanes per workgroup
+constexpr int kRolloutThreads = kRolloutLanes + kWave;  // + the loader wave
+constexpr int kActChunk = 16;                      // steps per LDS buffer (2 x 16 KiB per workgroup)
+
+__host__ __device__ constexpr size_t rollout_action_lds_bytes() {
+  return (size_t)2 * kActChunk * kRolloutLanes * sizeof(float);
+}
+
+// loader wave: actions of steps [t0, t0 + kActChunk) for this workgroup's 256 lanes.
+// A step's 256 actions are 1 KiB contiguous in HBM: one 16-byte load per loader lane.
+template <class AStore, class Action>
+__device__ __forceinline__ void stage_actions(Action* buf, const AStore* __restrict__ act, size_t n, int lane_base,
+                                              int t0, int n_steps) {
+  const int l = threadIdx.x - kRolloutLanes;  // 0..63
+  const int first = lane_base + 4 * l;
+  if constexpr (std::is_same_v<AStore, Action>) {
+    // wave-uniform fast path: whole workgroup in range, rows 16-byte aligned
+    // and a full chunk
+    if ((n % 4 == 0) && (lane_base + kRolloutLanes <= (int)n) && (t0 + kActChunk <= n_steps)) {
+      using V = std::conditional_t<std::is_same_v<Action, float>, float4, int4>;
+      V tmp[kActChunk];
+      const V* src = reinterpret_cast<const V*>(act + (size_t)t0 * n + first);
+      const size_t row_v = n / 4;
+      // all loads of the chunk in flight together, then all LDS writes
+#pragma unroll
+      for (int u = 0; u < kActChunk; ++u) tmp[u] = src[(size_t)u * row_v];
+#pragma unroll
+      for (int u = 0; u < kActChunk; ++u) *reinterpret_cast<V*>(buf + u * kRolloutLanes + 4 * l) = tmp[u];
+      return;
+    }
+  }
+#pragma unroll 1
+  for (int u = 0; u < kActChunk && t0 + u < n_steps; ++u) {  // ragged tail / int64 actions
+    const AStore* row = act + (size_t)(t0 + u) * n;
+    Action* dst = buf + u * kRolloutLanes + 4 * l;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dst[k] = (first + k < (int)n) ? (Action)row[first + k] : Action{};
+  }
+}
+
+template <class Fam, bool LDS, bool A64>
+__global__ void __launch_bounds__(kRolloutThreads) rollout_kernel(const carl_batch_t b, const carl_step_io_t io,
+                                                                  const int n_steps) {
+  extern __shared__ float lds_dyn[];
+  using AStore = action_store_t<Fam, A64>;
+  using Action = typename Fam::Action;
+  Action* act_buf = reinterpret_cast<Action*>(lds_dyn);                    // [2][kActChunk][256]
+  float* lds_ctx = lds_dyn + rollout_action_lds_bytes() / sizeof(float);  // [F][C] when LDS
   const ctx_t<LDS> ctx = make_ctx<LDS, Fam::F>(b, lds_ctx);
-  const int lane = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool active = lane < b.n_lanes;
+  const bool loader = threadIdx.x >= kRolloutLanes;
+  const int lane_base = blockIdx.x * kRolloutLanes;
+  const int lane = lane_base + (loader ? 0 : (int)threadIdx.x);
+  const bool active = !loader && lane < b.n_lanes;
   const uint64_t glane = (uint64_t)(b.lane_offset + lane);
   const size_t n = (size_t)b.n_lanes;
+  const int max_steps = b.max_episode_steps;
+  const AStore* act = static_cast<const AStore*>(io.action);
   LaneRegs<Fam> r{};
-  typename Fam::Action next{};
-  if (active) {
+  Cursors<Fam> cur = make_cursors<Fam>(io, active ? lane : 0);
+  if (loader)
+    stage_actions<AStore, Action>(act_buf, act, n, lane_base, 0, n_steps);
+  else if (active)
     load_lane<Fam>(b, ctx, lane, r);
-    next = load_action<typename Fam::Action>(io.action, io.action_dtype, (size_t)lane);
-  }
-  for (int t = 0; t < n_steps; ++t) {
-    const typename Fam::Action action = next;
-    if (active && t + 1 < n_steps)
-      next = load_action<typename Fam::Action>(io.action, io.action_dtype, (size_t)(t + 1) * n + lane);
-    step_lane<Fam>(b, ctx, io, active, lane, glane, (size_t)t * n + lane, action, r);
+  __syncthreads();
+  int buf = 0;
+  for (int t0 = 0; t0 < n_steps; t0 += kActChunk, buf ^= 1) {
+    if (loader) {
+      if (t0 + kActChunk < n_steps)
+        stage_actions<AStore, Action>(act_buf + (buf ^ 1) * kActChunk * kRolloutLanes, act, n, lane_base,
+                                      t0 + kActChunk, n_steps);
+    } else {
+      const Action* my = act_buf + buf * kActChunk * kRolloutLanes + threadIdx.x;
+      const int steps = min(kActChunk, n_steps - t0);
+#ifndef CARL_EXP_NO_ACTIONS
+      Action a_next = my[0];
+      for (int u = 0; u < steps; ++u) {
+        const Action a = a_next;
+        a_next = my[min(u + 1, kActChunk - 1) * kRolloutLanes];  // LDS read one step ahead
+        step_lane<Fam>(b, ctx, cur, max_steps, active, lane, glane, a, r);
+        cur.advance(n);
+      }
+#else  // ablation: no LDS action reads
+      (void)my;
+      for (int u = 0; u < steps; ++u) {
+        step_lane<Fam>(b, ctx, cur, max_steps, active, lane, glane, (Action)1, r);
+        cur.advance(n);
+      }
+#endif
+    }
+#ifndef CARL_EXP_NO_ACTIONS
+    __syncthreads();
+#endif
   }
   if (active) store_lane<Fam>(b, lane, r);
 }
