@@ -14,6 +14,7 @@ _LAZY = {
     "CARLAcrobot": "carl_amd.envs.gymnasium.classic_control",
     "CARLMountainCar": "carl_amd.envs.gymnasium.classic_control",
     "CARLMountainCarContinuous": "carl_amd.envs.gymnasium.classic_control",
+    "CARLBraxAnt": "carl_amd.envs.brax",
     "VecEngine": "carl_amd.engine",
 }
 

@@ -129,3 +129,54 @@ def family_info(family: int) -> FamilyInfo:
     info = FamilyInfo()
     check(load().carl_family_info(family, C.byref(info)))
     return info
+
+
+# ---- Brax-locomotion families (carl_brax_sys_t, include/carl_amd.h) ----------------------
+BRAX_MAX_LINKS, BRAX_MAX_DOF, BRAX_MAX_Q, BRAX_MAX_ACT, BRAX_MAX_COLL, BRAX_MAX_CTX_MASS = 16, 24, 32, 24, 32, 16
+BRAX_ANT, BRAX_HALFCHEETAH, BRAX_HUMANOID = range(3)
+BRAX_LINK_STATE = 13
+_f, _i = C.c_float, C.c_int32
+
+
+class BraxCtxMap(C.Structure):
+    _fields_ = [
+        ("gravity", _i), ("friction", _i), ("elasticity", _i), ("ang_damping", _i),
+        ("joint_stiffness_scale", _i), ("n_mass", _i),
+        ("mass_row", _i * BRAX_MAX_CTX_MASS), ("mass_link", _i * BRAX_MAX_CTX_MASS),
+        ("mass_nominal", _f * BRAX_MAX_CTX_MASS),
+    ]
+
+
+class BraxSys(C.Structure):
+    _fields_ = [
+        ("env_kind", _i), ("n_links", _i), ("n_q", _i), ("n_dof", _i), ("n_act", _i), ("n_coll", _i),
+        ("n_frames", _i), ("obs_dim", _i), ("max_episode_steps", _i), ("terminate_when_unhealthy", _i),
+        ("exclude_current_positions", _i), ("reserved", _i),
+        ("dt", _f), ("gravity_z", _f), ("vel_damping", _f), ("ang_damping", _f), ("baumgarte_erp", _f),
+        ("elasticity", _f), ("friction", _f),
+        ("healthy_z_lo", _f), ("healthy_z_hi", _f), ("healthy_reward", _f), ("ctrl_cost_weight", _f),
+        ("forward_reward_weight", _f), ("reset_noise_scale", _f), ("reset_vel_scale", _f),
+        ("parent", _i * BRAX_MAX_LINKS), ("n_link_dof", _i * BRAX_MAX_LINKS),
+        ("q_start", _i * BRAX_MAX_LINKS), ("dof_start", _i * BRAX_MAX_LINKS),
+        ("link_pos", (_f * 3) * BRAX_MAX_LINKS), ("link_rot", (_f * 4) * BRAX_MAX_LINKS),
+        ("joint_pos", (_f * 3) * BRAX_MAX_LINKS), ("joint_rot", (_f * 4) * BRAX_MAX_LINKS),
+        ("com", (_f * 3) * BRAX_MAX_LINKS), ("mass", _f * BRAX_MAX_LINKS),
+        ("inv_inertia", (_f * 3) * BRAX_MAX_LINKS),
+        ("k_pos", _f * BRAX_MAX_LINKS), ("k_vel", _f * BRAX_MAX_LINKS),
+        ("k_limit", _f * BRAX_MAX_LINKS), ("k_ang_damp", _f * BRAX_MAX_LINKS),
+        ("dof_lo", _f * BRAX_MAX_DOF), ("dof_hi", _f * BRAX_MAX_DOF),
+        ("dof_damping", _f * BRAX_MAX_DOF), ("dof_stiffness", _f * BRAX_MAX_DOF),
+        ("act_dof", _i * BRAX_MAX_ACT), ("act_gear", _f * BRAX_MAX_ACT),
+        ("act_lo", _f * BRAX_MAX_ACT), ("act_hi", _f * BRAX_MAX_ACT),
+        ("coll_link", _i * BRAX_MAX_COLL), ("coll_pos", (_f * 3) * BRAX_MAX_COLL),
+        ("coll_radius", _f * BRAX_MAX_COLL),
+        ("init_q", _f * BRAX_MAX_Q),
+        ("ctx", BraxCtxMap),
+    ]
+
+
+EXPORTS.update({
+    "carl_brax_reset": (C.c_int, [C.POINTER(Batch), _vp, C.POINTER(BraxSys), _vp, _vp, _vp]),
+    "carl_brax_step": (C.c_int, [C.POINTER(Batch), _vp, C.POINTER(BraxSys), C.POINTER(StepIO), _vp]),
+    "carl_brax_rollout": (C.c_int, [C.POINTER(Batch), _vp, C.POINTER(BraxSys), C.POINTER(StepIO), C.c_int32, _vp]),
+})

@@ -1,0 +1,515 @@
+// brax_kernels.cuh -- Brax "spring" locomotion step on MI355X (Ant / Halfcheetah / Humanoid
+// model tables; see include/carl_amd.h carl_brax_sys_t).
+//
+// Replaces, for N lanes at once: brax.envs.<env>.step/reset -> n_frames x
+// brax.spring.pipeline.step as reached from carl/envs/brax/carl_brax_env.py:163-190 and
+// carl/envs/brax/wrappers.py:54-78 [brax 0.12.1 is not in the reference tree: the
+// specification implemented here is written out in oracle/brax_spring.c's header and
+// DESIGN.md; PARITY UNPINNED].
+//
+// Mapping: one lane = one env.  A lane's whole maximal-coordinate state (13 floats per link)
+// plus the per-link force/torque accumulators live in LDS for the duration of the launch
+// (row-major [row][64 lanes]: a lane's column is bank-conflict free), so the n_frames
+// substeps -- and, in the fused rollout, all T env steps -- never touch HBM for state.
+// Link loops index LDS dynamically, which keeps the code compact and the VGPR count low
+// (no 117-register unrolled state).  Actions and observations are lane-major records
+// (A / O floats per lane): they are staged through LDS so that HBM sees contiguous
+// 64-lane x A (or O) blocks instead of 64 strided dwords.  The model table is copied to LDS
+// once per workgroup.  No MFMA: with spring_inertia_scale = 1 the world inverse inertia
+// R diag(1/I) R^T is evaluated as rotate . scale . rotate^-1 on three floats per lane; packing
+// 3x3 blocks of different lanes into MFMA tiles would cost more shuffles than it saves.
+#pragma once
+
+#include "carl_device.cuh"
+#include "fast_math.cuh"
+
+namespace carl {
+namespace brax {
+
+constexpr int kLanes = 64;  // lanes per workgroup = one wavefront
+constexpr float kPiF = 3.14159265358979323846f;
+
+struct v3 {
+  float x, y, z;
+};
+struct qt {
+  float w, x, y, z;
+};
+__device__ __forceinline__ v3 V(float x, float y, float z) { return v3{x, y, z}; }
+__device__ __forceinline__ v3 operator+(v3 a, v3 b) { return V(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ v3 operator-(v3 a, v3 b) { return V(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ v3 operator*(v3 a, float s) { return V(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ float dot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ v3 cross(v3 a, v3 b) {
+  return V(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ qt qmul(qt a, qt b) {
+  return qt{a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z, a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
+            a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x, a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w};
+}
+__device__ __forceinline__ qt qconj(qt a) { return qt{a.w, -a.x, -a.y, -a.z}; }
+__device__ __forceinline__ qt qnormalize(qt a) {
+  const float inv = rsqrtf(a.w * a.w + a.x * a.x + a.y * a.y + a.z * a.z);
+  return qt{a.w * inv, a.x * inv, a.y * inv, a.z * inv};
+}
+__device__ __forceinline__ v3 qrot(qt q, v3 v) {
+  const v3 u = V(q.x, q.y, q.z);
+  const v3 t = cross(u, v) * 2.0f;
+  return v + t * q.w + cross(u, t);
+}
+__device__ __forceinline__ qt qaxis(int k, float angle) {
+  float s, c;
+  sincos_fast(0.5f * angle, s, c);
+  return qt{c, k == 0 ? s : 0.0f, k == 1 ? s : 0.0f, k == 2 ? s : 0.0f};
+}
+__device__ __forceinline__ v3 f3(const float* p) { return V(p[0], p[1], p[2]); }
+__device__ __forceinline__ qt f4(const float* p) { return qt{p[0], p[1], p[2], p[3]}; }
+
+struct Body {
+  v3 p;
+  qt r;
+  v3 v, w;
+};
+
+// per-lane context: carl_brax_env.py:255-292 in its intended form
+struct LaneCtx {
+  float gravity_z, friction, elasticity, ang_damping, stiffness_scale;
+};
+
+// LDS layout of a workgroup (floats, each row = kLanes consecutive floats)
+struct Layout {
+  int state;  // 13 * L rows
+  int force;  // 6 * L rows  (F, T; reused for contact dv, dw)
+  int count;  // L rows       (active contacts per link)
+  int mass;   // L rows       (effective mass per link, context-scaled)
+  int tau;    // n_dof rows
+  int io;     // max(n_act, obs_dim) rows of staging for lane-major records
+  int total;
+  __host__ __device__ static Layout make(int L, int n_dof, int n_act, int obs_dim) {
+    Layout l;
+    l.state = 0;
+    l.force = l.state + 13 * L;
+    l.count = l.force + 6 * L;
+    l.mass = l.count + L;
+    l.tau = l.mass + L;
+    l.io = l.tau + n_dof;
+    l.total = l.io + (n_act > obs_dim ? n_act : obs_dim);
+    return l;
+  }
+};
+
+struct Lds {
+  float* base;
+  Layout lay;
+  int tid;
+  __device__ __forceinline__ float& at(int row) const { return base[row * kLanes + tid]; }
+  __device__ __forceinline__ Body body(int i) const {
+    const int r0 = lay.state + 13 * i;
+    Body b;
+    b.p = V(at(r0), at(r0 + 1), at(r0 + 2));
+    b.r = qt{at(r0 + 3), at(r0 + 4), at(r0 + 5), at(r0 + 6)};
+    b.v = V(at(r0 + 7), at(r0 + 8), at(r0 + 9));
+    b.w = V(at(r0 + 10), at(r0 + 11), at(r0 + 12));
+    return b;
+  }
+  __device__ __forceinline__ void put(int i, const Body& b) const {
+    const int r0 = lay.state + 13 * i;
+    at(r0) = b.p.x; at(r0 + 1) = b.p.y; at(r0 + 2) = b.p.z;
+    at(r0 + 3) = b.r.w; at(r0 + 4) = b.r.x; at(r0 + 5) = b.r.y; at(r0 + 6) = b.r.z;
+    at(r0 + 7) = b.v.x; at(r0 + 8) = b.v.y; at(r0 + 9) = b.v.z;
+    at(r0 + 10) = b.w.x; at(r0 + 11) = b.w.y; at(r0 + 12) = b.w.z;
+  }
+  __device__ __forceinline__ void add3(int row, v3 a) const {
+    at(row) += a.x; at(row + 1) += a.y; at(row + 2) += a.z;
+  }
+  __device__ __forceinline__ v3 get3(int row) const { return V(at(row), at(row + 1), at(row + 2)); }
+};
+
+__device__ __forceinline__ v3 apply_inv_inertia(const carl_brax_sys_t& s, int i, qt r, v3 t) {
+  const v3 l = qrot(qconj(r), t);
+  return qrot(r, V(l.x * s.inv_inertia[i][0], l.y * s.inv_inertia[i][1], l.z * s.inv_inertia[i][2]));
+}
+
+__device__ __forceinline__ float twist_angle(qt rel) {  // hinge about the joint frame's x axis
+  if (rel.w < 0.0f) { rel.w = -rel.w; rel.x = -rel.x; }
+  return 2.0f * atan2f(rel.x, rel.w);
+}
+
+// ---- one brax.spring.pipeline.step ---------------------------------------------------------
+__device__ __forceinline__ void substep(const carl_brax_sys_t& s, const LaneCtx& c, const Lds& m) {
+  const int L = s.n_links;
+  for (int k = 0; k < 6 * L; ++k) m.at(m.lay.force + k) = 0.0f;
+  // spring.joints.resolve
+  for (int i = 0; i < L; ++i) {
+    const int P = s.parent[i];
+    if (P < 0) continue;
+    const Body bc = m.body(i), bp = m.body(P);
+    const v3 a = f3(s.joint_pos[i]);
+    const qt lrot = f4(s.link_rot[i]), jr = f4(s.joint_rot[i]);
+    const v3 o_c = bc.p - qrot(bc.r, f3(s.com[i]));
+    const v3 o_p = bp.p - qrot(bp.r, f3(s.com[P]));
+    const v3 A_c = o_c + qrot(bc.r, a);
+    const v3 A_p = o_p + qrot(bp.r, f3(s.link_pos[i]) + qrot(lrot, a));
+    const v3 vA_c = bc.v + cross(bc.w, A_c - bc.p);
+    const v3 vA_p = bp.v + cross(bp.w, A_p - bp.p);
+    const float kp = s.k_pos[i] * c.stiffness_scale;
+    const v3 f = (A_p - A_c) * kp + (vA_p - vA_c) * s.k_vel[i];
+    const qt rc = qmul(bc.r, jr);
+    const qt rp = qmul(qmul(bp.r, lrot), jr);
+    const v3 x_c = qrot(rc, V(1, 0, 0)), x_p = qrot(rp, V(1, 0, 0));
+    v3 t = cross(x_c, x_p) * kp;
+    const float theta = twist_angle(qmul(qconj(rp), rc));
+    const v3 wrel = bc.w - bp.w;
+    const float thetadot = dot(x_c, wrel);
+    const int d = s.dof_start[i];
+    float ta = m.at(m.lay.tau + d) - s.dof_damping[d] * thetadot - s.dof_stiffness[d] * theta;
+    if (theta < s.dof_lo[d]) ta += s.k_limit[i] * (s.dof_lo[d] - theta);
+    if (theta > s.dof_hi[d]) ta -= s.k_limit[i] * (theta - s.dof_hi[d]);
+    t = t + x_c * ta - wrel * s.k_ang_damp[i];
+    const int fc = m.lay.force + 6 * i, fp = m.lay.force + 6 * P;
+    m.add3(fc, f);
+    m.add3(fc + 3, cross(A_c - bc.p, f) + t);
+    m.add3(fp, f * -1.0f);
+    m.add3(fp + 3, (cross(A_p - bp.p, f) + t) * -1.0f);
+  }
+  // semi-implicit Euler: velocities first
+  for (int i = 0; i < L; ++i) {
+    Body b = m.body(i);
+    const int fr = m.lay.force + 6 * i;
+    const float inv_m = 1.0f / m.at(m.lay.mass + i);
+    b.v = b.v + (m.get3(fr) * inv_m + V(0, 0, c.gravity_z)) * s.dt;
+    b.w = b.w + apply_inv_inertia(s, i, b.r, m.get3(fr + 3)) * s.dt;
+    m.put(i, b);
+    for (int k = 0; k < 6; ++k) m.at(fr + k) = 0.0f;  // rows reused for contact deltas
+    m.at(m.lay.count + i) = 0.0f;
+  }
+  // spring.collisions.resolve: spheres vs the plane z = 0
+  const v3 n = V(0, 0, 1);
+  for (int k = 0; k < s.n_coll; ++k) {
+    const int i = s.coll_link[k];
+    const Body b = m.body(i);
+    const v3 ctr = b.p - qrot(b.r, f3(s.com[i])) + qrot(b.r, f3(s.coll_pos[k]));
+    const float depth = s.coll_radius[k] - ctr.z;
+    if (!(depth > 0.0f)) continue;
+    const v3 r = V(ctr.x, ctr.y, ctr.z - s.coll_radius[k]) - b.p;
+    const v3 rel = b.v + cross(b.w, r);
+    const float vn = dot(n, rel);
+    const float inv_m = 1.0f / m.at(m.lay.mass + i);
+    const float ang = dot(n, cross(apply_inv_inertia(s, i, b.r, cross(r, n)), r));
+    const float imp = (-(1.0f + c.elasticity) * vn + s.baumgarte_erp * depth / s.dt) / (inv_m + ang);
+    if (!(imp > 0.0f) || !(vn < 0.0f)) continue;
+    v3 J = n * imp;
+    const v3 vt = rel - n * vn;
+    const float vt_len = sqrtf(dot(vt, vt));
+    if (vt_len > 1e-9f) {
+      const v3 dir = vt * (1.0f / vt_len);
+      const float ang_d = dot(dir, cross(apply_inv_inertia(s, i, b.r, cross(r, dir)), r));
+      const float imp_d = fminf(vt_len / (inv_m + ang_d), c.friction * imp);
+      J = J - dir * imp_d;
+    }
+    const int fr = m.lay.force + 6 * i;
+    m.add3(fr, J * inv_m);
+    m.add3(fr + 3, apply_inv_inertia(s, i, b.r, cross(r, J)));
+    m.at(m.lay.count + i) += 1.0f;
+  }
+  // spring.integrator.integrate
+  const float dl = __expf(s.vel_damping * s.dt), da = __expf(c.ang_damping * s.dt);
+  for (int i = 0; i < L; ++i) {
+    Body b = m.body(i);
+    b.v = b.v * dl;
+    b.w = b.w * da;
+    const float cnt = m.at(m.lay.count + i);
+    if (cnt > 0.0f) {
+      const int fr = m.lay.force + 6 * i;
+      const float ic = 1.0f / cnt;
+      b.v = b.v + m.get3(fr) * ic;
+      b.w = b.w + m.get3(fr + 3) * ic;
+    }
+    b.p = b.p + b.v * s.dt;
+    const qt dq = qmul(qt{0.0f, b.w.x, b.w.y, b.w.z}, b.r);
+    const float h = 0.5f * s.dt;
+    b.r = qnormalize(qt{b.r.w + h * dq.w, b.r.x + h * dq.x, b.r.y + h * dq.y, b.r.z + h * dq.z});
+    m.put(i, b);
+  }
+}
+
+// kinematics.world_to_joint + inverse -> observation rows (q[2:] ++ qd) in the io staging
+__device__ __forceinline__ void observe(const carl_brax_sys_t& s, const Lds& m) {
+  const int skip = s.exclude_current_positions ? 2 : 0;
+  const int qd0 = s.n_q - skip;  // first qd row in the observation
+  for (int i = 0; i < s.n_links; ++i) {
+    const int P = s.parent[i];
+    const Body b = m.body(i);
+    if (P < 0) {
+      const v3 c = qrot(b.r, f3(s.com[i]));
+      const v3 o = b.p - c;
+      const v3 vel = b.v - cross(b.w, c);
+      const float qv[7] = {o.x, o.y, o.z, b.r.w, b.r.x, b.r.y, b.r.z};
+      for (int k = 0; k < 7; ++k)
+        if (s.q_start[i] + k >= skip) m.at(m.lay.io + s.q_start[i] + k - skip) = qv[k];
+      const float dv[6] = {vel.x, vel.y, vel.z, b.w.x, b.w.y, b.w.z};
+      for (int k = 0; k < 6; ++k) m.at(m.lay.io + qd0 + s.dof_start[i] + k) = dv[k];
+    } else {
+      const Body bp = m.body(P);
+      const qt jr = f4(s.joint_rot[i]);
+      const qt rp = qmul(qmul(bp.r, f4(s.link_rot[i])), jr);
+      const qt rc = qmul(b.r, jr);
+      m.at(m.lay.io + s.q_start[i] - skip) = twist_angle(qmul(qconj(rp), rc));
+      m.at(m.lay.io + qd0 + s.dof_start[i]) = dot(qrot(rc, V(1, 0, 0)), b.w - bp.w);
+    }
+  }
+}
+
+// kinematics.forward + com.from_world from (q, qd) held in the io staging rows
+// (q at rows [0, n_q), qd at rows [n_q, n_q + n_dof)); writes the state rows.
+__device__ __noinline__ void forward_kinematics(const carl_brax_sys_t& s, const Lds& m) {
+  // link-frame origins and their velocities are kept in the force rows (free at this point)
+  for (int i = 0; i < s.n_links; ++i) {
+    const int P = s.parent[i];
+    qt rot;
+    v3 o, vel, ang;
+    const int q0 = m.lay.io + s.q_start[i], d0 = m.lay.io + s.n_q + s.dof_start[i];
+    if (P < 0) {
+      rot = qnormalize(qt{m.at(q0 + 3), m.at(q0 + 4), m.at(q0 + 5), m.at(q0 + 6)});
+      o = V(m.at(q0), m.at(q0 + 1), m.at(q0 + 2));
+      vel = V(m.at(d0), m.at(d0 + 1), m.at(d0 + 2));
+      ang = V(m.at(d0 + 3), m.at(d0 + 4), m.at(d0 + 5));
+    } else {
+      const Body bp = m.body(P);
+      const v3 o_p = m.get3(m.lay.force + 6 * P), ov_p = m.get3(m.lay.force + 6 * P + 3);
+      const qt jr = f4(s.joint_rot[i]), lrot = f4(s.link_rot[i]);
+      const float th = m.at(q0), rate = m.at(d0);
+      const qt rl = qmul(qmul(jr, qaxis(0, th)), qconj(jr));
+      const v3 a = f3(s.joint_pos[i]);
+      const v3 lpos = f3(s.link_pos[i]) + qrot(lrot, a - qrot(rl, a));
+      rot = qmul(bp.r, qmul(lrot, rl));
+      o = o_p + qrot(bp.r, lpos);
+      const v3 anchor_w = o + qrot(rot, a);
+      const v3 axis = qrot(qmul(qmul(bp.r, lrot), jr), V(1, 0, 0));
+      ang = bp.w + axis * rate;
+      vel = ov_p + cross(bp.w, o - o_p) + cross(axis * rate, o - anchor_w);
+    }
+    const int fr = m.lay.force + 6 * i;
+    m.at(fr) = o.x; m.at(fr + 1) = o.y; m.at(fr + 2) = o.z;
+    m.at(fr + 3) = vel.x; m.at(fr + 4) = vel.y; m.at(fr + 5) = vel.z;
+    const v3 c = qrot(rot, f3(s.com[i]));
+    Body b;
+    b.r = rot;
+    b.w = ang;
+    b.p = o + c;
+    b.v = vel + cross(ang, c);
+    m.put(i, b);
+  }
+}
+
+// brax.envs.<env>.reset: q = init_q + U(-noise, noise), qd = vel_scale * N(0, 1).
+// Draw k uses word (k mod 4) of Philox block k / 4 on sub-stream 0x80000000 | block.
+__device__ __forceinline__ float draw_u(uint64_t seed, uint64_t g, uint32_t ep, int k) {
+  const u32x4 w = lane_words(seed, g, ep, 0x80000000u | (uint32_t)(k >> 2));
+  const uint32_t x = (k & 3) == 0 ? w.x : (k & 3) == 1 ? w.y : (k & 3) == 2 ? w.z : w.w;
+  return u01(x);
+}
+
+__device__ __noinline__ void reset_state(const carl_brax_sys_t& s, const carl_batch_t& b, const Lds& m,
+                                         uint64_t glane, uint32_t episode) {
+  int k = 0;
+  u32x4 w{};
+  for (int i = 0; i < s.n_q; ++i, ++k) {
+    if ((k & 3) == 0) w = lane_words(b.seed, glane, episode, 0x80000000u | (uint32_t)(k >> 2));
+    const uint32_t x = (k & 3) == 0 ? w.x : (k & 3) == 1 ? w.y : (k & 3) == 2 ? w.z : w.w;
+    m.at(m.lay.io + i) = s.init_q[i] + s.reset_noise_scale * (2.0f * u01(x) - 1.0f);
+  }
+  for (int i = 0; i < s.n_dof; i += 2, k += 2) {
+    const float u1 = draw_u(b.seed, glane, episode, k), u2 = draw_u(b.seed, glane, episode, k + 1);
+    const float rad = sqrtf(-2.0f * logf(1.0f - u1));
+    float sn, cs;
+    sincos_fast(2.0f * kPiF * u2, sn, cs);
+    m.at(m.lay.io + s.n_q + i) = s.reset_vel_scale * rad * cs;
+    if (i + 1 < s.n_dof) m.at(m.lay.io + s.n_q + i + 1) = s.reset_vel_scale * rad * sn;
+  }
+  forward_kinematics(s, m);
+}
+
+__device__ __forceinline__ LaneCtx load_ctx(const carl_brax_sys_t& s, const carl_batch_t& b, const Lds& m, int c) {
+  const carl_brax_ctx_map_t& cm = s.ctx;
+  auto get = [&](int row, float dflt) { return row >= 0 ? b.ctx_table[(size_t)row * b.ctx_stride + c] : dflt; };
+  LaneCtx lc;
+  lc.gravity_z = get(cm.gravity, s.gravity_z);
+  lc.friction = get(cm.friction, s.friction);
+  lc.elasticity = get(cm.elasticity, s.elasticity);
+  lc.ang_damping = get(cm.ang_damping, s.ang_damping);
+  lc.stiffness_scale = get(cm.joint_stiffness_scale, 1.0f);
+  for (int i = 0; i < s.n_links; ++i) m.at(m.lay.mass + i) = s.mass[i];
+  for (int k = 0; k < cm.n_mass; ++k)
+    m.at(m.lay.mass + cm.mass_link[k]) =
+        s.mass[cm.mass_link[k]] * (b.ctx_table[(size_t)cm.mass_row[k] * b.ctx_stride + c] / cm.mass_nominal[k]);
+  return lc;
+}
+
+// lane-major records <-> LDS staging rows.  HBM side: 64 lanes x W floats contiguous.
+__device__ __forceinline__ void stage_in(const float* __restrict__ src, size_t lane_base, int n_lanes, int W,
+                                         const Lds& m) {
+  // element e of the block (lane = e / W, k = e % W) -> LDS row k, column lane
+  const int total = W * kLanes;
+  for (int e = m.tid; e < total; e += kLanes) {
+    const int lane = e / W, k = e - lane * W;
+    if ((int)lane_base + lane < n_lanes) m.base[(m.lay.io + k) * kLanes + lane] = src[lane_base * W + e];
+  }
+  __syncthreads();
+}
+// `only_flagged`: copy only lanes whose flag (first `count` row, free outside substep) is set
+__device__ __forceinline__ void stage_out(float* __restrict__ dst, size_t lane_base, int n_lanes, int W,
+                                          const Lds& m, bool only_flagged = false) {
+  __syncthreads();
+  const int total = W * kLanes;
+  for (int e = m.tid; e < total; e += kLanes) {
+    const int lane = e / W, k = e - lane * W;
+    if ((int)lane_base + lane < n_lanes && (!only_flagged || m.base[m.lay.count * kLanes + lane] != 0.0f))
+      dst[lane_base * W + e] = m.base[(m.lay.io + k) * kLanes + lane];
+  }
+  __syncthreads();
+}
+
+struct LaneState {
+  float ep_return;
+  int elapsed, cidx, n_new_calls, n_new_episodes;
+  uint32_t episode;
+  LaneCtx ctx;
+};
+
+// mode 0: reset (mask optional), mode 1: n_steps env steps (1 = per call, T = fused rollout)
+template <int MODE>
+__global__ void __launch_bounds__(kLanes) brax_kernel(const carl_batch_t b, const carl_brax_sys_t* __restrict__ sys_dev,
+                                                      const carl_step_io_t io, const uint8_t* __restrict__ mask,
+                                                      float* __restrict__ reset_obs, const int n_steps) {
+  __shared__ carl_brax_sys_t s;
+  extern __shared__ float lds_dyn[];
+  {  // model table -> LDS, once per workgroup
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(sys_dev);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(&s);
+    for (int k = threadIdx.x; k < (int)(sizeof(carl_brax_sys_t) / 4); k += kLanes) dst[k] = src[k];
+  }
+  __syncthreads();
+  Lds m{lds_dyn, Layout::make(s.n_links, s.n_dof, s.n_act, s.obs_dim > s.n_q + s.n_dof ? s.obs_dim : s.n_q + s.n_dof),
+        (int)threadIdx.x};
+  const size_t lane_base = (size_t)blockIdx.x * kLanes;
+  const int lane = (int)lane_base + (int)threadIdx.x;
+  const bool active = lane < b.n_lanes;
+  const uint64_t glane = (uint64_t)(b.lane_offset + lane);
+  const size_t n = (size_t)b.n_lanes;
+  const int S = CARL_BRAX_LINK_STATE * s.n_links;
+  LaneState r{};
+  if (active) {
+    r.cidx = b.ctx_idx[lane];
+    r.episode = b.episode[lane];
+    r.elapsed = b.elapsed[lane];
+    r.ep_return = b.ep_return[lane];
+  }
+
+  if constexpr (MODE == 0) {
+    const bool go = active && (mask == nullptr || mask[lane] != 0);
+    if (go) {
+      r.cidx = select_context(b, r.cidx, glane, r.episode);
+      reset_state(s, b, m, glane, r.episode);
+      r.episode += 1u;
+      for (int k = 0; k < S; ++k) b.state[(size_t)k * n + lane] = m.at(m.lay.state + k);
+      b.elapsed[lane] = 0;
+      b.ep_return[lane] = 0.0f;
+      b.ctx_idx[lane] = r.cidx;
+      b.episode[lane] = r.episode;
+      b.n_calls[lane] += 1;
+      if (b.ctx_obs != nullptr)
+        for (int k = 0; k < b.n_ctx_obs; ++k)
+          b.ctx_obs[(size_t)k * n + lane] = b.ctx_table[(size_t)b.ctx_obs_feat[k] * b.ctx_stride + r.cidx];
+      observe(s, m);
+      if (reset_obs != nullptr)  // masked resets write only their own rows (no block staging)
+        for (int k = 0; k < s.obs_dim; ++k) reset_obs[(size_t)lane * s.obs_dim + k] = m.at(m.lay.io + k);
+    }
+    return;
+  } else {
+    if (active) {
+      for (int k = 0; k < S; ++k) m.at(m.lay.state + k) = b.state[(size_t)k * n + lane];
+      r.ctx = load_ctx(s, b, m, r.cidx);
+    }
+    const float dt_env = s.dt * (float)s.n_frames;
+    for (int t = 0; t < n_steps; ++t) {
+      const size_t step_off = (size_t)t * n;
+      stage_in(static_cast<const float*>(io.action) + step_off * s.n_act, lane_base, b.n_lanes, s.n_act, m);
+      bool done = false, terminated = false, truncated = false;
+      float reward = 0.0f;
+      if (active) {
+        for (int d = 0; d < s.n_dof; ++d) m.at(m.lay.tau + d) = 0.0f;
+        float ctrl = 0.0f;
+        for (int k = 0; k < s.n_act; ++k) {  // actuator.to_tau
+          const float u = m.at(m.lay.io + k);
+          ctrl += u * u;
+          m.at(m.lay.tau + s.act_dof[k]) += s.act_gear[k] * fminf(fmaxf(u, s.act_lo[k]), s.act_hi[k]);
+        }
+        const Body b0 = m.body(0);
+        const float x0 = b0.p.x - qrot(b0.r, f3(s.com[0])).x;
+        for (int f = 0; f < s.n_frames; ++f) substep(s, r.ctx, m);
+        const Body b1 = m.body(0);
+        const v3 c1 = qrot(b1.r, f3(s.com[0]));
+        const float x1 = b1.p.x - c1.x, z1 = b1.p.z - c1.z;
+        const bool healthy = (z1 >= s.healthy_z_lo) && (z1 <= s.healthy_z_hi);
+        reward = s.forward_reward_weight * (x1 - x0) / dt_env +
+                 (s.terminate_when_unhealthy ? s.healthy_reward : (healthy ? s.healthy_reward : 0.0f)) -
+                 s.ctrl_cost_weight * ctrl;
+        terminated = s.terminate_when_unhealthy && !healthy;
+        r.elapsed += 1;
+        truncated = (b.max_episode_steps > 0) && (r.elapsed >= b.max_episode_steps);
+        r.ep_return += reward;
+        done = terminated | truncated;
+        io.reward[step_off + lane] = reward;
+        io.terminated[step_off + lane] = (uint8_t)terminated;
+        io.truncated[step_off + lane] = (uint8_t)truncated;
+        observe(s, m);
+      }
+      const unsigned long long any_done = __ballot(done);
+      if (any_done != 0ull) {
+        const float fin_ret = r.ep_return;
+        const int fin_len = r.elapsed;
+        if (done) {
+          if (b.last_return) b.last_return[lane] = fin_ret;
+          if (b.last_length) b.last_length[lane] = fin_len;
+          r.n_new_episodes += 1;
+        }
+        log_finished(b, done, glane, fin_ret, fin_len);
+        if (b.flags & CARL_FLAG_AUTORESET) {
+          if (io.final_obs != nullptr) {  // terminal observation, done lanes only
+            m.at(m.lay.count) = done ? 1.0f : 0.0f;
+            stage_out(io.final_obs + step_off * s.obs_dim, lane_base, b.n_lanes, s.obs_dim, m, true);
+          }
+          if (done) {
+            r.cidx = select_context(b, r.cidx, glane, r.episode);
+            reset_state(s, b, m, glane, r.episode);
+            r.episode += 1u;
+            r.ctx = load_ctx(s, b, m, r.cidx);
+            r.elapsed = 0;
+            r.ep_return = 0.0f;
+            r.n_new_calls += 1;
+            if (b.ctx_obs != nullptr)
+              for (int k = 0; k < b.n_ctx_obs; ++k)
+                b.ctx_obs[(size_t)k * n + lane] = b.ctx_table[(size_t)b.ctx_obs_feat[k] * b.ctx_stride + r.cidx];
+            observe(s, m);
+          }
+        }
+      }
+      stage_out(io.obs + step_off * s.obs_dim, lane_base, b.n_lanes, s.obs_dim, m);
+    }
+    if (active) {
+      for (int k = 0; k < S; ++k) b.state[(size_t)k * n + lane] = m.at(m.lay.state + k);
+      b.elapsed[lane] = r.elapsed;
+      b.ep_return[lane] = r.ep_return;
+      if (r.n_new_episodes != 0 && b.episodes_done != nullptr) b.episodes_done[lane] += r.n_new_episodes;
+      if (r.n_new_calls != 0) {
+        b.ctx_idx[lane] = r.cidx;
+        b.episode[lane] = r.episode;
+        b.n_calls[lane] += r.n_new_calls;
+      }
+    }
+  }
+}
+
+}  // namespace brax
+}  // namespace carl

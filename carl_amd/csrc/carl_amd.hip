@@ -7,6 +7,7 @@
 #include <cstring>
 
 #include "../../include/carl_amd.h"
+#include "brax_kernels.cuh"
 #include "classic_control.cuh"
 #include "engine_kernels.cuh"
 
@@ -143,6 +144,62 @@ int launch_step(const carl_batch_t* b, const carl_step_io_t* io, int n_steps, hi
     default: return fail(CARL_ERR_INVALID_ARGUMENT, "unknown family %d", family); \
   }
 
+// ---------------------------- Brax-locomotion families -----------------------------------
+int validate_brax(const carl_batch_t* b, const carl_brax_sys_t* sd, const carl_brax_sys_t* sh, const char* who) {
+  if (b == nullptr || sd == nullptr || sh == nullptr)
+    return fail(CARL_ERR_INVALID_ARGUMENT, "%s: batch / sys pointer is NULL", who);
+  if (b->n_lanes < 0) return fail(CARL_ERR_INVALID_ARGUMENT, "%s: n_lanes %d < 0", who, b->n_lanes);
+  if (b->n_contexts <= 0 || b->ctx_stride < b->n_contexts)
+    return fail(CARL_ERR_INVALID_ARGUMENT, "%s: n_contexts %d / ctx_stride %d invalid", who, b->n_contexts,
+                b->ctx_stride);
+  if (!b->state || !b->elapsed || !b->ctx_idx || !b->episode || !b->n_calls || !b->ep_return || !b->ctx_table)
+    return fail(CARL_ERR_INVALID_ARGUMENT, "%s: a required batch pointer is NULL", who);
+  if (sh->n_links < 1 || sh->n_links > CARL_BRAX_MAX_LINKS || sh->n_dof > CARL_BRAX_MAX_DOF ||
+      sh->n_q > CARL_BRAX_MAX_Q || sh->n_act > CARL_BRAX_MAX_ACT || sh->n_coll > CARL_BRAX_MAX_COLL ||
+      sh->n_frames < 1 || sh->obs_dim < 1)
+    return fail(CARL_ERR_INVALID_ARGUMENT, "%s: model table out of range", who);
+  for (int i = 0; i < sh->n_links; ++i)
+    if (sh->parent[i] >= i || (sh->parent[i] >= 0 && sh->n_link_dof[i] != 1))
+      return fail(CARL_ERR_UNSUPPORTED, "%s: link %d: only a free root and single-hinge links are supported", who, i);
+  if (b->fin_count != nullptr && (b->fin_capacity <= 0 || !b->fin_lane || !b->fin_return || !b->fin_length))
+    return fail(CARL_ERR_INVALID_ARGUMENT, "%s: finished-episode log is incomplete", who);
+  return 0;
+}
+
+template <int MODE>
+int launch_brax(const carl_batch_t* b, const carl_brax_sys_t* sd, const carl_brax_sys_t* sh,
+                       const carl_step_io_t* io, const uint8_t* mask, float* reset_obs, int n_steps, hipStream_t st,
+                       const char* who) {
+  if (b->n_lanes == 0 || (MODE == 1 && n_steps == 0)) return 0;
+  const int qrows = sh->n_q + sh->n_dof;
+  const carl::brax::Layout lay =
+      carl::brax::Layout::make(sh->n_links, sh->n_dof, sh->n_act, sh->obs_dim > qrows ? sh->obs_dim : qrows);
+  const size_t sh_bytes = (size_t)lay.total * carl::brax::kLanes * sizeof(float);
+  if (sh_bytes + sizeof(carl_brax_sys_t) > 160 * 1024)
+    return fail(CARL_ERR_UNSUPPORTED, "%s: model needs %zu B of LDS per wavefront", who, sh_bytes);
+  auto kern = carl::brax::brax_kernel<MODE>;
+  if (sh_bytes > 48 * 1024) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_bytes);
+    if (e != hipSuccess) return fail((int)e, "%s: hipFuncSetAttribute: %s", who, hipGetErrorString(e));
+  }
+  const int grid = (b->n_lanes + carl::brax::kLanes - 1) / carl::brax::kLanes;
+  carl_step_io_t io_v{};
+  if (io != nullptr) io_v = *io;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(carl::brax::kLanes), sh_bytes, st, *b, sd, io_v, mask, reset_obs, n_steps);
+  return check_launch(who);
+}
+
+int validate_brax_io(const carl_step_io_t* io, const char* who) {
+  if (io == nullptr) return fail(CARL_ERR_INVALID_ARGUMENT, "%s: io is NULL", who);
+  if (!io->action || !io->obs || !io->reward || !io->terminated || !io->truncated)
+    return fail(CARL_ERR_INVALID_ARGUMENT, "%s: a required io pointer is NULL", who);
+  if (io->action_dtype != CARL_ACTION_F32)
+    return fail(CARL_ERR_INVALID_ARGUMENT, "%s: Brax families take float32 actions", who);
+  return 0;
+}
+
+
 }  // namespace
 
 extern "C" {
@@ -214,6 +271,28 @@ int carl_done_compact(const uint8_t* terminated, const uint8_t* truncated, int32
   hipLaunchKernelGGL(carl::done_write_kernel, dim3(nb), dim3(carl::kCompactBlock), 0, s, terminated, truncated, n,
                      scratch, idx_out, count_out);
   return check_launch("carl_done_compact");
+}
+
+int carl_brax_reset(const carl_batch_t* batch, const carl_brax_sys_t* sys_dev, const carl_brax_sys_t* sys_host,
+                    const uint8_t* mask, float* obs, void* stream) {
+  if (int e = validate_brax(batch, sys_dev, sys_host, "carl_brax_reset")) return e;
+  return launch_brax<0>(batch, sys_dev, sys_host, nullptr, mask, obs, 0, (hipStream_t)stream, "carl_brax_reset");
+}
+
+int carl_brax_step(const carl_batch_t* batch, const carl_brax_sys_t* sys_dev, const carl_brax_sys_t* sys_host,
+                   const carl_step_io_t* io, void* stream) {
+  if (int e = validate_brax(batch, sys_dev, sys_host, "carl_brax_step")) return e;
+  if (int e = validate_brax_io(io, "carl_brax_step")) return e;
+  return launch_brax<1>(batch, sys_dev, sys_host, io, nullptr, nullptr, 1, (hipStream_t)stream, "carl_brax_step");
+}
+
+int carl_brax_rollout(const carl_batch_t* batch, const carl_brax_sys_t* sys_dev, const carl_brax_sys_t* sys_host,
+                      const carl_step_io_t* io, int32_t n_steps, void* stream) {
+  if (int e = validate_brax(batch, sys_dev, sys_host, "carl_brax_rollout")) return e;
+  if (int e = validate_brax_io(io, "carl_brax_rollout")) return e;
+  if (n_steps < 0) return fail(CARL_ERR_INVALID_ARGUMENT, "carl_brax_rollout: n_steps %d < 0", n_steps);
+  return launch_brax<1>(batch, sys_dev, sys_host, io, nullptr, nullptr, n_steps, (hipStream_t)stream,
+                        "carl_brax_rollout");
 }
 
 }  // extern "C"

@@ -57,7 +57,7 @@ class VecEngine:
         if isinstance(family, str):
             family = _FAMILY_BY_NAME[family]
         self.family = int(family)
-        self.info = _lib.family_info(self.family)
+        self.info = self._family_info()
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.CarlHipError(
@@ -164,6 +164,19 @@ class VecEngine:
             rows = torch.as_tensor(self.ctx_obs_rows, device=self.device)
             self.ctx_obs.copy_(self.ctx_table[rows][:, self.ctx_idx.long()])
 
+    # ------------------------------------------------------------------ family hooks
+    def _family_info(self):
+        return _lib.family_info(self.family)
+
+    def _c_reset(self, mask_ptr) -> int:
+        return self.lib.carl_reset(C.byref(self.b), mask_ptr, _ptr(self.obs), self._stream())
+
+    def _c_step(self, io) -> int:
+        return self.lib.carl_step(C.byref(self.b), C.byref(io), self._stream())
+
+    def _c_rollout(self, io, n_steps: int) -> int:
+        return self.lib.carl_rollout(C.byref(self.b), C.byref(io), n_steps, self._stream())
+
     # ------------------------------------------------------------------ plumbing
     def _sync_pointers(self) -> None:
         b = self.b
@@ -207,7 +220,7 @@ class VecEngine:
             dt = _lib.ACTION_F32
         if a.device != self.device:
             a = a.to(self.device)
-        n_expected = int(np.prod(lead)) * self.n
+        n_expected = int(np.prod(lead)) * self.n * int(self.info.action_dim)
         if a.numel() != n_expected:
             raise ValueError(f"action has {a.numel()} elements, expected {n_expected} ({lead} x {self.n} lanes)")
         return a.contiguous(), dt
@@ -226,7 +239,7 @@ class VecEngine:
             if m.numel() != self.n:
                 raise ValueError("mask must have one entry per lane")
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.carl_reset(C.byref(self.b), _ptr(m), _ptr(self.obs), self._stream()))
+            _lib.check(self._c_reset(_ptr(m)))
         return self.obs
 
     def done_compact(self) -> tuple[torch.Tensor, torch.Tensor]:
@@ -257,7 +270,7 @@ class VecEngine:
         io.terminated, io.truncated = _ptr(self.terminated), _ptr(self.truncated)
         io.final_obs = _ptr(self.final_obs)
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.carl_step(C.byref(self.b), C.byref(io), self._stream()))
+            _lib.check(self._c_step(io))
         return self.obs, self.reward, self.terminated, self.truncated
 
     def alloc_rollout(self, n_steps: int, final_obs: bool = False) -> dict:
@@ -287,7 +300,7 @@ class VecEngine:
         io.terminated, io.truncated = _ptr(out["terminated"]), _ptr(out["truncated"])
         io.final_obs = _ptr(out.get("final_obs"))
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.carl_rollout(C.byref(self.b), C.byref(io), T, self._stream()))
+            _lib.check(self._c_rollout(io, T))
         return out
 
     def drain_finished(self):

@@ -1,0 +1,152 @@
+"""Family adapter for the Brax-locomotion envs (reference: carl/envs/brax/carl_brax_env.py:115-336).
+
+The reference creates ``brax.envs.create(env_name, backend="spring", batch_size=...)``, wraps it
+with ``GymWrapper`` / ``VectorGymWrapper`` (carl/envs/brax/wrappers.py) and, on every context
+change, re-parses the MJCF and rebuilds the ``System`` (``_update_context``, :255-292) -- which,
+because of Quirk B1, never reaches the jitted step.  Here ``env_name`` selects a
+model table of the lane engine, and the context -> physics mapping the reference INTENDS
+(gravity, friction, elasticity, ang_damping, ``mass_<link>``) is applied per lane inside the
+kernels; ``reference_compat=True`` ignores physics contexts, which is what the reference
+effectively simulates.  ``viscosity`` is observed-only (Quirk B2).
+"""
+from __future__ import annotations
+
+from typing import Any
+
+import numpy as np
+import torch
+
+from carl_amd import spaces
+from carl_amd.brax_engine import BraxVecEngine
+from carl_amd.context.selection import AbstractSelector
+from carl_amd.envs.brax import models
+from carl_amd.envs.carl_env import CARLEnv
+from carl_amd.utils.types import Context, Contexts
+
+# features CARL can push into a brax System, plus anything starting with mass_
+# (reference: carl_brax_env.py:258-269)
+REGISTERED_CFS = [
+    "friction", "ang_damping", "gravity", "viscosity", "elasticity",
+    "target_distance", "target_direction", "target_radius",
+    "joint_stiffness",  # extension (SURVEY.md Quirk B4): scales the spring backend's constraint_stiffness
+]
+GOAL_FEATURES = ("target_distance", "target_direction", "target_radius")
+
+
+def check_context(context: dict[str, Any], registered_context_features: list[str]) -> None:
+    """reference: carl_brax_env.py:104-112"""
+    for cfname in context.keys():
+        if cfname not in registered_context_features and not cfname.startswith("mass_"):
+            raise RuntimeError(
+                f"Context feature {cfname} can not be updated in the brax system. Only "
+                f"{registered_context_features} are possible."
+            )
+
+
+class CARLBraxEnv(CARLEnv):
+    env_name: str
+    backend: str = "spring"
+
+    def __init__(
+        self,
+        env: BraxVecEngine | None = None,
+        batch_size: int = 1,
+        contexts: Contexts | None = None,
+        obs_context_features: list[str] | None = None,
+        obs_context_as_dict: bool = True,
+        context_selector: AbstractSelector | type[AbstractSelector] | None = None,
+        context_selector_kwargs: dict = None,
+        use_language_goals: bool = False,
+        *,
+        device: str | torch.device | None = None,
+        auto_reset: bool | None = None,
+        seed: int = 0,
+        lane_offset: int = 0,
+        reference_compat: bool = False,
+        fin_capacity: int = 0,
+        **kwargs,
+    ) -> None:
+        """Reference parameters (carl_brax_env.py:119-131) plus the lane-engine ones.
+        ``batch_size`` is the reference's name for the number of parallel envs (:164)."""
+        if use_language_goals:
+            raise NotImplementedError("language goals are strings on the host: out of scope (SURVEY.md section 2 row 7)")
+        if contexts is not None and len(contexts):
+            first = contexts[list(contexts.keys())[0]]
+            if "target_distance" in first or "target_direction" in first:
+                # the reference wraps the env with BraxWalkerGoalWrapper when goals vary (:195-223)
+                vals = [(c.get("target_direction", first.get("target_direction", 0)),
+                         c.get("target_distance", first.get("target_distance", 0))) for c in contexts.values()]
+                if max(v[0] - vals[0][0] for v in vals) > 0.1 or max(v[1] - vals[0][1] for v in vals) > 0.1:
+                    raise NotImplementedError(
+                        "goal-directed reward (BraxWalkerGoalWrapper) is the next row of the scope table "
+                        "(SURVEY.md section 8f rank 2) and not built yet")
+        names = list(self.get_context_features().keys())
+        if env is None:
+            sys_table = models.SYSTEMS[self.env_name](names, reference_compat=reference_compat)
+            n_auto = batch_size > 1
+            env = BraxVecEngine(
+                sys_table, len(names),
+                [[float(cf.default_value) for cf in self.get_context_features().values()]],
+                batch_size,
+                device="cuda" if device is None else device,
+                auto_reset=n_auto if auto_reset is None else auto_reset,
+                seed=seed, lane_offset=lane_offset, fin_capacity=fin_capacity,
+            )
+        self.use_language_goals = use_language_goals
+        super().__init__(
+            env=env,
+            contexts=contexts,
+            obs_context_features=obs_context_features,
+            obs_context_as_dict=obs_context_as_dict,
+            context_selector=context_selector,
+            context_selector_kwargs=context_selector_kwargs,
+            **kwargs,
+        )
+
+    def _base_observation_space(self) -> spaces.Space:
+        obs = np.inf * np.ones(self.env.D, dtype=np.float32)
+        return spaces.Box(-obs, obs, dtype=np.float32)  # wrappers.py:46-47
+
+    def _action_space(self) -> spaces.Space:
+        s = self.env.sys
+        lo = np.array(s.act_lo[: s.n_act], dtype=np.float32)
+        hi = np.array(s.act_hi[: s.n_act], dtype=np.float32)
+        return spaces.Box(lo, hi, dtype=np.float32)  # wrappers.py:50-51 (sys.actuator.ctrl_range)
+
+    def _update_context(self) -> None:
+        check_context(self.context, REGISTERED_CFS)
+        super()._update_context()
+
+    @property
+    def contexts(self) -> Contexts:
+        return self._contexts
+
+    @contexts.setter
+    def contexts(self, contexts: Contexts) -> None:
+        for c in contexts.values() if not hasattr(contexts, "names") else []:
+            check_context(c, REGISTERED_CFS)
+        CARLEnv.contexts.fset(self, contexts)
+
+    def step(self, action: Any):
+        if self._scalar_api:  # one env: action is a length-A vector
+            a = np.asarray(action, dtype=np.float32).reshape(1, -1)
+            obs, reward, term, trunc = self.env.step(a)
+            state = obs[0].cpu().numpy()
+            info: dict[str, Any] = {"context_id": self.context_id}
+            # wrappers.py:76-77: terminated = done, truncated = False; brax's EpisodeWrapper
+            # folds its 1000-step truncation into `done`
+            done = bool(term[0]) or bool(trunc[0])
+            return self._add_context_to_state(state), float(reward[0]), done, False, info
+        return super().step(action)
+
+    @classmethod
+    def get_default_context(cls) -> Context:
+        """Default context without goal features (reference: :308-324)."""
+        default_context = cls.get_context_space().get_default_context()
+        for k in GOAL_FEATURES:
+            default_context.pop(k, None)
+        return default_context
+
+    @classmethod
+    def get_default_goal_context(cls) -> Context:
+        return cls.get_context_space().get_default_context()

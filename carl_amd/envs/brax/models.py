@@ -1,0 +1,140 @@
+"""Model tables (``carl_brax_sys_t``) of the Brax locomotion systems CARL wraps.
+
+The reference loads these with ``brax.io.mjcf.load`` from XML assets shipped INSIDE the brax
+wheel (``envs/assets/ant.xml`` ...; carl/envs/brax/carl_ant.py:16) -- neither brax nor its
+assets are in the reference tree or installable here, so geometry, joint ranges, gears and
+the spring-backend constants below are restated from upstream memory [upstream-memory] of
+brax 0.12.1's ``ant.xml`` (a Gym-Ant derivative with brax ``<custom>`` numerics) and
+``brax/envs/ant.py``.  PARITY UNPINNED.
+
+Spring backend conventions restated here: ``spring_mass_scale = spring_inertia_scale = 1``
+in the asset, i.e. the pipeline runs every link with effective mass ``m**(1-1) = 1`` and
+identity inertia (what keeps its stiff joint springs stable at dt = 0.005); contexts scale
+the effective mass RELATIVE to CARL's default (``mass_torso`` 10 -> factor 1).
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+from carl_amd import _lib
+
+
+def _axis_quat(axis) -> tuple[float, float, float, float]:
+    """shortest-arc rotation taking e_x onto ``axis`` (the joint frame's x axis is the hinge)"""
+    u = np.asarray(axis, dtype=np.float64)
+    u = u / np.linalg.norm(u)
+    d = float(u[0])
+    if d < -1 + 1e-12:
+        return (0.0, 0.0, 0.0, 1.0)
+    c = np.cross([1.0, 0.0, 0.0], u)
+    q = np.array([1.0 + d, c[0], c[1], c[2]])
+    q /= np.linalg.norm(q)
+    return tuple(float(x) for x in q)
+
+
+def _set3(dst, i, v):
+    for k in range(len(v)):
+        dst[i][k] = float(v[k])
+
+
+def ant_sys(feature_names: list[str] | None = None, reference_compat: bool = False) -> _lib.BraxSys:
+    """Ant: torso (free root) + 4 x (hip link, ankle link); q 15, qd 14, 8 motors, obs 27.
+
+    ``feature_names``: the CARL class's context-feature order, to wire context columns to
+    physics parameters (carl/envs/brax/carl_brax_env.py:255-292 in its intended form);
+    ``reference_compat=True`` leaves every physics parameter at the asset's value, which is
+    what the reference effectively simulates (SURVEY.md Quirk B1)."""
+    s = _lib.BraxSys()
+    s.env_kind = _lib.BRAX_ANT
+    s.n_links, s.n_q, s.n_dof, s.n_act = 9, 15, 14, 8
+    s.n_frames, s.obs_dim = 10, 27
+    s.max_episode_steps = 1000
+    s.terminate_when_unhealthy = 1
+    s.exclude_current_positions = 1
+    s.dt = 0.005
+    s.gravity_z, s.vel_damping, s.ang_damping = -9.81, 0.0, 0.0
+    s.baumgarte_erp, s.elasticity, s.friction = 0.1, 0.0, 1.0
+    s.healthy_z_lo, s.healthy_z_hi, s.healthy_reward = 0.2, 1.0, 1.0
+    s.ctrl_cost_weight, s.forward_reward_weight = 0.5, 1.0
+    s.reset_noise_scale, s.reset_vel_scale = 0.1, 0.1
+
+    ident = (1.0, 0.0, 0.0, 0.0)
+    dirs = [(1, 1), (-1, 1), (-1, -1), (1, -1)]
+    ankle_axis = [(-1, 1, 0), (1, 1, 0), (-1, 1, 0), (1, 1, 0)]
+    ankle_range = [(30, 70), (-70, -30), (-70, -30), (30, 70)]
+    # link 0: torso
+    s.parent[0], s.n_link_dof[0], s.q_start[0], s.dof_start[0] = -1, 6, 0, 0
+    _set3(s.link_rot, 0, ident)
+    _set3(s.joint_rot, 0, ident)
+    coll = [(0, (0.0, 0.0, 0.0), 0.25)]
+    li, qi, di = 1, 7, 6
+    joint_dof = {}
+    for k, (dx, dy) in enumerate(dirs):
+        coll.append((0, (0.2 * dx, 0.2 * dy, 0.0), 0.08))  # far end of the aux capsule on the torso
+        hip = li
+        s.parent[hip], s.n_link_dof[hip], s.q_start[hip], s.dof_start[hip] = 0, 1, qi, di
+        _set3(s.link_pos, hip, (0.2 * dx, 0.2 * dy, 0.0))
+        _set3(s.link_rot, hip, ident)
+        _set3(s.joint_rot, hip, _axis_quat((0, 0, 1)))
+        _set3(s.com, hip, (0.1 * dx, 0.1 * dy, 0.0))
+        s.dof_lo[di], s.dof_hi[di] = math.radians(-30), math.radians(30)
+        joint_dof[f"hip_{k + 1}"] = di
+        coll += [(hip, (0.0, 0.0, 0.0), 0.08), (hip, (0.2 * dx, 0.2 * dy, 0.0), 0.08)]
+        ank = li + 1
+        s.parent[ank], s.n_link_dof[ank], s.q_start[ank], s.dof_start[ank] = hip, 1, qi + 1, di + 1
+        _set3(s.link_pos, ank, (0.2 * dx, 0.2 * dy, 0.0))
+        _set3(s.link_rot, ank, ident)
+        _set3(s.joint_rot, ank, _axis_quat(ankle_axis[k]))
+        _set3(s.com, ank, (0.2 * dx, 0.2 * dy, 0.0))
+        lo, hi = ankle_range[k]
+        s.dof_lo[di + 1], s.dof_hi[di + 1] = math.radians(lo), math.radians(hi)
+        joint_dof[f"ankle_{k + 1}"] = di + 1
+        coll += [(ank, (0.0, 0.0, 0.0), 0.08), (ank, (0.4 * dx, 0.4 * dy, 0.0), 0.08)]
+        li, qi, di = li + 2, qi + 2, di + 2
+    for i in range(s.n_links):
+        s.mass[i] = 1.0          # m ** (1 - spring_mass_scale), spring_mass_scale = 1
+        _set3(s.inv_inertia, i, (1.0, 1.0, 1.0))
+        s.k_pos[i], s.k_vel[i], s.k_limit[i], s.k_ang_damp[i] = 4000.0, 20.0, 1000.0, 10.0
+    for d in range(6, s.n_dof):
+        s.dof_damping[d], s.dof_stiffness[d] = 1.0, 0.0
+    for k, name in enumerate(["hip_4", "ankle_4", "hip_1", "ankle_1", "hip_2", "ankle_2", "hip_3", "ankle_3"]):
+        s.act_dof[k], s.act_gear[k], s.act_lo[k], s.act_hi[k] = joint_dof[name], 150.0, -1.0, 1.0
+    s.n_coll = len(coll)
+    for k, (link, pos, rad) in enumerate(coll):
+        s.coll_link[k], s.coll_radius[k] = link, rad
+        _set3(s.coll_pos, k, pos)
+    init_q = [0.0, 0.0, 0.55, 1.0, 0.0, 0.0, 0.0, 0.0, 1.0, 0.0, -1.0, 0.0, -1.0, 0.0, 1.0]
+    for i, v in enumerate(init_q):
+        s.init_q[i] = v
+    _wire_context(s, feature_names, reference_compat, {"torso": 0}, {"mass_torso": 10.0})
+    return s
+
+
+def _wire_context(s, feature_names, reference_compat, link_ids, mass_defaults):
+    m = s.ctx
+    m.gravity = m.friction = m.elasticity = m.ang_damping = m.joint_stiffness_scale = -1
+    m.n_mass = 0
+    if reference_compat or not feature_names:
+        return
+    col = {n: i for i, n in enumerate(feature_names)}
+    m.gravity = col.get("gravity", -1)
+    m.friction = col.get("friction", -1)
+    m.elasticity = col.get("elasticity", -1)
+    m.ang_damping = col.get("ang_damping", -1)
+    m.joint_stiffness_scale = col.get("joint_stiffness", -1)
+    for name, i in col.items():
+        if name.startswith("mass_"):
+            link = name.split("_", 1)[-1]
+            if link not in link_ids:
+                # same failure as the reference's _set_masses (carl_brax_env.py:70-73)
+                raise RuntimeError(
+                    f"Link {link} not in available link names {list(link_ids)}. Probably "
+                    "something went wrong during context creation.")
+            k = m.n_mass
+            m.mass_row[k], m.mass_link[k], m.mass_nominal[k] = i, link_ids[link], float(mass_defaults[name])
+            m.n_mass = k + 1
+
+
+SYSTEMS = {"ant": ant_sys}

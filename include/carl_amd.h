@@ -194,6 +194,81 @@ int carl_done_compact(const uint8_t* terminated, const uint8_t* truncated, int32
                       int32_t* idx_out, int32_t* count_out, int32_t* scratch, void* stream);
 int32_t carl_done_compact_scratch_elems(int32_t n);
 
+/* ======================= Brax-locomotion families (spring backend) =======================
+ * Replaces CARLBraxEnv + BraxGymWrapper/VectorGymWrapper + brax.spring.pipeline.step x
+ * n_frames + brax.envs.<env>.step/reset (carl/envs/brax/carl_brax_env.py:115-336,
+ * carl/envs/brax/wrappers.py:32-158; brax==0.12.1 itself is NOT in the reference tree:
+ * the pipeline is restated from upstream memory, SURVEY.md section 8a "Brax restatement";
+ * PARITY UNPINNED).  One maximal-coordinate rigid-body system per lane; the model (links,
+ * joints, colliders, actuators, env reward constants) is a carl_brax_sys_t table shared by
+ * all lanes, the per-lane context overrides gravity / friction / elasticity / ang_damping /
+ * link masses / joint-stiffness scale. */
+#define CARL_BRAX_MAX_LINKS 16
+#define CARL_BRAX_MAX_DOF 24
+#define CARL_BRAX_MAX_Q 32
+#define CARL_BRAX_MAX_ACT 24
+#define CARL_BRAX_MAX_COLL 32
+#define CARL_BRAX_MAX_CTX_MASS 16
+
+enum { CARL_BRAX_ANT = 0, CARL_BRAX_HALFCHEETAH = 1, CARL_BRAX_HUMANOID = 2 };
+
+/* context-table rows the physics reads (row index in the family's feature table, -1 =
+ * feature absent -> the model default is used) */
+typedef struct carl_brax_ctx_map {
+  int32_t gravity, friction, elasticity, ang_damping, joint_stiffness_scale;
+  int32_t n_mass;                               /* mass_<link> features */
+  int32_t mass_row[CARL_BRAX_MAX_CTX_MASS];     /* table row */
+  int32_t mass_link[CARL_BRAX_MAX_CTX_MASS];    /* link it scales */
+  float mass_nominal[CARL_BRAX_MAX_CTX_MASS];   /* CARL default: value / nominal scales the link's effective mass */
+} carl_brax_ctx_map_t;
+
+typedef struct carl_brax_sys {
+  int32_t env_kind;      /* CARL_BRAX_* : selects reward / obs / done rule */
+  int32_t n_links, n_q, n_dof, n_act, n_coll, n_frames, obs_dim;
+  int32_t max_episode_steps;   /* brax EpisodeWrapper episode_length (1000) */
+  int32_t terminate_when_unhealthy;
+  int32_t exclude_current_positions;
+  int32_t reserved;
+  float dt;              /* substep */
+  float gravity_z, vel_damping, ang_damping, baumgarte_erp, elasticity, friction;
+  float healthy_z_lo, healthy_z_hi, healthy_reward, ctrl_cost_weight, forward_reward_weight;
+  float reset_noise_scale, reset_vel_scale;
+  /* links, topological order, parent < child */
+  int32_t parent[CARL_BRAX_MAX_LINKS];      /* -1: free root */
+  int32_t n_link_dof[CARL_BRAX_MAX_LINKS];  /* 6 = free, else 1..3 revolute dofs about the joint frame's x,y,z */
+  int32_t q_start[CARL_BRAX_MAX_LINKS], dof_start[CARL_BRAX_MAX_LINKS];
+  float link_pos[CARL_BRAX_MAX_LINKS][3], link_rot[CARL_BRAX_MAX_LINKS][4];   /* child frame in parent frame at q = 0 */
+  float joint_pos[CARL_BRAX_MAX_LINKS][3], joint_rot[CARL_BRAX_MAX_LINKS][4]; /* anchor / joint frame in the child frame */
+  float com[CARL_BRAX_MAX_LINKS][3];        /* centre of mass in the link frame */
+  float mass[CARL_BRAX_MAX_LINKS];          /* effective (spring_mass_scale applied) */
+  float inv_inertia[CARL_BRAX_MAX_LINKS][3];/* effective inverse principal moments, link frame */
+  float k_pos[CARL_BRAX_MAX_LINKS], k_vel[CARL_BRAX_MAX_LINKS];        /* constraint_stiffness / _vel_damping */
+  float k_limit[CARL_BRAX_MAX_LINKS], k_ang_damp[CARL_BRAX_MAX_LINKS]; /* constraint_limit_stiffness / _ang_damping */
+  float dof_lo[CARL_BRAX_MAX_DOF], dof_hi[CARL_BRAX_MAX_DOF];
+  float dof_damping[CARL_BRAX_MAX_DOF], dof_stiffness[CARL_BRAX_MAX_DOF];
+  int32_t act_dof[CARL_BRAX_MAX_ACT];
+  float act_gear[CARL_BRAX_MAX_ACT], act_lo[CARL_BRAX_MAX_ACT], act_hi[CARL_BRAX_MAX_ACT];
+  int32_t coll_link[CARL_BRAX_MAX_COLL];    /* collision spheres vs the ground plane z = 0 */
+  float coll_pos[CARL_BRAX_MAX_COLL][3], coll_radius[CARL_BRAX_MAX_COLL];
+  float init_q[CARL_BRAX_MAX_Q];
+  carl_brax_ctx_map_t ctx;
+} carl_brax_sys_t;
+
+/* floats of persistent state per lane: per link COM position 3, rotation 4 (w,x,y,z),
+ * linear velocity 3, angular velocity 3 (world frame) */
+#define CARL_BRAX_LINK_STATE 13
+
+/* carl_batch_t is reused: family = CARL_N_FAMILIES + env_kind is ignored here (sys decides),
+ * state is [13 * n_links][n_lanes], ctx_table rows follow the CARL class's feature table.
+ * action is float32 [n_lanes][n_act] (lane-major, like obs).  `sys` is a DEVICE pointer to
+ * one carl_brax_sys_t.  */
+int carl_brax_reset(const carl_batch_t* batch, const carl_brax_sys_t* sys_dev, const carl_brax_sys_t* sys_host,
+                    const uint8_t* mask, float* obs, void* stream);
+int carl_brax_step(const carl_batch_t* batch, const carl_brax_sys_t* sys_dev, const carl_brax_sys_t* sys_host,
+                   const carl_step_io_t* io, void* stream);
+int carl_brax_rollout(const carl_batch_t* batch, const carl_brax_sys_t* sys_dev, const carl_brax_sys_t* sys_host,
+                      const carl_step_io_t* io, int32_t n_steps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

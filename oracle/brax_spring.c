@@ -1,0 +1,459 @@
+/* brax_spring.c -- TEST INFRASTRUCTURE (oracle), not product code.
+ *
+ * CPU restatement, in float64, of the Brax "spring" path CARL's locomotion envs run:
+ *   brax.envs.<env>.reset/step  ->  n_frames x brax.spring.pipeline.step
+ *   (actuator.to_tau -> spring.joints.resolve -> semi-implicit Euler ->
+ *    spring.collisions.resolve -> spring.integrator.integrate -> com.to_world ->
+ *    kinematics.world_to_joint / inverse)
+ * reached from carl/envs/brax/carl_brax_env.py:163-190 (backend = "spring", :117) through
+ * carl/envs/brax/wrappers.py:54-78, with the context -> System mapping of
+ * carl_brax_env.py:255-292 in its INTENDED form (SURVEY.md Quirk B1: in the reference the
+ * rebuilt System never reaches the jitted step).
+ *
+ * brax==0.12.1 (pyproject.toml:62-65) is NOT vendored in /root/reference and not
+ * installable here; neither are jax/mujoco.  Everything below is [upstream-memory]:
+ * the structure follows SURVEY.md section 8a "Brax restatement"; coefficients and the exact
+ * form of the joint constraint are this build's reconstruction.  PARITY UNPINNED -- the
+ * reference's tests hold no Brax step value (test/test_brax_env.py:8-23 is a smoke test).
+ * What this file pins is the HIP kernel against an independent fp64 implementation of the
+ * same specification, plus physical invariants (tests/test_brax_oracle.py).
+ *
+ * Specification (per substep dt, all vectors in the world frame, state per link =
+ * COM position p, rotation r, linear velocity v, angular velocity w):
+ *  1. tau_k = gear_k * clip(act_k, ctrl range)                       (actuator.to_tau)
+ *  2. per non-root link c with parent p (spring.joints.resolve):
+ *       anchors A_c, A_p; F = k_pos (A_p - A_c) + k_vel (vA_p - vA_c) on c at A_c, -F on p at A_p
+ *       hinge axis alignment: T = k_pos (x_c cross x_p)
+ *       about the axis n: tau - dof_damping * thetadot - k_stiff * theta + limit spring
+ *       relative angular damping: -k_ang_damp (w_c - w_p)
+ *  3. v += dt (F / m + g);  w += dt R diag(inv_inertia) R^T T             (no gyroscopic term)
+ *  4. contacts, sphere vs plane z = 0 (spring.collisions.resolve): for penetrating,
+ *     approaching points an impulse with restitution `elasticity`, Baumgarte term
+ *     erp * depth / dt and Coulomb friction (<= friction * normal impulse), averaged over the
+ *     link's active contacts
+ *  5. v, w damped by exp(vel_damping dt), exp(ang_damping dt), + contact deltas;
+ *     p += dt v;  r = normalize(r + dt/2 * (0, w) (x) r)                   (integrator.integrate)
+ *  6. q, qd by inverse kinematics (root pose/twist, hinge angles / rates)  (kinematics.inverse)
+ * Env level (brax.envs.ant.Ant.step/reset): reward = forward_weight * dx/dt_env + healthy
+ * - ctrl_cost_weight |a|^2, done when torso z leaves [healthy_z_lo, healthy_z_hi],
+ * obs = q[2:] ++ qd, reset q = init_q + U(+-noise), qd = vel_scale * N(0,1);
+ * brax EpisodeWrapper(1000) truncation.
+ */
+#define _USE_MATH_DEFINES
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "../include/carl_amd.h"
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+typedef struct {
+  int32_t family, n_lanes, n_contexts, max_steps, selector, selector_stride, autoreset, cartpole_recompute;
+  int64_t lane_offset;
+  uint64_t seed;
+} oracle_cfg_t;
+
+void oracle_lane_words(uint64_t seed, uint64_t glane, uint32_t episode, uint32_t sub, uint32_t out[4]);
+float oracle_u01(uint32_t w);
+
+#define L_MAX CARL_BRAX_MAX_LINKS
+
+typedef struct { double x, y, z; } v3;
+typedef struct { double w, x, y, z; } qt;
+
+static v3 V(double x, double y, double z) { v3 r = {x, y, z}; return r; }
+static v3 vadd(v3 a, v3 b) { return V(a.x + b.x, a.y + b.y, a.z + b.z); }
+static v3 vsub(v3 a, v3 b) { return V(a.x - b.x, a.y - b.y, a.z - b.z); }
+static v3 vscale(v3 a, double s) { return V(a.x * s, a.y * s, a.z * s); }
+static double vdot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+static v3 vcross(v3 a, v3 b) { return V(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+static qt qmul(qt a, qt b) {
+  qt r = {a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z, a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
+          a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x, a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w};
+  return r;
+}
+static qt qconj(qt a) { qt r = {a.w, -a.x, -a.y, -a.z}; return r; }
+static qt qnorm(qt a) {
+  const double n = sqrt(a.w * a.w + a.x * a.x + a.y * a.y + a.z * a.z);
+  qt r = {a.w / n, a.x / n, a.y / n, a.z / n};
+  return r;
+}
+static v3 qrot(qt q, v3 v) { /* v + 2 w (u x v) + 2 u x (u x v) */
+  const v3 u = V(q.x, q.y, q.z);
+  const v3 t = vscale(vcross(u, v), 2.0);
+  return vadd(vadd(v, vscale(t, q.w)), vcross(u, t));
+}
+static qt qaxis(int k, double angle) { /* rotation about basis axis k */
+  qt r = {cos(0.5 * angle), 0, 0, 0};
+  const double s = sin(0.5 * angle);
+  if (k == 0) r.x = s; else if (k == 1) r.y = s; else r.z = s;
+  return r;
+}
+static v3 f3(const float* p) { return V(p[0], p[1], p[2]); }
+static qt f4(const float* p) { qt r = {p[0], p[1], p[2], p[3]}; return r; }
+
+/* per-lane context view: carl_brax_env.py:255-292 in its intended form */
+typedef struct {
+  double gravity_z, friction, elasticity, ang_damping, stiffness_scale;
+  double mass[L_MAX];
+} lane_ctx;
+
+static lane_ctx make_ctx(const carl_brax_sys_t* s, const double* row) {
+  lane_ctx c;
+  const carl_brax_ctx_map_t* m = &s->ctx;
+  c.gravity_z = (m->gravity >= 0) ? (double)(float)row[m->gravity] : s->gravity_z;
+  c.friction = (m->friction >= 0) ? (double)(float)row[m->friction] : s->friction;
+  c.elasticity = (m->elasticity >= 0) ? (double)(float)row[m->elasticity] : s->elasticity;
+  c.ang_damping = (m->ang_damping >= 0) ? (double)(float)row[m->ang_damping] : s->ang_damping;
+  c.stiffness_scale = (m->joint_stiffness_scale >= 0) ? (double)(float)row[m->joint_stiffness_scale] : 1.0;
+  for (int i = 0; i < s->n_links; ++i) c.mass[i] = s->mass[i];
+  for (int k = 0; k < m->n_mass; ++k)
+    c.mass[m->mass_link[k]] = s->mass[m->mass_link[k]] * ((double)(float)row[m->mass_row[k]] / m->mass_nominal[k]);
+  return c;
+}
+
+typedef struct { v3 p; qt r; v3 v; v3 w; } body;
+
+static void load_bodies(const carl_brax_sys_t* s, const double* st, body* b) {
+  for (int i = 0; i < s->n_links; ++i) {
+    const double* x = st + 13 * i;
+    b[i].p = V(x[0], x[1], x[2]);
+    b[i].r.w = x[3]; b[i].r.x = x[4]; b[i].r.y = x[5]; b[i].r.z = x[6];
+    b[i].v = V(x[7], x[8], x[9]);
+    b[i].w = V(x[10], x[11], x[12]);
+  }
+}
+static void store_bodies(const carl_brax_sys_t* s, const body* b, double* st) {
+  for (int i = 0; i < s->n_links; ++i) {
+    double* x = st + 13 * i;
+    x[0] = b[i].p.x; x[1] = b[i].p.y; x[2] = b[i].p.z;
+    x[3] = b[i].r.w; x[4] = b[i].r.x; x[5] = b[i].r.y; x[6] = b[i].r.z;
+    x[7] = b[i].v.x; x[8] = b[i].v.y; x[9] = b[i].v.z;
+    x[10] = b[i].w.x; x[11] = b[i].w.y; x[12] = b[i].w.z;
+  }
+}
+
+/* kinematics.forward + com.from_world: (q, qd) -> per-link COM state */
+static void forward_kinematics(const carl_brax_sys_t* s, const double* q, const double* qd, body* b) {
+  v3 org[L_MAX], ovel[L_MAX];
+  for (int i = 0; i < s->n_links; ++i) {
+    const int P = s->parent[i];
+    qt rot; v3 o, vel, ang;
+    if (P < 0) { /* free joint: q = (pos, quat), qd = (vel, ang) in the world frame */
+      const double* qi = q + s->q_start[i];
+      const double* di = qd + s->dof_start[i];
+      qt qq = {qi[3], qi[4], qi[5], qi[6]};
+      rot = qnorm(qq);
+      o = V(qi[0], qi[1], qi[2]);
+      vel = V(di[0], di[1], di[2]);
+      ang = V(di[3], di[4], di[5]);
+    } else {
+      const qt jr = f4(s->joint_rot[i]);
+      qt rj = {1, 0, 0, 0};
+      for (int k = 0; k < s->n_link_dof[i]; ++k) rj = qmul(rj, qaxis(k, q[s->q_start[i] + k]));
+      const qt rl = qmul(qmul(jr, rj), qconj(jr)); /* joint rotation in child coordinates */
+      const qt lrot = f4(s->link_rot[i]);
+      const v3 a = f3(s->joint_pos[i]);
+      /* the anchor stays put: pos = link_pos + link_rot (a - R a) */
+      const v3 lpos = vadd(f3(s->link_pos[i]), qrot(lrot, vsub(a, qrot(rl, a))));
+      rot = qmul(b[P].r, qmul(lrot, rl));
+      o = vadd(org[P], qrot(b[P].r, lpos));
+      ang = b[P].w;
+      vel = vadd(ovel[P], vcross(b[P].w, vsub(o, org[P])));
+      const v3 anchor_w = vadd(o, qrot(rot, a));
+      /* dof k turns about the joint frame's k-th axis as carried by the preceding dofs */
+      qt acc = qmul(qmul(b[P].r, lrot), jr);
+      for (int k = 0; k < s->n_link_dof[i]; ++k) {
+        const v3 ek = V(k == 0, k == 1, k == 2);
+        const v3 axis = qrot(acc, ek);
+        const double rate = qd[s->dof_start[i] + k];
+        ang = vadd(ang, vscale(axis, rate));
+        vel = vadd(vel, vcross(vscale(axis, rate), vsub(o, anchor_w)));
+        acc = qmul(acc, qaxis(k, q[s->q_start[i] + k]));
+      }
+    }
+    org[i] = o; ovel[i] = vel;
+    b[i].r = rot; b[i].w = ang;
+    const v3 c = qrot(rot, f3(s->com[i]));
+    b[i].p = vadd(o, c);
+    b[i].v = vadd(vel, vcross(ang, c));
+  }
+}
+
+/* kinematics.world_to_joint + inverse: per-link COM state -> (q, qd) */
+static void inverse_kinematics(const carl_brax_sys_t* s, const body* b, double* q, double* qd) {
+  for (int i = 0; i < s->n_links; ++i) {
+    const int P = s->parent[i];
+    if (P < 0) {
+      const v3 c = qrot(b[i].r, f3(s->com[i]));
+      const v3 o = vsub(b[i].p, c);
+      const v3 vel = vsub(b[i].v, vcross(b[i].w, c));
+      double* qi = q + s->q_start[i];
+      double* di = qd + s->dof_start[i];
+      qi[0] = o.x; qi[1] = o.y; qi[2] = o.z;
+      qi[3] = b[i].r.w; qi[4] = b[i].r.x; qi[5] = b[i].r.y; qi[6] = b[i].r.z;
+      di[0] = vel.x; di[1] = vel.y; di[2] = vel.z;
+      di[3] = b[i].w.x; di[4] = b[i].w.y; di[5] = b[i].w.z;
+    } else {
+      const qt jr = f4(s->joint_rot[i]);
+      const qt rp = qmul(qmul(b[P].r, f4(s->link_rot[i])), jr);
+      const qt rc = qmul(b[i].r, jr);
+      qt rel = qmul(qconj(rp), rc);
+      if (rel.w < 0) { rel.w = -rel.w; rel.x = -rel.x; rel.y = -rel.y; rel.z = -rel.z; }
+      /* single hinge about the joint frame's x axis: twist angle */
+      const double theta = 2.0 * atan2(rel.x, rel.w);
+      q[s->q_start[i]] = theta;
+      const v3 axis = qrot(rc, V(1, 0, 0));
+      qd[s->dof_start[i]] = vdot(axis, vsub(b[i].w, b[P].w));
+    }
+  }
+}
+
+static v3 apply_inv_inertia(const carl_brax_sys_t* s, int i, qt r, v3 t) {
+  const v3 l = qrot(qconj(r), t);
+  return qrot(r, V(l.x * s->inv_inertia[i][0], l.y * s->inv_inertia[i][1], l.z * s->inv_inertia[i][2]));
+}
+
+/* one brax.spring.pipeline.step */
+static void substep(const carl_brax_sys_t* s, const lane_ctx* c, const double* tau, body* b) {
+  v3 F[L_MAX], T[L_MAX];
+  const int L = s->n_links;
+  for (int i = 0; i < L; ++i) { F[i] = V(0, 0, 0); T[i] = V(0, 0, 0); }
+  /* --- spring.joints.resolve ------------------------------------------------------- */
+  for (int i = 0; i < L; ++i) {
+    const int P = s->parent[i];
+    if (P < 0) continue;
+    const v3 a = f3(s->joint_pos[i]);
+    const qt lrot = f4(s->link_rot[i]);
+    const qt jr = f4(s->joint_rot[i]);
+    const v3 o_c = vsub(b[i].p, qrot(b[i].r, f3(s->com[i])));
+    const v3 o_p = vsub(b[P].p, qrot(b[P].r, f3(s->com[P])));
+    const v3 A_c = vadd(o_c, qrot(b[i].r, a));
+    const v3 A_p = vadd(o_p, qrot(b[P].r, vadd(f3(s->link_pos[i]), qrot(lrot, a))));
+    const v3 vA_c = vadd(b[i].v, vcross(b[i].w, vsub(A_c, b[i].p)));
+    const v3 vA_p = vadd(b[P].v, vcross(b[P].w, vsub(A_p, b[P].p)));
+    const double kp = s->k_pos[i] * c->stiffness_scale;
+    const v3 f = vadd(vscale(vsub(A_p, A_c), kp), vscale(vsub(vA_p, vA_c), s->k_vel[i]));
+    F[i] = vadd(F[i], f);
+    T[i] = vadd(T[i], vcross(vsub(A_c, b[i].p), f));
+    F[P] = vsub(F[P], f);
+    T[P] = vsub(T[P], vcross(vsub(A_p, b[P].p), f));
+    /* angular part */
+    const qt rc = qmul(b[i].r, jr);
+    const qt rp = qmul(qmul(b[P].r, lrot), jr);
+    const v3 x_c = qrot(rc, V(1, 0, 0)), x_p = qrot(rp, V(1, 0, 0));
+    v3 t = vscale(vcross(x_c, x_p), kp); /* keep the hinge axes aligned */
+    qt rel = qmul(qconj(rp), rc);
+    if (rel.w < 0) { rel.w = -rel.w; rel.x = -rel.x; rel.y = -rel.y; rel.z = -rel.z; }
+    const double theta = 2.0 * atan2(rel.x, rel.w);
+    const v3 wrel = vsub(b[i].w, b[P].w);
+    const double thetadot = vdot(x_c, wrel);
+    const int d = s->dof_start[i];
+    double ta = tau[d] - s->dof_damping[d] * thetadot - s->dof_stiffness[d] * theta;
+    if (theta < s->dof_lo[d]) ta += s->k_limit[i] * (s->dof_lo[d] - theta);
+    if (theta > s->dof_hi[d]) ta -= s->k_limit[i] * (theta - s->dof_hi[d]);
+    t = vadd(t, vscale(x_c, ta));
+    t = vsub(t, vscale(wrel, s->k_ang_damp[i]));
+    T[i] = vadd(T[i], t);
+    T[P] = vsub(T[P], t);
+  }
+  /* --- semi-implicit Euler: velocity update before the collision pass -------------- */
+  for (int i = 0; i < L; ++i) {
+    b[i].v = vadd(b[i].v, vscale(vadd(vscale(F[i], 1.0 / c->mass[i]), V(0, 0, c->gravity_z)), s->dt));
+    b[i].w = vadd(b[i].w, vscale(apply_inv_inertia(s, i, b[i].r, T[i]), s->dt));
+  }
+  /* --- spring.collisions.resolve: spheres vs the plane z = 0 ------------------------ */
+  v3 dv[L_MAX], dw[L_MAX];
+  int cnt[L_MAX];
+  for (int i = 0; i < L; ++i) { dv[i] = V(0, 0, 0); dw[i] = V(0, 0, 0); cnt[i] = 0; }
+  const v3 n = V(0, 0, 1);
+  for (int k = 0; k < s->n_coll; ++k) {
+    const int i = s->coll_link[k];
+    const v3 o = vsub(b[i].p, qrot(b[i].r, f3(s->com[i])));
+    const v3 ctr = vadd(o, qrot(b[i].r, f3(s->coll_pos[k])));
+    const double depth = s->coll_radius[k] - ctr.z; /* > 0: penetrating */
+    if (!(depth > 0)) continue;
+    const v3 pos = V(ctr.x, ctr.y, ctr.z - s->coll_radius[k]); /* lowest point of the sphere */
+    const v3 r = vsub(pos, b[i].p);
+    const v3 rel = vadd(b[i].v, vcross(b[i].w, r));
+    const double vn = vdot(n, rel);
+    const double inv_m = 1.0 / c->mass[i];
+    const double ang = vdot(n, vcross(apply_inv_inertia(s, i, b[i].r, vcross(r, n)), r));
+    const double baum = s->baumgarte_erp * depth / s->dt;
+    const double imp = (-(1.0 + c->elasticity) * vn + baum) / (inv_m + ang);
+    if (!(imp > 0) || !(vn < 0)) continue; /* only approaching contacts push */
+    v3 J = vscale(n, imp);
+    const v3 vt = vsub(rel, vscale(n, vn));
+    const double vt_len = sqrt(vdot(vt, vt));
+    if (vt_len > 1e-9) {
+      const v3 dir = vscale(vt, 1.0 / vt_len);
+      const double ang_d = vdot(dir, vcross(apply_inv_inertia(s, i, b[i].r, vcross(r, dir)), r));
+      double imp_d = vt_len / (inv_m + ang_d);
+      const double cap = c->friction * imp;
+      if (imp_d > cap) imp_d = cap;
+      J = vsub(J, vscale(dir, imp_d));
+    }
+    dv[i] = vadd(dv[i], vscale(J, inv_m));
+    dw[i] = vadd(dw[i], apply_inv_inertia(s, i, b[i].r, vcross(r, J)));
+    cnt[i] += 1;
+  }
+  /* --- spring.integrator.integrate --------------------------------------------------- */
+  const double dl = exp(s->vel_damping * s->dt), da = exp(c->ang_damping * s->dt);
+  for (int i = 0; i < L; ++i) {
+    b[i].v = vscale(b[i].v, dl);
+    b[i].w = vscale(b[i].w, da);
+    if (cnt[i] > 0) {
+      b[i].v = vadd(b[i].v, vscale(dv[i], 1.0 / cnt[i]));
+      b[i].w = vadd(b[i].w, vscale(dw[i], 1.0 / cnt[i]));
+    }
+    b[i].p = vadd(b[i].p, vscale(b[i].v, s->dt));
+    const qt wq = {0, b[i].w.x, b[i].w.y, b[i].w.z};
+    const qt dq = qmul(wq, b[i].r);
+    qt r2 = {b[i].r.w + 0.5 * s->dt * dq.w, b[i].r.x + 0.5 * s->dt * dq.x, b[i].r.y + 0.5 * s->dt * dq.y,
+             b[i].r.z + 0.5 * s->dt * dq.z};
+    b[i].r = qnorm(r2);
+  }
+}
+
+static void observe(const carl_brax_sys_t* s, const body* b, float* obs) {
+  double q[CARL_BRAX_MAX_Q], qd[CARL_BRAX_MAX_DOF];
+  inverse_kinematics(s, b, q, qd);
+  int k = 0;
+  for (int i = s->exclude_current_positions ? 2 : 0; i < s->n_q; ++i) obs[k++] = (float)q[i];
+  for (int i = 0; i < s->n_dof; ++i) obs[k++] = (float)qd[i];
+}
+
+/* brax.envs.<env>.reset: q = init_q + U(-noise, noise), qd = vel_scale * N(0, 1).
+ * Draw k of a lane's reset uses word (k mod 4) of Philox block k/4 on sub-stream
+ * 0x80000000 | block; normals are Box-Muller pairs from two consecutive draws. */
+static double draw_u(uint64_t seed, uint64_t g, uint32_t ep, int k) {
+  uint32_t w[4];
+  oracle_lane_words(seed, g, ep, 0x80000000u | (uint32_t)(k >> 2), w);
+  return (double)oracle_u01(w[k & 3]);
+}
+
+static void reset_lane(const carl_brax_sys_t* s, uint64_t seed, uint64_t g, uint32_t ep, body* b) {
+  double q[CARL_BRAX_MAX_Q], qd[CARL_BRAX_MAX_DOF];
+  int k = 0;
+  for (int i = 0; i < s->n_q; ++i, ++k)
+    q[i] = (double)s->init_q[i] + (double)s->reset_noise_scale * (2.0 * draw_u(seed, g, ep, k) - 1.0);
+  for (int i = 0; i < s->n_dof; i += 2, k += 2) {
+    const double u1 = draw_u(seed, g, ep, k), u2 = draw_u(seed, g, ep, k + 1);
+    const double rad = sqrt(-2.0 * log(1.0 - u1));
+    qd[i] = s->reset_vel_scale * rad * cos(2.0 * M_PI * u2);
+    if (i + 1 < s->n_dof) qd[i + 1] = s->reset_vel_scale * rad * sin(2.0 * M_PI * u2);
+  }
+  forward_kinematics(s, q, qd, b);
+}
+
+static int32_t select_ctx(const oracle_cfg_t* cfg, int32_t idx, uint64_t g, uint32_t episode) {
+  const int32_t C = cfg->n_contexts;
+  if (cfg->selector == 1) { int64_t v = ((int64_t)idx + cfg->selector_stride) % C; return (int32_t)(v < 0 ? v + C : v); }
+  if (cfg->selector == 2) { uint32_t w[4]; oracle_lane_words(cfg->seed, g, episode, 1u, w);
+                            return (int32_t)(((uint64_t)w[0] * (uint64_t)(uint32_t)C) >> 32); }
+  return idx;
+}
+
+/* exported: pure helpers for tests */
+void obx_forward_kinematics(const carl_brax_sys_t* s, const double* q, const double* qd, double* state) {
+  body b[L_MAX];
+  forward_kinematics(s, q, qd, b);
+  store_bodies(s, b, state);
+}
+void obx_inverse_kinematics(const carl_brax_sys_t* s, const double* state, double* q, double* qd) {
+  body b[L_MAX];
+  load_bodies(s, state, b);
+  inverse_kinematics(s, b, q, qd);
+}
+/* n_sub pipeline substeps on one lane's state with constant joint torques (tests) */
+void obx_substeps(const carl_brax_sys_t* s, const double* ctx_row, const double* tau, int n_sub, double* state) {
+  body b[L_MAX];
+  const lane_ctx c = make_ctx(s, ctx_row);
+  load_bodies(s, state, b);
+  for (int k = 0; k < n_sub; ++k) substep(s, &c, tau, b);
+  store_bodies(s, b, state);
+}
+
+void obx_engine_reset(const carl_brax_sys_t* s, const oracle_cfg_t* cfg, const double* ctx_table, int n_feat,
+                      const uint8_t* mask, double* state, int32_t* elapsed, int32_t* ctx_idx, uint32_t* episode,
+                      int32_t* n_calls, double* ep_return, float* obs) {
+  const int S = 13 * s->n_links;
+  (void)ctx_table; (void)n_feat;
+  for (int i = 0; i < cfg->n_lanes; ++i) {
+    if (mask && !mask[i]) continue;
+    const uint64_t g = (uint64_t)(cfg->lane_offset + i);
+    ctx_idx[i] = select_ctx(cfg, ctx_idx[i], g, episode[i]);
+    n_calls[i] += 1;
+    body b[L_MAX];
+    reset_lane(s, cfg->seed, g, episode[i], b);
+    store_bodies(s, b, state + (size_t)i * S);
+    episode[i] += 1;
+    elapsed[i] = 0;
+    ep_return[i] = 0.0;
+    observe(s, b, obs + (size_t)i * s->obs_dim);
+  }
+}
+
+/* one env step of every lane: n_frames substeps + reward/done/obs + EpisodeWrapper
+ * truncation + (cfg->autoreset) in-step reset */
+void obx_engine_step(const carl_brax_sys_t* s, const oracle_cfg_t* cfg, const double* ctx_table, int n_feat,
+                     const float* action, double* state, int32_t* elapsed, int32_t* ctx_idx, uint32_t* episode,
+                     int32_t* n_calls, double* ep_return, float* obs, float* reward, uint8_t* terminated,
+                     uint8_t* truncated, float* final_obs, float* last_return, int32_t* last_length,
+                     int32_t* episodes_done) {
+  const int S = 13 * s->n_links, D = s->obs_dim;
+  for (int i = 0; i < cfg->n_lanes; ++i) {
+    const uint64_t g = (uint64_t)(cfg->lane_offset + i);
+    const lane_ctx c = make_ctx(s, ctx_table + (size_t)ctx_idx[i] * n_feat);
+    body b[L_MAX];
+    load_bodies(s, state + (size_t)i * S, b);
+    const float* a = action + (size_t)i * s->n_act;
+    double tau[CARL_BRAX_MAX_DOF];
+    for (int d = 0; d < s->n_dof; ++d) tau[d] = 0.0;
+    double ctrl = 0.0;
+    for (int k = 0; k < s->n_act; ++k) {
+      double u = a[k];
+      ctrl += u * u;
+      if (u < s->act_lo[k]) u = s->act_lo[k];
+      if (u > s->act_hi[k]) u = s->act_hi[k];
+      tau[s->act_dof[k]] += s->act_gear[k] * u;
+    }
+    const v3 c0 = qrot(b[0].r, f3(s->com[0]));
+    const double x0 = b[0].p.x - c0.x;
+    for (int k = 0; k < s->n_frames; ++k) substep(s, &c, tau, b);
+    const v3 c1 = qrot(b[0].r, f3(s->com[0]));
+    const double x1 = b[0].p.x - c1.x, z1 = b[0].p.z - c1.z;
+    const double dt_env = (double)s->dt * s->n_frames;
+    const int healthy = (z1 >= s->healthy_z_lo) && (z1 <= s->healthy_z_hi);
+    const double r = s->forward_reward_weight * (x1 - x0) / dt_env +
+                     (s->terminate_when_unhealthy ? s->healthy_reward : s->healthy_reward * healthy) -
+                     s->ctrl_cost_weight * ctrl;
+    const int term = s->terminate_when_unhealthy ? !healthy : 0;
+    elapsed[i] += 1;
+    const int trunc = elapsed[i] >= cfg->max_steps;
+    ep_return[i] += (double)(float)r;
+    reward[i] = (float)r;
+    terminated[i] = (uint8_t)term;
+    truncated[i] = (uint8_t)trunc;
+    observe(s, b, obs + (size_t)i * D);
+    if (term || trunc) {
+      if (last_return) last_return[i] = (float)ep_return[i];
+      if (last_length) last_length[i] = elapsed[i];
+      if (episodes_done) episodes_done[i] += 1;
+      if (cfg->autoreset) {
+        if (final_obs) memcpy(final_obs + (size_t)i * D, obs + (size_t)i * D, sizeof(float) * D);
+        ctx_idx[i] = select_ctx(cfg, ctx_idx[i], g, episode[i]);
+        n_calls[i] += 1;
+        reset_lane(s, cfg->seed, g, episode[i], b);
+        episode[i] += 1;
+        elapsed[i] = 0;
+        ep_return[i] = 0.0;
+        observe(s, b, obs + (size_t)i * D);
+      }
+    }
+    store_bodies(s, b, state + (size_t)i * S);
+  }
+}

@@ -1,0 +1,158 @@
+"""Brax spring-pipeline restatement (oracle/brax_spring.c): internal consistency and physical
+invariants on CPU.  brax itself is not importable here and the reference's tests hold no Brax
+step value (test/test_brax_env.py:8-23 is construct/reset only), so this is NOT parity with
+brax -- it pins the specification the HIP kernel is then compared against."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from carl_amd import _lib
+from carl_amd.envs.brax.models import ant_sys
+from oracle import brax as B
+from oracle import oracle as O
+
+NAMES = ["gravity", "friction", "elasticity", "ang_damping", "mass_torso", "viscosity", "target_distance",
+         "target_direction", "target_radius"]
+DEFAULT = np.array([-9.8, 1.0, 0.0, -0.05, 10.0, 0.0, 100.0, 1.0, 5.0])
+
+
+@pytest.fixture(scope="module")
+def ant():
+    return ant_sys(NAMES)
+
+
+def test_model_table_shape(ant):
+    assert (ant.n_links, ant.n_q, ant.n_dof, ant.n_act, ant.obs_dim) == (9, 15, 14, 8, 27)
+    assert ant.n_frames * ant.dt == pytest.approx(0.05)  # brax Ant: dt 0.005 x 10 frames on "spring"
+    assert list(ant.parent[:9]) == [-1, 0, 1, 0, 3, 0, 5, 0, 7]
+    assert sorted(ant.act_dof[:8]) == list(range(6, 14))
+    assert ant.ctx.gravity == 0 and ant.ctx.friction == 1 and ant.ctx.n_mass == 1 and ant.ctx.mass_row[0] == 4
+    compat = ant_sys(NAMES, reference_compat=True)
+    assert compat.ctx.gravity == -1 and compat.ctx.n_mass == 0
+    with pytest.raises(RuntimeError):
+        ant_sys(NAMES + ["mass_nonexistent"])
+
+
+def test_brax_struct_layout_matches_c(tmp_path):
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fields = [f[0] for f in _lib.BraxSys._fields_]
+    src = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{root}/include/carl_amd.h"', "int main(void){",
+           'printf("%zu %zu\\n", sizeof(carl_brax_sys_t), sizeof(carl_brax_ctx_map_t));']
+    src += [f'printf("%zu\\n", offsetof(carl_brax_sys_t, {f}));' for f in fields] + ["return 0;}"]
+    (tmp_path / "l.c").write_text("\n".join(src))
+    subprocess.run(["gcc", "-o", str(tmp_path / "l"), str(tmp_path / "l.c")], check=True)
+    out = list(map(int, subprocess.run([str(tmp_path / "l")], capture_output=True, text=True, check=True).stdout.split()))
+    assert out[:2] == [C.sizeof(_lib.BraxSys), C.sizeof(_lib.BraxCtxMap)]
+    assert out[2:] == [getattr(_lib.BraxSys, f).offset for f in fields]
+
+
+def test_forward_inverse_kinematics_roundtrip(ant):
+    rng = np.random.default_rng(0)
+    for _ in range(20):
+        q = np.array(ant.init_q[:15], dtype=np.float64) + rng.uniform(-0.2, 0.2, 15)
+        q[3:7] /= np.linalg.norm(q[3:7])
+        qd = rng.normal(0, 1.0, 14)
+        st = B.forward_kinematics(ant, q, qd)
+        q2, qd2 = B.inverse_kinematics(ant, st)
+        # the model table is float32 (joint-frame quaternions are unit to ~1e-7 only)
+        np.testing.assert_allclose(q2, q, atol=2e-6)
+        np.testing.assert_allclose(qd2, qd, atol=5e-6)
+        assert np.allclose(np.linalg.norm(st[:, 3:7], axis=1), 1.0)
+
+
+def test_joint_anchors_coincide_after_forward_kinematics(ant):
+    """with exact kinematics the joint springs are at rest: zero torque -> only gravity acts"""
+    q = np.array(ant.init_q[:15], dtype=np.float64)
+    st = B.forward_kinematics(ant, q, np.zeros(14))
+    st[:, 2] += 5.0  # lift off the ground: no contacts
+    row = DEFAULT.copy()
+    out = B.substeps(ant, row, np.zeros(14), 1, st)
+    # every link accelerates with g only (joint damping is zero at rest, limits inactive except
+    # the ankles resting INSIDE their range at init_q)
+    np.testing.assert_allclose(out[:, 9], -9.8 * ant.dt, atol=1e-9)
+    np.testing.assert_allclose(out[:, 7:9], 0.0, atol=1e-9)
+
+
+def test_free_flight_conserves_momentum(ant):
+    """no gravity, no contact, no damping: internal joint forces are equal and opposite"""
+    rng = np.random.default_rng(1)
+    q = np.array(ant.init_q[:15], dtype=np.float64)
+    qd = rng.normal(0, 1.0, 14)
+    st = B.forward_kinematics(ant, q, qd)
+    st[:, 2] += 10.0
+    row = DEFAULT.copy()
+    row[0] = -1e-6  # gravity ~ 0 (feature bound is < 0)
+    row[3] = 0.0    # ang_damping off
+    mass = np.ones(9)
+    p0 = (mass[:, None] * st[:, 7:10]).sum(0)
+    tau = rng.uniform(-50, 50, 14)
+    tau[:6] = 0
+    out = B.substeps(ant, row, tau, 200, st)
+    p1 = (mass[:, None] * out[:, 7:10]).sum(0)
+    np.testing.assert_allclose(p1[:2], p0[:2], atol=1e-9)
+    assert abs(p1[2] - p0[2]) < 1e-3  # 200 * dt * 9 * 1e-6
+    # and the joints hold: anchors stay within millimetres
+    qq, _ = B.inverse_kinematics(ant, out)
+    re = B.forward_kinematics(ant, qq, np.zeros(14))
+    assert np.abs(re[:, :3] - out[:, :3]).max() < 0.02
+
+
+def test_zero_action_ant_stands(ant):
+    e = B.Engine(ant, DEFAULT[None], 8, selector=O.SEL_STATIC, seed=3)
+    obs = e.reset()
+    assert obs.shape == (8, 27) and (np.abs(obs[:, 0] - 0.55) < 0.11).all()
+    for _ in range(200):
+        out = e.step(np.zeros((8, 8), np.float32))
+    assert not out.terminated.any() and (out.obs[:, 0] > 0.35).all() and (out.obs[:, 0] < 0.7).all()
+    assert np.abs(out.obs[:, 13:]).max() < 0.5  # came to rest
+    assert np.allclose(out.reward, 1.0, atol=0.1)  # healthy reward only
+
+
+def test_contexts_change_the_dynamics(ant):
+    rows = np.tile(DEFAULT, (4, 1))
+    rows[1, 0] = -20.0   # stronger gravity
+    rows[2, 4] = 40.0    # heavier torso
+    rows[3, 1] = 0.05    # slippery floor
+    e = B.Engine(ant, rows, 4, selector=O.SEL_STATIC, seed=9, ctx_idx0=np.arange(4))
+    e.reset()
+    e.state[1:] = e.state[0]  # same initial state, different contexts
+    rng = np.random.default_rng(0)
+    for _ in range(60):
+        a = np.tile(rng.uniform(-1, 1, (1, 8)).astype(np.float32), (4, 1))
+        out = e.step(a)
+    for k in (1, 2, 3):
+        assert np.abs(out.obs[k] - out.obs[0]).max() > 1e-2
+    compat = ant_sys(NAMES, reference_compat=True)
+    e2 = B.Engine(compat, rows, 4, selector=O.SEL_STATIC, seed=9, ctx_idx0=np.arange(4))
+    e2.reset()
+    e2.state[1:] = e2.state[0]
+    for _ in range(20):
+        out2 = e2.step(np.zeros((4, 8), np.float32))
+    assert np.abs(out2.obs[1:] - out2.obs[0]).max() == 0.0  # reference_compat: contexts are observed-only
+
+
+def test_random_policy_is_stable_and_episodes_end(ant):
+    rng = np.random.default_rng(5)
+    n = 32
+    e = B.Engine(ant, DEFAULT[None], n, selector=O.SEL_STATIC, seed=1, max_steps=50)
+    e.reset()
+    for t in range(120):
+        out = e.step(rng.uniform(-1, 1, (n, 8)).astype(np.float32))
+        assert np.isfinite(out.obs).all() and np.abs(out.obs).max() < 50
+        if (t + 1) % 50 == 0:
+            assert (out.truncated | out.terminated).all()
+    assert (e.episodes_done >= 2).all()
+
+
+def test_reset_is_a_function_of_seed_lane_episode(ant):
+    a = B.Engine(ant, DEFAULT[None], 6, seed=4, lane_offset=100)
+    b = B.Engine(ant, DEFAULT[None], 3, seed=4, lane_offset=103)
+    a.reset()
+    b.reset()
+    np.testing.assert_array_equal(a.state[3:], b.state)
+    q, qd = B.inverse_kinematics(ant, a.state[0])
+    assert np.abs(q[:3] - np.array(ant.init_q[:3])).max() <= 0.1 + 1e-9 and np.abs(qd).max() < 0.6
