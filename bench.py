@@ -36,14 +36,17 @@ HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); ~6300 GB/s achievabl
 
 # algorithmic bytes per env-step
 # (a) SURVEY.md 8(d), per-call model (state/ctx/elapsed re-read every step)
-BYTES_8D = {"pendulum": 66, "cartpole": 90, "acrobot": 110, "mountaincar": 74, "mountaincar_cont": 70}
+BYTES_8D = {"pendulum": 66, "cartpole": 90, "acrobot": 110, "mountaincar": 74, "mountaincar_cont": 70,
+            "ant": 1110}
 # (b) fused rollout: per step only action in + transition out must cross HBM; state,
 #     context params and counters cross once per launch (DESIGN.md "Kernels")
 IO_PER_STEP = {"pendulum": 4 + 12 + 4 + 2, "cartpole": 4 + 16 + 4 + 2, "acrobot": 4 + 24 + 4 + 2,
-               "mountaincar": 4 + 8 + 4 + 2, "mountaincar_cont": 4 + 8 + 4 + 2}
+               "mountaincar": 4 + 8 + 4 + 2, "mountaincar_cont": 4 + 8 + 4 + 2,
+               "ant": 4 * 8 + 4 * 27 + 4 + 2}
 PER_LAUNCH = {"pendulum": 8 + 4 + 16 + 4 + 4 + 8 + 4 + 4, "cartpole": 16 + 4 + 20 + 4 + 4 + 16 + 4 + 4,
               "acrobot": 16 + 4 + 36 + 4 + 4 + 4 + 16 + 4 + 4, "mountaincar": 8 + 4 + 28 + 4 + 4 + 8 + 4 + 4,
-              "mountaincar_cont": 8 + 4 + 24 + 4 + 4 + 8 + 4 + 4}
+              "mountaincar_cont": 8 + 4 + 24 + 4 + 4 + 8 + 4 + 4,
+              "ant": 2 * 13 * 9 * 4 + 4 + 5 * 4 + 4 + 4 + 4 + 4}
 
 
 def parse():
@@ -70,7 +73,8 @@ def make_env(args, rank, world, device):
     from carl_amd import envs as E
 
     cls = {"pendulum": E.CARLPendulum, "cartpole": E.CARLCartPole, "acrobot": E.CARLAcrobot,
-           "mountaincar": E.CARLMountainCar, "mountaincar_cont": E.CARLMountainCarContinuous}[args.env]
+           "mountaincar": E.CARLMountainCar, "mountaincar_cont": E.CARLMountainCarContinuous,
+           "ant": E.CARLBraxAnt}[args.env]
     dists = {
         "pendulum": [U("g", 1, 20), U("l", 0.5, 2.0)],
         "cartpole": [U("gravity", 5, 15), U("length", 0.3, 1.0), U("masspole", 0.05, 0.3)],
@@ -78,6 +82,8 @@ def make_env(args, rank, world, device):
                     U("LINK_COM_POS_1", 0.3, 0.7), U("LINK_COM_POS_2", 0.3, 0.7)],
         "mountaincar": [U("force", 5e-4, 2e-3), U("gravity", 1.5e-3, 3.5e-3), U("goal_position", 0.3, 0.55)],
         "mountaincar_cont": [U("power", 5e-4, 3e-3), U("goal_position", 0.3, 0.55)],
+        # BASELINE config 4
+        "ant": [U("mass_torso", 5, 15), U("gravity", -15, -5), U("friction", 0.3, 1.5)],
     }[args.env]
     n = args.lanes
     # one global context set (seed 0), each rank uploads only its lanes' rows
@@ -85,8 +91,9 @@ def make_env(args, rank, world, device):
     from carl_amd.context.table import ContextTable
 
     local = ContextTable(table.names, table.values_2d[rank * n:(rank + 1) * n])
-    env = cls(contexts=local, num_envs=n, device=device, context_selector=StaticSelector, seed=0,
-              lane_offset=rank * n, fin_capacity=0)
+    size_kw = {"batch_size": n} if args.env == "ant" else {"num_envs": n}
+    env = cls(contexts=local, device=device, context_selector=StaticSelector, seed=0,
+              lane_offset=rank * n, fin_capacity=0, **size_kw)
     return env, table
 
 
@@ -99,7 +106,8 @@ def make_actions(args, env, T, device, rank):
     if info.action_is_discrete:
         return torch.randint(0, info.n_actions, (T, env.num_envs), generator=g, device=device, dtype=torch.int32)
     lo, hi = float(info.action_low), float(info.action_high)
-    return torch.rand((T, env.num_envs), generator=g, device=device, dtype=torch.float32) * (hi - lo) + lo
+    shape = (T, env.num_envs) if info.action_dim == 1 else (T, env.num_envs, int(info.action_dim))
+    return torch.rand(shape, generator=g, device=device, dtype=torch.float32) * (hi - lo) + lo
 
 
 def _cpu_worker(job):
@@ -310,7 +318,7 @@ def main():
             "value": n * world * K / elapsed, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"CARL{args.env} x {n} contexts/GPU (BASELINE configs[1] shape), StaticSelector "
+            "config": {"workload": f"CARL{args.env} x {n} contexts/GPU, StaticSelector "
                                    f"lane<->context, auto-reset, fused carl_rollout in launches of {T} steps, "
                                    "full transition written per step",
                        "lanes_per_gpu": n, "total_lanes": n * world, "chunk": T, "parallelism": f"lane-shard x{world}"},
