@@ -43,6 +43,8 @@ struct CartPole {
 
   struct Params {
     float gravity, masspole, length, force_mag, tau, inv_total_mass, polemass_length;
+    float init_lo, init_hi;  // CARL reset distribution (kept with the physics so that a reset
+                             // of a lane whose context does not change touches no memory)
   };
 
   template <class Ctx>
@@ -65,6 +67,8 @@ struct CartPole {
       p.polemass_length = 0.1f * 0.5f;
     }
     p.inv_total_mass = 1.0f / total_mass;
+    p.init_lo = ctx.get(INIT_LO, c);
+    p.init_hi = ctx.get(INIT_HI, c);
     return p;
   }
 
@@ -109,9 +113,8 @@ struct CartPole {
   }
 
   // carl_cartpole.py:51-61: state = U(initial_state_lower, initial_state_upper, 4)
-  template <class Ctx>
-  __device__ static __forceinline__ void reset(const Ctx& ctx, int c, const u32x4& w, float (&s)[S]) {
-    const float lo = ctx.get(INIT_LO, c), hi = ctx.get(INIT_HI, c);
+  __device__ static __forceinline__ void reset(const Params& p, const u32x4& w, float (&s)[S]) {
+    const float lo = p.init_lo, hi = p.init_hi;
     s[0] = uniform_between(lo, hi, w.x);
     s[1] = uniform_between(lo, hi, w.y);
     s[2] = uniform_between(lo, hi, w.z);
@@ -134,6 +137,7 @@ struct Pendulum {
     float c_sin;  // 3 g / (2 l)
     float c_u;    // 3 / (m l^2)
     float dt;
+    float init_angle_max, init_vel_max;
   };
   // sin/cos of the current angle: the observation of step t and the torque term of
   // step t+1 need the same pair, so one sincos per step serves both
@@ -144,7 +148,8 @@ struct Pendulum {
   template <class Ctx>
   __device__ static __forceinline__ Params load(const Ctx& ctx, int c, int) {
     const float g = ctx.get(G, c), m = ctx.get(M, c), l = ctx.get(L, c);
-    return Params{3.0f * g / (2.0f * l), 3.0f / (m * (l * l)), ctx.get(DT, c)};
+    return Params{3.0f * g / (2.0f * l), 3.0f / (m * (l * l)), ctx.get(DT, c), ctx.get(INIT_ANGLE_MAX, c),
+                  ctx.get(INIT_VEL_MAX, c)};
   }
 
   __device__ static __forceinline__ void prepare(const float (&s)[S], Aux& a) { sincos_fast(s[0], a.sn, a.cs); }
@@ -158,9 +163,10 @@ struct Pendulum {
     // angle_normalize(x) = ((x + pi) % (2 pi)) - pi with Python's floor-mod
     const float two_pi = 2.0f * kPi, inv_two_pi = 1.0f / (2.0f * kPi);
     const float y = th + kPi;
-    float r = __fmaf_rn(-floorf(y * inv_two_pi), two_pi, y);
-    r = (r < 0.0f) ? r + two_pi : r;
-    r = (r >= two_pi) ? r - two_pi : r;
+    // r may land a rounding error outside [0, 2 pi); the reference's own float64 mod has the
+    // same ambiguity at the seam, and an^2 is continuous there ((-pi - e)^2 vs (pi - e)^2
+    // differ by 4 pi e), so no fix-up is needed for the cost
+    const float r = __fmaf_rn(-floorf(y * inv_two_pi), two_pi, y);
     const float an = r - kPi;
     const float costs = an * an + 0.1f * (thdot * thdot) + 0.001f * (u * u);
     float newthdot = thdot + (p.c_sin * aux.sn + p.c_u * u) * p.dt;
@@ -181,10 +187,9 @@ struct Pendulum {
 
   // carl_pendulum.py:44-60: theta = U(0, initial_angle_max), thdot = U(0, initial_velocity_max)
   // (one-sided: `low` defaults to 0 -- Quirk P2)
-  template <class Ctx>
-  __device__ static __forceinline__ void reset(const Ctx& ctx, int c, const u32x4& w, float (&s)[S]) {
-    s[0] = uniform_between(0.0f, ctx.get(INIT_ANGLE_MAX, c), w.x);
-    s[1] = uniform_between(0.0f, ctx.get(INIT_VEL_MAX, c), w.y);
+  __device__ static __forceinline__ void reset(const Params& p, const u32x4& w, float (&s)[S]) {
+    s[0] = uniform_between(0.0f, p.init_angle_max, w.x);
+    s[1] = uniform_between(0.0f, p.init_vel_max, w.y);
   }
 };
 
@@ -209,6 +214,7 @@ struct AcrobotT {
     Real m1, m2, l1, lc1, lc2, moi;
     Real max_vel_1, max_vel_2;
     float noise_max;
+    float ia_lo, ia_hi, iv_lo, iv_hi;
   };
   struct Aux {  // cos/sin of theta1, theta2 of the current state (for the observation)
     float c0, s0, c1, s1;
@@ -227,6 +233,10 @@ struct AcrobotT {
     p.max_vel_1 = ctx.get(MAXV1, c);
     p.max_vel_2 = ctx.get(MAXV2, c);
     p.noise_max = ctx.get(NOISE, c);
+    p.ia_lo = ctx.get(IA_LO, c);
+    p.ia_hi = ctx.get(IA_HI, c);
+    p.iv_lo = ctx.get(IV_LO, c);
+    p.iv_hi = ctx.get(IV_HI, c);
     return p;
   }
 
@@ -326,10 +336,9 @@ struct AcrobotT {
   }
 
   // carl_acrobot.py:78-100
-  template <class Ctx>
-  __device__ static __forceinline__ void reset(const Ctx& ctx, int c, const u32x4& w, float (&s)[S]) {
-    const float alo = ctx.get(IA_LO, c), ahi = ctx.get(IA_HI, c);
-    const float vlo = ctx.get(IV_LO, c), vhi = ctx.get(IV_HI, c);
+  __device__ static __forceinline__ void reset(const Params& p, const u32x4& w, float (&s)[S]) {
+    const float alo = p.ia_lo, ahi = p.ia_hi;
+    const float vlo = p.iv_lo, vhi = p.iv_hi;
     s[0] = uniform_between(alo, ahi, w.x);
     s[1] = uniform_between(alo, ahi, w.y);
     s[2] = uniform_between(vlo, vhi, w.z);
@@ -350,12 +359,14 @@ struct MountainCar {
 
   struct Params {
     float min_position, max_position, max_speed, goal_position, goal_velocity, force, gravity;
+    float minp_start, maxp_start, minv_start, maxv_start;
   };
 
   template <class Ctx>
   __device__ static __forceinline__ Params load(const Ctx& ctx, int c, int) {
-    return Params{ctx.get(MIN_POS, c),  ctx.get(MAX_POS, c), ctx.get(MAX_SPEED, c), ctx.get(GOAL_POS, c),
-                  ctx.get(GOAL_VEL, c), ctx.get(FORCE, c),   ctx.get(GRAVITY, c)};
+    return Params{ctx.get(MIN_POS, c),    ctx.get(MAX_POS, c),    ctx.get(MAX_SPEED, c),  ctx.get(GOAL_POS, c),
+                  ctx.get(GOAL_VEL, c),   ctx.get(FORCE, c),      ctx.get(GRAVITY, c),    ctx.get(MINP_START, c),
+                  ctx.get(MAXP_START, c), ctx.get(MINV_START, c), ctx.get(MAXV_START, c)};
   }
 
   __device__ static __forceinline__ void prepare(const float (&)[S], Aux&) {}
@@ -381,10 +392,9 @@ struct MountainCar {
   }
 
   // carl_mountaincar.py:60-80
-  template <class Ctx>
-  __device__ static __forceinline__ void reset(const Ctx& ctx, int c, const u32x4& w, float (&s)[S]) {
-    s[0] = uniform_between(ctx.get(MINP_START, c), ctx.get(MAXP_START, c), w.x);
-    s[1] = uniform_between(ctx.get(MINV_START, c), ctx.get(MAXV_START, c), w.y);
+  __device__ static __forceinline__ void reset(const Params& p, const u32x4& w, float (&s)[S]) {
+    s[0] = uniform_between(p.minp_start, p.maxp_start, w.x);
+    s[1] = uniform_between(p.minv_start, p.maxv_start, w.y);
   }
 };
 
@@ -399,12 +409,14 @@ struct MountainCarCont {
 
   struct Params {
     float min_position, max_position, max_speed, goal_position, goal_velocity, power;
+    float minp_start, maxp_start, minv_start, maxv_start;
   };
 
   template <class Ctx>
   __device__ static __forceinline__ Params load(const Ctx& ctx, int c, int) {
-    return Params{ctx.get(MIN_POS, c),  ctx.get(MAX_POS, c),  ctx.get(MAX_SPEED, c),
-                  ctx.get(GOAL_POS, c), ctx.get(GOAL_VEL, c), ctx.get(POWER, c)};
+    return Params{ctx.get(MIN_POS, c),    ctx.get(MAX_POS, c),    ctx.get(MAX_SPEED, c),  ctx.get(GOAL_POS, c),
+                  ctx.get(GOAL_VEL, c),   ctx.get(POWER, c),      ctx.get(MINP_START, c), ctx.get(MAXP_START, c),
+                  ctx.get(MINV_START, c), ctx.get(MAXV_START, c)};
   }
 
   __device__ static __forceinline__ void prepare(const float (&)[S], Aux&) {}
@@ -434,10 +446,9 @@ struct MountainCarCont {
   }
 
   // carl_mountaincarcontinuous.py:57-77
-  template <class Ctx>
-  __device__ static __forceinline__ void reset(const Ctx& ctx, int c, const u32x4& w, float (&s)[S]) {
-    s[0] = uniform_between(ctx.get(MINP_START, c), ctx.get(MAXP_START, c), w.x);
-    s[1] = uniform_between(ctx.get(MINV_START, c), ctx.get(MAXV_START, c), w.y);
+  __device__ static __forceinline__ void reset(const Params& p, const u32x4& w, float (&s)[S]) {
+    s[0] = uniform_between(p.minp_start, p.maxp_start, w.x);
+    s[1] = uniform_between(p.minv_start, p.maxv_start, w.y);
   }
 };
 

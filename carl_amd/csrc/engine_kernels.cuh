@@ -29,17 +29,28 @@ __device__ __forceinline__ ctx_t<LDS> make_ctx(const carl_batch_t& b, float* lds
 
 // Reset of one lane: selector advance -> init-state draw -> context observation.
 // carl/envs/carl_env.py:245-274 + the family's reset override.
+// `p` holds the parameters of context `cidx` on entry; they are re-gathered (and the lane's
+// context observation rewritten) only when the selector moves the lane to another context
+// (`force`: first reset).  With a static selector a reset therefore reads no memory at all.
+// Returns true when memory was read.
 template <class Fam, class Ctx>
-__device__ __forceinline__ void reset_lane(const carl_batch_t& b, const Ctx& ctx, int lane, uint64_t glane,
-                                           int& cidx, uint32_t& episode, float (&s)[Fam::S]) {
+__device__ __forceinline__ bool reset_lane(const carl_batch_t& b, const Ctx& ctx, int lane, uint64_t glane,
+                                           int& cidx, uint32_t& episode, typename Fam::Params& p,
+                                           float (&s)[Fam::S], bool force) {
+  const int old = cidx;
   cidx = select_context(b, cidx, glane, episode);
-  const u32x4 w = lane_words(b.seed, glane, episode, kSubInit);
-  Fam::reset(ctx, cidx, w, s);
-  episode += 1u;
-  if (b.ctx_obs != nullptr) {
-    for (int k = 0; k < b.n_ctx_obs; ++k)
-      b.ctx_obs[(size_t)k * b.n_lanes + lane] = ctx.get(b.ctx_obs_feat[k], cidx);
+  const bool changed = force || (cidx != old);
+  if (changed) {
+    p = Fam::load(ctx, cidx, b.flags);
+    if (b.ctx_obs != nullptr) {
+      for (int k = 0; k < b.n_ctx_obs; ++k)
+        b.ctx_obs[(size_t)k * b.n_lanes + lane] = ctx.get(b.ctx_obs_feat[k], cidx);
+    }
   }
+  const u32x4 w = lane_words(b.seed, glane, episode, kSubInit);
+  Fam::reset(p, w, s);
+  episode += 1u;
+  return changed;
 }
 
 // -------------------------------- reset -------------------------------------------
@@ -60,7 +71,8 @@ __global__ void __launch_bounds__(256) reset_kernel(const carl_batch_t b, const 
     int cidx = b.ctx_idx[lane];
     uint32_t episode = b.episode[lane];
     float s[Fam::S];
-    reset_lane<Fam>(b, ctx, lane, glane, cidx, episode, s);
+    typename Fam::Params p;
+    reset_lane<Fam>(b, ctx, lane, glane, cidx, episode, p, s, true);
 #pragma unroll
     for (int j = 0; j < Fam::S; ++j) b.state[(size_t)j * b.n_lanes + lane] = s[j];
     b.elapsed[lane] = 0;
@@ -131,12 +143,13 @@ __device__ __forceinline__ void finish_episodes(const carl_batch_t& b, const Ctx
   log_finished(b, done, glane, fin_ret, fin_len);
   if ((b.flags & CARL_FLAG_AUTORESET) && done) {
     if (final_obs != nullptr) store_obs<Fam::D>(final_obs, 0, o);
+    bool loaded = false;
     if (!r.episode_valid) {
       r.episode = b.episode[lane];
       r.episode_valid = true;
+      loaded = true;
     }
-    reset_lane<Fam>(b, ctx, lane, glane, r.cidx, r.episode, r.s);
-    r.p = Fam::load(ctx, r.cidx, b.flags);
+    loaded |= reset_lane<Fam>(b, ctx, lane, glane, r.cidx, r.episode, r.p, r.s, false);
     r.elapsed = 0;
     r.ep_return = 0.0f;
     r.n_new_calls += 1;
@@ -145,20 +158,27 @@ __device__ __forceinline__ void finish_episodes(const carl_batch_t& b, const Ctx
     // Every value this path loaded from memory must have ARRIVED before control returns
     // to the step loop: otherwise the compiler parks the matching `s_waitcnt vmcnt(0)`
     // at the loop head, where it also drains the previous step's stores on EVERY
-    // iteration (one wave per SIMD => a full store round trip per step).
-    settle(r.p);
-    settle(r.s);
-    settle(r.aux);
-    settle(r.cidx);
-    settle(r.episode);
+    // iteration (one wave per SIMD => a full store round trip per step).  Only when
+    // something WAS loaded: a static-selector reset after the lane's first one reads
+    // nothing, and must not pay the drain either.
+    if (loaded) {
+      settle(r.p);
+      settle(r.s);
+      settle(r.aux);
+      settle(r.cidx);
+      settle(r.episode);
+    }
   }
 }
 
 // One step of one lane.  `cur` points at this step's output records for this lane.
-template <class Fam, class Ctx>
+// ALL_ACTIVE: the whole wave is inside the batch (every full workgroup), so the per-step
+// `if (active)` exec-mask dance disappears from the loop.
+template <class Fam, class Ctx, bool ALL_ACTIVE = false>
 __device__ __forceinline__ void step_lane(const carl_batch_t& b, const Ctx& ctx, const Cursors<Fam>& cur,
-                                          int max_steps, bool active, int lane, uint64_t glane,
+                                          int max_steps, bool active_in, int lane, uint64_t glane,
                                           typename Fam::Action action, LaneRegs<Fam>& r) {
+  const bool active = ALL_ACTIVE || active_in;
   bool done = false;
   float o[Fam::D];
   if (active) {
@@ -338,8 +358,14 @@ __global__ void __launch_bounds__(kRolloutThreads) rollout_kernel(const carl_bat
   Cursors<Fam> cur = make_cursors<Fam>(io, active ? lane : 0);
   if (loader)
     stage_actions<AStore, Action>(act_buf, act, n, lane_base, 0, n_steps);
-  else if (active)
+  else if (active) {
     load_lane<Fam>(b, ctx, lane, r);
+    if (!r.episode_valid) {  // a T-step rollout will reset: fetch the RNG counter up front so
+      r.episode = b.episode[lane];  // that no reset inside the loop has to wait on memory
+      r.episode_valid = true;
+      settle(r.episode);
+    }
+  }
   __syncthreads();
   int buf = 0;
   for (int t0 = 0; t0 < n_steps; t0 += kActChunk, buf ^= 1) {
@@ -352,11 +378,20 @@ __global__ void __launch_bounds__(kRolloutThreads) rollout_kernel(const carl_bat
       const int steps = min(kActChunk, n_steps - t0);
 #ifndef CARL_EXP_NO_ACTIONS
       Action a_next = my[0];
-      for (int u = 0; u < steps; ++u) {
-        const Action a = a_next;
-        a_next = my[min(u + 1, kActChunk - 1) * kRolloutLanes];  // LDS read one step ahead
-        step_lane<Fam>(b, ctx, cur, max_steps, active, lane, glane, a, r);
-        cur.advance(n);
+      if (lane_base + kRolloutLanes <= b.n_lanes) {  // full workgroup: no per-step predicate
+        for (int u = 0; u < steps; ++u) {
+          const Action a = a_next;
+          a_next = my[min(u + 1, kActChunk - 1) * kRolloutLanes];  // LDS read one step ahead
+          step_lane<Fam, ctx_t<LDS>, true>(b, ctx, cur, max_steps, true, lane, glane, a, r);
+          cur.advance(n);
+        }
+      } else {
+        for (int u = 0; u < steps; ++u) {
+          const Action a = a_next;
+          a_next = my[min(u + 1, kActChunk - 1) * kRolloutLanes];
+          step_lane<Fam>(b, ctx, cur, max_steps, active, lane, glane, a, r);
+          cur.advance(n);
+        }
       }
 #else  // ablation: no LDS action reads
       (void)my;

@@ -16,10 +16,6 @@
 namespace carl {
 
 __device__ __forceinline__ void sincos_fast(float x, float& sn, float& cs) {
-  if (__builtin_expect(!(fabsf(x) <= 1.0e5f), 0)) {  // also catches NaN/inf
-    sincosf(x, &sn, &cs);
-    return;
-  }
   const float two_over_pi = 0x1.45f306p-1f;
   const float hi = 0x1.921fb6p+0f, mid = -0x1.777a5cp-25f, lo = -0x1.ee59dap-50f;
   const float k = rintf(x * two_over_pi);
@@ -39,6 +35,14 @@ __device__ __forceinline__ void sincos_fast(float x, float& sn, float& cs) {
   const float s2 = (q & 1) ? C : S, c2 = (q & 1) ? S : C;
   sn = (q & 2) ? -s2 : s2;
   cs = ((q + 1) & 2) ? -c2 : c2;
+  // huge / non-finite arguments: library path.  Tested with ONE wave-uniform branch (ballot)
+  // after the unconditional fast path -- an exec-masked if/else around the fast path costs
+  // ~8 scalar instructions per call, which matters when a single wave issues one
+  // instruction per 4-cycle slot.
+  const bool big = !(fabsf(x) <= 1.0e5f);  // also catches NaN/inf
+  if (__builtin_expect(__ballot(big) != 0ull, 0)) {
+    if (big) sincosf(x, &sn, &cs);
+  }
 }
 
 __device__ __forceinline__ void sincos_fast(double x, double& sn, double& cs) {
