@@ -123,6 +123,37 @@ struct Cursors {
     trunc += n;
     if (final_obs != nullptr) final_obs += n * Fam::D;
   }
+  // output-sink interface of step_lane
+  __device__ __forceinline__ void put_reward(float r) const { *reward = r; }
+  __device__ __forceinline__ void put_flags(bool te, bool tr) const {
+    *term = (uint8_t)te;
+    *trunc = (uint8_t)tr;
+  }
+  __device__ __forceinline__ void put_obs(const float (&o)[Fam::D]) const { store_obs<Fam::D>(obs, 0, o); }
+  __device__ __forceinline__ float* final_obs_ptr() const { return final_obs; }
+};
+
+// LDS output sink of the staged rollout: a step's records of one workgroup, laid out exactly
+// like the workgroup's slice of the HBM arrays ([256][D] obs | [256] reward | [256] term |
+// [256] trunc), so the storer wave can drain them with 16-byte stores.
+template <class Fam>
+struct LdsSink {
+  static constexpr int kObsBytes = 256 * Fam::D * 4;
+  static constexpr int kStepBytes = kObsBytes + 256 * 4 + 256 + 256;
+  char* step_base;   // this step's record block in LDS
+  float* final_obs;  // HBM cursor for terminal observations (cold path stores directly), nullable
+  int tid;
+  __device__ __forceinline__ void put_reward(float r) const {
+    reinterpret_cast<float*>(step_base + kObsBytes)[tid] = r;
+  }
+  __device__ __forceinline__ void put_flags(bool te, bool tr) const {
+    reinterpret_cast<uint8_t*>(step_base + kObsBytes + 1024)[tid] = (uint8_t)te;
+    reinterpret_cast<uint8_t*>(step_base + kObsBytes + 1280)[tid] = (uint8_t)tr;
+  }
+  __device__ __forceinline__ void put_obs(const float (&o)[Fam::D]) const {
+    store_obs<Fam::D>(reinterpret_cast<float*>(step_base), (size_t)tid, o);
+  }
+  __device__ __forceinline__ float* final_obs_ptr() const { return final_obs; }
 };
 
 // The rarely-taken part of a step, entered only by wavefronts in which some lane just
@@ -174,8 +205,8 @@ __device__ __forceinline__ void finish_episodes(const carl_batch_t& b, const Ctx
 // One step of one lane.  `cur` points at this step's output records for this lane.
 // ALL_ACTIVE: the whole wave is inside the batch (every full workgroup), so the per-step
 // `if (active)` exec-mask dance disappears from the loop.
-template <class Fam, class Ctx, bool ALL_ACTIVE = false>
-__device__ __forceinline__ void step_lane(const carl_batch_t& b, const Ctx& ctx, const Cursors<Fam>& cur,
+template <class Fam, class Ctx, bool ALL_ACTIVE = false, class Sink = Cursors<Fam>>
+__device__ __forceinline__ void step_lane(const carl_batch_t& b, const Ctx& ctx, const Sink& cur,
                                           int max_steps, bool active_in, int lane, uint64_t glane,
                                           typename Fam::Action action, LaneRegs<Fam>& r) {
   const bool active = ALL_ACTIVE || active_in;
@@ -192,19 +223,18 @@ __device__ __forceinline__ void step_lane(const carl_batch_t& b, const Ctx& ctx,
     r.ep_return += reward;
     Fam::observe(r.s, r.aux, o);
 #ifndef CARL_EXP_NO_REWARD_STORE  // CARL_EXP_*: ablation builds for profiling only
-    *cur.reward = reward;
+    cur.put_reward(reward);
 #else
     asm volatile("" ::"v"(reward));
 #endif
 #ifndef CARL_EXP_NO_FLAG_STORES
-    *cur.term = (uint8_t)terminated;
-    *cur.trunc = (uint8_t)truncated;
+    cur.put_flags(terminated, truncated);
 #endif
     done = terminated | truncated;
   }
-  if (__builtin_expect(__ballot(done) != 0ull, 0)) finish_episodes<Fam>(b, ctx, done, lane, glane, cur.final_obs, o, r);
+  if (__builtin_expect(__ballot(done) != 0ull, 0)) finish_episodes<Fam>(b, ctx, done, lane, glane, cur.final_obs_ptr(), o, r);
 #ifndef CARL_EXP_NO_OBS_STORE
-  if (active) store_obs<Fam::D>(cur.obs, 0, o);
+  if (active) cur.put_obs(o);
 #else
 #pragma unroll
   for (int d = 0; d < Fam::D; ++d) asm volatile("" ::"v"(o[d]));
@@ -307,7 +337,7 @@ __host__ __device__ constexpr size_t rollout_action_lds_bytes() {
 
 // loader wave: actions of steps [t0, t0 + kActChunk) for this workgroup's 256 lanes.
 // A step's 256 actions are 1 KiB contiguous in HBM: one 16-byte load per loader lane.
-template <class AStore, class Action>
+template <class AStore, class Action, int CHUNK = kActChunk>
 __device__ __forceinline__ void stage_actions(Action* buf, const AStore* __restrict__ act, size_t n, int lane_base,
                                               int t0, int n_steps) {
   const int l = threadIdx.x - kRolloutLanes;  // 0..63
@@ -315,21 +345,21 @@ __device__ __forceinline__ void stage_actions(Action* buf, const AStore* __restr
   if constexpr (std::is_same_v<AStore, Action>) {
     // wave-uniform fast path: whole workgroup in range, rows 16-byte aligned
     // and a full chunk
-    if ((n % 4 == 0) && (lane_base + kRolloutLanes <= (int)n) && (t0 + kActChunk <= n_steps)) {
+    if ((n % 4 == 0) && (lane_base + kRolloutLanes <= (int)n) && (t0 + CHUNK <= n_steps)) {
       using V = std::conditional_t<std::is_same_v<Action, float>, float4, int4>;
-      V tmp[kActChunk];
+      V tmp[CHUNK];
       const V* src = reinterpret_cast<const V*>(act + (size_t)t0 * n + first);
       const size_t row_v = n / 4;
       // all loads of the chunk in flight together, then all LDS writes
 #pragma unroll
-      for (int u = 0; u < kActChunk; ++u) tmp[u] = src[(size_t)u * row_v];
+      for (int u = 0; u < CHUNK; ++u) tmp[u] = src[(size_t)u * row_v];
 #pragma unroll
-      for (int u = 0; u < kActChunk; ++u) *reinterpret_cast<V*>(buf + u * kRolloutLanes + 4 * l) = tmp[u];
+      for (int u = 0; u < CHUNK; ++u) *reinterpret_cast<V*>(buf + u * kRolloutLanes + 4 * l) = tmp[u];
       return;
     }
   }
 #pragma unroll 1
-  for (int u = 0; u < kActChunk && t0 + u < n_steps; ++u) {  // ragged tail / int64 actions
+  for (int u = 0; u < CHUNK && t0 + u < n_steps; ++u) {  // ragged tail / int64 actions
     const AStore* row = act + (size_t)(t0 + u) * n;
     Action* dst = buf + u * kRolloutLanes + 4 * l;
 #pragma unroll
@@ -406,6 +436,112 @@ __global__ void __launch_bounds__(kRolloutThreads) rollout_kernel(const carl_bat
 #endif
   }
   if (active) store_lane<Fam>(b, lane, r);
+}
+
+// -------------------------------- rollout, LDS-staged outputs -----------------------
+// Measured on the direct-store kernel (profiles/r01b + ablations): the four per-step store
+// instructions of a compute wave (dwordx3 / dword / byte / byte, 64 lane addresses each) cost
+// ~27 % of the step at 65 536 lanes and cap the kernel at 3.3 TB/s at 1 M lanes, against
+// 6.9 TB/s for a plain fill: the per-CU address path is paid per lane address, not per byte.
+// Here the compute waves write their records into LDS (ds_write, no address VGPR arithmetic)
+// and the workgroup's fifth wave -- already streaming actions in -- also streams the records
+// out: a step's records of 256 lanes are contiguous in HBM, so it drains them with 16-byte
+// per-lane stores (1 KiB per instruction): 6 wide stores per workgroup-step instead of 16
+// narrow ones.  Double-buffered in chunks of kStageChunk steps, one barrier per chunk.
+constexpr int kStageChunk = 8;
+
+template <class Fam>
+__host__ __device__ constexpr size_t rollout_staged_lds_bytes() {
+  return (size_t)2 * kStageChunk * (LdsSink<Fam>::kStepBytes + kRolloutLanes * sizeof(float));
+}
+
+// storer half of the fifth wave: records of steps [t0, t0 + steps) from LDS to HBM
+template <class Fam>
+__device__ __forceinline__ void drain_records(const char* buf, const carl_step_io_t& io, size_t n, int lane_base,
+                                              int t0, int steps) {
+  using SK = LdsSink<Fam>;
+  const int l = threadIdx.x - kRolloutLanes;  // 0..63
+  for (int u = 0; u < steps; ++u) {
+    const char* rec = buf + (size_t)u * SK::kStepBytes;
+    const size_t row = (size_t)(t0 + u) * n + lane_base;
+    char* g_obs = reinterpret_cast<char*>(io.obs + row * Fam::D);
+#pragma unroll
+    for (int off = 0; off < SK::kObsBytes; off += 1024)
+      *reinterpret_cast<float4*>(g_obs + off + 16 * l) = *reinterpret_cast<const float4*>(rec + off + 16 * l);
+    *reinterpret_cast<float4*>(reinterpret_cast<char*>(io.reward + row) + 16 * l) =
+        *reinterpret_cast<const float4*>(rec + SK::kObsBytes + 16 * l);
+    if (l < 16) {
+      *reinterpret_cast<float4*>(io.terminated + row + 16 * l) =
+          *reinterpret_cast<const float4*>(rec + SK::kObsBytes + 1024 + 16 * l);
+    } else if (l < 32) {
+      *reinterpret_cast<float4*>(io.truncated + row + 16 * (l - 16)) =
+          *reinterpret_cast<const float4*>(rec + SK::kObsBytes + 1280 + 16 * (l - 16));
+    }
+  }
+}
+
+// Preconditions (checked by the host): n_lanes % 256 == 0, global context table.
+template <class Fam, bool A64>
+__global__ void __launch_bounds__(kRolloutThreads) rollout_staged_kernel(const carl_batch_t b, const carl_step_io_t io,
+                                                                         const int n_steps) {
+  extern __shared__ float lds_dyn[];
+  using AStore = action_store_t<Fam, A64>;
+  using Action = typename Fam::Action;
+  using SK = LdsSink<Fam>;
+  Action* act_buf = reinterpret_cast<Action*>(lds_dyn);  // [2][kStageChunk][256]
+  char* out_buf = reinterpret_cast<char*>(lds_dyn) + (size_t)2 * kStageChunk * kRolloutLanes * sizeof(float);
+  const GlobalCtx ctx{b.ctx_table, b.ctx_stride};
+  const bool loader = threadIdx.x >= kRolloutLanes;
+  const int lane_base = blockIdx.x * kRolloutLanes;
+  const int lane = lane_base + (loader ? 0 : (int)threadIdx.x);
+  const uint64_t glane = (uint64_t)(b.lane_offset + lane);
+  const size_t n = (size_t)b.n_lanes;
+  const int max_steps = b.max_episode_steps;
+  const AStore* act = static_cast<const AStore*>(io.action);
+  LaneRegs<Fam> r{};
+  float* final_obs = (io.final_obs != nullptr && !loader) ? io.final_obs + (size_t)lane * Fam::D : nullptr;
+  if (loader) {
+    stage_actions<AStore, Action, kStageChunk>(act_buf, act, n, lane_base, 0, n_steps);
+  } else {
+    load_lane<Fam>(b, ctx, lane, r);
+    if (!r.episode_valid) {
+      r.episode = b.episode[lane];
+      r.episode_valid = true;
+      settle(r.episode);
+    }
+  }
+  __syncthreads();
+  int buf = 0;
+  for (int t0 = 0; t0 < n_steps; t0 += kStageChunk, buf ^= 1) {
+    const int steps = min(kStageChunk, n_steps - t0);
+    if (loader) {
+      if (t0 + kStageChunk < n_steps)
+        stage_actions<AStore, Action, kStageChunk>(act_buf + (buf ^ 1) * kStageChunk * kRolloutLanes, act, n,
+                                                   lane_base, t0 + kStageChunk, n_steps);
+      if (t0 > 0)  // the previous chunk's records (always a full chunk)
+        drain_records<Fam>(out_buf + (size_t)(buf ^ 1) * kStageChunk * SK::kStepBytes, io, n, lane_base,
+                           t0 - kStageChunk, kStageChunk);
+    } else {
+      const Action* my = act_buf + buf * kStageChunk * kRolloutLanes + threadIdx.x;
+      char* rec = out_buf + (size_t)buf * kStageChunk * SK::kStepBytes;
+      Action a_next = my[0];
+      for (int u = 0; u < steps; ++u) {
+        const Action a = a_next;
+        a_next = my[min(u + 1, kStageChunk - 1) * kRolloutLanes];
+        const SK sink{rec + (size_t)u * SK::kStepBytes, final_obs, (int)threadIdx.x};
+        step_lane<Fam, GlobalCtx, true, SK>(b, ctx, sink, max_steps, true, lane, glane, a, r);
+        if (final_obs != nullptr) final_obs += n * Fam::D;
+      }
+    }
+    __syncthreads();
+  }
+  if (loader) {  // records of the last chunk
+    const int last_t0 = ((n_steps - 1) / kStageChunk) * kStageChunk;
+    drain_records<Fam>(out_buf + (size_t)(buf ^ 1) * kStageChunk * SK::kStepBytes, io, n, lane_base, last_t0,
+                       n_steps - last_t0);
+  } else {
+    store_lane<Fam>(b, lane, r);
+  }
 }
 
 // -------------------------------- done-mask compaction ------------------------------

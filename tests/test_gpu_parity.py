@@ -316,6 +316,35 @@ def test_rollout_equals_repeated_step_bit_exact(fam, device):
     assert k1 == k2
 
 
+@pytest.mark.parametrize("fam", range(5), ids=O.FAMILY_NAMES)
+@pytest.mark.parametrize("T", [1, 7, 8, 9, 37])
+def test_staged_rollout_equals_repeated_step_bit_exact(fam, T, device):
+    """n % 256 == 0 takes the LDS-staged-output kernel (records drained by the loader/storer
+    wave with 16-byte stores); chunk boundaries (8 steps) and ragged tails must not matter.
+    int64 actions exercise the converting loader path."""
+    rng = np.random.default_rng(fam * 10 + T)
+    n, n_ctx = 1024, 1024  # lane <-> context identity, global table
+    table = random_table(fam, rng, n_ctx)
+    a_np = random_actions(fam, rng, (T, n))
+    acts = torch.as_tensor(a_np, device=device)
+    if fam not in O.CONTINUOUS and T % 2 == 1:
+        acts = acts.to(torch.int64)
+    kw = dict(selector=O.SEL_STATIC, seed=3, max_episode_steps=5, ctx_idx0=np.arange(n))
+    e1 = _engine(fam, table, n, device, **kw)
+    e2 = _engine(fam, table, n, device, **kw)
+    e1.reset()
+    e2.reset()
+    out = e1.rollout(acts, e1.alloc_rollout(T, final_obs=True))
+    for t in range(T):
+        obs, rew, term, trunc = e2.step(acts[t])
+        assert torch.equal(out["obs"][t], obs) and torch.equal(out["reward"][t], rew)
+        assert torch.equal(out["terminated"][t], term) and torch.equal(out["truncated"][t], trunc)
+        d = (term | trunc).bool()
+        assert torch.equal(out["final_obs"][t][d], e2.final_obs[d])
+    for name in ("state", "elapsed", "ctx_idx", "episode", "n_calls", "ep_return", "episodes_done"):
+        assert torch.equal(getattr(e1, name), getattr(e2, name)), name
+
+
 def test_lds_staged_context_table_matches_global_path(device):
     """C << N stages the [F, C] table in LDS; must be bit-identical to the gather path"""
     fam = O.ACROBOT
