@@ -15,6 +15,7 @@ _LAZY = {
     "CARLMountainCar": "carl_amd.envs.gymnasium.classic_control",
     "CARLMountainCarContinuous": "carl_amd.envs.gymnasium.classic_control",
     "CARLBraxAnt": "carl_amd.envs.brax",
+    "CARLBraxHalfcheetah": "carl_amd.envs.brax",
     "VecEngine": "carl_amd.engine",
 }
 

@@ -171,6 +171,7 @@ class BraxSys(C.Structure):
         ("coll_link", _i * BRAX_MAX_COLL), ("coll_pos", (_f * 3) * BRAX_MAX_COLL),
         ("coll_radius", _f * BRAX_MAX_COLL),
         ("init_q", _f * BRAX_MAX_Q),
+        ("n_slide", _i * BRAX_MAX_LINKS), ("slide_axis", ((_f * 3) * 2) * BRAX_MAX_LINKS),
         ("ctx", BraxCtxMap),
     ]
 

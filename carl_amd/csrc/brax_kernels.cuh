@@ -135,6 +135,39 @@ __device__ __forceinline__ float twist_angle(qt rel) {  // hinge about the joint
   return 2.0f * atan2f(rel.x, rel.w);
 }
 
+// the static world as a parent body (planar roots are jointed to it)
+__device__ __forceinline__ Body world_body() {
+  return Body{V(0, 0, 0), qt{1, 0, 0, 0}, V(0, 0, 0), V(0, 0, 0)};
+}
+
+// joint geometry shared by joints.resolve and inverse kinematics
+struct JointGeom {
+  v3 A_c, A_p, vA_c, vA_p, x_c, x_p, wrel;
+  float theta, thetadot;
+};
+
+__device__ __forceinline__ JointGeom joint_geometry(const carl_brax_sys_t& s, int i, const Body& bc, const Body& bp) {
+  JointGeom g;
+  const int P = s.parent[i];
+  const v3 a = f3(s.joint_pos[i]);
+  const qt lrot = f4(s.link_rot[i]), jr = f4(s.joint_rot[i]);
+  const v3 com_p = (P < 0) ? V(0, 0, 0) : f3(s.com[P]);
+  const v3 o_c = bc.p - qrot(bc.r, f3(s.com[i]));
+  const v3 o_p = bp.p - qrot(bp.r, com_p);
+  g.A_c = o_c + qrot(bc.r, a);
+  g.A_p = o_p + qrot(bp.r, f3(s.link_pos[i]) + qrot(lrot, a));  // at zero slide
+  g.vA_c = bc.v + cross(bc.w, g.A_c - bc.p);
+  g.vA_p = bp.v + cross(bp.w, g.A_p - bp.p);
+  const qt rc = qmul(bc.r, jr);
+  const qt rp = qmul(qmul(bp.r, lrot), jr);
+  g.x_c = qrot(rc, V(1, 0, 0));
+  g.x_p = qrot(rp, V(1, 0, 0));
+  g.theta = twist_angle(qmul(qconj(rp), rc));
+  g.wrel = bc.w - bp.w;
+  g.thetadot = dot(g.x_c, g.wrel);
+  return g;
+}
+
 // ---- one brax.spring.pipeline.step ---------------------------------------------------------
 __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const LaneCtx& c, const Lds& m) {
   const int L = s.n_links;
@@ -142,35 +175,36 @@ __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const LaneCtx&
   // spring.joints.resolve
   for (int i = 0; i < L; ++i) {
     const int P = s.parent[i];
-    if (P < 0) continue;
-    const Body bc = m.body(i), bp = m.body(P);
-    const v3 a = f3(s.joint_pos[i]);
-    const qt lrot = f4(s.link_rot[i]), jr = f4(s.joint_rot[i]);
-    const v3 o_c = bc.p - qrot(bc.r, f3(s.com[i]));
-    const v3 o_p = bp.p - qrot(bp.r, f3(s.com[P]));
-    const v3 A_c = o_c + qrot(bc.r, a);
-    const v3 A_p = o_p + qrot(bp.r, f3(s.link_pos[i]) + qrot(lrot, a));
-    const v3 vA_c = bc.v + cross(bc.w, A_c - bc.p);
-    const v3 vA_p = bp.v + cross(bp.w, A_p - bp.p);
+    if (P < 0 && s.n_link_dof[i] == 6) continue;
+    const Body bc = m.body(i);
+    const Body bp = (P < 0) ? world_body() : m.body(P);
+    const JointGeom g = joint_geometry(s, i, bc, bp);
     const float kp = s.k_pos[i] * c.stiffness_scale;
-    const v3 f = (A_p - A_c) * kp + (vA_p - vA_c) * s.k_vel[i];
-    const qt rc = qmul(bc.r, jr);
-    const qt rp = qmul(qmul(bp.r, lrot), jr);
-    const v3 x_c = qrot(rc, V(1, 0, 0)), x_p = qrot(rp, V(1, 0, 0));
-    v3 t = cross(x_c, x_p) * kp;
-    const float theta = twist_angle(qmul(qconj(rp), rc));
-    const v3 wrel = bc.w - bp.w;
-    const float thetadot = dot(x_c, wrel);
-    const int d = s.dof_start[i];
-    float ta = m.at(m.lay.tau + d) - s.dof_damping[d] * thetadot - s.dof_stiffness[d] * theta;
-    if (theta < s.dof_lo[d]) ta += s.k_limit[i] * (s.dof_lo[d] - theta);
-    if (theta > s.dof_hi[d]) ta -= s.k_limit[i] * (theta - s.dof_hi[d]);
-    t = t + x_c * ta - wrel * s.k_ang_damp[i];
-    const int fc = m.lay.force + 6 * i, fp = m.lay.force + 6 * P;
+    v3 e = g.A_p - g.A_c, ev = g.vA_p - g.vA_c;
+    v3 f = V(0, 0, 0);
+    const int ns = s.n_slide[i], d0 = s.dof_start[i];
+    for (int k = 0; k < ns; ++k) {  // prismatic dofs: free along the axis, own spring/damper/force
+      const v3 ax = qrot(bp.r, f3(s.slide_axis[i][k]));
+      const float qk = -dot(e, ax), qdk = -dot(ev, ax);
+      e = e + ax * qk;
+      ev = ev + ax * qdk;
+      f = f + ax * (m.at(m.lay.tau + d0 + k) - s.dof_damping[d0 + k] * qdk - s.dof_stiffness[d0 + k] * qk);
+    }
+    f = f + e * kp + ev * s.k_vel[i];
+    v3 t = cross(g.x_c, g.x_p) * kp;
+    const int d = d0 + ns;
+    float ta = m.at(m.lay.tau + d) - s.dof_damping[d] * g.thetadot - s.dof_stiffness[d] * g.theta;
+    if (g.theta < s.dof_lo[d]) ta += s.k_limit[i] * (s.dof_lo[d] - g.theta);
+    if (g.theta > s.dof_hi[d]) ta -= s.k_limit[i] * (g.theta - s.dof_hi[d]);
+    t = t + g.x_c * ta - g.wrel * s.k_ang_damp[i];
+    const int fc = m.lay.force + 6 * i;
     m.add3(fc, f);
-    m.add3(fc + 3, cross(A_c - bc.p, f) + t);
-    m.add3(fp, f * -1.0f);
-    m.add3(fp + 3, (cross(A_p - bp.p, f) + t) * -1.0f);
+    m.add3(fc + 3, cross(g.A_c - bc.p, f) + t);
+    if (P >= 0) {
+      const int fp = m.lay.force + 6 * P;
+      m.add3(fp, f * -1.0f);
+      m.add3(fp + 3, (cross(g.A_p - bp.p, f) + t) * -1.0f);
+    }
   }
   // semi-implicit Euler: velocities first
   for (int i = 0; i < L; ++i) {
@@ -233,14 +267,14 @@ __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const LaneCtx&
   }
 }
 
-// kinematics.world_to_joint + inverse -> observation rows (q[2:] ++ qd) in the io staging
+// kinematics.world_to_joint + inverse -> observation rows (q[skip:] ++ qd) in the io staging
 __device__ __forceinline__ void observe(const carl_brax_sys_t& s, const Lds& m) {
-  const int skip = s.exclude_current_positions ? 2 : 0;
+  const int skip = s.exclude_current_positions;
   const int qd0 = s.n_q - skip;  // first qd row in the observation
   for (int i = 0; i < s.n_links; ++i) {
     const int P = s.parent[i];
     const Body b = m.body(i);
-    if (P < 0) {
+    if (P < 0 && s.n_link_dof[i] == 6) {
       const v3 c = qrot(b.r, f3(s.com[i]));
       const v3 o = b.p - c;
       const v3 vel = b.v - cross(b.w, c);
@@ -250,12 +284,16 @@ __device__ __forceinline__ void observe(const carl_brax_sys_t& s, const Lds& m) 
       const float dv[6] = {vel.x, vel.y, vel.z, b.w.x, b.w.y, b.w.z};
       for (int k = 0; k < 6; ++k) m.at(m.lay.io + qd0 + s.dof_start[i] + k) = dv[k];
     } else {
-      const Body bp = m.body(P);
-      const qt jr = f4(s.joint_rot[i]);
-      const qt rp = qmul(qmul(bp.r, f4(s.link_rot[i])), jr);
-      const qt rc = qmul(b.r, jr);
-      m.at(m.lay.io + s.q_start[i] - skip) = twist_angle(qmul(qconj(rp), rc));
-      m.at(m.lay.io + qd0 + s.dof_start[i]) = dot(qrot(rc, V(1, 0, 0)), b.w - bp.w);
+      const Body bp = (P < 0) ? world_body() : m.body(P);
+      const JointGeom g = joint_geometry(s, i, b, bp);
+      const int ns = s.n_slide[i];
+      for (int k = 0; k < ns; ++k) {
+        const v3 ax = qrot(bp.r, f3(s.slide_axis[i][k]));
+        if (s.q_start[i] + k >= skip) m.at(m.lay.io + s.q_start[i] + k - skip) = dot(g.A_c - g.A_p, ax);
+        m.at(m.lay.io + qd0 + s.dof_start[i] + k) = dot(g.vA_c - g.vA_p, ax);
+      }
+      if (s.q_start[i] + ns >= skip) m.at(m.lay.io + s.q_start[i] + ns - skip) = g.theta;
+      m.at(m.lay.io + qd0 + s.dof_start[i] + ns) = g.thetadot;
     }
   }
 }
@@ -269,25 +307,33 @@ __device__ __noinline__ void forward_kinematics(const carl_brax_sys_t& s, const 
     qt rot;
     v3 o, vel, ang;
     const int q0 = m.lay.io + s.q_start[i], d0 = m.lay.io + s.n_q + s.dof_start[i];
-    if (P < 0) {
+    if (P < 0 && s.n_link_dof[i] == 6) {
       rot = qnormalize(qt{m.at(q0 + 3), m.at(q0 + 4), m.at(q0 + 5), m.at(q0 + 6)});
       o = V(m.at(q0), m.at(q0 + 1), m.at(q0 + 2));
       vel = V(m.at(d0), m.at(d0 + 1), m.at(d0 + 2));
       ang = V(m.at(d0 + 3), m.at(d0 + 4), m.at(d0 + 5));
     } else {
-      const Body bp = m.body(P);
-      const v3 o_p = m.get3(m.lay.force + 6 * P), ov_p = m.get3(m.lay.force + 6 * P + 3);
+      const Body bp = (P < 0) ? world_body() : m.body(P);
+      const v3 o_p = (P < 0) ? V(0, 0, 0) : m.get3(m.lay.force + 6 * P);
+      const v3 ov_p = (P < 0) ? V(0, 0, 0) : m.get3(m.lay.force + 6 * P + 3);
+      const int ns = s.n_slide[i];
       const qt jr = f4(s.joint_rot[i]), lrot = f4(s.link_rot[i]);
-      const float th = m.at(q0), rate = m.at(d0);
+      const float th = m.at(q0 + ns), rate = m.at(d0 + ns);
       const qt rl = qmul(qmul(jr, qaxis(0, th)), qconj(jr));
       const v3 a = f3(s.joint_pos[i]);
-      const v3 lpos = f3(s.link_pos[i]) + qrot(lrot, a - qrot(rl, a));
+      v3 lpos = f3(s.link_pos[i]) + qrot(lrot, a - qrot(rl, a));
+      v3 slide_vel = V(0, 0, 0);
+      for (int k = 0; k < ns; ++k) {
+        const v3 ax = f3(s.slide_axis[i][k]);
+        lpos = lpos + ax * m.at(q0 + k);
+        slide_vel = slide_vel + qrot(bp.r, ax) * m.at(d0 + k);
+      }
       rot = qmul(bp.r, qmul(lrot, rl));
       o = o_p + qrot(bp.r, lpos);
       const v3 anchor_w = o + qrot(rot, a);
       const v3 axis = qrot(qmul(qmul(bp.r, lrot), jr), V(1, 0, 0));
       ang = bp.w + axis * rate;
-      vel = ov_p + cross(bp.w, o - o_p) + cross(axis * rate, o - anchor_w);
+      vel = ov_p + cross(bp.w, o - o_p) + slide_vel + cross(axis * rate, o - anchor_w);
     }
     const int fr = m.lay.force + 6 * i;
     m.at(fr) = o.x; m.at(fr + 1) = o.y; m.at(fr + 2) = o.z;

@@ -174,9 +174,13 @@ int validate_brax(const carl_batch_t* b, const carl_brax_sys_t* sd, const carl_b
       sh->n_q > CARL_BRAX_MAX_Q || sh->n_act > CARL_BRAX_MAX_ACT || sh->n_coll > CARL_BRAX_MAX_COLL ||
       sh->n_frames < 1 || sh->obs_dim < 1)
     return fail(CARL_ERR_INVALID_ARGUMENT, "%s: model table out of range", who);
-  for (int i = 0; i < sh->n_links; ++i)
-    if (sh->parent[i] >= i || (sh->parent[i] >= 0 && sh->n_link_dof[i] != 1))
-      return fail(CARL_ERR_UNSUPPORTED, "%s: link %d: only a free root and single-hinge links are supported", who, i);
+  for (int i = 0; i < sh->n_links; ++i) {
+    const bool free_root = sh->parent[i] < 0 && sh->n_link_dof[i] == 6;
+    const bool hinge = sh->n_slide[i] >= 0 && sh->n_slide[i] <= 2 && sh->n_link_dof[i] - sh->n_slide[i] == 1;
+    if (sh->parent[i] >= i || !(free_root || hinge))
+      return fail(CARL_ERR_UNSUPPORTED,
+                  "%s: link %d: supported joints are a free root, or 0-2 prismatic dofs + one hinge", who, i);
+  }
   if (b->fin_count != nullptr && (b->fin_capacity <= 0 || !b->fin_lane || !b->fin_return || !b->fin_length))
     return fail(CARL_ERR_INVALID_ARGUMENT, "%s: finished-episode log is incomplete", who);
   return 0;

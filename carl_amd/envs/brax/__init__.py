@@ -1,5 +1,6 @@
 # flake8: noqa: F401
 from carl_amd.envs.brax.carl_ant import CARLBraxAnt
 from carl_amd.envs.brax.carl_brax_env import CARLBraxEnv
+from carl_amd.envs.brax.carl_halfcheetah import CARLBraxHalfcheetah
 
-__all__ = ["CARLBraxEnv", "CARLBraxAnt"]
+__all__ = ["CARLBraxEnv", "CARLBraxAnt", "CARLBraxHalfcheetah"]

@@ -52,7 +52,7 @@ def ant_sys(feature_names: list[str] | None = None, reference_compat: bool = Fal
     s.n_frames, s.obs_dim = 10, 27
     s.max_episode_steps = 1000
     s.terminate_when_unhealthy = 1
-    s.exclude_current_positions = 1
+    s.exclude_current_positions = 2  # obs = q[2:] ++ qd
     s.dt = 0.005
     s.gravity_z, s.vel_damping, s.ang_damping = -9.81, 0.0, 0.0
     s.baumgarte_erp, s.elasticity, s.friction = 0.1, 0.0, 1.0
@@ -137,4 +137,95 @@ def _wire_context(s, feature_names, reference_compat, link_ids, mass_defaults):
             m.n_mass = k + 1
 
 
-SYSTEMS = {"ant": ant_sys}
+def _capsule_ends(pos, theta_y, half):
+    """ends of a capsule given MJCF `pos`, `axisangle="0 1 0 theta"` and half-length (local z axis)"""
+    d = np.array([math.sin(theta_y), 0.0, math.cos(theta_y)])
+    p = np.asarray(pos, dtype=np.float64)
+    return p - half * d, p + half * d
+
+
+def halfcheetah_sys(feature_names: list[str] | None = None, reference_compat: bool = False) -> _lib.BraxSys:
+    """Halfcheetah: planar torso (slide x, slide z, hinge y against the world) + 6 hinge links;
+    q 9, qd 9, 6 motors, obs 17 (q[1:] ++ qd).  Geometry, joint ranges / stiffness / damping
+    and gears restated from upstream memory of brax's ``half_cheetah.xml`` (a Gym HalfCheetah
+    derivative) and ``brax/envs/half_cheetah.py`` (spring backend: dt 0.003125 x 16 frames);
+    the spring-constraint constants are this build's choice (CARL's legacy docs list
+    joint_stiffness 15000 for Halfcheetah).  PARITY UNPINNED."""
+    s = _lib.BraxSys()
+    s.env_kind = _lib.BRAX_HALFCHEETAH
+    s.n_links, s.n_q, s.n_dof, s.n_act = 7, 9, 9, 6
+    s.n_frames, s.obs_dim = 16, 17
+    s.max_episode_steps = 1000
+    s.terminate_when_unhealthy = 0
+    s.exclude_current_positions = 1
+    s.dt = 0.003125
+    s.gravity_z, s.vel_damping, s.ang_damping = -9.81, 0.0, 0.0
+    s.baumgarte_erp, s.elasticity, s.friction = 0.1, 0.0, 0.4
+    s.healthy_z_lo, s.healthy_z_hi, s.healthy_reward = -1e9, 1e9, 0.0
+    s.ctrl_cost_weight, s.forward_reward_weight = 0.1, 1.0
+    s.reset_noise_scale, s.reset_vel_scale = 0.1, 0.1
+    ident = (1.0, 0.0, 0.0, 0.0)
+    hinge_y = _axis_quat((0, 1, 0))
+    r = 0.046
+    # (name, parent, body pos, range, stiffness, damping, geoms[(pos, theta, half)])
+    links = [
+        ("torso", -1, (0.0, 0.0, 0.7), None, 0.0, 0.0, [((0.0, 0, 0.0), math.pi / 2, 0.5), ((0.6, 0, 0.1), 0.87, 0.15)]),
+        ("bthigh", 0, (-0.5, 0, 0), (-0.52, 1.05), 240.0, 6.0, [((0.1, 0, -0.13), -3.8, 0.145)]),
+        ("bshin", 1, (0.16, 0, -0.25), (-0.785, 0.785), 180.0, 4.5, [((-0.14, 0, -0.07), -2.03, 0.15)]),
+        ("bfoot", 2, (-0.28, 0, -0.14), (-0.4, 0.785), 120.0, 3.0, [((0.03, 0, -0.097), -0.27, 0.094)]),
+        ("fthigh", 0, (0.5, 0, 0), (-1.0, 0.7), 180.0, 4.5, [((-0.07, 0, -0.12), 0.52, 0.133)]),
+        ("fshin", 4, (-0.14, 0, -0.24), (-1.2, 0.87), 120.0, 3.0, [((0.065, 0, -0.09), -0.6, 0.106)]),
+        ("ffoot", 5, (0.13, 0, -0.18), (-0.5, 0.5), 60.0, 1.5, [((0.045, 0, -0.07), -0.6, 0.07)]),
+    ]
+    coll = []
+    qi = di = 0
+    link_ids, joint_dof = {}, {}
+    for i, (name, parent, pos, rng, stiff, damp, geoms) in enumerate(links):
+        link_ids[name] = i
+        s.parent[i] = parent
+        _set3(s.link_pos, i, pos)
+        _set3(s.link_rot, i, ident)
+        _set3(s.joint_rot, i, hinge_y)
+        ns = 2 if parent < 0 else 0
+        s.n_slide[i], s.n_link_dof[i] = ns, ns + 1
+        s.q_start[i], s.dof_start[i] = qi, di
+        if ns:
+            for k, ax in enumerate([(1.0, 0.0, 0.0), (0.0, 0.0, 1.0)]):
+                for c in range(3):
+                    s.slide_axis[i][k][c] = ax[c]
+            lo, hi = -1e9, 1e9  # rooty is unlimited
+        else:
+            lo, hi = rng
+        d = di + ns
+        s.dof_lo[d], s.dof_hi[d] = lo, hi
+        s.dof_stiffness[d], s.dof_damping[d] = stiff, damp
+        joint_dof[name] = d
+        # centre of mass: capsule-volume weighted mean of the geom centres
+        vols, ctrs = [], []
+        for gpos, th, half in geoms:
+            vols.append(math.pi * r * r * 2 * half + 4.0 / 3.0 * math.pi * r**3)
+            ctrs.append(np.asarray(gpos, dtype=np.float64))
+            e0, e1 = _capsule_ends(gpos, th, half)
+            coll += [(i, e0, r), (i, e1, r)]
+        com = sum(v * c for v, c in zip(vols, ctrs)) / sum(vols)
+        _set3(s.com, i, com)
+        s.mass[i] = 1.0
+        _set3(s.inv_inertia, i, (1.0, 1.0, 1.0))
+        s.k_pos[i], s.k_vel[i], s.k_limit[i], s.k_ang_damp[i] = 15000.0, 100.0, 1000.0, 20.0
+        qi, di = qi + ns + 1, di + ns + 1
+    for k, (name, gear) in enumerate([("bthigh", 120.0), ("bshin", 90.0), ("bfoot", 60.0), ("fthigh", 120.0),
+                                      ("fshin", 60.0), ("ffoot", 30.0)]):
+        s.act_dof[k], s.act_gear[k], s.act_lo[k], s.act_hi[k] = joint_dof[name], gear, -1.0, 1.0
+    s.n_coll = len(coll)
+    for k, (link, pos, rad) in enumerate(coll):
+        s.coll_link[k], s.coll_radius[k] = link, rad
+        _set3(s.coll_pos, k, pos)
+    for i in range(s.n_q):
+        s.init_q[i] = 0.0
+    _wire_context(s, feature_names, reference_compat, link_ids,
+                  {"mass_torso": 10.0, "mass_bthigh": 1.5435146, "mass_bshin": 1.5874476, "mass_bfoot": 1.0953975,
+                   "mass_fthigh": 1.4380753, "mass_fshin": 1.2008368, "mass_ffoot": 0.8845188})
+    return s
+
+
+SYSTEMS = {"ant": ant_sys, "halfcheetah": halfcheetah_sys}

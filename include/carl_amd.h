@@ -227,7 +227,7 @@ typedef struct carl_brax_sys {
   int32_t n_links, n_q, n_dof, n_act, n_coll, n_frames, obs_dim;
   int32_t max_episode_steps;   /* brax EpisodeWrapper episode_length (1000) */
   int32_t terminate_when_unhealthy;
-  int32_t exclude_current_positions;
+  int32_t exclude_current_positions;  /* leading q entries left out of the observation (Ant 2, Halfcheetah 1) */
   int32_t reserved;
   float dt;              /* substep */
   float gravity_z, vel_damping, ang_damping, baumgarte_erp, elasticity, friction;
@@ -235,7 +235,9 @@ typedef struct carl_brax_sys {
   float reset_noise_scale, reset_vel_scale;
   /* links, topological order, parent < child */
   int32_t parent[CARL_BRAX_MAX_LINKS];      /* -1: free root */
-  int32_t n_link_dof[CARL_BRAX_MAX_LINKS];  /* 6 = free, else 1..3 revolute dofs about the joint frame's x,y,z */
+  int32_t n_link_dof[CARL_BRAX_MAX_LINKS];  /* 6 = free root; else n_slide prismatic dofs followed by ONE hinge
+                                               about the joint frame's x axis.  parent -1 with n_link_dof < 6 =
+                                               jointed to the static world (planar roots) */
   int32_t q_start[CARL_BRAX_MAX_LINKS], dof_start[CARL_BRAX_MAX_LINKS];
   float link_pos[CARL_BRAX_MAX_LINKS][3], link_rot[CARL_BRAX_MAX_LINKS][4];   /* child frame in parent frame at q = 0 */
   float joint_pos[CARL_BRAX_MAX_LINKS][3], joint_rot[CARL_BRAX_MAX_LINKS][4]; /* anchor / joint frame in the child frame */
@@ -251,6 +253,8 @@ typedef struct carl_brax_sys {
   int32_t coll_link[CARL_BRAX_MAX_COLL];    /* collision spheres vs the ground plane z = 0 */
   float coll_pos[CARL_BRAX_MAX_COLL][3], coll_radius[CARL_BRAX_MAX_COLL];
   float init_q[CARL_BRAX_MAX_Q];
+  int32_t n_slide[CARL_BRAX_MAX_LINKS];        /* 0..2 prismatic dofs (q order: slides, then the hinge) */
+  float slide_axis[CARL_BRAX_MAX_LINKS][2][3]; /* unit axes in the PARENT frame, mutually orthogonal */
   carl_brax_ctx_map_t ctx;
 } carl_brax_sys_t;
 

@@ -136,13 +136,16 @@ static void store_bodies(const carl_brax_sys_t* s, const body* b, double* st) {
   }
 }
 
+/* the static world as a parent body (planar roots are jointed to it) */
+static const body WORLD = {{0, 0, 0}, {1, 0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+
 /* kinematics.forward + com.from_world: (q, qd) -> per-link COM state */
 static void forward_kinematics(const carl_brax_sys_t* s, const double* q, const double* qd, body* b) {
   v3 org[L_MAX], ovel[L_MAX];
   for (int i = 0; i < s->n_links; ++i) {
     const int P = s->parent[i];
     qt rot; v3 o, vel, ang;
-    if (P < 0) { /* free joint: q = (pos, quat), qd = (vel, ang) in the world frame */
+    if (P < 0 && s->n_link_dof[i] == 6) { /* free joint: q = (pos, quat), qd = (vel, ang), world frame */
       const double* qi = q + s->q_start[i];
       const double* di = qd + s->dof_start[i];
       qt qq = {qi[3], qi[4], qi[5], qi[6]};
@@ -151,29 +154,29 @@ static void forward_kinematics(const carl_brax_sys_t* s, const double* q, const 
       vel = V(di[0], di[1], di[2]);
       ang = V(di[3], di[4], di[5]);
     } else {
+      const body bp = (P < 0) ? WORLD : b[P];
+      const v3 o_p = (P < 0) ? V(0, 0, 0) : org[P];
+      const v3 ov_p = (P < 0) ? V(0, 0, 0) : ovel[P];
+      const int ns = s->n_slide[i];
       const qt jr = f4(s->joint_rot[i]);
-      qt rj = {1, 0, 0, 0};
-      for (int k = 0; k < s->n_link_dof[i]; ++k) rj = qmul(rj, qaxis(k, q[s->q_start[i] + k]));
-      const qt rl = qmul(qmul(jr, rj), qconj(jr)); /* joint rotation in child coordinates */
+      const double th = q[s->q_start[i] + ns], rate = qd[s->dof_start[i] + ns];
+      const qt rl = qmul(qmul(jr, qaxis(0, th)), qconj(jr)); /* hinge rotation in child coordinates */
       const qt lrot = f4(s->link_rot[i]);
       const v3 a = f3(s->joint_pos[i]);
-      /* the anchor stays put: pos = link_pos + link_rot (a - R a) */
-      const v3 lpos = vadd(f3(s->link_pos[i]), qrot(lrot, vsub(a, qrot(rl, a))));
-      rot = qmul(b[P].r, qmul(lrot, rl));
-      o = vadd(org[P], qrot(b[P].r, lpos));
-      ang = b[P].w;
-      vel = vadd(ovel[P], vcross(b[P].w, vsub(o, org[P])));
-      const v3 anchor_w = vadd(o, qrot(rot, a));
-      /* dof k turns about the joint frame's k-th axis as carried by the preceding dofs */
-      qt acc = qmul(qmul(b[P].r, lrot), jr);
-      for (int k = 0; k < s->n_link_dof[i]; ++k) {
-        const v3 ek = V(k == 0, k == 1, k == 2);
-        const v3 axis = qrot(acc, ek);
-        const double rate = qd[s->dof_start[i] + k];
-        ang = vadd(ang, vscale(axis, rate));
-        vel = vadd(vel, vcross(vscale(axis, rate), vsub(o, anchor_w)));
-        acc = qmul(acc, qaxis(k, q[s->q_start[i] + k]));
+      v3 lpos = vadd(f3(s->link_pos[i]), qrot(lrot, vsub(a, qrot(rl, a)))); /* the anchor stays put */
+      v3 slide_vel = V(0, 0, 0);
+      for (int k = 0; k < ns; ++k) {
+        const v3 ax = f3(s->slide_axis[i][k]);
+        lpos = vadd(lpos, vscale(ax, q[s->q_start[i] + k]));
+        slide_vel = vadd(slide_vel, vscale(qrot(bp.r, ax), qd[s->dof_start[i] + k]));
       }
+      rot = qmul(bp.r, qmul(lrot, rl));
+      o = vadd(o_p, qrot(bp.r, lpos));
+      const v3 anchor_w = vadd(o, qrot(rot, a));
+      const v3 axis = qrot(qmul(qmul(bp.r, lrot), jr), V(1, 0, 0));
+      ang = vadd(bp.w, vscale(axis, rate));
+      vel = vadd(vadd(ov_p, vcross(bp.w, vsub(o, o_p))),
+                 vadd(slide_vel, vcross(vscale(axis, rate), vsub(o, anchor_w))));
     }
     org[i] = o; ovel[i] = vel;
     b[i].r = rot; b[i].w = ang;
@@ -183,11 +186,41 @@ static void forward_kinematics(const carl_brax_sys_t* s, const double* q, const 
   }
 }
 
+/* joint geometry shared by inverse kinematics and joints.resolve */
+typedef struct {
+  v3 A_c, A_p, vA_c, vA_p, x_c, x_p, wrel;
+  double theta, thetadot;
+} joint_geom;
+
+static joint_geom joint_geometry(const carl_brax_sys_t* s, int i, const body* bc, const body* bp) {
+  joint_geom g;
+  const int P = s->parent[i];
+  const v3 a = f3(s->joint_pos[i]);
+  const qt lrot = f4(s->link_rot[i]), jr = f4(s->joint_rot[i]);
+  const v3 com_p = (P < 0) ? V(0, 0, 0) : f3(s->com[P]);
+  const v3 o_c = vsub(bc->p, qrot(bc->r, f3(s->com[i])));
+  const v3 o_p = vsub(bp->p, qrot(bp->r, com_p));
+  g.A_c = vadd(o_c, qrot(bc->r, a));
+  g.A_p = vadd(o_p, qrot(bp->r, vadd(f3(s->link_pos[i]), qrot(lrot, a)))); /* at zero slide */
+  g.vA_c = vadd(bc->v, vcross(bc->w, vsub(g.A_c, bc->p)));
+  g.vA_p = vadd(bp->v, vcross(bp->w, vsub(g.A_p, bp->p)));
+  const qt rc = qmul(bc->r, jr);
+  const qt rp = qmul(qmul(bp->r, lrot), jr);
+  g.x_c = qrot(rc, V(1, 0, 0));
+  g.x_p = qrot(rp, V(1, 0, 0));
+  qt rel = qmul(qconj(rp), rc);
+  if (rel.w < 0) { rel.w = -rel.w; rel.x = -rel.x; }
+  g.theta = 2.0 * atan2(rel.x, rel.w); /* twist about the hinge (joint frame x) */
+  g.wrel = vsub(bc->w, bp->w);
+  g.thetadot = vdot(g.x_c, g.wrel);
+  return g;
+}
+
 /* kinematics.world_to_joint + inverse: per-link COM state -> (q, qd) */
 static void inverse_kinematics(const carl_brax_sys_t* s, const body* b, double* q, double* qd) {
   for (int i = 0; i < s->n_links; ++i) {
     const int P = s->parent[i];
-    if (P < 0) {
+    if (P < 0 && s->n_link_dof[i] == 6) {
       const v3 c = qrot(b[i].r, f3(s->com[i]));
       const v3 o = vsub(b[i].p, c);
       const v3 vel = vsub(b[i].v, vcross(b[i].w, c));
@@ -198,16 +231,16 @@ static void inverse_kinematics(const carl_brax_sys_t* s, const body* b, double* 
       di[0] = vel.x; di[1] = vel.y; di[2] = vel.z;
       di[3] = b[i].w.x; di[4] = b[i].w.y; di[5] = b[i].w.z;
     } else {
-      const qt jr = f4(s->joint_rot[i]);
-      const qt rp = qmul(qmul(b[P].r, f4(s->link_rot[i])), jr);
-      const qt rc = qmul(b[i].r, jr);
-      qt rel = qmul(qconj(rp), rc);
-      if (rel.w < 0) { rel.w = -rel.w; rel.x = -rel.x; rel.y = -rel.y; rel.z = -rel.z; }
-      /* single hinge about the joint frame's x axis: twist angle */
-      const double theta = 2.0 * atan2(rel.x, rel.w);
-      q[s->q_start[i]] = theta;
-      const v3 axis = qrot(rc, V(1, 0, 0));
-      qd[s->dof_start[i]] = vdot(axis, vsub(b[i].w, b[P].w));
+      const body bp = (P < 0) ? WORLD : b[P];
+      const joint_geom g = joint_geometry(s, i, &b[i], &bp);
+      const int ns = s->n_slide[i];
+      for (int k = 0; k < ns; ++k) {
+        const v3 ax = qrot(bp.r, f3(s->slide_axis[i][k]));
+        q[s->q_start[i] + k] = vdot(vsub(g.A_c, g.A_p), ax);
+        qd[s->dof_start[i] + k] = vdot(vsub(g.vA_c, g.vA_p), ax);
+      }
+      q[s->q_start[i] + ns] = g.theta;
+      qd[s->dof_start[i] + ns] = g.thetadot;
     }
   }
 }
@@ -225,40 +258,35 @@ static void substep(const carl_brax_sys_t* s, const lane_ctx* c, const double* t
   /* --- spring.joints.resolve ------------------------------------------------------- */
   for (int i = 0; i < L; ++i) {
     const int P = s->parent[i];
-    if (P < 0) continue;
-    const v3 a = f3(s->joint_pos[i]);
-    const qt lrot = f4(s->link_rot[i]);
-    const qt jr = f4(s->joint_rot[i]);
-    const v3 o_c = vsub(b[i].p, qrot(b[i].r, f3(s->com[i])));
-    const v3 o_p = vsub(b[P].p, qrot(b[P].r, f3(s->com[P])));
-    const v3 A_c = vadd(o_c, qrot(b[i].r, a));
-    const v3 A_p = vadd(o_p, qrot(b[P].r, vadd(f3(s->link_pos[i]), qrot(lrot, a))));
-    const v3 vA_c = vadd(b[i].v, vcross(b[i].w, vsub(A_c, b[i].p)));
-    const v3 vA_p = vadd(b[P].v, vcross(b[P].w, vsub(A_p, b[P].p)));
+    if (P < 0 && s->n_link_dof[i] == 6) continue;
+    const body bp = (P < 0) ? WORLD : b[P];
+    const joint_geom g = joint_geometry(s, i, &b[i], &bp);
     const double kp = s->k_pos[i] * c->stiffness_scale;
-    const v3 f = vadd(vscale(vsub(A_p, A_c), kp), vscale(vsub(vA_p, vA_c), s->k_vel[i]));
+    v3 e = vsub(g.A_p, g.A_c), ev = vsub(g.vA_p, g.vA_c);
+    v3 f = V(0, 0, 0);
+    const int ns = s->n_slide[i], d0 = s->dof_start[i];
+    for (int k = 0; k < ns; ++k) { /* prismatic dofs: free along the axis, own spring/damper/force */
+      const v3 ax = qrot(bp.r, f3(s->slide_axis[i][k]));
+      const double qk = -vdot(e, ax), qdk = -vdot(ev, ax);
+      e = vadd(e, vscale(ax, qk));
+      ev = vadd(ev, vscale(ax, qdk));
+      f = vadd(f, vscale(ax, tau[d0 + k] - s->dof_damping[d0 + k] * qdk - s->dof_stiffness[d0 + k] * qk));
+    }
+    f = vadd(f, vadd(vscale(e, kp), vscale(ev, s->k_vel[i])));
     F[i] = vadd(F[i], f);
-    T[i] = vadd(T[i], vcross(vsub(A_c, b[i].p), f));
-    F[P] = vsub(F[P], f);
-    T[P] = vsub(T[P], vcross(vsub(A_p, b[P].p), f));
-    /* angular part */
-    const qt rc = qmul(b[i].r, jr);
-    const qt rp = qmul(qmul(b[P].r, lrot), jr);
-    const v3 x_c = qrot(rc, V(1, 0, 0)), x_p = qrot(rp, V(1, 0, 0));
-    v3 t = vscale(vcross(x_c, x_p), kp); /* keep the hinge axes aligned */
-    qt rel = qmul(qconj(rp), rc);
-    if (rel.w < 0) { rel.w = -rel.w; rel.x = -rel.x; rel.y = -rel.y; rel.z = -rel.z; }
-    const double theta = 2.0 * atan2(rel.x, rel.w);
-    const v3 wrel = vsub(b[i].w, b[P].w);
-    const double thetadot = vdot(x_c, wrel);
-    const int d = s->dof_start[i];
-    double ta = tau[d] - s->dof_damping[d] * thetadot - s->dof_stiffness[d] * theta;
-    if (theta < s->dof_lo[d]) ta += s->k_limit[i] * (s->dof_lo[d] - theta);
-    if (theta > s->dof_hi[d]) ta -= s->k_limit[i] * (theta - s->dof_hi[d]);
-    t = vadd(t, vscale(x_c, ta));
-    t = vsub(t, vscale(wrel, s->k_ang_damp[i]));
+    T[i] = vadd(T[i], vcross(vsub(g.A_c, b[i].p), f));
+    v3 t = vscale(vcross(g.x_c, g.x_p), kp); /* keep the hinge axes aligned */
+    const int d = d0 + ns;
+    double ta = tau[d] - s->dof_damping[d] * g.thetadot - s->dof_stiffness[d] * g.theta;
+    if (g.theta < s->dof_lo[d]) ta += s->k_limit[i] * (s->dof_lo[d] - g.theta);
+    if (g.theta > s->dof_hi[d]) ta -= s->k_limit[i] * (g.theta - s->dof_hi[d]);
+    t = vadd(t, vscale(g.x_c, ta));
+    t = vsub(t, vscale(g.wrel, s->k_ang_damp[i]));
     T[i] = vadd(T[i], t);
-    T[P] = vsub(T[P], t);
+    if (P >= 0) {
+      F[P] = vsub(F[P], f);
+      T[P] = vsub(T[P], vadd(vcross(vsub(g.A_p, b[P].p), f), t));
+    }
   }
   /* --- semi-implicit Euler: velocity update before the collision pass -------------- */
   for (int i = 0; i < L; ++i) {
@@ -322,7 +350,7 @@ static void observe(const carl_brax_sys_t* s, const body* b, float* obs) {
   double q[CARL_BRAX_MAX_Q], qd[CARL_BRAX_MAX_DOF];
   inverse_kinematics(s, b, q, qd);
   int k = 0;
-  for (int i = s->exclude_current_positions ? 2 : 0; i < s->n_q; ++i) obs[k++] = (float)q[i];
+  for (int i = s->exclude_current_positions; i < s->n_q; ++i) obs[k++] = (float)q[i];
   for (int i = 0; i < s->n_dof; ++i) obs[k++] = (float)qd[i];
 }
 

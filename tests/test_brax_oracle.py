@@ -156,3 +156,63 @@ def test_reset_is_a_function_of_seed_lane_episode(ant):
     np.testing.assert_array_equal(a.state[3:], b.state)
     q, qd = B.inverse_kinematics(ant, a.state[0])
     assert np.abs(q[:3] - np.array(ant.init_q[:3])).max() <= 0.1 + 1e-9 and np.abs(qd).max() < 0.6
+
+
+# ------------------------------------------------------------------ Halfcheetah
+from carl_amd.envs.brax.models import halfcheetah_sys  # noqa: E402
+
+HC_NAMES = ["gravity", "friction", "elasticity", "ang_damping", "viscosity", "mass_torso", "mass_bthigh",
+            "mass_bshin", "mass_bfoot", "mass_fthigh", "mass_fshin", "mass_ffoot", "target_distance",
+            "target_direction", "target_radius", "joint_stiffness"]
+HC_DEFAULT = np.array([-9.8, 1.0, 0.0, -0.05, 0.0, 10.0, 1.5435146, 1.5874476, 1.0953975, 1.4380753, 1.2008368,
+                       0.8845188, 100.0, 1.0, 5.0, 1.0])
+
+
+@pytest.fixture(scope="module")
+def cheetah():
+    return halfcheetah_sys(HC_NAMES)
+
+
+def test_halfcheetah_table_and_kinematics(cheetah):
+    s = cheetah
+    assert (s.n_links, s.n_q, s.n_dof, s.n_act, s.obs_dim) == (7, 9, 9, 6, 17)
+    assert s.n_frames * s.dt == pytest.approx(0.05)
+    assert list(s.parent[:7]) == [-1, 0, 1, 2, 0, 4, 5] and list(s.n_slide[:7]) == [2, 0, 0, 0, 0, 0, 0]
+    assert s.ctx.n_mass == 7 and s.ctx.joint_stiffness_scale == 15
+    rng = np.random.default_rng(0)
+    for _ in range(10):
+        q = rng.uniform(-0.3, 0.3, 9)
+        qd = rng.normal(0, 1, 9)
+        st = B.forward_kinematics(s, q, qd)
+        q2, qd2 = B.inverse_kinematics(s, st)
+        np.testing.assert_allclose(q2, q, atol=2e-6)
+        np.testing.assert_allclose(qd2, qd, atol=5e-6)
+        assert np.abs(st[:, 1]).max() < 1e-9  # planar: y = 0
+
+
+def test_halfcheetah_stays_planar_and_stable(cheetah):
+    rng = np.random.default_rng(2)
+    n = 16
+    e = B.Engine(cheetah, HC_DEFAULT[None], n, selector=O.SEL_STATIC, seed=2)
+    obs = e.reset()
+    assert obs.shape == (n, 17)
+    for t in range(150):
+        out = e.step(rng.uniform(-1, 1, (n, 6)).astype(np.float32))
+        assert np.isfinite(out.obs).all() and np.abs(out.obs).max() < 60
+        assert not out.terminated.any()  # Halfcheetah never terminates
+    st = e.state.reshape(n, 7, 13)
+    assert np.abs(st[:, :, 1]).max() < 1e-6      # y
+    assert np.abs(st[:, :, 4]).max() < 1e-6 and np.abs(st[:, :, 6]).max() < 1e-6  # roll / yaw quaternion parts
+
+
+def test_halfcheetah_joint_stiffness_context_acts(cheetah):
+    rows = np.tile(HC_DEFAULT, (2, 1))
+    rows[1, 15] = 0.2  # softer constraint springs: joints separate more under load
+    e = B.Engine(cheetah, rows, 2, selector=O.SEL_STATIC, seed=3, ctx_idx0=np.arange(2))
+    e.reset()
+    e.state[1] = e.state[0]
+    rng = np.random.default_rng(0)
+    for _ in range(40):
+        a = np.tile(rng.uniform(-1, 1, (1, 6)).astype(np.float32), (2, 1))
+        out = e.step(a)
+    assert np.abs(out.obs[1] - out.obs[0]).max() > 1e-3

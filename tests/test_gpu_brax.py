@@ -213,3 +213,91 @@ def test_env_api(device):
     o, r, term, trunc, info = benv.step(torch.zeros(n, 8, device=device))
     assert r.shape == (n,) and term.dtype == torch.bool
     assert benv.observation_space["obs"].shape == (n, 27) and benv.action_space.shape == (n, 8)
+
+
+# ------------------------------------------------------------------ Halfcheetah
+def _cheetah():
+    from carl_amd.envs import CARLBraxHalfcheetah
+    from carl_amd.envs.brax.models import halfcheetah_sys
+
+    feats = CARLBraxHalfcheetah.get_context_features()
+    names = list(feats)
+    default = np.array([float(f.default_value) for f in feats.values()])
+    return halfcheetah_sys(names), names, default
+
+
+def _cheetah_rows(rng, n, default, names):
+    """BASELINE config 5 shape: joint_stiffness scale ~ U(0.5, 2), gravity ~ U(-15, -5)"""
+    rows = np.tile(default, (n, 1))
+    rows[:, names.index("joint_stiffness")] = rng.uniform(0.5, 2.0, n)
+    rows[:, names.index("gravity")] = rng.uniform(-15, -5, n)
+    return rows.astype(np.float32).astype(np.float64)
+
+
+def test_halfcheetah_stepwise_parity_and_reset(device):
+    from carl_amd.brax_engine import BraxVecEngine
+
+    s, names, default = _cheetah()
+    rng = np.random.default_rng(11)
+    n = 2048
+    rows = _cheetah_rows(rng, n, default, names)
+    kw = dict(selector=O.SEL_STATIC, seed=6, ctx_idx0=np.arange(n))
+    eng = BraxVecEngine(s, len(names), rows, n, device, max_episode_steps=25, **kw)
+    ora = B.Engine(s, rows, n, max_steps=25, **kw)
+    obs = eng.reset().cpu().numpy()
+    want = ora.reset()
+    assert obs.shape == (n, 17) and rel_err(obs, want).max() < 5e-6
+    assert rel_err(eng.state.t().cpu().numpy(), ora.state).max() < 2e-6
+    errs = []
+    for t in range(60):
+        ora.state[:] = eng.state.t().cpu().numpy()
+        a = rng.uniform(-1.2, 1.2, (n, 6)).astype(np.float32)
+        o, rew, term, trunc = eng.step(torch.as_tensor(a))
+        out = ora.step(a)
+        np.testing.assert_array_equal(trunc.cpu().numpy(), out.truncated)
+        assert not term.any() and not out.terminated.any()
+        done = trunc.cpu().numpy() != 0
+        got = np.where(done[:, None], eng.final_obs.cpu().numpy(), o.cpu().numpy())
+        wnt = np.where(done[:, None], out.final_obs, out.obs)
+        errs.append(np.maximum(rel_err(got, wnt).max(1), rel_err(rew.cpu().numpy(), out.reward)))
+        np.testing.assert_array_equal(eng.elapsed.cpu().numpy(), ora.elapsed)
+    e = np.concatenate(errs)
+    # stiffer constraint springs (k = 15000 x up to 2) and 16 substeps per env step: the same
+    # fp32 conditioning argument as for Ant, one notch looser
+    assert np.percentile(e, 50) <= 3e-5 and np.percentile(e, 99) <= 3e-4 and (e > 3e-3).mean() < 3e-3, (
+        np.percentile(e, [50, 99, 99.9]))
+    # planar: y and the roll / yaw quaternion components stay zero
+    st = eng.state.view(7, 13, n)
+    assert float(st[:, 1].abs().max()) < 1e-5 and float(st[:, 4].abs().max()) < 1e-5
+
+
+def test_halfcheetah_rollout_equals_step_and_env_api(device):
+    from carl_amd.brax_engine import BraxVecEngine
+    from carl_amd.context.selection import StaticSelector
+    from carl_amd.context.table import ContextTable
+    from carl_amd.envs import CARLBraxHalfcheetah
+
+    s, names, default = _cheetah()
+    rng = np.random.default_rng(12)
+    n, T = 256, 20
+    rows = _cheetah_rows(rng, n, default, names)
+    acts = torch.as_tensor(rng.uniform(-1, 1, (T, n, 6)).astype(np.float32), device=device)
+    kw = dict(selector=O.SEL_STATIC, seed=1, ctx_idx0=np.arange(n), max_episode_steps=9)
+    e1 = BraxVecEngine(s, len(names), rows, n, device, **kw)
+    e2 = BraxVecEngine(s, len(names), rows, n, device, **kw)
+    e1.reset()
+    e2.reset()
+    out = e1.rollout(acts)
+    for t in range(T):
+        o, r, te, tr = e2.step(acts[t])
+        assert torch.equal(out["obs"][t], o) and torch.equal(out["reward"][t], r) and torch.equal(out["truncated"][t], tr)
+    assert torch.equal(e1.state, e2.state)
+    env = CARLBraxHalfcheetah(batch_size=n, contexts=ContextTable(names, rows), context_selector=StaticSelector)
+    obs, info = env.reset(seed=0)
+    assert obs["obs"].shape == (n, 17) and env.action_space.shape == (n, 6)
+    assert "joint_stiffness" in obs["context"] and obs["context"]["mass_bthigh"].shape == (n,)
+    single = CARLBraxHalfcheetah()
+    o, _ = single.reset()
+    assert o["obs"].shape == (17,)
+    o, r, te, tr, _ = single.step(np.zeros(6, np.float32))
+    assert te is False and tr is False
