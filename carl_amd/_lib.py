@@ -15,7 +15,7 @@ import torch  # noqa: F401  (must precede the CDLL load, see module docstring)
 
 from carl_amd import build as _build
 
-CARL_ABI_VERSION = 1
+CARL_ABI_VERSION = 2
 CARL_MAX_CTX_OBS = 32
 
 # carl_family_t
@@ -52,6 +52,7 @@ class Batch(C.Structure):
         ("fin_capacity", C.c_int32),
         ("last_return", _vp), ("last_length", _vp), ("episodes_done", _vp),
         ("fin_count", _vp), ("fin_lane", _vp), ("fin_return", _vp), ("fin_length", _vp),
+        ("goal_pos", _vp), ("success", _vp),
     ]
 
 
@@ -141,7 +142,8 @@ _f, _i = C.c_float, C.c_int32
 class BraxCtxMap(C.Structure):
     _fields_ = [
         ("gravity", _i), ("friction", _i), ("elasticity", _i), ("ang_damping", _i),
-        ("joint_stiffness_scale", _i), ("n_mass", _i),
+        ("joint_stiffness_scale", _i), ("target_distance", _i), ("target_direction", _i), ("target_radius", _i),
+        ("n_mass", _i),
         ("mass_row", _i * BRAX_MAX_CTX_MASS), ("mass_link", _i * BRAX_MAX_CTX_MASS),
         ("mass_nominal", _f * BRAX_MAX_CTX_MASS),
     ]
@@ -171,6 +173,7 @@ class BraxSys(C.Structure):
         ("coll_link", _i * BRAX_MAX_COLL), ("coll_pos", (_f * 3) * BRAX_MAX_COLL),
         ("coll_radius", _f * BRAX_MAX_COLL),
         ("init_q", _f * BRAX_MAX_Q),
+        ("goal_mode", _i), ("goal_obs_idx", _i * 2), ("goal_dt", _f),
         ("n_slide", _i * BRAX_MAX_LINKS), ("slide_axis", ((_f * 3) * 2) * BRAX_MAX_LINKS),
         ("ctx", BraxCtxMap),
     ]

@@ -32,7 +32,12 @@ class BraxVecEngine(VecEngine):
         self.sys = sys_table
         self._n_features = int(n_features)
         kw.pop("cartpole_recompute", None)
+        self.goal_pos = self.success = None
         super().__init__(-1, ctx_table, n_lanes, device, **kw)
+        if self.sys.goal_mode:  # BraxWalkerGoalWrapper state: integrated (x, y) + per-step success flag
+            self.goal_pos = torch.zeros((2, self.n), dtype=torch.float32, device=self.device)
+            self.success = torch.zeros(self.n, dtype=torch.uint8, device=self.device)
+            self._sync_pointers()
         # device copy of the model table (the kernels stage it into LDS once per workgroup)
         raw = bytes(self.sys)
         self.sys_dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
@@ -53,6 +58,23 @@ class BraxVecEngine(VecEngine):
     def _c_rollout(self, io, n_steps: int) -> int:
         return self.lib.carl_brax_rollout(C.byref(self.b), _ptr(self.sys_dev), C.byref(self.sys), C.byref(io),
                                           n_steps, self._stream())
+
+    def alloc_rollout(self, n_steps: int, final_obs: bool = False) -> dict:
+        out = super().alloc_rollout(n_steps, final_obs)
+        if self.sys.goal_mode:
+            out["success"] = torch.zeros((n_steps, self.n), dtype=torch.uint8, device=self.device)
+        return out
+
+    def rollout(self, actions, out: dict | None = None) -> dict:
+        if not self.sys.goal_mode:
+            return super().rollout(actions, out)
+        if out is None:
+            out = self.alloc_rollout(int(actions.shape[0]))
+        self.b.success = out["success"].data_ptr()  # [T][N] for the duration of this launch
+        try:
+            return super().rollout(actions, out)
+        finally:
+            self.b.success = self.success.data_ptr()
 
     def reset_indexed(self, idx, count):
         raise NotImplementedError("Brax families reset through a lane mask (reset(mask)) or in-kernel auto-reset")

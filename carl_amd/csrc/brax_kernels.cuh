@@ -421,7 +421,40 @@ struct LaneState {
   int elapsed, cidx, n_new_calls, n_new_episodes;
   uint32_t episode;
   LaneCtx ctx;
+  float goal_x, goal_y, goal_radius, pos_x, pos_y;  // goal mode only
 };
+
+// BraxWalkerGoalWrapper (carl/envs/brax/brax_walker_goal_wrapper.py:69-121): compass code ->
+// goal position = direction * target_distance; radius
+__device__ __forceinline__ void load_goal(const carl_brax_sys_t& s, const carl_batch_t& b, int c, LaneState& r) {
+  const carl_brax_ctx_map_t& cm = s.ctx;
+  const int code = __float2int_rn(b.ctx_table[(size_t)cm.target_direction * b.ctx_stride + c]);
+  const float dist = b.ctx_table[(size_t)cm.target_distance * b.ctx_stride + c];
+  r.goal_radius = b.ctx_table[(size_t)cm.target_radius * b.ctx_stride + c];
+  const float cc = 0.92387953251128674f, sn = 0.38268343236508977f, h = 0.70710678118654752f;  // 22.5 deg, sqrt(1/2)
+  float dx = 0.0f, dy = 0.0f;
+  switch (code) {
+    case 3: dy = -1.0f; break;
+    case 1: dy = 1.0f; break;
+    case 2: dx = 1.0f; break;
+    case 4: dx = -1.0f; break;
+    case 34: dx = -h; dy = -h; break;
+    case 14: dx = -h; dy = h; break;
+    case 32: dx = h; dy = -h; break;
+    case 12: dx = h; dy = h; break;
+    case 334: dx = -cc; dy = -sn; break;
+    case 434: dx = -sn; dy = -cc; break;
+    case 114: dx = -cc; dy = sn; break;
+    case 414: dx = -sn; dy = cc; break;
+    case 332: dx = cc; dy = -sn; break;
+    case 232: dx = sn; dy = -cc; break;
+    case 112: dx = cc; dy = sn; break;
+    case 212: dx = sn; dy = cc; break;
+    default: break;
+  }
+  r.goal_x = dx * dist;
+  r.goal_y = dy * dist;
+}
 
 // mode 0: reset (mask optional), mode 1: n_steps env steps (1 = per call, T = fused rollout)
 template <int MODE>
@@ -445,6 +478,7 @@ __global__ void __launch_bounds__(kLanes) brax_kernel(const carl_batch_t b, cons
   const size_t n = (size_t)b.n_lanes;
   const int S = CARL_BRAX_LINK_STATE * s.n_links;
   LaneState r{};
+  const bool goal = s.goal_mode != 0 && b.goal_pos != nullptr;
   if (active) {
     r.cidx = b.ctx_idx[lane];
     r.episode = b.episode[lane];
@@ -464,6 +498,10 @@ __global__ void __launch_bounds__(kLanes) brax_kernel(const carl_batch_t b, cons
       b.ctx_idx[lane] = r.cidx;
       b.episode[lane] = r.episode;
       b.n_calls[lane] += 1;
+      if (goal) {  // wrapper reset: position = (0, 0)
+        b.goal_pos[lane] = 0.0f;
+        b.goal_pos[n + lane] = 0.0f;
+      }
       if (b.ctx_obs != nullptr)
         for (int k = 0; k < b.n_ctx_obs; ++k)
           b.ctx_obs[(size_t)k * n + lane] = b.ctx_table[(size_t)b.ctx_obs_feat[k] * b.ctx_stride + r.cidx];
@@ -476,6 +514,11 @@ __global__ void __launch_bounds__(kLanes) brax_kernel(const carl_batch_t b, cons
     if (active) {
       for (int k = 0; k < S; ++k) m.at(m.lay.state + k) = b.state[(size_t)k * n + lane];
       r.ctx = load_ctx(s, b, m, r.cidx);
+      if (goal) {
+        load_goal(s, b, r.cidx, r);
+        r.pos_x = b.goal_pos[lane];
+        r.pos_y = b.goal_pos[n + lane];
+      }
     }
     const float dt_env = s.dt * (float)s.n_frames;
     for (int t = 0; t < n_steps; ++t) {
@@ -504,12 +547,24 @@ __global__ void __launch_bounds__(kLanes) brax_kernel(const carl_batch_t b, cons
         terminated = s.terminate_when_unhealthy && !healthy;
         r.elapsed += 1;
         truncated = (b.max_episode_steps > 0) && (r.elapsed >= b.max_episode_steps);
+        observe(s, m);
+        if (goal) {  // brax_walker_goal_wrapper.py:124-140: progress reward replaces the env reward
+          const float nx = r.pos_x + m.at(m.lay.io + s.goal_obs_idx[0]) * s.goal_dt;
+          const float ny = r.pos_y + m.at(m.lay.io + s.goal_obs_idx[1]) * s.goal_dt;
+          const float cur = sqrtf((r.goal_x - nx) * (r.goal_x - nx) + (r.goal_y - ny) * (r.goal_y - ny));
+          const float prev = sqrtf((r.goal_x - r.pos_x) * (r.goal_x - r.pos_x) + (r.goal_y - r.pos_y) * (r.goal_y - r.pos_y));
+          r.pos_x = nx;
+          r.pos_y = ny;
+          const bool ok = cur <= r.goal_radius;
+          terminated = terminated | ok;
+          reward = fmaxf(0.0f, prev - cur);
+          if (b.success != nullptr) b.success[step_off + lane] = (uint8_t)ok;
+        }
         r.ep_return += reward;
         done = terminated | truncated;
         io.reward[step_off + lane] = reward;
         io.terminated[step_off + lane] = (uint8_t)terminated;
         io.truncated[step_off + lane] = (uint8_t)truncated;
-        observe(s, m);
       }
       const unsigned long long any_done = __ballot(done);
       if (any_done != 0ull) {
@@ -531,6 +586,10 @@ __global__ void __launch_bounds__(kLanes) brax_kernel(const carl_batch_t b, cons
             reset_state(s, b, m, glane, r.episode);
             r.episode += 1u;
             r.ctx = load_ctx(s, b, m, r.cidx);
+            if (goal) {
+              load_goal(s, b, r.cidx, r);
+              r.pos_x = r.pos_y = 0.0f;
+            }
             r.elapsed = 0;
             r.ep_return = 0.0f;
             r.n_new_calls += 1;
@@ -547,6 +606,10 @@ __global__ void __launch_bounds__(kLanes) brax_kernel(const carl_batch_t b, cons
       for (int k = 0; k < S; ++k) b.state[(size_t)k * n + lane] = m.at(m.lay.state + k);
       b.elapsed[lane] = r.elapsed;
       b.ep_return[lane] = r.ep_return;
+      if (goal) {
+        b.goal_pos[lane] = r.pos_x;
+        b.goal_pos[n + lane] = r.pos_y;
+      }
       if (r.n_new_episodes != 0 && b.episodes_done != nullptr) b.episodes_done[lane] += r.n_new_episodes;
       if (r.n_new_calls != 0) {
         b.ctx_idx[lane] = r.cidx;

@@ -192,6 +192,8 @@ class VecEngine:
         b.fin_capacity = self.fin_capacity
         b.fin_count, b.fin_lane = _ptr(self.fin_count), _ptr(self.fin_lane)
         b.fin_return, b.fin_length = _ptr(self.fin_return), _ptr(self.fin_length)
+        b.goal_pos = _ptr(getattr(self, "goal_pos", None))
+        b.success = _ptr(getattr(self, "success", None))
 
     def _stream(self) -> int:
         return torch.cuda.current_stream(self.device).cuda_stream

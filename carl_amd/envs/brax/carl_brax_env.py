@@ -70,6 +70,7 @@ class CARLBraxEnv(CARLEnv):
         ``batch_size`` is the reference's name for the number of parallel envs (:164)."""
         if use_language_goals:
             raise NotImplementedError("language goals are strings on the host: out of scope (SURVEY.md section 2 row 7)")
+        goal_mode = False
         if contexts is not None and len(contexts):
             first = contexts[list(contexts.keys())[0]]
             if "target_distance" in first or "target_direction" in first:
@@ -77,12 +78,13 @@ class CARLBraxEnv(CARLEnv):
                 vals = [(c.get("target_direction", first.get("target_direction", 0)),
                          c.get("target_distance", first.get("target_distance", 0))) for c in contexts.values()]
                 if max(v[0] - vals[0][0] for v in vals) > 0.1 or max(v[1] - vals[0][1] for v in vals) > 0.1:
-                    raise NotImplementedError(
-                        "goal-directed reward (BraxWalkerGoalWrapper) is the next row of the scope table "
-                        "(SURVEY.md section 8f rank 2) and not built yet")
+                    goal_mode = True
         names = list(self.get_context_features().keys())
         if env is None:
             sys_table = models.SYSTEMS[self.env_name](names, reference_compat=reference_compat)
+            # goals vary across contexts -> the reference wraps the env with BraxWalkerGoalWrapper
+            # (:195-223); here the wrapper's step/reset are an epilogue fused into the kernels
+            sys_table.goal_mode = 1 if goal_mode else 0
             n_auto = batch_size > 1
             env = BraxVecEngine(
                 sys_table, len(names),
@@ -136,8 +138,19 @@ class CARLBraxEnv(CARLEnv):
             # wrappers.py:76-77: terminated = done, truncated = False; brax's EpisodeWrapper
             # folds its 1000-step truncation into `done`
             done = bool(term[0]) or bool(trunc[0])
+            if self.env.sys.goal_mode:
+                info["success"] = int(self.env.success[0])
             return self._add_context_to_state(state), float(reward[0]), done, False, info
-        return super().step(action)
+        out = super().step(action)
+        if self.env.sys.goal_mode:
+            out[4]["success"] = self.env.success
+        return out
+
+    def reset(self, *, seed: int | None = None, options: dict[str, Any] | None = None):
+        obs, info = super().reset(seed=seed, options=options)
+        if self.env.sys.goal_mode:  # brax_walker_goal_wrapper.py:121
+            info["success"] = 0 if self._scalar_api else torch.zeros_like(self.env.success)
+        return obs, info
 
     @classmethod
     def get_default_context(cls) -> Context:

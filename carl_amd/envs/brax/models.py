@@ -109,16 +109,26 @@ def ant_sys(feature_names: list[str] | None = None, reference_compat: bool = Fal
     for i, v in enumerate(init_q):
         s.init_q[i] = v
     _wire_context(s, feature_names, reference_compat, {"torso": 0}, {"mass_torso": 10.0})
+    # goal mode constants: STATE_INDICES["ant"] (brax_walker_goal_wrapper.py:7) and the raw MJCF
+    # `opt.timestep` of ant.xml the wrapper integrates with (:109-111, Quirk B3)
+    s.goal_obs_idx[0], s.goal_obs_idx[1], s.goal_dt = 13, 14, 0.01
     return s
 
 
 def _wire_context(s, feature_names, reference_compat, link_ids, mass_defaults):
     m = s.ctx
     m.gravity = m.friction = m.elasticity = m.ang_damping = m.joint_stiffness_scale = -1
+    m.target_distance = m.target_direction = m.target_radius = -1
     m.n_mass = 0
-    if reference_compat or not feature_names:
+    if not feature_names:
         return
     col = {n: i for i, n in enumerate(feature_names)}
+    # goal features are read by the goal-reward epilogue whatever the physics mode
+    m.target_distance = col.get("target_distance", -1)
+    m.target_direction = col.get("target_direction", -1)
+    m.target_radius = col.get("target_radius", -1)
+    if reference_compat:
+        return
     m.gravity = col.get("gravity", -1)
     m.friction = col.get("friction", -1)
     m.elasticity = col.get("elasticity", -1)
@@ -225,6 +235,9 @@ def halfcheetah_sys(feature_names: list[str] | None = None, reference_compat: bo
     _wire_context(s, feature_names, reference_compat, link_ids,
                   {"mass_torso": 10.0, "mass_bthigh": 1.5435146, "mass_bshin": 1.5874476, "mass_bfoot": 1.0953975,
                    "mass_fthigh": 1.4380753, "mass_fshin": 1.2008368, "mass_ffoot": 0.8845188})
+    # STATE_INDICES["halfcheetah"] = [14, 15] (brax_walker_goal_wrapper.py:9; Quirk B3: these are not
+    # the root x/y velocities of the 17-dim obs -- replicated as written), half_cheetah.xml timestep 0.01
+    s.goal_obs_idx[0], s.goal_obs_idx[1], s.goal_dt = 14, 15, 0.01
     return s
 
 

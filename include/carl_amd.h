@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define CARL_ABI_VERSION 1
+#define CARL_ABI_VERSION 2
 #define CARL_MAX_CTX_OBS 32
 
 #define CARL_ERR_INVALID_ARGUMENT (-1)
@@ -136,6 +136,10 @@ typedef struct carl_batch {
   int64_t* fin_lane;         /* [fin_capacity] global lane id */
   float* fin_return;         /* [fin_capacity] */
   int32_t* fin_length;       /* [fin_capacity] */
+  /* goal-directed Brax mode (BraxWalkerGoalWrapper, brax_walker_goal_wrapper.py:113-140);
+   * NULL otherwise */
+  float* goal_pos;           /* [2][n_lanes] position integrated from the observed x/y velocities */
+  uint8_t* success;          /* [n_lanes] (or [T][n_lanes] in a rollout): goal reached on this step */
 } carl_batch_t;
 
 /* Inputs/outputs of one step (or, for carl_rollout, of T steps: every array gains
@@ -216,6 +220,7 @@ enum { CARL_BRAX_ANT = 0, CARL_BRAX_HALFCHEETAH = 1, CARL_BRAX_HUMANOID = 2 };
  * feature absent -> the model default is used) */
 typedef struct carl_brax_ctx_map {
   int32_t gravity, friction, elasticity, ang_damping, joint_stiffness_scale;
+  int32_t target_distance, target_direction, target_radius; /* goal mode rows (carl_ant.py:40-48) */
   int32_t n_mass;                               /* mass_<link> features */
   int32_t mass_row[CARL_BRAX_MAX_CTX_MASS];     /* table row */
   int32_t mass_link[CARL_BRAX_MAX_CTX_MASS];    /* link it scales */
@@ -253,6 +258,12 @@ typedef struct carl_brax_sys {
   int32_t coll_link[CARL_BRAX_MAX_COLL];    /* collision spheres vs the ground plane z = 0 */
   float coll_pos[CARL_BRAX_MAX_COLL][3], coll_radius[CARL_BRAX_MAX_COLL];
   float init_q[CARL_BRAX_MAX_Q];
+  /* goal-directed reward epilogue (carl/envs/brax/brax_walker_goal_wrapper.py:113-140): position +=
+   * obs[goal_obs_idx] * goal_dt (the RAW MJCF timestep, Quirk B3); reward = max(0, d_prev - d_cur);
+   * terminate with success when d_cur <= target_radius */
+  int32_t goal_mode;
+  int32_t goal_obs_idx[2];
+  float goal_dt;
   int32_t n_slide[CARL_BRAX_MAX_LINKS];        /* 0..2 prismatic dofs (q order: slides, then the hinge) */
   float slide_axis[CARL_BRAX_MAX_LINKS][2][3]; /* unit axes in the PARENT frame, mutually orthogonal */
   carl_brax_ctx_map_t ctx;

@@ -85,12 +85,14 @@ class Engine:
         self.last_return = np.zeros(n, dtype=np.float32)
         self.last_length = np.zeros(n, dtype=np.int32)
         self.episodes_done = np.zeros(n, dtype=np.int32)
+        self.goal_pos = np.zeros((n, 2), dtype=np.float64)
+        self.success = np.zeros(n, dtype=np.uint8)
 
     def reset(self, mask=None):
         m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
         O.lib().obx_engine_reset(self.sys.ptr, C.byref(self.cfg), _p(self.ctx), C.c_int(self.F), _p(m),
                                  _p(self.state), _p(self.elapsed), _p(self.ctx_idx), _p(self.episode),
-                                 _p(self.n_calls), _p(self.ep_return), _p(self.obs))
+                                 _p(self.n_calls), _p(self.ep_return), _p(self.obs), _p(self.goal_pos))
         return self.obs.copy()
 
     def step(self, action):
@@ -102,5 +104,6 @@ class Engine:
         O.lib().obx_engine_step(self.sys.ptr, C.byref(self.cfg), _p(self.ctx), C.c_int(self.F), _p(a),
                                 _p(self.state), _p(self.elapsed), _p(self.ctx_idx), _p(self.episode),
                                 _p(self.n_calls), _p(self.ep_return), _p(self.obs), _p(rew), _p(term), _p(trunc),
-                                _p(final_obs), _p(self.last_return), _p(self.last_length), _p(self.episodes_done))
+                                _p(final_obs), _p(self.last_return), _p(self.last_length), _p(self.episodes_done),
+                                _p(self.goal_pos), _p(self.success))
         return O.StepOut(self.obs.copy(), rew, term, trunc, final_obs)

@@ -385,6 +385,49 @@ static int32_t select_ctx(const oracle_cfg_t* cfg, int32_t idx, uint64_t g, uint
   return idx;
 }
 
+/* BraxWalkerGoalWrapper (carl/envs/brax/brax_walker_goal_wrapper.py:69-140): compass code ->
+ * unit direction (direction_values :69-106) */
+static void goal_direction(int code, double* dx, double* dy) {
+  const double c = cos(22.5 * M_PI / 180.0), sn = sin(22.5 * M_PI / 180.0), h = sqrt(0.5);
+  switch (code) {
+    case 3: *dx = 0; *dy = -1; break;
+    case 1: *dx = 0; *dy = 1; break;
+    case 2: *dx = 1; *dy = 0; break;
+    case 4: *dx = -1; *dy = 0; break;
+    case 34: *dx = -h; *dy = -h; break;
+    case 14: *dx = -h; *dy = h; break;
+    case 32: *dx = h; *dy = -h; break;
+    case 12: *dx = h; *dy = h; break;
+    case 334: *dx = -c; *dy = -sn; break;
+    case 434: *dx = -sn; *dy = -c; break;
+    case 114: *dx = -c; *dy = sn; break;
+    case 414: *dx = -sn; *dy = c; break;
+    case 332: *dx = c; *dy = -sn; break;
+    case 232: *dx = sn; *dy = -c; break;
+    case 112: *dx = c; *dy = sn; break;
+    case 212: *dx = sn; *dy = c; break;
+    default: *dx = 0; *dy = 0; break;
+  }
+}
+
+/* step() of the goal wrapper (:124-140) on the transition's own observation: returns the
+ * progress reward, sets *success; pos is the integrated (x, y) */
+static double goal_epilogue(const carl_brax_sys_t* s, const double* ctx_row, const float* obs, double* pos,
+                            int* success) {
+  double dx, dy;
+  goal_direction((int)lrint((double)(float)ctx_row[s->ctx.target_direction]), &dx, &dy);
+  const double dist = (double)(float)ctx_row[s->ctx.target_distance];
+  const double gx = dx * dist, gy = dy * dist;
+  const double nx = pos[0] + (double)obs[s->goal_obs_idx[0]] * s->goal_dt;
+  const double ny = pos[1] + (double)obs[s->goal_obs_idx[1]] * s->goal_dt;
+  const double cur = sqrt((gx - nx) * (gx - nx) + (gy - ny) * (gy - ny));
+  const double prev = sqrt((gx - pos[0]) * (gx - pos[0]) + (gy - pos[1]) * (gy - pos[1]));
+  pos[0] = nx; pos[1] = ny;
+  *success = cur <= (double)(float)ctx_row[s->ctx.target_radius];
+  const double r = prev - cur;
+  return r > 0 ? r : 0;
+}
+
 /* exported: pure helpers for tests */
 void obx_forward_kinematics(const carl_brax_sys_t* s, const double* q, const double* qd, double* state) {
   body b[L_MAX];
@@ -407,7 +450,7 @@ void obx_substeps(const carl_brax_sys_t* s, const double* ctx_row, const double*
 
 void obx_engine_reset(const carl_brax_sys_t* s, const oracle_cfg_t* cfg, const double* ctx_table, int n_feat,
                       const uint8_t* mask, double* state, int32_t* elapsed, int32_t* ctx_idx, uint32_t* episode,
-                      int32_t* n_calls, double* ep_return, float* obs) {
+                      int32_t* n_calls, double* ep_return, float* obs, double* goal_pos) {
   const int S = 13 * s->n_links;
   (void)ctx_table; (void)n_feat;
   for (int i = 0; i < cfg->n_lanes; ++i) {
@@ -421,6 +464,7 @@ void obx_engine_reset(const carl_brax_sys_t* s, const oracle_cfg_t* cfg, const d
     episode[i] += 1;
     elapsed[i] = 0;
     ep_return[i] = 0.0;
+    if (goal_pos) { goal_pos[2 * i] = 0.0; goal_pos[2 * i + 1] = 0.0; } /* wrapper reset: position = (0, 0) */
     observe(s, b, obs + (size_t)i * s->obs_dim);
   }
 }
@@ -431,7 +475,7 @@ void obx_engine_step(const carl_brax_sys_t* s, const oracle_cfg_t* cfg, const do
                      const float* action, double* state, int32_t* elapsed, int32_t* ctx_idx, uint32_t* episode,
                      int32_t* n_calls, double* ep_return, float* obs, float* reward, uint8_t* terminated,
                      uint8_t* truncated, float* final_obs, float* last_return, int32_t* last_length,
-                     int32_t* episodes_done) {
+                     int32_t* episodes_done, double* goal_pos, uint8_t* success) {
   const int S = 13 * s->n_links, D = s->obs_dim;
   for (int i = 0; i < cfg->n_lanes; ++i) {
     const uint64_t g = (uint64_t)(cfg->lane_offset + i);
@@ -459,14 +503,21 @@ void obx_engine_step(const carl_brax_sys_t* s, const oracle_cfg_t* cfg, const do
     const double r = s->forward_reward_weight * (x1 - x0) / dt_env +
                      (s->terminate_when_unhealthy ? s->healthy_reward : s->healthy_reward * healthy) -
                      s->ctrl_cost_weight * ctrl;
-    const int term = s->terminate_when_unhealthy ? !healthy : 0;
+    int term = s->terminate_when_unhealthy ? !healthy : 0;
+    double r_out = r;
     elapsed[i] += 1;
     const int trunc = elapsed[i] >= cfg->max_steps;
-    ep_return[i] += (double)(float)r;
-    reward[i] = (float)r;
+    observe(s, b, obs + (size_t)i * D);
+    if (s->goal_mode && goal_pos) { /* the goal wrapper REPLACES the reward and may terminate */
+      int ok = 0;
+      r_out = goal_epilogue(s, ctx_table + (size_t)ctx_idx[i] * n_feat, obs + (size_t)i * D, goal_pos + 2 * i, &ok);
+      if (ok) term = 1;
+      if (success) success[i] = (uint8_t)ok;
+    }
+    ep_return[i] += (double)(float)r_out;
+    reward[i] = (float)r_out;
     terminated[i] = (uint8_t)term;
     truncated[i] = (uint8_t)trunc;
-    observe(s, b, obs + (size_t)i * D);
     if (term || trunc) {
       if (last_return) last_return[i] = (float)ep_return[i];
       if (last_length) last_length[i] = elapsed[i];
@@ -479,6 +530,7 @@ void obx_engine_step(const carl_brax_sys_t* s, const oracle_cfg_t* cfg, const do
         episode[i] += 1;
         elapsed[i] = 0;
         ep_return[i] = 0.0;
+        if (goal_pos) { goal_pos[2 * i] = 0.0; goal_pos[2 * i + 1] = 0.0; }
         observe(s, b, obs + (size_t)i * D);
       }
     }
