@@ -14,7 +14,7 @@ if not l:
 else:
     d = json.loads(l[-1]); r = d["roofline"]; p = d["per_call"]
     s = f"{e:12s} value {d['value']:.3e} launch_ms {r['avg_launch_ms']:.4f} frac {r['frac']:.3f} (8d-bytes {r['achieved_with_survey_8d_bytes']/8000:.3f})"
-    if p:
+    if p and p.get("graph_value"):
         s += f" | per-call eager {p['eager_value']:.2e} graph {p['graph_value']:.2e} ({p['graph_ms_per_step']*1e3:.2f} us/step)"
     print(s)
 PY
