@@ -227,3 +227,22 @@ def test_batched_round_robin_lanes_advance_on_their_own_resets(device):
             ids = (ids + 1) % n_ctx
         np.testing.assert_array_equal(info["context_id"].cpu().numpy(), ids)
         np.testing.assert_array_equal(obs["context"]["g"].cpu().numpy(), 5.0 + ids)
+
+
+def test_flatten_observation_adapter(device):
+    """the documented SB3 flow wraps CARL envs in FlattenObservation (examples/carl_with_sb3.py:22-36)"""
+    from carl_amd.wrappers import FlattenObservation
+
+    env = FlattenObservation(E.CARLPendulum(obs_context_features=["l", "g"]))
+    obs, info = env.reset()
+    assert obs.shape == (5,) and obs.dtype == np.float32 and env.observation_space.shape == (5,)
+    np.testing.assert_allclose(obs[:2], [10.0, 1.0])  # context first, keys sorted: g, l
+    o, r, te, tr, info = env.step(np.array([0.5], dtype=np.float32))
+    assert o.shape == (5,)
+    n = 128
+    benv = FlattenObservation(E.CARLPendulum(num_envs=n, obs_context_features=["l", "g"], max_episode_steps=3))
+    obs, _ = benv.reset()
+    assert obs.shape == (n, 5) and obs.is_cuda and benv.observation_space.shape == (n, 5)
+    for _ in range(3):
+        obs, r, te, tr, info = benv.step(torch.zeros(n, 1, device=device))
+    assert info["final_observation"].shape == (n, 5) and bool(tr.all())
