@@ -37,16 +37,22 @@ HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); ~6300 GB/s achievabl
 # algorithmic bytes per env-step
 # (a) SURVEY.md 8(d), per-call model (state/ctx/elapsed re-read every step)
 BYTES_8D = {"pendulum": 66, "cartpole": 90, "acrobot": 110, "mountaincar": 74, "mountaincar_cont": 70,
-            "ant": 1110}
+            "ant": 1110, "halfcheetah": 4 * 6 + 4 * 17 + 6 + 2 * 13 * 7 * 4, "humanoid": 4 * 17 + 4 * 244 + 6 + 2 * 13 * 11 * 4}
 # (b) fused rollout: per step only action in + transition out must cross HBM; state,
 #     context params and counters cross once per launch (DESIGN.md "Kernels")
 IO_PER_STEP = {"pendulum": 4 + 12 + 4 + 2, "cartpole": 4 + 16 + 4 + 2, "acrobot": 4 + 24 + 4 + 2,
                "mountaincar": 4 + 8 + 4 + 2, "mountaincar_cont": 4 + 8 + 4 + 2,
-               "ant": 4 * 8 + 4 * 27 + 4 + 2}
+               "ant": 4 * 8 + 4 * 27 + 4 + 2, "halfcheetah": 4 * 6 + 4 * 17 + 4 + 2,
+               "humanoid": 4 * 17 + 4 * 244 + 4 + 2}
 PER_LAUNCH = {"pendulum": 8 + 4 + 16 + 4 + 4 + 8 + 4 + 4, "cartpole": 16 + 4 + 20 + 4 + 4 + 16 + 4 + 4,
               "acrobot": 16 + 4 + 36 + 4 + 4 + 4 + 16 + 4 + 4, "mountaincar": 8 + 4 + 28 + 4 + 4 + 8 + 4 + 4,
               "mountaincar_cont": 8 + 4 + 24 + 4 + 4 + 8 + 4 + 4,
-              "ant": 2 * 13 * 9 * 4 + 4 + 5 * 4 + 4 + 4 + 4 + 4}
+              "ant": 2 * 13 * 9 * 4 + 4 + 5 * 4 + 4 + 4 + 4 + 4,
+              "halfcheetah": 2 * 13 * 7 * 4 + 4 + 12 * 4 + 4 + 4 + 4 + 4,
+              "humanoid": 2 * 13 * 11 * 4 + 4 + 15 * 4 + 4 + 4 + 4 + 4}
+
+
+BRAX_ENVS = ("ant", "halfcheetah", "humanoid")
 
 
 def parse():
@@ -74,7 +80,7 @@ def make_env(args, rank, world, device):
 
     cls = {"pendulum": E.CARLPendulum, "cartpole": E.CARLCartPole, "acrobot": E.CARLAcrobot,
            "mountaincar": E.CARLMountainCar, "mountaincar_cont": E.CARLMountainCarContinuous,
-           "ant": E.CARLBraxAnt}[args.env]
+           "ant": E.CARLBraxAnt, "halfcheetah": E.CARLBraxHalfcheetah, "humanoid": E.CARLBraxHumanoid}[args.env]
     dists = {
         "pendulum": [U("g", 1, 20), U("l", 0.5, 2.0)],
         "cartpole": [U("gravity", 5, 15), U("length", 0.3, 1.0), U("masspole", 0.05, 0.3)],
@@ -84,6 +90,9 @@ def make_env(args, rank, world, device):
         "mountaincar_cont": [U("power", 5e-4, 3e-3), U("goal_position", 0.3, 0.55)],
         # BASELINE config 4
         "ant": [U("mass_torso", 5, 15), U("gravity", -15, -5), U("friction", 0.3, 1.5)],
+        # BASELINE config 5
+        "halfcheetah": [U("joint_stiffness", 0.5, 2.0), U("gravity", -15, -5), U("mass_torso", 5, 15)],
+        "humanoid": [U("mass_torso", 5, 15), U("gravity", -15, -5), U("friction", 0.3, 1.5)],
     }[args.env]
     n = args.lanes
     # one global context set (seed 0), each rank uploads only its lanes' rows
@@ -91,7 +100,7 @@ def make_env(args, rank, world, device):
     from carl_amd.context.table import ContextTable
 
     local = ContextTable(table.names, table.values_2d[rank * n:(rank + 1) * n])
-    size_kw = {"batch_size": n} if args.env == "ant" else {"num_envs": n}
+    size_kw = {"batch_size": n} if args.env in BRAX_ENVS else {"num_envs": n}
     env = cls(contexts=local, device=device, context_selector=StaticSelector, seed=0,
               lane_offset=rank * n, fin_capacity=0, **size_kw)
     return env, table
@@ -118,11 +127,60 @@ def _cpu_worker(job):
     return R.time_loop(family, contexts, steps)
 
 
+def _cpu_worker_brax(job):
+    env, names, rows, steps = job
+    import numpy as np
+
+    from carl_amd.envs.brax.models import SYSTEMS
+    from oracle import brax as B
+    from oracle import oracle as O
+
+    sys_t = SYSTEMS[env](names)
+    rows = np.asarray(rows, dtype=np.float64)
+    n = len(rows)
+    eng = B.Engine(sys_t, rows, n, selector=O.SEL_STATIC, ctx_idx0=np.arange(n), seed=0)
+    eng.reset()
+    rng = np.random.default_rng(0)
+    a = rng.uniform(-0.4, 0.4, (n, sys_t.n_act)).astype(np.float32)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.step(a)
+    return n * steps, time.perf_counter() - t0
+
+
+def cpu_baseline_brax(args, table):
+    """Brax families: the fp64 C restatement of the spring pipeline (oracle/brax_spring.c), one
+    process per host core, on a bounded sample of the same context set.  kind = "port" (brax /
+    jax are not installable here)."""
+    import multiprocessing as mp
+
+    cores = os.cpu_count() or 1
+    per, steps = 16, 200
+    rows = table.values_2d
+    names = list(table.names)
+    jobs = [(args.env, names, rows[(c * per) % len(rows):(c * per) % len(rows) + per].tolist(), steps)
+            for c in range(cores)]
+    ctx = mp.get_context("spawn")
+    with ctx.Pool(cores) as pool:
+        pool.map(_cpu_worker_brax, [(args.env, names, j[2][:2], 2) for j in jobs])  # warm the workers
+        t0 = time.perf_counter()
+        res = pool.map(_cpu_worker_brax, jobs)
+        wall = time.perf_counter() - t0
+    return {
+        "value": sum(r[0] for r in res) / wall, "unit": "env-steps/s", "cores": cores, "kind": "port",
+        "sample": f"fp64 C oracle of the spring pipeline (oracle/brax_spring.c), {cores} processes x {per} contexts "
+                  f"x {steps} env steps of the same {args.env} context set, auto-reset on",
+        "single_core_value": res[0][0] / res[0][1],
+    }
+
+
 def cpu_baseline(args, table):
     """The reference-style scalar Python loop (oracle/ref_style.py: CARL wrapper ->
     TimeLimit -> env object, dict obs rebuilt per step) on all host cores, on a bounded
     sample of the same contexts.  kind = "port": the reference itself cannot run here
     (gymnasium is not installed)."""
+    if args.env in BRAX_ENVS:
+        return cpu_baseline_brax(args, table)
     import multiprocessing as mp
 
     import numpy as np

@@ -16,6 +16,7 @@ _LAZY = {
     "CARLMountainCarContinuous": "carl_amd.envs.gymnasium.classic_control",
     "CARLBraxAnt": "carl_amd.envs.brax",
     "CARLBraxHalfcheetah": "carl_amd.envs.brax",
+    "CARLBraxHumanoid": "carl_amd.envs.brax",
     "VecEngine": "carl_amd.engine",
 }
 

@@ -174,7 +174,9 @@ class BraxSys(C.Structure):
         ("coll_radius", _f * BRAX_MAX_COLL),
         ("init_q", _f * BRAX_MAX_Q),
         ("goal_mode", _i), ("goal_obs_idx", _i * 2), ("goal_dt", _f),
-        ("n_slide", _i * BRAX_MAX_LINKS), ("slide_axis", ((_f * 3) * 2) * BRAX_MAX_LINKS),
+        ("n_slide", _i * BRAX_MAX_LINKS), ("dof_sign3", _f * BRAX_MAX_LINKS),
+        ("reset_vel_uniform", _i), ("reward_on_com", _i), ("obs_extended", _i), ("reserved2", _i),
+        ("slide_axis", ((_f * 3) * 2) * BRAX_MAX_LINKS),
         ("ctx", BraxCtxMap),
     ]
 

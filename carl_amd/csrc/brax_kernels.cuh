@@ -130,11 +130,6 @@ __device__ __forceinline__ v3 apply_inv_inertia(const carl_brax_sys_t& s, int i,
   return qrot(r, V(l.x * s.inv_inertia[i][0], l.y * s.inv_inertia[i][1], l.z * s.inv_inertia[i][2]));
 }
 
-__device__ __forceinline__ float twist_angle(qt rel) {  // hinge about the joint frame's x axis
-  if (rel.w < 0.0f) { rel.w = -rel.w; rel.x = -rel.x; }
-  return 2.0f * atan2f(rel.x, rel.w);
-}
-
 // the static world as a parent body (planar roots are jointed to it)
 __device__ __forceinline__ Body world_body() {
   return Body{V(0, 0, 0), qt{1, 0, 0, 0}, V(0, 0, 0), V(0, 0, 0)};
@@ -143,7 +138,9 @@ __device__ __forceinline__ Body world_body() {
 // joint geometry shared by joints.resolve and inverse kinematics
 struct JointGeom {
   v3 A_c, A_p, vA_c, vA_p, x_c, x_p, wrel;
-  float theta, thetadot;
+  float theta, thetadot;  // single hinge
+  v3 axis[3];             // 2-3 stacked hinges: current world axes ...
+  float ang[3], rate[3];  // ... Euler x-y-z angles (third signed by dof_sign3) and their rates
 };
 
 __device__ __forceinline__ JointGeom joint_geometry(const carl_brax_sys_t& s, int i, const Body& bc, const Body& bp) {
@@ -162,9 +159,34 @@ __device__ __forceinline__ JointGeom joint_geometry(const carl_brax_sys_t& s, in
   const qt rp = qmul(qmul(bp.r, lrot), jr);
   g.x_c = qrot(rc, V(1, 0, 0));
   g.x_p = qrot(rp, V(1, 0, 0));
-  g.theta = twist_angle(qmul(qconj(rp), rc));
+  qt rel = qmul(qconj(rp), rc);
+  if (rel.w < 0.0f) { rel.w = -rel.w; rel.x = -rel.x; }
+  g.theta = 2.0f * atan2f(rel.x, rel.w);  // twist about the hinge (joint frame x)
   g.wrel = bc.w - bp.w;
   g.thetadot = dot(g.x_c, g.wrel);
+  const int nr = s.n_link_dof[i] - s.n_slide[i];
+  if (nr >= 2) {  // rel = Rx(al) Ry(be) Rz(ga): decompose, ga = sign * theta_3 (wave-uniform branch)
+    const float R00 = 1.0f - 2.0f * (rel.y * rel.y + rel.z * rel.z), R01 = 2.0f * (rel.x * rel.y - rel.w * rel.z);
+    const float R02 = fminf(fmaxf(2.0f * (rel.x * rel.z + rel.w * rel.y), -1.0f), 1.0f);
+    const float R12 = 2.0f * (rel.y * rel.z - rel.w * rel.x), R22 = 1.0f - 2.0f * (rel.x * rel.x + rel.y * rel.y);
+    const float al = atan2f(-R12, R22), be = asinf(R02), ga = atan2f(-R01, R00);
+    const float sg = s.dof_sign3[i];
+    g.ang[0] = al; g.ang[1] = be; g.ang[2] = sg * ga;
+    g.axis[0] = g.x_p;
+    const qt rpx = qmul(rp, qaxis(0, al));
+    g.axis[1] = qrot(rpx, V(0, 1, 0));
+    g.axis[2] = qrot(qmul(rpx, qaxis(1, be)), V(0, 0, 1)) * sg;
+    const float w0 = dot(g.wrel, g.axis[0]), w1 = dot(g.wrel, g.axis[1]), w2 = dot(g.wrel, g.axis[2]);
+    g.rate[1] = w1;
+    if (nr == 3) {  // axis0 and axis2 are not orthogonal: axis0 . axis2 = sign * sin(be)
+      const float cc = dot(g.axis[0], g.axis[2]), den = 1.0f - cc * cc;
+      g.rate[0] = (w0 - cc * w2) / den;
+      g.rate[2] = (w2 - cc * w0) / den;
+    } else {
+      g.rate[0] = w0;
+      g.rate[2] = w2;  // locked direction: damped by k_ang_damp
+    }
+  }
   return g;
 }
 
@@ -191,12 +213,32 @@ __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const LaneCtx&
       f = f + ax * (m.at(m.lay.tau + d0 + k) - s.dof_damping[d0 + k] * qdk - s.dof_stiffness[d0 + k] * qk);
     }
     f = f + e * kp + ev * s.k_vel[i];
-    v3 t = cross(g.x_c, g.x_p) * kp;
-    const int d = d0 + ns;
-    float ta = m.at(m.lay.tau + d) - s.dof_damping[d] * g.thetadot - s.dof_stiffness[d] * g.theta;
-    if (g.theta < s.dof_lo[d]) ta += s.k_limit[i] * (s.dof_lo[d] - g.theta);
-    if (g.theta > s.dof_hi[d]) ta -= s.k_limit[i] * (g.theta - s.dof_hi[d]);
-    t = t + g.x_c * ta - g.wrel * s.k_ang_damp[i];
+    v3 t;
+    const int d = d0 + ns, nr = s.n_link_dof[i] - ns;
+    if (nr == 1) {
+      t = cross(g.x_c, g.x_p) * kp;  // keep the hinge axes aligned
+      float ta = m.at(m.lay.tau + d) - s.dof_damping[d] * g.thetadot - s.dof_stiffness[d] * g.theta;
+      if (g.theta < s.dof_lo[d]) ta += s.k_limit[i] * (s.dof_lo[d] - g.theta);
+      if (g.theta > s.dof_hi[d]) ta -= s.k_limit[i] * (g.theta - s.dof_hi[d]);
+      t = t + g.x_c * ta;
+    } else {  // 2 or 3 stacked hinges: per-dof torques about the current axes; a missing third
+              // dof is locked by the constraint spring on its Euler angle
+      t = V(0, 0, 0);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        float ta;
+        if (k < nr) {
+          const int dk = d + k;
+          ta = m.at(m.lay.tau + dk) - s.dof_damping[dk] * g.rate[k] - s.dof_stiffness[dk] * g.ang[k];
+          if (g.ang[k] < s.dof_lo[dk]) ta += s.k_limit[i] * (s.dof_lo[dk] - g.ang[k]);
+          if (g.ang[k] > s.dof_hi[dk]) ta -= s.k_limit[i] * (g.ang[k] - s.dof_hi[dk]);
+        } else {
+          ta = -kp * g.ang[k];
+        }
+        t = t + g.axis[k] * ta;
+      }
+    }
+    t = t - g.wrel * s.k_ang_damp[i];
     const int fc = m.lay.force + 6 * i;
     m.add3(fc, f);
     m.add3(fc + 3, cross(g.A_c - bc.p, f) + t);
@@ -267,8 +309,24 @@ __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const LaneCtx&
   }
 }
 
-// kinematics.world_to_joint + inverse -> observation rows (q[skip:] ++ qd) in the io staging
-__device__ __forceinline__ void observe(const carl_brax_sys_t& s, const Lds& m) {
+// whole-body centre of mass (brax.envs.humanoid.Humanoid._com); *mass_sum = total mass
+__device__ __forceinline__ v3 system_com(const carl_brax_sys_t& s, const Lds& m, float* mass_sum) {
+  v3 com = V(0, 0, 0);
+  float M = 0.0f;
+  for (int i = 0; i < s.n_links; ++i) {
+    const float mi = m.at(m.lay.mass + i);
+    const int r0 = m.lay.state + 13 * i;
+    com = com + m.get3(r0) * mi;
+    M += mi;
+  }
+  *mass_sum = M;
+  return com * (1.0f / M);
+}
+
+// kinematics.world_to_joint + inverse -> observation rows (q[skip:] ++ qd) in the io staging;
+// obs_extended (humanoid) appends com inertia (L x 10), com velocity (L x 6) and qfrc_actuator
+// (the tau rows; `zero_frc`: reset observations see a zero action)
+__device__ __forceinline__ void observe(const carl_brax_sys_t& s, const Lds& m, bool zero_frc = false) {
   const int skip = s.exclude_current_positions;
   const int qd0 = s.n_q - skip;  // first qd row in the observation
   for (int i = 0; i < s.n_links; ++i) {
@@ -292,10 +350,51 @@ __device__ __forceinline__ void observe(const carl_brax_sys_t& s, const Lds& m) 
         if (s.q_start[i] + k >= skip) m.at(m.lay.io + s.q_start[i] + k - skip) = dot(g.A_c - g.A_p, ax);
         m.at(m.lay.io + qd0 + s.dof_start[i] + k) = dot(g.vA_c - g.vA_p, ax);
       }
-      if (s.q_start[i] + ns >= skip) m.at(m.lay.io + s.q_start[i] + ns - skip) = g.theta;
-      m.at(m.lay.io + qd0 + s.dof_start[i] + ns) = g.thetadot;
+      const int nr = s.n_link_dof[i] - ns;
+      if (nr == 1) {
+        if (s.q_start[i] + ns >= skip) m.at(m.lay.io + s.q_start[i] + ns - skip) = g.theta;
+        m.at(m.lay.io + qd0 + s.dof_start[i] + ns) = g.thetadot;
+      } else {
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+          if (k < nr) {
+            if (s.q_start[i] + ns + k >= skip) m.at(m.lay.io + s.q_start[i] + ns + k - skip) = g.ang[k];
+            m.at(m.lay.io + qd0 + s.dof_start[i] + ns + k) = g.rate[k];
+          }
+      }
     }
   }
+  if (!s.obs_extended) return;
+  int k = m.lay.io + qd0 + s.n_dof;
+  float M;
+  const v3 com = system_com(s, m, &M);
+  for (int i = 0; i < s.n_links; ++i) {  // inertia about the system com, world axes, row-major, then mass
+    const Body b = m.body(i);
+    const v3 d = b.p - com;
+    const float mi = m.at(m.lay.mass + i), dd = dot(d, d);
+    const float I0 = 1.0f / s.inv_inertia[i][0], I1 = 1.0f / s.inv_inertia[i][1], I2 = 1.0f / s.inv_inertia[i][2];
+    const v3 ex = qrot(b.r, V(1, 0, 0)), ey = qrot(b.r, V(0, 1, 0)), ez = qrot(b.r, V(0, 0, 1));
+    const float e[3][3] = {{ex.x, ey.x, ez.x}, {ex.y, ey.y, ez.y}, {ex.z, ey.z, ez.z}};
+    const float dv[3] = {d.x, d.y, d.z};
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc) {
+        float v = e[r][0] * I0 * e[cc][0];
+        v += e[r][1] * I1 * e[cc][1];
+        v += e[r][2] * I2 * e[cc][2];
+        v += mi * ((r == cc ? dd : 0.0f) - dv[r] * dv[cc]);
+        m.at(k++) = v;
+      }
+    m.at(k++) = mi;
+  }
+  for (int i = 0; i < s.n_links; ++i) {
+    const Body b = m.body(i);
+    const float f = m.at(m.lay.mass + i) / M;
+    m.at(k++) = f * b.v.x; m.at(k++) = f * b.v.y; m.at(k++) = f * b.v.z;
+    m.at(k++) = b.w.x; m.at(k++) = b.w.y; m.at(k++) = b.w.z;
+  }
+  for (int i = 0; i < s.n_dof; ++i) m.at(k++) = zero_frc ? 0.0f : m.at(m.lay.tau + i);
 }
 
 // kinematics.forward + com.from_world from (q, qd) held in the io staging rows
@@ -316,10 +415,19 @@ __device__ __noinline__ void forward_kinematics(const carl_brax_sys_t& s, const 
       const Body bp = (P < 0) ? world_body() : m.body(P);
       const v3 o_p = (P < 0) ? V(0, 0, 0) : m.get3(m.lay.force + 6 * P);
       const v3 ov_p = (P < 0) ? V(0, 0, 0) : m.get3(m.lay.force + 6 * P + 3);
-      const int ns = s.n_slide[i];
+      const int ns = s.n_slide[i], nr = s.n_link_dof[i] - ns;
       const qt jr = f4(s.joint_rot[i]), lrot = f4(s.link_rot[i]);
-      const float th = m.at(q0 + ns), rate = m.at(d0 + ns);
-      const qt rl = qmul(qmul(jr, qaxis(0, th)), qconj(jr));
+      const qt rpj = qmul(qmul(bp.r, lrot), jr);  // parent-side joint frame in the world
+      // hinges stack intrinsically about the joint frame's x, y, +-z
+      qt rj{1.0f, 0.0f, 0.0f, 0.0f};
+      v3 wj = V(0, 0, 0);
+      for (int k = 0; k < nr; ++k) {
+        const float sg = (k == 2) ? s.dof_sign3[i] : 1.0f;
+        const v3 axis = qrot(qmul(rpj, rj), V(k == 0 ? 1.0f : 0.0f, k == 1 ? 1.0f : 0.0f, k == 2 ? 1.0f : 0.0f)) * sg;
+        wj = wj + axis * m.at(d0 + ns + k);
+        rj = qmul(rj, qaxis(k, sg * m.at(q0 + ns + k)));
+      }
+      const qt rl = qmul(qmul(jr, rj), qconj(jr));  // joint rotation in child coordinates
       const v3 a = f3(s.joint_pos[i]);
       v3 lpos = f3(s.link_pos[i]) + qrot(lrot, a - qrot(rl, a));
       v3 slide_vel = V(0, 0, 0);
@@ -331,9 +439,8 @@ __device__ __noinline__ void forward_kinematics(const carl_brax_sys_t& s, const 
       rot = qmul(bp.r, qmul(lrot, rl));
       o = o_p + qrot(bp.r, lpos);
       const v3 anchor_w = o + qrot(rot, a);
-      const v3 axis = qrot(qmul(qmul(bp.r, lrot), jr), V(1, 0, 0));
-      ang = bp.w + axis * rate;
-      vel = ov_p + cross(bp.w, o - o_p) + slide_vel + cross(axis * rate, o - anchor_w);
+      ang = bp.w + wj;
+      vel = ov_p + cross(bp.w, o - o_p) + slide_vel + cross(wj, o - anchor_w);
     }
     const int fr = m.lay.force + 6 * i;
     m.at(fr) = o.x; m.at(fr + 1) = o.y; m.at(fr + 2) = o.z;
@@ -365,6 +472,10 @@ __device__ __noinline__ void reset_state(const carl_brax_sys_t& s, const carl_ba
     const uint32_t x = (k & 3) == 0 ? w.x : (k & 3) == 1 ? w.y : (k & 3) == 2 ? w.z : w.w;
     m.at(m.lay.io + i) = s.init_q[i] + s.reset_noise_scale * (2.0f * u01(x) - 1.0f);
   }
+  if (s.reset_vel_uniform) {  // brax.envs.humanoid: qvel = U(-scale, scale)
+    for (int i = 0; i < s.n_dof; ++i, ++k)
+      m.at(m.lay.io + s.n_q + i) = s.reset_vel_scale * (2.0f * draw_u(b.seed, glane, episode, k) - 1.0f);
+  } else
   for (int i = 0; i < s.n_dof; i += 2, k += 2) {
     const float u1 = draw_u(b.seed, glane, episode, k), u2 = draw_u(b.seed, glane, episode, k + 1);
     const float rad = sqrtf(-2.0f * logf(1.0f - u1));
@@ -505,7 +616,8 @@ __global__ void __launch_bounds__(kLanes) brax_kernel(const carl_batch_t b, cons
       if (b.ctx_obs != nullptr)
         for (int k = 0; k < b.n_ctx_obs; ++k)
           b.ctx_obs[(size_t)k * n + lane] = b.ctx_table[(size_t)b.ctx_obs_feat[k] * b.ctx_stride + r.cidx];
-      observe(s, m);
+      if (s.obs_extended) load_ctx(s, b, m, r.cidx);  // com inertia / velocity use the lane's masses
+      observe(s, m, true);
       if (reset_obs != nullptr)  // masked resets write only their own rows (no block staging)
         for (int k = 0; k < s.obs_dim; ++k) reset_obs[(size_t)lane * s.obs_dim + k] = m.at(m.lay.io + k);
     }
@@ -535,11 +647,12 @@ __global__ void __launch_bounds__(kLanes) brax_kernel(const carl_batch_t b, cons
           m.at(m.lay.tau + s.act_dof[k]) += s.act_gear[k] * fminf(fmaxf(u, s.act_lo[k]), s.act_hi[k]);
         }
         const Body b0 = m.body(0);
-        const float x0 = b0.p.x - qrot(b0.r, f3(s.com[0])).x;
+        float msum;
+        const float x0 = s.reward_on_com ? system_com(s, m, &msum).x : b0.p.x - qrot(b0.r, f3(s.com[0])).x;
         for (int f = 0; f < s.n_frames; ++f) substep(s, r.ctx, m);
         const Body b1 = m.body(0);
         const v3 c1 = qrot(b1.r, f3(s.com[0]));
-        const float x1 = b1.p.x - c1.x, z1 = b1.p.z - c1.z;
+        const float x1 = s.reward_on_com ? system_com(s, m, &msum).x : b1.p.x - c1.x, z1 = b1.p.z - c1.z;
         const bool healthy = (z1 >= s.healthy_z_lo) && (z1 <= s.healthy_z_hi);
         reward = s.forward_reward_weight * (x1 - x0) / dt_env +
                  (s.terminate_when_unhealthy ? s.healthy_reward : (healthy ? s.healthy_reward : 0.0f)) -
@@ -596,7 +709,7 @@ __global__ void __launch_bounds__(kLanes) brax_kernel(const carl_batch_t b, cons
             if (b.ctx_obs != nullptr)
               for (int k = 0; k < b.n_ctx_obs; ++k)
                 b.ctx_obs[(size_t)k * n + lane] = b.ctx_table[(size_t)b.ctx_obs_feat[k] * b.ctx_stride + r.cidx];
-            observe(s, m);
+            observe(s, m, true);
           }
         }
       }

@@ -176,10 +176,19 @@ int validate_brax(const carl_batch_t* b, const carl_brax_sys_t* sd, const carl_b
     return fail(CARL_ERR_INVALID_ARGUMENT, "%s: model table out of range", who);
   for (int i = 0; i < sh->n_links; ++i) {
     const bool free_root = sh->parent[i] < 0 && sh->n_link_dof[i] == 6;
-    const bool hinge = sh->n_slide[i] >= 0 && sh->n_slide[i] <= 2 && sh->n_link_dof[i] - sh->n_slide[i] == 1;
+    const int n_rot = sh->n_link_dof[i] - sh->n_slide[i];
+    const bool hinge = sh->n_slide[i] >= 0 && sh->n_slide[i] <= 2 && n_rot >= 1 && n_rot <= 3;
     if (sh->parent[i] >= i || !(free_root || hinge))
       return fail(CARL_ERR_UNSUPPORTED,
-                  "%s: link %d: supported joints are a free root, or 0-2 prismatic dofs + one hinge", who, i);
+                  "%s: link %d: supported joints are a free root, or 0-2 prismatic dofs + 1-3 stacked hinges", who, i);
+    if (!free_root && n_rot == 3 && sh->dof_sign3[i] != 1.0f && sh->dof_sign3[i] != -1.0f)
+      return fail(CARL_ERR_INVALID_ARGUMENT, "%s: link %d: dof_sign3 must be +1 or -1", who, i);
+  }
+  {
+    const int base = sh->n_q - sh->exclude_current_positions + sh->n_dof;
+    const int want = sh->obs_extended ? base + 16 * sh->n_links + sh->n_dof : base;
+    if (sh->obs_dim != want)
+      return fail(CARL_ERR_INVALID_ARGUMENT, "%s: obs_dim %d does not match the model (%d)", who, sh->obs_dim, want);
   }
   if (b->fin_count != nullptr && (b->fin_capacity <= 0 || !b->fin_lane || !b->fin_return || !b->fin_length))
     return fail(CARL_ERR_INVALID_ARGUMENT, "%s: finished-episode log is incomplete", who);

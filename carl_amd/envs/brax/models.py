@@ -241,4 +241,180 @@ def halfcheetah_sys(feature_names: list[str] | None = None, reference_compat: bo
     return s
 
 
-SYSTEMS = {"ant": ant_sys, "halfcheetah": halfcheetah_sys}
+def _frame_quat(a0, a1) -> tuple[float, float, float, float]:
+    """quaternion of the joint frame whose x / y axes are the (orthogonal) hinge axes a0 / a1"""
+    x = np.asarray(a0, dtype=np.float64)
+    x = x / np.linalg.norm(x)
+    y = np.asarray(a1, dtype=np.float64)
+    y = y - x * float(x @ y)
+    y = y / np.linalg.norm(y)
+    z = np.cross(x, y)
+    R = np.stack([x, y, z], axis=1)
+    # Shepperd's method
+    t = np.trace(R)
+    if t > 0:
+        w = math.sqrt(1.0 + t) / 2
+        q = (w, (R[2, 1] - R[1, 2]) / (4 * w), (R[0, 2] - R[2, 0]) / (4 * w), (R[1, 0] - R[0, 1]) / (4 * w))
+    else:
+        i = int(np.argmax(np.diag(R)))
+        j, k = (i + 1) % 3, (i + 2) % 3
+        r = math.sqrt(1.0 + R[i, i] - R[j, j] - R[k, k])
+        v = [0.0, 0.0, 0.0]
+        v[i] = r / 2
+        v[j] = (R[j, i] + R[i, j]) / (2 * r)
+        v[k] = (R[k, i] + R[i, k]) / (2 * r)
+        q = ((R[k, j] - R[j, k]) / (2 * r), v[0], v[1], v[2])
+    n = math.sqrt(sum(c * c for c in q))
+    return tuple(float(c / n) for c in q)
+
+
+def _vol(kind, a, b, r):
+    if kind == "sphere":
+        return 4.0 / 3.0 * math.pi * r**3
+    return math.pi * r * r * float(np.linalg.norm(np.subtract(b, a))) + 4.0 / 3.0 * math.pi * r**3
+
+
+HUMANOID_MASSES = {
+    "mass_torso": 10.0, "mass_lwaist": 2.2619467, "mass_pelvis": 6.6161942, "mass_right_thigh": 4.751751,
+    "mass_right_shin": 4.522842, "mass_left_thigh": 4.751751, "mass_left_shin": 4.522842,
+    "mass_right_upper_arm": 1.6610805, "mass_right_lower_arm": 1.2295402, "mass_left_upper_arm": 1.6610805,
+    "mass_left_lower_arm": 1.2295402,
+}
+
+
+def humanoid_sys(feature_names: list[str] | None = None, reference_compat: bool = False) -> _lib.BraxSys:
+    """Humanoid: torso (free root) + lwaist (2 hinges), pelvis (1), 2 x (thigh: 3 hinges, shin: 1),
+    2 x (upper arm: 2 hinges, lower arm: 1); q 24, qd 23, 17 motors, obs 244 =
+    q[2:] (22) ++ qd (23) ++ com inertia (11 x 10) ++ com velocity (11 x 6) ++ qfrc_actuator (23).
+
+    Geometry, joint axes / ranges / stiffness, gears and env constants restated from upstream
+    memory of brax's ``humanoid.xml`` (a Gym-Humanoid derivative) and ``brax/envs/humanoid.py``
+    (spring backend: dt 0.0015 x 10 frames; forward weight 1.25 on the whole-body COM velocity,
+    healthy reward 5 while z in [1, 2], ctrl cost 0.1, reset noise U(+-0.01) on q AND qd).
+    Multi-dof joints stack intrinsically in MJCF joint order about the joint frame's x, y, +-z
+    (``dof_sign3``); the spring-constraint constants are this build's choice.  PARITY UNPINNED."""
+    s = _lib.BraxSys()
+    s.env_kind = _lib.BRAX_HUMANOID
+    s.n_links, s.n_q, s.n_dof, s.n_act = 11, 24, 23, 17
+    s.n_frames = 10
+    s.max_episode_steps = 1000
+    s.terminate_when_unhealthy = 1
+    s.exclude_current_positions = 2
+    s.obs_extended, s.reset_vel_uniform, s.reward_on_com = 1, 1, 1
+    s.obs_dim = (s.n_q - 2) + s.n_dof + 16 * s.n_links + s.n_dof  # 244
+    s.dt = 0.0015
+    s.gravity_z, s.vel_damping, s.ang_damping = -9.81, 0.0, 0.0
+    s.baumgarte_erp, s.elasticity, s.friction = 0.1, 0.0, 1.0
+    s.healthy_z_lo, s.healthy_z_hi, s.healthy_reward = 1.0, 2.0, 5.0
+    s.ctrl_cost_weight, s.forward_reward_weight = 0.1, 1.25
+    s.reset_noise_scale, s.reset_vel_scale = 0.01, 0.01
+    ident = (1.0, 0.0, 0.0, 0.0)
+    tilt = (1.0, 0.0, -0.002, 0.0)
+    X, Y, Z = (1, 0, 0), (0, 1, 0), (0, 0, 1)
+    cap, sph = "capsule", "sphere"
+    # (name, parent, body pos, body quat, joint pos, joints[(name, axis, (lo, hi) deg, stiffness, damping)], geoms)
+    links = [
+        ("torso", -1, (0, 0, 1.4), ident, (0, 0, 0), None,
+         [(cap, (0, -0.07, 0), (0, 0.07, 0), 0.07), (sph, (0, 0, 0.19), None, 0.09),
+          (cap, (-0.01, -0.06, -0.12), (-0.01, 0.06, -0.12), 0.06)]),
+        ("lwaist", 0, (-0.01, 0, -0.26), tilt, (0, 0, 0.065),
+         [("abdomen_z", Z, (-45, 45), 20, 5), ("abdomen_y", Y, (-75, 30), 10, 5)],
+         [(cap, (0, -0.06, 0), (0, 0.06, 0), 0.06)]),
+        ("pelvis", 1, (0, 0, -0.165), tilt, (0, 0, 0.1), [("abdomen_x", X, (-35, 35), 10, 5)],
+         [(cap, (-0.02, -0.07, 0), (-0.02, 0.07, 0), 0.09)]),
+        ("right_thigh", 2, (0, -0.1, -0.04), ident, (0, 0, 0),
+         [("right_hip_x", X, (-25, 5), 10, 5), ("right_hip_z", Z, (-60, 35), 10, 5),
+          ("right_hip_y", Y, (-110, 20), 20, 5)],
+         [(cap, (0, 0, 0), (0, 0.01, -0.34), 0.06)]),
+        ("right_shin", 3, (0, 0.01, -0.403), ident, (0, 0, 0.02), [("right_knee", (0, -1, 0), (-160, -2), 1, 1)],
+         [(cap, (0, 0, 0), (0, 0, -0.3), 0.049), (sph, (0, 0, -0.35), None, 0.075)]),
+        ("left_thigh", 2, (0, 0.1, -0.04), ident, (0, 0, 0),
+         [("left_hip_x", (-1, 0, 0), (-25, 5), 10, 5), ("left_hip_z", (0, 0, -1), (-60, 35), 10, 5),
+          ("left_hip_y", Y, (-110, 20), 20, 5)],
+         [(cap, (0, 0, 0), (0, -0.01, -0.34), 0.06)]),
+        ("left_shin", 5, (0, -0.01, -0.403), ident, (0, 0, 0.02), [("left_knee", (0, -1, 0), (-160, -2), 1, 1)],
+         [(cap, (0, 0, 0), (0, 0, -0.3), 0.049), (sph, (0, 0, -0.35), None, 0.075)]),
+        ("right_upper_arm", 0, (0, -0.17, 0.06), ident, (0, 0, 0),
+         [("right_shoulder1", (2, 1, 1), (-85, 60), 1, 1), ("right_shoulder2", (0, -1, 1), (-85, 60), 1, 1)],
+         [(cap, (0, 0, 0), (0.16, -0.16, -0.16), 0.04)]),
+        ("right_lower_arm", 7, (0.18, -0.18, -0.18), ident, (0, 0, 0),
+         [("right_elbow", (0, -1, 1), (-90, 50), 0, 1)],
+         [(cap, (0.01, 0.01, 0.01), (0.17, 0.17, 0.17), 0.031), (sph, (0.18, 0.18, 0.18), None, 0.04)]),
+        ("left_upper_arm", 0, (0, 0.17, 0.06), ident, (0, 0, 0),
+         [("left_shoulder1", (2, -1, 1), (-60, 85), 1, 1), ("left_shoulder2", (0, 1, 1), (-60, 85), 1, 1)],
+         [(cap, (0, 0, 0), (0.16, 0.16, -0.16), 0.04)]),
+        ("left_lower_arm", 9, (0.18, 0.18, -0.18), ident, (0, 0, 0),
+         [("left_elbow", (0, -1, -1), (-90, 50), 0, 1)],
+         [(cap, (0.01, -0.01, 0.01), (0.17, -0.17, 0.17), 0.031), (sph, (0.18, -0.18, 0.18), None, 0.04)]),
+    ]
+    coll, link_ids, joint_dof = [], {}, {}
+    qi = di = 0
+    for i, (name, parent, pos, quat, jpos, joints, geoms) in enumerate(links):
+        link_ids[name] = i
+        s.parent[i] = parent
+        _set3(s.link_pos, i, pos)
+        qn = np.asarray(quat, dtype=np.float64)
+        _set3(s.link_rot, i, qn / np.linalg.norm(qn))
+        _set3(s.joint_pos, i, jpos)
+        s.q_start[i], s.dof_start[i] = qi, di
+        s.n_slide[i] = 0
+        s.dof_sign3[i] = 1.0
+        if joints is None:
+            s.n_link_dof[i] = 6
+            _set3(s.joint_rot, i, ident)
+            qi, di = qi + 7, di + 6
+        else:
+            nr = len(joints)
+            s.n_link_dof[i] = nr
+            axes = [np.asarray(j[1], dtype=np.float64) / np.linalg.norm(j[1]) for j in joints]
+            if nr == 1:
+                _set3(s.joint_rot, i, _axis_quat(axes[0]))
+            else:
+                assert abs(float(axes[0] @ axes[1])) < 1e-12
+                _set3(s.joint_rot, i, _frame_quat(axes[0], axes[1]))
+                if nr == 3:
+                    sg = float(np.cross(axes[0], axes[1]) @ axes[2])
+                    assert abs(abs(sg) - 1.0) < 1e-12
+                    s.dof_sign3[i] = 1.0 if sg > 0 else -1.0
+            for k, (jn, _ax, (lo, hi), stiff, damp) in enumerate(joints):
+                d = di + k
+                joint_dof[jn] = d
+                s.dof_lo[d], s.dof_hi[d] = math.radians(lo), math.radians(hi)
+                s.dof_stiffness[d], s.dof_damping[d] = float(stiff), float(damp)
+            qi, di = qi + nr, di + nr
+        vols, ctrs = [], []
+        for kind, a, b, r in geoms:
+            vols.append(_vol(kind, a, b, r))
+            if kind == "sphere":
+                ctrs.append(np.asarray(a, dtype=np.float64))
+                coll.append((i, a, r))
+            else:
+                ctrs.append((np.asarray(a, dtype=np.float64) + np.asarray(b, dtype=np.float64)) / 2)
+                coll += [(i, a, r), (i, b, r)]
+        _set3(s.com, i, sum(v * c for v, c in zip(vols, ctrs)) / sum(vols))
+        s.mass[i] = 1.0
+        _set3(s.inv_inertia, i, (1.0, 1.0, 1.0))
+        s.k_pos[i], s.k_vel[i], s.k_limit[i], s.k_ang_damp[i] = 20000.0, 100.0, 1000.0, 20.0
+    assert qi == s.n_q and di == s.n_dof
+    motors = [("abdomen_y", 100), ("abdomen_z", 100), ("abdomen_x", 100), ("right_hip_x", 100), ("right_hip_z", 100),
+              ("right_hip_y", 300), ("right_knee", 200), ("left_hip_x", 100), ("left_hip_z", 100), ("left_hip_y", 300),
+              ("left_knee", 200), ("right_shoulder1", 25), ("right_shoulder2", 25), ("right_elbow", 25),
+              ("left_shoulder1", 25), ("left_shoulder2", 25), ("left_elbow", 25)]
+    for k, (jn, gear) in enumerate(motors):
+        s.act_dof[k], s.act_gear[k], s.act_lo[k], s.act_hi[k] = joint_dof[jn], float(gear), -0.4, 0.4
+    s.n_coll = len(coll)
+    assert s.n_coll <= _lib.BRAX_MAX_COLL
+    for k, (link, pos, rad) in enumerate(coll):
+        s.coll_link[k], s.coll_radius[k] = link, rad
+        _set3(s.coll_pos, k, pos)
+    init_q = [0.0, 0.0, 1.4, 1.0, 0.0, 0.0, 0.0] + [0.0] * 17
+    for i, v in enumerate(init_q):
+        s.init_q[i] = v
+    _wire_context(s, feature_names, reference_compat, link_ids, HUMANOID_MASSES)
+    # STATE_INDICES["humanoid"] = [22, 23] (brax_walker_goal_wrapper.py:8) on the 244-dim obs
+    # (= qd[0], qd[1], the root's world x / y velocity); humanoid.xml timestep 0.003 (Quirk B3)
+    s.goal_obs_idx[0], s.goal_obs_idx[1], s.goal_dt = 22, 23, 0.003
+    return s
+
+
+SYSTEMS = {"ant": ant_sys, "halfcheetah": halfcheetah_sys, "humanoid": humanoid_sys}

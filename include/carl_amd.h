@@ -240,8 +240,10 @@ typedef struct carl_brax_sys {
   float reset_noise_scale, reset_vel_scale;
   /* links, topological order, parent < child */
   int32_t parent[CARL_BRAX_MAX_LINKS];      /* -1: free root */
-  int32_t n_link_dof[CARL_BRAX_MAX_LINKS];  /* 6 = free root; else n_slide prismatic dofs followed by ONE hinge
-                                               about the joint frame's x axis.  parent -1 with n_link_dof < 6 =
+  int32_t n_link_dof[CARL_BRAX_MAX_LINKS];  /* 6 = free root; else n_slide prismatic dofs followed by 1..3
+                                               revolute dofs turning, in order, about the joint frame's x, y,
+                                               +-z axes (each carried by the preceding ones: MuJoCo's stacking of
+                                               several hinges in one body).  parent -1 with n_link_dof < 6 =
                                                jointed to the static world (planar roots) */
   int32_t q_start[CARL_BRAX_MAX_LINKS], dof_start[CARL_BRAX_MAX_LINKS];
   float link_pos[CARL_BRAX_MAX_LINKS][3], link_rot[CARL_BRAX_MAX_LINKS][4];   /* child frame in parent frame at q = 0 */
@@ -264,7 +266,12 @@ typedef struct carl_brax_sys {
   int32_t goal_mode;
   int32_t goal_obs_idx[2];
   float goal_dt;
-  int32_t n_slide[CARL_BRAX_MAX_LINKS];        /* 0..2 prismatic dofs (q order: slides, then the hinge) */
+  int32_t n_slide[CARL_BRAX_MAX_LINKS];        /* 0..2 prismatic dofs (q order: slides, then the hinges) */
+  float dof_sign3[CARL_BRAX_MAX_LINKS];        /* +1 / -1: third hinge axis = sign * (x cross y) of the joint frame */
+  int32_t reset_vel_uniform;                   /* qd noise: 1 = U(-scale, scale) (humanoid), 0 = scale * N(0,1) */
+  int32_t reward_on_com;                       /* forward velocity of the whole-body centre of mass (humanoid) */
+  int32_t obs_extended;                        /* append com inertia (L x 10), com velocity (L x 6), qfrc_actuator */
+  int32_t reserved2;
   float slide_axis[CARL_BRAX_MAX_LINKS][2][3]; /* unit axes in the PARENT frame, mutually orthogonal */
   carl_brax_ctx_map_t ctx;
 } carl_brax_sys_t;

@@ -157,11 +157,20 @@ static void forward_kinematics(const carl_brax_sys_t* s, const double* q, const 
       const body bp = (P < 0) ? WORLD : b[P];
       const v3 o_p = (P < 0) ? V(0, 0, 0) : org[P];
       const v3 ov_p = (P < 0) ? V(0, 0, 0) : ovel[P];
-      const int ns = s->n_slide[i];
+      const int ns = s->n_slide[i], nr = s->n_link_dof[i] - ns;
       const qt jr = f4(s->joint_rot[i]);
-      const double th = q[s->q_start[i] + ns], rate = qd[s->dof_start[i] + ns];
-      const qt rl = qmul(qmul(jr, qaxis(0, th)), qconj(jr)); /* hinge rotation in child coordinates */
       const qt lrot = f4(s->link_rot[i]);
+      const qt rpj = qmul(qmul(bp.r, lrot), jr); /* parent-side joint frame in the world */
+      /* hinges stack intrinsically about the joint frame's x, y, +-z */
+      qt rj = {1, 0, 0, 0};
+      v3 wj = V(0, 0, 0);
+      for (int k = 0; k < nr; ++k) {
+        const double sg = (k == 2) ? (double)s->dof_sign3[i] : 1.0;
+        const v3 axis = vscale(qrot(qmul(rpj, rj), V(k == 0, k == 1, k == 2)), sg);
+        wj = vadd(wj, vscale(axis, qd[s->dof_start[i] + ns + k]));
+        rj = qmul(rj, qaxis(k, sg * q[s->q_start[i] + ns + k]));
+      }
+      const qt rl = qmul(qmul(jr, rj), qconj(jr)); /* joint rotation in child coordinates */
       const v3 a = f3(s->joint_pos[i]);
       v3 lpos = vadd(f3(s->link_pos[i]), qrot(lrot, vsub(a, qrot(rl, a)))); /* the anchor stays put */
       v3 slide_vel = V(0, 0, 0);
@@ -173,10 +182,8 @@ static void forward_kinematics(const carl_brax_sys_t* s, const double* q, const 
       rot = qmul(bp.r, qmul(lrot, rl));
       o = vadd(o_p, qrot(bp.r, lpos));
       const v3 anchor_w = vadd(o, qrot(rot, a));
-      const v3 axis = qrot(qmul(qmul(bp.r, lrot), jr), V(1, 0, 0));
-      ang = vadd(bp.w, vscale(axis, rate));
-      vel = vadd(vadd(ov_p, vcross(bp.w, vsub(o, o_p))),
-                 vadd(slide_vel, vcross(vscale(axis, rate), vsub(o, anchor_w))));
+      ang = vadd(bp.w, wj);
+      vel = vadd(vadd(ov_p, vcross(bp.w, vsub(o, o_p))), vadd(slide_vel, vcross(wj, vsub(o, anchor_w))));
     }
     org[i] = o; ovel[i] = vel;
     b[i].r = rot; b[i].w = ang;
@@ -189,7 +196,9 @@ static void forward_kinematics(const carl_brax_sys_t* s, const double* q, const 
 /* joint geometry shared by inverse kinematics and joints.resolve */
 typedef struct {
   v3 A_c, A_p, vA_c, vA_p, x_c, x_p, wrel;
-  double theta, thetadot;
+  double theta, thetadot;        /* single hinge */
+  v3 axis[3];                    /* multi-hinge joints: current world axes ... */
+  double ang[3], rate[3];        /* ... Euler x-y-z angles (third signed) and their rates */
 } joint_geom;
 
 static joint_geom joint_geometry(const carl_brax_sys_t* s, int i, const body* bc, const body* bp) {
@@ -213,6 +222,31 @@ static joint_geom joint_geometry(const carl_brax_sys_t* s, int i, const body* bc
   g.theta = 2.0 * atan2(rel.x, rel.w); /* twist about the hinge (joint frame x) */
   g.wrel = vsub(bc->w, bp->w);
   g.thetadot = vdot(g.x_c, g.wrel);
+  const int nr = s->n_link_dof[i] - s->n_slide[i];
+  if (nr >= 2) { /* rel = Rx(al) Ry(be) Rz(ga): decompose, ga = sign * theta_3 */
+    const double R00 = 1 - 2 * (rel.y * rel.y + rel.z * rel.z), R01 = 2 * (rel.x * rel.y - rel.w * rel.z);
+    double R02 = 2 * (rel.x * rel.z + rel.w * rel.y);
+    const double R12 = 2 * (rel.y * rel.z - rel.w * rel.x), R22 = 1 - 2 * (rel.x * rel.x + rel.y * rel.y);
+    if (R02 > 1) R02 = 1;
+    if (R02 < -1) R02 = -1;
+    const double al = atan2(-R12, R22), be = asin(R02), ga = atan2(-R01, R00);
+    const double sg = s->dof_sign3[i];
+    g.ang[0] = al; g.ang[1] = be; g.ang[2] = sg * ga;
+    g.axis[0] = g.x_p;
+    const qt rx = qaxis(0, al);
+    g.axis[1] = qrot(qmul(rp, rx), V(0, 1, 0));
+    g.axis[2] = vscale(qrot(qmul(qmul(rp, rx), qaxis(1, be)), V(0, 0, 1)), sg);
+    const double w0 = vdot(g.wrel, g.axis[0]), w1 = vdot(g.wrel, g.axis[1]), w2 = vdot(g.wrel, g.axis[2]);
+    g.rate[1] = w1;
+    if (nr == 3) { /* axis0 and axis2 are not orthogonal: axis0 . axis2 = sign * sin(be) */
+      const double c = vdot(g.axis[0], g.axis[2]), den = 1 - c * c;
+      g.rate[0] = (w0 - c * w2) / den;
+      g.rate[2] = (w2 - c * w0) / den;
+    } else {
+      g.rate[0] = w0;
+      g.rate[2] = w2; /* locked direction: any rate here is constraint violation, damped below */
+    }
+  }
   return g;
 }
 
@@ -239,8 +273,16 @@ static void inverse_kinematics(const carl_brax_sys_t* s, const body* b, double* 
         q[s->q_start[i] + k] = vdot(vsub(g.A_c, g.A_p), ax);
         qd[s->dof_start[i] + k] = vdot(vsub(g.vA_c, g.vA_p), ax);
       }
-      q[s->q_start[i] + ns] = g.theta;
-      qd[s->dof_start[i] + ns] = g.thetadot;
+      const int nr = s->n_link_dof[i] - ns;
+      if (nr == 1) {
+        q[s->q_start[i] + ns] = g.theta;
+        qd[s->dof_start[i] + ns] = g.thetadot;
+      } else {
+        for (int k = 0; k < nr; ++k) {
+          q[s->q_start[i] + ns + k] = g.ang[k];
+          qd[s->dof_start[i] + ns + k] = g.rate[k];
+        }
+      }
     }
   }
 }
@@ -275,12 +317,30 @@ static void substep(const carl_brax_sys_t* s, const lane_ctx* c, const double* t
     f = vadd(f, vadd(vscale(e, kp), vscale(ev, s->k_vel[i])));
     F[i] = vadd(F[i], f);
     T[i] = vadd(T[i], vcross(vsub(g.A_c, b[i].p), f));
-    v3 t = vscale(vcross(g.x_c, g.x_p), kp); /* keep the hinge axes aligned */
-    const int d = d0 + ns;
-    double ta = tau[d] - s->dof_damping[d] * g.thetadot - s->dof_stiffness[d] * g.theta;
-    if (g.theta < s->dof_lo[d]) ta += s->k_limit[i] * (s->dof_lo[d] - g.theta);
-    if (g.theta > s->dof_hi[d]) ta -= s->k_limit[i] * (g.theta - s->dof_hi[d]);
-    t = vadd(t, vscale(g.x_c, ta));
+    v3 t;
+    const int d = d0 + ns, nr = s->n_link_dof[i] - ns;
+    if (nr == 1) {
+      t = vscale(vcross(g.x_c, g.x_p), kp); /* keep the hinge axes aligned */
+      double ta = tau[d] - s->dof_damping[d] * g.thetadot - s->dof_stiffness[d] * g.theta;
+      if (g.theta < s->dof_lo[d]) ta += s->k_limit[i] * (s->dof_lo[d] - g.theta);
+      if (g.theta > s->dof_hi[d]) ta -= s->k_limit[i] * (g.theta - s->dof_hi[d]);
+      t = vadd(t, vscale(g.x_c, ta));
+    } else { /* 2 or 3 stacked hinges: per-dof torques about the current axes; a missing third
+                dof is locked by the constraint spring on its Euler angle */
+      t = V(0, 0, 0);
+      for (int k = 0; k < 3; ++k) {
+        double ta;
+        if (k < nr) {
+          const int dk = d + k;
+          ta = tau[dk] - s->dof_damping[dk] * g.rate[k] - s->dof_stiffness[dk] * g.ang[k];
+          if (g.ang[k] < s->dof_lo[dk]) ta += s->k_limit[i] * (s->dof_lo[dk] - g.ang[k]);
+          if (g.ang[k] > s->dof_hi[dk]) ta -= s->k_limit[i] * (g.ang[k] - s->dof_hi[dk]);
+        } else {
+          ta = -kp * g.ang[k];
+        }
+        t = vadd(t, vscale(g.axis[k], ta));
+      }
+    }
     t = vsub(t, vscale(g.wrel, s->k_ang_damp[i]));
     T[i] = vadd(T[i], t);
     if (P >= 0) {
@@ -346,12 +406,48 @@ static void substep(const carl_brax_sys_t* s, const lane_ctx* c, const double* t
   }
 }
 
-static void observe(const carl_brax_sys_t* s, const body* b, float* obs) {
+/* whole-body centre of mass (brax.envs.humanoid.Humanoid._com) */
+static v3 system_com(const carl_brax_sys_t* s, const lane_ctx* c, const body* b, double* mass_sum) {
+  v3 com = V(0, 0, 0);
+  double M = 0;
+  for (int i = 0; i < s->n_links; ++i) { com = vadd(com, vscale(b[i].p, c->mass[i])); M += c->mass[i]; }
+  *mass_sum = M;
+  return vscale(com, 1.0 / M);
+}
+
+/* brax.envs.<env>._get_obs: q[skip:] ++ qd, and for the humanoid ++ com_inertia (L x 10) ++
+ * com_velocity (L x 6) ++ qfrc_actuator (n_dof) */
+static void observe(const carl_brax_sys_t* s, const lane_ctx* c, const body* b, const double* tau, float* obs) {
   double q[CARL_BRAX_MAX_Q], qd[CARL_BRAX_MAX_DOF];
   inverse_kinematics(s, b, q, qd);
   int k = 0;
   for (int i = s->exclude_current_positions; i < s->n_q; ++i) obs[k++] = (float)q[i];
   for (int i = 0; i < s->n_dof; ++i) obs[k++] = (float)qd[i];
+  if (!s->obs_extended) return;
+  double M;
+  const v3 com = system_com(s, c, b, &M);
+  for (int i = 0; i < s->n_links; ++i) { /* inertia about the system com, world axes, row-major, then mass */
+    const v3 d = vsub(b[i].p, com);
+    const double m = c->mass[i], dd = vdot(d, d);
+    const double Ib[3] = {1.0 / s->inv_inertia[i][0], 1.0 / s->inv_inertia[i][1], 1.0 / s->inv_inertia[i][2]};
+    const v3 ex = qrot(b[i].r, V(1, 0, 0)), ey = qrot(b[i].r, V(0, 1, 0)), ez = qrot(b[i].r, V(0, 0, 1));
+    const double e[3][3] = {{ex.x, ey.x, ez.x}, {ex.y, ey.y, ez.y}, {ex.z, ey.z, ez.z}}; /* R */
+    const double dv[3] = {d.x, d.y, d.z};
+    for (int r = 0; r < 3; ++r)
+      for (int cc = 0; cc < 3; ++cc) {
+        double v = 0;
+        for (int j = 0; j < 3; ++j) v += e[r][j] * Ib[j] * e[cc][j];
+        v += m * ((r == cc ? dd : 0.0) - dv[r] * dv[cc]);
+        obs[k++] = (float)v;
+      }
+    obs[k++] = (float)m;
+  }
+  for (int i = 0; i < s->n_links; ++i) {
+    const double f = c->mass[i] / M;
+    obs[k++] = (float)(f * b[i].v.x); obs[k++] = (float)(f * b[i].v.y); obs[k++] = (float)(f * b[i].v.z);
+    obs[k++] = (float)b[i].w.x; obs[k++] = (float)b[i].w.y; obs[k++] = (float)b[i].w.z;
+  }
+  for (int i = 0; i < s->n_dof; ++i) obs[k++] = (float)(tau ? tau[i] : 0.0);
 }
 
 /* brax.envs.<env>.reset: q = init_q + U(-noise, noise), qd = vel_scale * N(0, 1).
@@ -368,6 +464,9 @@ static void reset_lane(const carl_brax_sys_t* s, uint64_t seed, uint64_t g, uint
   int k = 0;
   for (int i = 0; i < s->n_q; ++i, ++k)
     q[i] = (double)s->init_q[i] + (double)s->reset_noise_scale * (2.0 * draw_u(seed, g, ep, k) - 1.0);
+  if (s->reset_vel_uniform) { /* brax.envs.humanoid: qvel = U(-scale, scale) */
+    for (int i = 0; i < s->n_dof; ++i, ++k) qd[i] = (double)s->reset_vel_scale * (2.0 * draw_u(seed, g, ep, k) - 1.0);
+  } else
   for (int i = 0; i < s->n_dof; i += 2, k += 2) {
     const double u1 = draw_u(seed, g, ep, k), u2 = draw_u(seed, g, ep, k + 1);
     const double rad = sqrt(-2.0 * log(1.0 - u1));
@@ -452,7 +551,6 @@ void obx_engine_reset(const carl_brax_sys_t* s, const oracle_cfg_t* cfg, const d
                       const uint8_t* mask, double* state, int32_t* elapsed, int32_t* ctx_idx, uint32_t* episode,
                       int32_t* n_calls, double* ep_return, float* obs, double* goal_pos) {
   const int S = 13 * s->n_links;
-  (void)ctx_table; (void)n_feat;
   for (int i = 0; i < cfg->n_lanes; ++i) {
     if (mask && !mask[i]) continue;
     const uint64_t g = (uint64_t)(cfg->lane_offset + i);
@@ -465,7 +563,8 @@ void obx_engine_reset(const carl_brax_sys_t* s, const oracle_cfg_t* cfg, const d
     elapsed[i] = 0;
     ep_return[i] = 0.0;
     if (goal_pos) { goal_pos[2 * i] = 0.0; goal_pos[2 * i + 1] = 0.0; } /* wrapper reset: position = (0, 0) */
-    observe(s, b, obs + (size_t)i * s->obs_dim);
+    const lane_ctx c = make_ctx(s, ctx_table + (size_t)ctx_idx[i] * n_feat);
+    observe(s, &c, b, NULL, obs + (size_t)i * s->obs_dim); /* reset obs: qfrc_actuator of a zero action */
   }
 }
 
@@ -494,10 +593,12 @@ void obx_engine_step(const carl_brax_sys_t* s, const oracle_cfg_t* cfg, const do
       tau[s->act_dof[k]] += s->act_gear[k] * u;
     }
     const v3 c0 = qrot(b[0].r, f3(s->com[0]));
-    const double x0 = b[0].p.x - c0.x;
+    double M;
+    double x0 = s->reward_on_com ? system_com(s, &c, b, &M).x : b[0].p.x - c0.x;
     for (int k = 0; k < s->n_frames; ++k) substep(s, &c, tau, b);
     const v3 c1 = qrot(b[0].r, f3(s->com[0]));
-    const double x1 = b[0].p.x - c1.x, z1 = b[0].p.z - c1.z;
+    const double x1 = s->reward_on_com ? system_com(s, &c, b, &M).x : b[0].p.x - c1.x;
+    const double z1 = b[0].p.z - c1.z;
     const double dt_env = (double)s->dt * s->n_frames;
     const int healthy = (z1 >= s->healthy_z_lo) && (z1 <= s->healthy_z_hi);
     const double r = s->forward_reward_weight * (x1 - x0) / dt_env +
@@ -507,7 +608,7 @@ void obx_engine_step(const carl_brax_sys_t* s, const oracle_cfg_t* cfg, const do
     double r_out = r;
     elapsed[i] += 1;
     const int trunc = elapsed[i] >= cfg->max_steps;
-    observe(s, b, obs + (size_t)i * D);
+    observe(s, &c, b, tau, obs + (size_t)i * D);
     if (s->goal_mode && goal_pos) { /* the goal wrapper REPLACES the reward and may terminate */
       int ok = 0;
       r_out = goal_epilogue(s, ctx_table + (size_t)ctx_idx[i] * n_feat, obs + (size_t)i * D, goal_pos + 2 * i, &ok);
@@ -531,7 +632,8 @@ void obx_engine_step(const carl_brax_sys_t* s, const oracle_cfg_t* cfg, const do
         elapsed[i] = 0;
         ep_return[i] = 0.0;
         if (goal_pos) { goal_pos[2 * i] = 0.0; goal_pos[2 * i + 1] = 0.0; }
-        observe(s, b, obs + (size_t)i * D);
+        const lane_ctx c2 = make_ctx(s, ctx_table + (size_t)ctx_idx[i] * n_feat);
+        observe(s, &c2, b, NULL, obs + (size_t)i * D);
       }
     }
     store_bodies(s, b, state + (size_t)i * S);

@@ -216,3 +216,92 @@ def test_halfcheetah_joint_stiffness_context_acts(cheetah):
         a = np.tile(rng.uniform(-1, 1, (1, 6)).astype(np.float32), (2, 1))
         out = e.step(a)
     assert np.abs(out.obs[1] - out.obs[0]).max() > 1e-3
+
+
+# ------------------------------------------------------------------ Humanoid
+from carl_amd.envs.brax.models import HUMANOID_MASSES, humanoid_sys  # noqa: E402
+
+HU_NAMES = (["gravity", "friction", "elasticity", "ang_damping", "viscosity"] + list(HUMANOID_MASSES) +
+            ["target_distance", "target_direction", "target_radius"])
+HU_DEFAULT = np.array([-9.8, 1.0, 0.0, 0.0, 0.0] + list(HUMANOID_MASSES.values()) + [100.0, 1.0, 5.0])
+
+
+@pytest.fixture(scope="module")
+def humanoid():
+    return humanoid_sys(HU_NAMES)
+
+
+def test_humanoid_table_and_kinematics(humanoid):
+    """brax Humanoid shape: q 24, qd 23, 17 motors, 244-dim obs; 2- and 3-dof joints round-trip
+    through forward / inverse kinematics (Euler x-y-+-z decomposition)."""
+    s = humanoid
+    assert (s.n_links, s.n_q, s.n_dof, s.n_act, s.obs_dim) == (11, 24, 23, 17, 244)
+    assert s.n_frames * s.dt == pytest.approx(0.015)
+    assert list(s.parent[:11]) == [-1, 0, 1, 2, 3, 2, 5, 0, 7, 0, 9]
+    assert list(s.n_link_dof[:11]) == [6, 2, 1, 3, 1, 3, 1, 2, 1, 2, 1]
+    assert s.dof_sign3[3] == -1.0 and s.dof_sign3[5] == -1.0  # hips: x, z, y = x cross z reversed
+    assert s.ctx.n_mass == 11 and list(s.ctx.mass_link[:11]) == list(range(11))
+    assert sorted(s.act_dof[:17]) == list(range(6, 23))
+    rng = np.random.default_rng(0)
+    for _ in range(30):
+        q = np.array(s.init_q[:24], dtype=np.float64)
+        q[:7] += rng.uniform(-0.2, 0.2, 7)
+        q[7:] += rng.uniform(-0.6, 0.6, 17)
+        q[3:7] /= np.linalg.norm(q[3:7])
+        qd = rng.normal(0, 1.0, 23)
+        st = B.forward_kinematics(s, q, qd)
+        q2, qd2 = B.inverse_kinematics(s, st)
+        np.testing.assert_allclose(q2, q, atol=5e-6)
+        np.testing.assert_allclose(qd2, qd, atol=1e-5)
+
+
+def test_humanoid_consistent_state_has_no_constraint_force(humanoid):
+    """At a kinematically consistent pose with zero velocity, zero gravity and in-range joints, the
+    joint springs see zero anchor / alignment error: only the dof springs (stiffness * angle) act,
+    so with those angles at zero the state is a fixed point of the substep."""
+    s = humanoid
+    q = np.array(s.init_q[:24], dtype=np.float64)
+    q[13] = q[17] = -0.5  # knees inside their (-160, -2) deg range; their dof stiffness is the only spring
+    st = B.forward_kinematics(s, q, np.zeros(23))
+    row = HU_DEFAULT.copy()
+    row[0] = -1e-6
+    st2 = B.substeps(s, row, np.zeros(23), 1, st.copy())
+    dv = np.abs(st2.reshape(11, 13)[:, 7:] - st.reshape(11, 13)[:, 7:])
+    others = [i for i in range(11) if i not in (3, 4, 5, 6)]  # thigh/shin pairs feel the knee spring
+    assert dv[others].max() < 1e-6
+    assert dv[[4, 6]].max() > 1e-5
+
+
+def test_humanoid_stands_then_random_actions_stay_finite(humanoid):
+    rng = np.random.default_rng(5)
+    n = 8
+    e = B.Engine(humanoid, HU_DEFAULT[None], n, selector=O.SEL_STATIC, seed=4)
+    obs = e.reset()
+    assert obs.shape == (n, 244)
+    np.testing.assert_allclose(obs[:, 0], 1.4, atol=0.011)            # torso z = init + U(+-0.01)
+    assert np.abs(obs[:, 22:45]).max() <= 0.0100001                    # qd ~ U(-0.01, 0.01)
+    assert np.all(obs[:, -23:] == 0)                                   # qfrc_actuator of the reset obs
+    np.testing.assert_allclose(obs[:, 45 + 9], 1.0)                    # com_inertia block: [.., mass] per link
+    total = 0.0
+    for t in range(40):
+        a = rng.uniform(-0.4, 0.4, (n, 17)).astype(np.float32)
+        out = e.step(a)
+        assert np.isfinite(out.obs).all() and np.abs(out.obs).max() < 400
+        total += out.reward.mean()
+        # qfrc_actuator = gear * clipped action scattered to the dofs
+        frc = out.final_obs[:, -23:] if out.terminated.any() else out.obs[:, -23:]
+        live = ~(out.terminated | out.truncated).astype(bool)
+        want = np.zeros((n, 23))
+        for k in range(17):
+            want[:, humanoid.act_dof[k]] += humanoid.act_gear[k] * a[:, k]
+        np.testing.assert_allclose(frc[live], want[live], rtol=1e-6, atol=1e-5)
+    assert total / 40 > 3.0  # healthy reward 5 dominates while upright
+
+
+def test_humanoid_mass_context_changes_com_terms(humanoid):
+    rows = np.tile(HU_DEFAULT, (2, 1))
+    rows[1, HU_NAMES.index("mass_torso")] = 20.0
+    e = B.Engine(humanoid, rows, 2, selector=O.SEL_STATIC, seed=3, ctx_idx0=np.arange(2))
+    obs = e.reset()
+    assert obs[0, 45 + 9] == pytest.approx(1.0) and obs[1, 45 + 9] == pytest.approx(2.0)  # effective mass, link 0
+    assert obs[1, 45 + 19] == pytest.approx(1.0)                                           # link 1 untouched
