@@ -130,7 +130,7 @@ int launch_step(const carl_batch_t* b, const carl_step_io_t* io, int n_steps, hi
     return check_launch("carl_step");
   }
   // full workgroups + global context table: records are staged in LDS and written out by the
-  // workgroup's loader/storer wave with 16-byte stores (see rollout_staged_kernel)
+  // workgroup's storer wave with 16-byte stores (see rollout_staged_kernel)
   static const bool no_staged = getenv("CARL_AMD_NO_STAGED") != nullptr;
   if (!lds && !no_staged && b->n_lanes % carl::kRolloutLanes == 0) {
     const size_t sh_staged = carl::rollout_staged_lds_bytes<Fam>();
@@ -138,10 +138,11 @@ int launch_step(const carl_batch_t* b, const carl_step_io_t* io, int n_steps, hi
                          : reinterpret_cast<const void*>(carl::rollout_staged_kernel<Fam, false>);
     const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_staged);
     if (e != hipSuccess) return fail((int)e, "carl_rollout: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    const dim3 ts(carl::kStagedThreads);  // 4 compute waves + loader wave + storer wave
     if (a64)
-      hipLaunchKernelGGL((carl::rollout_staged_kernel<Fam, true>), g, t, sh_staged, s, *b, *io, n_steps);
+      hipLaunchKernelGGL((carl::rollout_staged_kernel<Fam, true>), g, ts, sh_staged, s, *b, *io, n_steps);
     else
-      hipLaunchKernelGGL((carl::rollout_staged_kernel<Fam, false>), g, t, sh_staged, s, *b, *io, n_steps);
+      hipLaunchKernelGGL((carl::rollout_staged_kernel<Fam, false>), g, ts, sh_staged, s, *b, *io, n_steps);
     return check_launch("carl_rollout");
   }
   CARL_LAUNCH(rollout_kernel, *b, *io, n_steps);

@@ -124,6 +124,7 @@ struct Cursors {
     if (final_obs != nullptr) final_obs += n * Fam::D;
   }
   // output-sink interface of step_lane
+  static constexpr bool kLazyFlags = false;  // flags are written on every step
   __device__ __forceinline__ void put_reward(float r) const { *reward = r; }
   __device__ __forceinline__ void put_flags(bool te, bool tr) const {
     *term = (uint8_t)te;
@@ -139,21 +140,31 @@ struct Cursors {
 template <class Fam>
 struct LdsSink {
   static constexpr int kObsBytes = 256 * Fam::D * 4;
+  static constexpr int kFlagOff = kObsBytes + 1024;  // [256] term | [256] trunc
   static constexpr int kStepBytes = kObsBytes + 256 * 4 + 256 + 256;
-  char* step_base;   // this step's record block in LDS
-  float* final_obs;  // HBM cursor for terminal observations (cold path stores directly), nullable
+  // The flag rows are all-zero except on steps where some lane of the wave finishes an episode:
+  // the storer re-zeroes them after draining, and step_lane writes them only on the (wave-
+  // uniform) done path -- two LDS writes and their operands less in every ordinary step.
+  static constexpr bool kLazyFlags = true;
+  char* step_base;    // this step's record block in LDS
+  float* final_base;  // this lane's terminal-observation slot of step 0 in HBM, nullable
+  size_t n_obs;       // n_lanes * D: elements per step of the observation arrays
+  int t;              // global step index of this record
   int tid;
   __device__ __forceinline__ void put_reward(float r) const {
     reinterpret_cast<float*>(step_base + kObsBytes)[tid] = r;
   }
   __device__ __forceinline__ void put_flags(bool te, bool tr) const {
-    reinterpret_cast<uint8_t*>(step_base + kObsBytes + 1024)[tid] = (uint8_t)te;
-    reinterpret_cast<uint8_t*>(step_base + kObsBytes + 1280)[tid] = (uint8_t)tr;
+    reinterpret_cast<uint8_t*>(step_base + kFlagOff)[tid] = (uint8_t)te;
+    reinterpret_cast<uint8_t*>(step_base + kFlagOff + 256)[tid] = (uint8_t)tr;
   }
   __device__ __forceinline__ void put_obs(const float (&o)[Fam::D]) const {
     store_obs<Fam::D>(reinterpret_cast<float*>(step_base), (size_t)tid, o);
   }
-  __device__ __forceinline__ float* final_obs_ptr() const { return final_obs; }
+  // only evaluated on the done path (the terminal observation is stored to HBM directly)
+  __device__ __forceinline__ float* final_obs_ptr() const {
+    return final_base != nullptr ? final_base + (size_t)t * n_obs : nullptr;
+  }
 };
 
 // The rarely-taken part of a step, entered only by wavefronts in which some lane just
@@ -200,6 +211,11 @@ __device__ __forceinline__ void finish_episodes(const carl_batch_t& b, const Ctx
       settle(r.episode);
     }
   }
+  // ... and every scalar (kernarg) load too: LDS operations retire in order but scalar loads do
+  // not, so a possibly-outstanding s_load anywhere on this path would turn every LDS wait of the
+  // step loop into lgkmcnt(0) (= also wait for the record writes just issued).  The compiler
+  // models an explicit s_waitcnt: vmcnt/expcnt untouched, lgkmcnt(0).
+  __builtin_amdgcn_s_waitcnt(0xC07F);
 }
 
 // One step of one lane.  `cur` points at this step's output records for this lane.
@@ -211,6 +227,7 @@ __device__ __forceinline__ void step_lane(const carl_batch_t& b, const Ctx& ctx,
                                           typename Fam::Action action, LaneRegs<Fam>& r) {
   const bool active = ALL_ACTIVE || active_in;
   bool done = false;
+  bool te = false, tr = false;
   float o[Fam::D];
   if (active) {
     float noise = 0.0f;
@@ -228,11 +245,20 @@ __device__ __forceinline__ void step_lane(const carl_batch_t& b, const Ctx& ctx,
     asm volatile("" ::"v"(reward));
 #endif
 #ifndef CARL_EXP_NO_FLAG_STORES
-    cur.put_flags(terminated, truncated);
+    if constexpr (!Sink::kLazyFlags) cur.put_flags(terminated, truncated);
 #endif
+    te = terminated;
+    tr = truncated;
     done = terminated | truncated;
   }
-  if (__builtin_expect(__ballot(done) != 0ull, 0)) finish_episodes<Fam>(b, ctx, done, lane, glane, cur.final_obs_ptr(), o, r);
+  if (__builtin_expect(__ballot(done) != 0ull, 0)) {
+#ifndef CARL_EXP_NO_FLAG_STORES
+    if constexpr (Sink::kLazyFlags) {  // the flag rows are pre-zeroed: only waves with a finished lane write
+      if (active) cur.put_flags(te, tr);
+    }
+#endif
+    finish_episodes<Fam>(b, ctx, done, lane, glane, cur.final_obs_ptr(), o, r);
+  }
 #ifndef CARL_EXP_NO_OBS_STORE
   if (active) cur.put_obs(o);
 #else
@@ -408,6 +434,7 @@ __global__ void __launch_bounds__(kRolloutThreads) rollout_kernel(const carl_bat
       const int steps = min(kActChunk, n_steps - t0);
 #ifndef CARL_EXP_NO_ACTIONS
       Action a_next = my[0];
+      settle(a_next);  // see rollout_staged_kernel
       if (lane_base + kRolloutLanes <= b.n_lanes) {  // full workgroup: no per-step predicate
         for (int u = 0; u < steps; ++u) {
           const Action a = a_next;
@@ -444,46 +471,142 @@ __global__ void __launch_bounds__(kRolloutThreads) rollout_kernel(const carl_bat
 // ~27 % of the step at 65 536 lanes and cap the kernel at 3.3 TB/s at 1 M lanes, against
 // 6.9 TB/s for a plain fill: the per-CU address path is paid per lane address, not per byte.
 // Here the compute waves write their records into LDS (ds_write, no address VGPR arithmetic)
-// and the workgroup's fifth wave -- already streaming actions in -- also streams the records
-// out: a step's records of 256 lanes are contiguous in HBM, so it drains them with 16-byte
-// per-lane stores (1 KiB per instruction): 6 wide stores per workgroup-step instead of 16
-// narrow ones.  Double-buffered in chunks of kStageChunk steps, one barrier per chunk.
+// and a STORER wave streams them out: a step's records of 256 lanes are contiguous in HBM, so
+// it drains them with 16-byte per-lane stores (1 KiB per instruction): 6 wide stores per
+// workgroup-step instead of 16 narrow ones.  Double-buffered in chunks of kStageChunk steps,
+// one barrier per chunk.
+//
+// Loading and storing are SEPARATE helper waves (wave 4 loads, waves 5-7 store).  With one
+// wave doing both, every chunk paid the full HBM load latency on the barrier path: the loads
+// of the next chunk sat behind the previous drain's stores in the wave's single in-order vmcnt
+// queue, and had to land before the barrier (~350 ns/step floor for every family, r01d).  The
+// loader now holds a chunk of actions IN REGISTERS across the barrier: at iteration c it
+// commits chunk c+1 (loaded during iteration c-1) to LDS and issues the loads of chunk c+2, so
+// the HBM latency overlaps a whole chunk of compute.  The storer never waits on vmcnt.
 constexpr int kStageChunk = 8;
+#ifndef CARL_STORERS
+#define CARL_STORERS 3
+#endif
+constexpr int kStorers = CARL_STORERS;                                   // storer waves per workgroup
+constexpr int kStagedThreads = kRolloutLanes + (1 + kStorers) * kWave;  // + loader wave + storer waves
 
 template <class Fam>
 __host__ __device__ constexpr size_t rollout_staged_lds_bytes() {
   return (size_t)2 * kStageChunk * (LdsSink<Fam>::kStepBytes + kRolloutLanes * sizeof(float));
 }
 
-// storer half of the fifth wave: records of steps [t0, t0 + steps) from LDS to HBM
+// A chunk of actions in flight: issue() starts the HBM loads into registers, commit() writes
+// them to the LDS buffer the compute waves will read.  Chunks that are ragged (tail of the
+// rollout) or need conversion (int64 actions) are loaded at commit time instead.
+template <class AStore, class Action, int CHUNK>
+struct ActionPipe {
+  static_assert(CHUNK == 8, "the in-flight chunk is held in eight named registers quads");
+  // native 16-byte vectors in named members: first-class register values.  (A float4 array
+  // member that is live across the chunk loop stayed a private-memory object -> scratch.)
+  typedef float vf4 __attribute__((ext_vector_type(4)));
+  typedef int vi4 __attribute__((ext_vector_type(4)));
+  using V = std::conditional_t<std::is_same_v<Action, float>, vf4, vi4>;
+  V a0, a1, a2, a3, a4, a5, a6, a7;
+  bool fast;
+  int t0;
+  // l: lane of the loader wave (0..63); workgroup fully inside the batch, n % 4 == 0
+  __device__ __forceinline__ void issue(const AStore* __restrict__ act, size_t n, int lane_base, int l, int t0_,
+                                        int n_steps) {
+    t0 = t0_;
+    fast = false;
+    if constexpr (std::is_same_v<AStore, Action>) {
+      fast = t0 + CHUNK <= n_steps;
+      if (fast) {
+        const V* src = reinterpret_cast<const V*>(act + (size_t)t0 * n + lane_base + 4 * l);
+        const size_t row_v = n / 4;
+#ifndef CARL_EXP_TEMPORAL
+#define CARL_LD(p) __builtin_nontemporal_load(p)  // read once
+#else
+#define CARL_LD(p) (*(p))
+#endif
+        a0 = CARL_LD(src);
+        a1 = CARL_LD(src + row_v);
+        a2 = CARL_LD(src + 2 * row_v);
+        a3 = CARL_LD(src + 3 * row_v);
+        a4 = CARL_LD(src + 4 * row_v);
+        a5 = CARL_LD(src + 5 * row_v);
+        a6 = CARL_LD(src + 6 * row_v);
+        a7 = CARL_LD(src + 7 * row_v);
+#undef CARL_LD
+      }
+    }
+  }
+  __device__ __forceinline__ void commit(Action* buf, const AStore* __restrict__ act, size_t n, int lane_base, int l,
+                                         int n_steps) const {
+    if (fast) {
+      V* dst = reinterpret_cast<V*>(buf + 4 * l);
+      constexpr int row = kRolloutLanes / 4;
+      dst[0] = a0;
+      dst[row] = a1;
+      dst[2 * row] = a2;
+      dst[3 * row] = a3;
+      dst[4 * row] = a4;
+      dst[5 * row] = a5;
+      dst[6 * row] = a6;
+      dst[7 * row] = a7;
+      return;
+    }
+#pragma unroll 1
+    for (int u = 0; u < CHUNK && t0 + u < n_steps; ++u) {  // ragged tail / int64 actions
+      const AStore* row = act + (size_t)(t0 + u) * n + lane_base + 4 * l;
+      Action* dst = buf + u * kRolloutLanes + 4 * l;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) dst[k] = (Action)row[k];
+    }
+  }
+};
+
+// storer wave `which` of kStorers: its share (every kStorers-th step) of the records of steps
+// [t0, t0 + steps) from LDS to HBM; l = lane of the wave (0..63)
 template <class Fam>
-__device__ __forceinline__ void drain_records(const char* buf, const carl_step_io_t& io, size_t n, int lane_base,
-                                              int t0, int steps) {
+__device__ __forceinline__ void drain_records(char* buf, const carl_step_io_t& io, size_t n, int lane_base, int l,
+                                              int which, int t0, int steps) {
   using SK = LdsSink<Fam>;
-  const int l = threadIdx.x - kRolloutLanes;  // 0..63
-  for (int u = 0; u < steps; ++u) {
-    const char* rec = buf + (size_t)u * SK::kStepBytes;
+  typedef float vf4 __attribute__((ext_vector_type(4)));
+  // streamed once, never re-read by this kernel: non-temporal stores (CARL_EXP_TEMPORAL: ablation)
+  auto put = [](char* dst, const char* src) {
+    const vf4 v = *reinterpret_cast<const vf4*>(src);
+#ifndef CARL_EXP_TEMPORAL
+    __builtin_nontemporal_store(v, reinterpret_cast<vf4*>(dst));
+#else
+    *reinterpret_cast<vf4*>(dst) = v;
+#endif
+  };
+  for (int u = which; u < steps; u += kStorers) {
+    char* rec = buf + (size_t)u * SK::kStepBytes;
     const size_t row = (size_t)(t0 + u) * n + lane_base;
     char* g_obs = reinterpret_cast<char*>(io.obs + row * Fam::D);
 #pragma unroll
-    for (int off = 0; off < SK::kObsBytes; off += 1024)
-      *reinterpret_cast<float4*>(g_obs + off + 16 * l) = *reinterpret_cast<const float4*>(rec + off + 16 * l);
-    *reinterpret_cast<float4*>(reinterpret_cast<char*>(io.reward + row) + 16 * l) =
-        *reinterpret_cast<const float4*>(rec + SK::kObsBytes + 16 * l);
-    if (l < 16) {
-      *reinterpret_cast<float4*>(io.terminated + row + 16 * l) =
-          *reinterpret_cast<const float4*>(rec + SK::kObsBytes + 1024 + 16 * l);
-    } else if (l < 32) {
-      *reinterpret_cast<float4*>(io.truncated + row + 16 * (l - 16)) =
-          *reinterpret_cast<const float4*>(rec + SK::kObsBytes + 1280 + 16 * (l - 16));
+    for (int off = 0; off < SK::kObsBytes; off += 1024) put(g_obs + off + 16 * l, rec + off + 16 * l);
+    put(reinterpret_cast<char*>(io.reward + row) + 16 * l, rec + SK::kObsBytes + 16 * l);
+    if (l < 32) {  // [256] term | [256] trunc are contiguous in the record: 16 lanes each
+      char* fl = rec + SK::kFlagOff + 16 * l;
+      uint8_t* dst = (l < 16) ? io.terminated + row + 16 * l : io.truncated + row + 16 * (l - 16);
+      put(reinterpret_cast<char*>(dst), fl);
+      *reinterpret_cast<vf4*>(fl) = vf4{0.0f, 0.0f, 0.0f, 0.0f};  // LdsSink::kLazyFlags
     }
   }
 }
 
+// before the first step: all flag rows of both record buffers to zero (LdsSink::kLazyFlags)
+template <class Fam>
+__device__ __forceinline__ void zero_flag_rows(char* out_buf, int l, int which) {
+  using SK = LdsSink<Fam>;
+  typedef float vf4 __attribute__((ext_vector_type(4)));
+  if (l < 32)
+    for (int u = which; u < 2 * kStageChunk; u += kStorers)
+      *reinterpret_cast<vf4*>(out_buf + (size_t)u * SK::kStepBytes + SK::kFlagOff + 16 * l) = vf4{0.0f, 0.0f, 0.0f, 0.0f};
+}
+
 // Preconditions (checked by the host): n_lanes % 256 == 0, global context table.
 template <class Fam, bool A64>
-__global__ void __launch_bounds__(kRolloutThreads) rollout_staged_kernel(const carl_batch_t b, const carl_step_io_t io,
-                                                                         const int n_steps) {
+__global__ void __launch_bounds__(kStagedThreads) rollout_staged_kernel(const carl_batch_t b, const carl_step_io_t io,
+                                                                        const int n_steps) {
   extern __shared__ float lds_dyn[];
   using AStore = action_store_t<Fam, A64>;
   using Action = typename Fam::Action;
@@ -491,18 +614,30 @@ __global__ void __launch_bounds__(kRolloutThreads) rollout_staged_kernel(const c
   Action* act_buf = reinterpret_cast<Action*>(lds_dyn);  // [2][kStageChunk][256]
   char* out_buf = reinterpret_cast<char*>(lds_dyn) + (size_t)2 * kStageChunk * kRolloutLanes * sizeof(float);
   const GlobalCtx ctx{b.ctx_table, b.ctx_stride};
-  const bool loader = threadIdx.x >= kRolloutLanes;
+  // 0..3 compute, 4 loader, 5.. storers (wave-uniform).  Eight waves = two per SIMD: every
+  // compute wave shares its SIMD with exactly one light helper wave, so no compute wave is
+  // slowed more than the others before the chunk barrier.
+  const int wave = threadIdx.x / kWave;
+  const int storer = wave - (kRolloutLanes / kWave + 1);  // 0..kStorers-1 on storer waves
+  const bool compute = wave < kRolloutLanes / kWave;
+  const bool loader = wave == kRolloutLanes / kWave;
+  const int hl = threadIdx.x % kWave;    // lane within a helper wave
   const int lane_base = blockIdx.x * kRolloutLanes;
-  const int lane = lane_base + (loader ? 0 : (int)threadIdx.x);
+  const int lane = lane_base + (compute ? (int)threadIdx.x : 0);
   const uint64_t glane = (uint64_t)(b.lane_offset + lane);
   const size_t n = (size_t)b.n_lanes;
   const int max_steps = b.max_episode_steps;
   const AStore* act = static_cast<const AStore*>(io.action);
+  constexpr int kBufActs = kStageChunk * kRolloutLanes;
   LaneRegs<Fam> r{};
-  float* final_obs = (io.final_obs != nullptr && !loader) ? io.final_obs + (size_t)lane * Fam::D : nullptr;
+  ActionPipe<AStore, Action, kStageChunk> pipe;
+  float* const final_base = (io.final_obs != nullptr && compute) ? io.final_obs + (size_t)lane * Fam::D : nullptr;
+  if (!compute && !loader) zero_flag_rows<Fam>(out_buf, hl, storer);
   if (loader) {
-    stage_actions<AStore, Action, kStageChunk>(act_buf, act, n, lane_base, 0, n_steps);
-  } else {
+    pipe.issue(act, n, lane_base, hl, 0, n_steps);
+    pipe.commit(act_buf, act, n, lane_base, hl, n_steps);
+    pipe.issue(act, n, lane_base, hl, kStageChunk, n_steps);  // in flight across the barrier
+  } else if (compute) {
     load_lane<Fam>(b, ctx, lane, r);
     if (!r.episode_valid) {
       r.episode = b.episode[lane];
@@ -514,33 +649,38 @@ __global__ void __launch_bounds__(kRolloutThreads) rollout_staged_kernel(const c
   int buf = 0;
   for (int t0 = 0; t0 < n_steps; t0 += kStageChunk, buf ^= 1) {
     const int steps = min(kStageChunk, n_steps - t0);
-    if (loader) {
-      if (t0 + kStageChunk < n_steps)
-        stage_actions<AStore, Action, kStageChunk>(act_buf + (buf ^ 1) * kStageChunk * kRolloutLanes, act, n,
-                                                   lane_base, t0 + kStageChunk, n_steps);
-      if (t0 > 0)  // the previous chunk's records (always a full chunk)
-        drain_records<Fam>(out_buf + (size_t)(buf ^ 1) * kStageChunk * SK::kStepBytes, io, n, lane_base,
-                           t0 - kStageChunk, kStageChunk);
-    } else {
-      const Action* my = act_buf + buf * kStageChunk * kRolloutLanes + threadIdx.x;
+    if (compute) {
+      const Action* my = act_buf + buf * kBufActs + threadIdx.x;
       char* rec = out_buf + (size_t)buf * kStageChunk * SK::kStepBytes;
       Action a_next = my[0];
+      settle(a_next);  // arrive before the loop: its head then only waits for the read issued one
+                       // step earlier (lgkmcnt(#record writes)), not for the record writes
       for (int u = 0; u < steps; ++u) {
         const Action a = a_next;
         a_next = my[min(u + 1, kStageChunk - 1) * kRolloutLanes];
-        const SK sink{rec + (size_t)u * SK::kStepBytes, final_obs, (int)threadIdx.x};
+        const SK sink{rec + (size_t)u * SK::kStepBytes, final_base, n * Fam::D, t0 + u, (int)threadIdx.x};
         step_lane<Fam, GlobalCtx, true, SK>(b, ctx, sink, max_steps, true, lane, glane, a, r);
-        if (final_obs != nullptr) final_obs += n * Fam::D;
       }
+    } else if (loader) {
+#ifndef CARL_EXP_NO_LOADER
+      // chunk c+1 (loads issued one iteration ago) -> LDS; then start chunk c+2
+      pipe.commit(act_buf + (buf ^ 1) * kBufActs, act, n, lane_base, hl, n_steps);
+      pipe.issue(act, n, lane_base, hl, t0 + 2 * kStageChunk, n_steps);
+#endif
+    } else if (t0 > 0) {  // storer: the previous chunk's records (always a full chunk)
+#ifndef CARL_EXP_NO_DRAIN
+      drain_records<Fam>(out_buf + (size_t)(buf ^ 1) * kStageChunk * SK::kStepBytes, io, n, lane_base, hl, storer,
+                         t0 - kStageChunk, kStageChunk);
+#endif
     }
     __syncthreads();
   }
-  if (loader) {  // records of the last chunk
-    const int last_t0 = ((n_steps - 1) / kStageChunk) * kStageChunk;
-    drain_records<Fam>(out_buf + (size_t)(buf ^ 1) * kStageChunk * SK::kStepBytes, io, n, lane_base, last_t0,
-                       n_steps - last_t0);
-  } else {
+  if (compute) {
     store_lane<Fam>(b, lane, r);
+  } else if (!loader) {  // records of the last chunk
+    const int last_t0 = ((n_steps - 1) / kStageChunk) * kStageChunk;
+    drain_records<Fam>(out_buf + (size_t)(buf ^ 1) * kStageChunk * SK::kStepBytes, io, n, lane_base, hl, storer,
+                       last_t0, n_steps - last_t0);
   }
 }
 
