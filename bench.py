@@ -288,8 +288,10 @@ def main():
     avg_launch_s = e_first.elapsed_time(e_last) * 1e-3 * T / K
     bytes_per_step = IO_PER_STEP[args.env] + PER_LAUNCH[args.env] / T
     achieved = bytes_per_step * n * T / avg_launch_s / 1e9
+    kernel_name = ("brax_kernel<1>" if args.env in BRAX_ENVS else
+                   "rollout_staged_kernel" if n % 256 == 0 else "rollout_kernel")
     roofline = {
-        "bound": "hbm", "kernel": "rollout_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
         "bytes_per_unit": bytes_per_step, "bytes_per_unit_survey_8d": BYTES_8D[args.env],
         "achieved_with_survey_8d_bytes": BYTES_8D[args.env] * n * T / avg_launch_s / 1e9,
