@@ -1,23 +1,32 @@
 // brax_kernels.cuh -- Brax "spring" locomotion step on MI355X (Ant / Halfcheetah / Humanoid
 // model tables; see include/carl_amd.h carl_brax_sys_t).
 //
-// Replaces, for N lanes at once: brax.envs.<env>.step/reset -> n_frames x
+// Replaces, for N envs at once: brax.envs.<env>.step/reset -> n_frames x
 // brax.spring.pipeline.step as reached from carl/envs/brax/carl_brax_env.py:163-190 and
 // carl/envs/brax/wrappers.py:54-78 [brax 0.12.1 is not in the reference tree: the
 // specification implemented here is written out in oracle/brax_spring.c's header and
 // DESIGN.md; PARITY UNPINNED].
 //
-// Mapping: one lane = one env.  A lane's whole maximal-coordinate state (13 floats per link)
-// plus the per-link force/torque accumulators live in LDS for the duration of the launch
-// (row-major [row][64 lanes]: a lane's column is bank-conflict free), so the n_frames
-// substeps -- and, in the fused rollout, all T env steps -- never touch HBM for state.
-// Link loops index LDS dynamically, which keeps the code compact and the VGPR count low
-// (no 117-register unrolled state).  Actions and observations are lane-major records
-// (A / O floats per lane): they are staged through LDS so that HBM sees contiguous
-// 64-lane x A (or O) blocks instead of 64 strided dwords.  The model table is copied to LDS
-// once per workgroup.  No MFMA: with spring_inertia_scale = 1 the world inverse inertia
-// R diag(1/I) R^T is evaluated as rotate . scale . rotate^-1 on three floats per lane; packing
-// 3x3 blocks of different lanes into MFMA tiles would cost more shuffles than it saves.
+// Mapping: one env = a group of kSub = 8 adjacent lanes; one wavefront (= one workgroup) = 8 envs.
+// Within an env the lanes split the work by link: lane `sub` owns joints / bodies sub, sub + 8,
+// ... (Ant: 8 joints in one round, 9 bodies in two; Halfcheetah 7 / 7 in one round each;
+// Humanoid 10 / 11 in two).  32 768 envs are 4 096 wavefronts = 4 per SIMD, where the earlier
+// one-lane-per-env kernel (r01c) had 512 wavefronts for 1 024 SIMDs, each walking all links
+// serially through LDS.  An env's maximal-coordinate state (13 floats per link), the per-joint
+// wrenches, masses, joint torques and the action / observation record live in LDS for the whole
+// launch ([row][8 envs]); the n_frames substeps -- and in the fused rollout all T env steps --
+// never touch HBM for state.  A substep is two lockstep phases with a wavefront-wide LDS
+// hand-over between them:
+//   A  per joint:  joint geometry -> spring/damper/limit/actuator wrench on the child and the
+//                  reaction on the parent, written to the joint's own wrench rows (no atomics);
+//   B  per body:   own wrench + its children's reactions -> semi-implicit Euler velocity
+//                  update -> this body's sphere-plane contacts (registers) -> integrate.
+// Sums run in the oracle's order (own joint, then children ascending; colliders ascending).
+// Per-env scalars (reward, done, counters, context scalars) are computed redundantly by the
+// 8 lanes of the env from the same LDS data, so they agree without any exchange; lane sub == 0
+// writes them.  The model table is copied to LDS once per workgroup.  No MFMA: with
+// spring_inertia_scale = 1 the world inverse inertia R diag(1/I) R^T is rotate . scale .
+// rotate^-1 on three floats per lane.
 #pragma once
 
 #include "carl_device.cuh"
@@ -26,7 +35,9 @@
 namespace carl {
 namespace brax {
 
-constexpr int kLanes = 64;  // lanes per workgroup = one wavefront
+constexpr int kSub = 8;                 // lanes per env
+constexpr int kLanes = 64;              // lanes per workgroup = one wavefront
+constexpr int kEnvs = kLanes / kSub;    // envs per workgroup
 constexpr float kPiF = 3.14159265358979323846f;
 
 struct v3 {
@@ -71,38 +82,72 @@ struct Body {
   v3 v, w;
 };
 
-// per-lane context: carl_brax_env.py:255-292 in its intended form
+// per-env context scalars: carl_brax_env.py:255-292 in its intended form
 struct LaneCtx {
   float gravity_z, friction, elasticity, ang_damping, stiffness_scale;
 };
 
-// LDS layout of a workgroup (floats, each row = kLanes consecutive floats)
+// LDS layout of a workgroup (floats; each row = kEnvs consecutive floats, one per env)
 struct Layout {
-  int state;  // 13 * L rows
-  int force;  // 6 * L rows  (F, T; reused for contact dv, dw)
-  int count;  // L rows       (active contacts per link)
-  int mass;   // L rows       (effective mass per link, context-scaled)
-  int tau;    // n_dof rows
-  int io;     // max(n_act, obs_dim) rows of staging for lane-major records
+  int state;   // 13 * L rows
+  int wrench;  // 12 * L rows: per joint (f, t) on the child, (-f, -t') on the parent; reused by FK
+  int mass;    // L rows (effective mass per link, context-scaled)
+  int tau;     // n_dof rows
+  int io;      // staging of the env's action / observation record, and of (q, qd) in reset
   int total;
-  __host__ __device__ static Layout make(int L, int n_dof, int n_act, int obs_dim) {
+  __host__ __device__ static Layout make(int L, int n_dof, int io_rows) {
     Layout l;
     l.state = 0;
-    l.force = l.state + 13 * L;
-    l.count = l.force + 6 * L;
-    l.mass = l.count + L;
+    l.wrench = l.state + 13 * L;
+    l.mass = l.wrench + 12 * L;
     l.tau = l.mass + L;
     l.io = l.tau + n_dof;
-    l.total = l.io + (n_act > obs_dim ? n_act : obs_dim);
+    l.total = l.io + io_rows;
     return l;
   }
 };
 
+__host__ __device__ inline int io_rows_of(const carl_brax_sys_t& s) {
+  const int qrows = s.n_q + s.n_dof;
+  int r = s.obs_dim > qrows ? s.obs_dim : qrows;
+  return r > s.n_act ? r : s.n_act;
+}
+
+// tree topology derived from the model table once per workgroup
+struct Topo {
+  uint8_t child_begin[CARL_BRAX_MAX_LINKS + 1], child_idx[CARL_BRAX_MAX_LINKS];
+  uint8_t coll_begin[CARL_BRAX_MAX_LINKS + 1], coll_idx[CARL_BRAX_MAX_COLL];
+  uint8_t depth[CARL_BRAX_MAX_LINKS];
+  int max_depth;
+  int first_joint;  // 1 when link 0 is a free root (it has no joint), else 0
+};
+
+__device__ inline void build_topo(const carl_brax_sys_t& s, Topo& t) {
+  const int L = s.n_links;
+  int nc = 0, nk = 0, md = 0;
+  for (int i = 0; i < L; ++i) {
+    t.child_begin[i] = (uint8_t)nc;
+    for (int c = i + 1; c < L; ++c)
+      if (s.parent[c] == i) t.child_idx[nc++] = (uint8_t)c;
+    t.coll_begin[i] = (uint8_t)nk;
+    for (int k = 0; k < s.n_coll; ++k)
+      if (s.coll_link[k] == i) t.coll_idx[nk++] = (uint8_t)k;
+    const int d = s.parent[i] < 0 ? 0 : t.depth[s.parent[i]] + 1;
+    t.depth[i] = (uint8_t)d;
+    md = d > md ? d : md;
+  }
+  t.child_begin[L] = (uint8_t)nc;
+  t.coll_begin[L] = (uint8_t)nk;
+  t.max_depth = md;
+  t.first_joint = (s.parent[0] < 0 && s.n_link_dof[0] == 6) ? 1 : 0;
+}
+
 struct Lds {
   float* base;
   Layout lay;
-  int tid;
-  __device__ __forceinline__ float& at(int row) const { return base[row * kLanes + tid]; }
+  int env;  // env within the workgroup (0..kEnvs-1)
+  int sub;  // lane within the env (0..kSub-1)
+  __device__ __forceinline__ float& at(int row) const { return base[row * kEnvs + env]; }
   __device__ __forceinline__ Body body(int i) const {
     const int r0 = lay.state + 13 * i;
     Body b;
@@ -119,11 +164,15 @@ struct Lds {
     at(r0 + 7) = b.v.x; at(r0 + 8) = b.v.y; at(r0 + 9) = b.v.z;
     at(r0 + 10) = b.w.x; at(r0 + 11) = b.w.y; at(r0 + 12) = b.w.z;
   }
-  __device__ __forceinline__ void add3(int row, v3 a) const {
-    at(row) += a.x; at(row + 1) += a.y; at(row + 2) += a.z;
+  __device__ __forceinline__ void put3(int row, v3 a) const {
+    at(row) = a.x; at(row + 1) = a.y; at(row + 2) = a.z;
   }
   __device__ __forceinline__ v3 get3(int row) const { return V(at(row), at(row + 1), at(row + 2)); }
 };
+
+// hand-over between lockstep phases: the workgroup is ONE wavefront, so this is an LDS
+// drain (s_waitcnt) plus a compiler fence; s_barrier itself is trivially satisfied
+__device__ __forceinline__ void phase_sync() { __syncthreads(); }
 
 __device__ __forceinline__ v3 apply_inv_inertia(const carl_brax_sys_t& s, int i, qt r, v3 t) {
   const v3 l = qrot(qconj(r), t);
@@ -133,6 +182,10 @@ __device__ __forceinline__ v3 apply_inv_inertia(const carl_brax_sys_t& s, int i,
 // the static world as a parent body (planar roots are jointed to it)
 __device__ __forceinline__ Body world_body() {
   return Body{V(0, 0, 0), qt{1, 0, 0, 0}, V(0, 0, 0), V(0, 0, 0)};
+}
+
+__device__ __forceinline__ bool is_free_root(const carl_brax_sys_t& s, int i) {
+  return s.parent[i] < 0 && s.n_link_dof[i] == 6;
 }
 
 // joint geometry shared by joints.resolve and inverse kinematics
@@ -165,7 +218,7 @@ __device__ __forceinline__ JointGeom joint_geometry(const carl_brax_sys_t& s, in
   g.wrel = bc.w - bp.w;
   g.thetadot = dot(g.x_c, g.wrel);
   const int nr = s.n_link_dof[i] - s.n_slide[i];
-  if (nr >= 2) {  // rel = Rx(al) Ry(be) Rz(ga): decompose, ga = sign * theta_3 (wave-uniform branch)
+  if (nr >= 2) {  // rel = Rx(al) Ry(be) Rz(ga): decompose, ga = sign * theta_3
     const float R00 = 1.0f - 2.0f * (rel.y * rel.y + rel.z * rel.z), R01 = 2.0f * (rel.x * rel.y - rel.w * rel.z);
     const float R02 = fminf(fmaxf(2.0f * (rel.x * rel.z + rel.w * rel.y), -1.0f), 1.0f);
     const float R12 = 2.0f * (rel.y * rel.z - rel.w * rel.x), R22 = 1.0f - 2.0f * (rel.x * rel.x + rel.y * rel.y);
@@ -191,13 +244,12 @@ __device__ __forceinline__ JointGeom joint_geometry(const carl_brax_sys_t& s, in
 }
 
 // ---- one brax.spring.pipeline.step ---------------------------------------------------------
-__device__ __forceinline__ void substep(const carl_brax_sys_t& s, const LaneCtx& c, const Lds& m) {
+__device__ __forceinline__ void substep(const carl_brax_sys_t& s, const Topo& tp, const LaneCtx& c, const Lds& m) {
   const int L = s.n_links;
-  for (int k = 0; k < 6 * L; ++k) m.at(m.lay.force + k) = 0.0f;
-  // spring.joints.resolve
-  for (int i = 0; i < L; ++i) {
+  // phase A -- spring.joints.resolve, one joint per lane
+  for (int i = tp.first_joint + m.sub; i < L; i += kSub) {
     const int P = s.parent[i];
-    if (P < 0 && s.n_link_dof[i] == 6) continue;
+    if (is_free_root(s, i)) continue;
     const Body bc = m.body(i);
     const Body bp = (P < 0) ? world_body() : m.body(P);
     const JointGeom g = joint_geometry(s, i, bc, bp);
@@ -239,67 +291,66 @@ __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const LaneCtx&
       }
     }
     t = t - g.wrel * s.k_ang_damp[i];
-    const int fc = m.lay.force + 6 * i;
-    m.add3(fc, f);
-    m.add3(fc + 3, cross(g.A_c - bc.p, f) + t);
-    if (P >= 0) {
-      const int fp = m.lay.force + 6 * P;
-      m.add3(fp, f * -1.0f);
-      m.add3(fp + 3, (cross(g.A_p - bp.p, f) + t) * -1.0f);
-    }
+    const int wr = m.lay.wrench + 12 * i;
+    m.put3(wr, f);
+    m.put3(wr + 3, cross(g.A_c - bc.p, f) + t);
+    m.put3(wr + 6, f * -1.0f);
+    m.put3(wr + 9, (cross(g.A_p - bp.p, f) + t) * -1.0f);
   }
-  // semi-implicit Euler: velocities first
-  for (int i = 0; i < L; ++i) {
-    Body b = m.body(i);
-    const int fr = m.lay.force + 6 * i;
-    const float inv_m = 1.0f / m.at(m.lay.mass + i);
-    b.v = b.v + (m.get3(fr) * inv_m + V(0, 0, c.gravity_z)) * s.dt;
-    b.w = b.w + apply_inv_inertia(s, i, b.r, m.get3(fr + 3)) * s.dt;
-    m.put(i, b);
-    for (int k = 0; k < 6; ++k) m.at(fr + k) = 0.0f;  // rows reused for contact deltas
-    m.at(m.lay.count + i) = 0.0f;
-  }
-  // spring.collisions.resolve: spheres vs the plane z = 0
-  const v3 n = V(0, 0, 1);
-  for (int k = 0; k < s.n_coll; ++k) {
-    const int i = s.coll_link[k];
-    const Body b = m.body(i);
-    const v3 ctr = b.p - qrot(b.r, f3(s.com[i])) + qrot(b.r, f3(s.coll_pos[k]));
-    const float depth = s.coll_radius[k] - ctr.z;
-    if (!(depth > 0.0f)) continue;
-    const v3 r = V(ctr.x, ctr.y, ctr.z - s.coll_radius[k]) - b.p;
-    const v3 rel = b.v + cross(b.w, r);
-    const float vn = dot(n, rel);
-    const float inv_m = 1.0f / m.at(m.lay.mass + i);
-    const float ang = dot(n, cross(apply_inv_inertia(s, i, b.r, cross(r, n)), r));
-    const float imp = (-(1.0f + c.elasticity) * vn + s.baumgarte_erp * depth / s.dt) / (inv_m + ang);
-    if (!(imp > 0.0f) || !(vn < 0.0f)) continue;
-    v3 J = n * imp;
-    const v3 vt = rel - n * vn;
-    const float vt_len = sqrtf(dot(vt, vt));
-    if (vt_len > 1e-9f) {
-      const v3 dir = vt * (1.0f / vt_len);
-      const float ang_d = dot(dir, cross(apply_inv_inertia(s, i, b.r, cross(r, dir)), r));
-      const float imp_d = fminf(vt_len / (inv_m + ang_d), c.friction * imp);
-      J = J - dir * imp_d;
-    }
-    const int fr = m.lay.force + 6 * i;
-    m.add3(fr, J * inv_m);
-    m.add3(fr + 3, apply_inv_inertia(s, i, b.r, cross(r, J)));
-    m.at(m.lay.count + i) += 1.0f;
-  }
-  // spring.integrator.integrate
+  phase_sync();
+  // phase B -- per body: wrench sum, semi-implicit Euler, its contacts, integrate
   const float dl = __expf(s.vel_damping * s.dt), da = __expf(c.ang_damping * s.dt);
-  for (int i = 0; i < L; ++i) {
+  const v3 n = V(0, 0, 1);
+  for (int i = m.sub; i < L; i += kSub) {
     Body b = m.body(i);
+    v3 F = V(0, 0, 0), T = V(0, 0, 0);
+    if (!is_free_root(s, i)) {
+      F = m.get3(m.lay.wrench + 12 * i);
+      T = m.get3(m.lay.wrench + 12 * i + 3);
+    }
+    for (int cc = tp.child_begin[i]; cc < tp.child_begin[i + 1]; ++cc) {
+      const int wr = m.lay.wrench + 12 * tp.child_idx[cc];
+      F = F + m.get3(wr + 6);
+      T = T + m.get3(wr + 9);
+    }
+    const float inv_m = 1.0f / m.at(m.lay.mass + i);
+    b.v = b.v + (F * inv_m + V(0, 0, c.gravity_z)) * s.dt;
+    b.w = b.w + apply_inv_inertia(s, i, b.r, T) * s.dt;
+    // spring.collisions.resolve: this body's spheres vs the plane z = 0
+    v3 dv = V(0, 0, 0), dw = V(0, 0, 0);
+    float cnt = 0.0f;
+    const v3 org = b.p - qrot(b.r, f3(s.com[i]));
+    for (int kk = tp.coll_begin[i]; kk < tp.coll_begin[i + 1]; ++kk) {
+      const int k = tp.coll_idx[kk];
+      const v3 ctr = org + qrot(b.r, f3(s.coll_pos[k]));
+      const float depth = s.coll_radius[k] - ctr.z;
+      if (!(depth > 0.0f)) continue;
+      const v3 r = V(ctr.x, ctr.y, ctr.z - s.coll_radius[k]) - b.p;
+      const v3 rel = b.v + cross(b.w, r);
+      const float vn = dot(n, rel);
+      const float ang = dot(n, cross(apply_inv_inertia(s, i, b.r, cross(r, n)), r));
+      const float imp = (-(1.0f + c.elasticity) * vn + s.baumgarte_erp * depth / s.dt) / (inv_m + ang);
+      if (!(imp > 0.0f) || !(vn < 0.0f)) continue;
+      v3 J = n * imp;
+      const v3 vt = rel - n * vn;
+      const float vt_len = sqrtf(dot(vt, vt));
+      if (vt_len > 1e-9f) {
+        const v3 dir = vt * (1.0f / vt_len);
+        const float ang_d = dot(dir, cross(apply_inv_inertia(s, i, b.r, cross(r, dir)), r));
+        const float imp_d = fminf(vt_len / (inv_m + ang_d), c.friction * imp);
+        J = J - dir * imp_d;
+      }
+      dv = dv + J * inv_m;
+      dw = dw + apply_inv_inertia(s, i, b.r, cross(r, J));
+      cnt += 1.0f;
+    }
+    // spring.integrator.integrate
     b.v = b.v * dl;
     b.w = b.w * da;
-    const float cnt = m.at(m.lay.count + i);
     if (cnt > 0.0f) {
-      const int fr = m.lay.force + 6 * i;
       const float ic = 1.0f / cnt;
-      b.v = b.v + m.get3(fr) * ic;
-      b.w = b.w + m.get3(fr + 3) * ic;
+      b.v = b.v + dv * ic;
+      b.w = b.w + dw * ic;
     }
     b.p = b.p + b.v * s.dt;
     const qt dq = qmul(qt{0.0f, b.w.x, b.w.y, b.w.z}, b.r);
@@ -307,6 +358,7 @@ __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const LaneCtx&
     b.r = qnormalize(qt{b.r.w + h * dq.w, b.r.x + h * dq.x, b.r.y + h * dq.y, b.r.z + h * dq.z});
     m.put(i, b);
   }
+  phase_sync();
 }
 
 // whole-body centre of mass (brax.envs.humanoid.Humanoid._com); *mass_sum = total mass
@@ -315,32 +367,39 @@ __device__ __forceinline__ v3 system_com(const carl_brax_sys_t& s, const Lds& m,
   float M = 0.0f;
   for (int i = 0; i < s.n_links; ++i) {
     const float mi = m.at(m.lay.mass + i);
-    const int r0 = m.lay.state + 13 * i;
-    com = com + m.get3(r0) * mi;
+    com = com + m.get3(m.lay.state + 13 * i) * mi;
     M += mi;
   }
   *mass_sum = M;
   return com * (1.0f / M);
 }
 
-// kinematics.world_to_joint + inverse -> observation rows (q[skip:] ++ qd) in the io staging;
-// obs_extended (humanoid) appends com inertia (L x 10), com velocity (L x 6) and qfrc_actuator
-// (the tau rows; `zero_frc`: reset observations see a zero action)
-__device__ __forceinline__ void observe(const carl_brax_sys_t& s, const Lds& m, bool zero_frc = false) {
+// kinematics.world_to_joint + inverse -> observation rows (q[skip:] ++ qd) in the io staging, one
+// link per lane; obs_extended (humanoid) appends com inertia (L x 10), com velocity (L x 6) and
+// qfrc_actuator (the tau rows; `zero_frc`: reset observations see a zero action).  `go`: envs
+// that take part (the calls are wavefront-uniform).  Ends with a phase_sync.
+__device__ __forceinline__ void observe(const carl_brax_sys_t& s, const Lds& m, bool go, bool zero_frc) {
   const int skip = s.exclude_current_positions;
   const int qd0 = s.n_q - skip;  // first qd row in the observation
-  for (int i = 0; i < s.n_links; ++i) {
+  const int L = s.n_links;
+  float M = 1.0f;
+  v3 com = V(0, 0, 0);
+  if (s.obs_extended && go) com = system_com(s, m, &M);
+  for (int i = m.sub; i < L; i += kSub) {
+    if (!go) continue;
     const int P = s.parent[i];
     const Body b = m.body(i);
-    if (P < 0 && s.n_link_dof[i] == 6) {
+    if (is_free_root(s, i)) {
       const v3 c = qrot(b.r, f3(s.com[i]));
       const v3 o = b.p - c;
       const v3 vel = b.v - cross(b.w, c);
       const float qv[7] = {o.x, o.y, o.z, b.r.w, b.r.x, b.r.y, b.r.z};
+#pragma unroll
       for (int k = 0; k < 7; ++k)
         if (s.q_start[i] + k >= skip) m.at(m.lay.io + s.q_start[i] + k - skip) = qv[k];
-      const float dv[6] = {vel.x, vel.y, vel.z, b.w.x, b.w.y, b.w.z};
-      for (int k = 0; k < 6; ++k) m.at(m.lay.io + qd0 + s.dof_start[i] + k) = dv[k];
+      const float dvv[6] = {vel.x, vel.y, vel.z, b.w.x, b.w.y, b.w.z};
+#pragma unroll
+      for (int k = 0; k < 6; ++k) m.at(m.lay.io + qd0 + s.dof_start[i] + k) = dvv[k];
     } else {
       const Body bp = (P < 0) ? world_body() : m.body(P);
       const JointGeom g = joint_geometry(s, i, b, bp);
@@ -363,168 +422,169 @@ __device__ __forceinline__ void observe(const carl_brax_sys_t& s, const Lds& m, 
           }
       }
     }
-  }
-  if (!s.obs_extended) return;
-  int k = m.lay.io + qd0 + s.n_dof;
-  float M;
-  const v3 com = system_com(s, m, &M);
-  for (int i = 0; i < s.n_links; ++i) {  // inertia about the system com, world axes, row-major, then mass
-    const Body b = m.body(i);
-    const v3 d = b.p - com;
-    const float mi = m.at(m.lay.mass + i), dd = dot(d, d);
-    const float I0 = 1.0f / s.inv_inertia[i][0], I1 = 1.0f / s.inv_inertia[i][1], I2 = 1.0f / s.inv_inertia[i][2];
-    const v3 ex = qrot(b.r, V(1, 0, 0)), ey = qrot(b.r, V(0, 1, 0)), ez = qrot(b.r, V(0, 0, 1));
-    const float e[3][3] = {{ex.x, ey.x, ez.x}, {ex.y, ey.y, ez.y}, {ex.z, ey.z, ez.z}};
-    const float dv[3] = {d.x, d.y, d.z};
+    if (s.obs_extended) {  // inertia about the system com, world axes, row-major, then mass; com velocity
+      const int e0 = m.lay.io + qd0 + s.n_dof;
+      const v3 d = b.p - com;
+      const float mi = m.at(m.lay.mass + i), dd = dot(d, d);
+      const float I0 = 1.0f / s.inv_inertia[i][0], I1 = 1.0f / s.inv_inertia[i][1], I2 = 1.0f / s.inv_inertia[i][2];
+      const v3 ex = qrot(b.r, V(1, 0, 0)), ey = qrot(b.r, V(0, 1, 0)), ez = qrot(b.r, V(0, 0, 1));
+      const float e[3][3] = {{ex.x, ey.x, ez.x}, {ex.y, ey.y, ez.y}, {ex.z, ey.z, ez.z}};
+      const float dc[3] = {d.x, d.y, d.z};
+      int k = e0 + 10 * i;
 #pragma unroll
-    for (int r = 0; r < 3; ++r)
+      for (int r = 0; r < 3; ++r)
 #pragma unroll
-      for (int cc = 0; cc < 3; ++cc) {
-        float v = e[r][0] * I0 * e[cc][0];
-        v += e[r][1] * I1 * e[cc][1];
-        v += e[r][2] * I2 * e[cc][2];
-        v += mi * ((r == cc ? dd : 0.0f) - dv[r] * dv[cc]);
-        m.at(k++) = v;
-      }
-    m.at(k++) = mi;
-  }
-  for (int i = 0; i < s.n_links; ++i) {
-    const Body b = m.body(i);
-    const float f = m.at(m.lay.mass + i) / M;
-    m.at(k++) = f * b.v.x; m.at(k++) = f * b.v.y; m.at(k++) = f * b.v.z;
-    m.at(k++) = b.w.x; m.at(k++) = b.w.y; m.at(k++) = b.w.z;
-  }
-  for (int i = 0; i < s.n_dof; ++i) m.at(k++) = zero_frc ? 0.0f : m.at(m.lay.tau + i);
-}
-
-// kinematics.forward + com.from_world from (q, qd) held in the io staging rows
-// (q at rows [0, n_q), qd at rows [n_q, n_q + n_dof)); writes the state rows.
-__device__ __noinline__ void forward_kinematics(const carl_brax_sys_t& s, const Lds& m) {
-  // link-frame origins and their velocities are kept in the force rows (free at this point)
-  for (int i = 0; i < s.n_links; ++i) {
-    const int P = s.parent[i];
-    qt rot;
-    v3 o, vel, ang;
-    const int q0 = m.lay.io + s.q_start[i], d0 = m.lay.io + s.n_q + s.dof_start[i];
-    if (P < 0 && s.n_link_dof[i] == 6) {
-      rot = qnormalize(qt{m.at(q0 + 3), m.at(q0 + 4), m.at(q0 + 5), m.at(q0 + 6)});
-      o = V(m.at(q0), m.at(q0 + 1), m.at(q0 + 2));
-      vel = V(m.at(d0), m.at(d0 + 1), m.at(d0 + 2));
-      ang = V(m.at(d0 + 3), m.at(d0 + 4), m.at(d0 + 5));
-    } else {
-      const Body bp = (P < 0) ? world_body() : m.body(P);
-      const v3 o_p = (P < 0) ? V(0, 0, 0) : m.get3(m.lay.force + 6 * P);
-      const v3 ov_p = (P < 0) ? V(0, 0, 0) : m.get3(m.lay.force + 6 * P + 3);
-      const int ns = s.n_slide[i], nr = s.n_link_dof[i] - ns;
-      const qt jr = f4(s.joint_rot[i]), lrot = f4(s.link_rot[i]);
-      const qt rpj = qmul(qmul(bp.r, lrot), jr);  // parent-side joint frame in the world
-      // hinges stack intrinsically about the joint frame's x, y, +-z
-      qt rj{1.0f, 0.0f, 0.0f, 0.0f};
-      v3 wj = V(0, 0, 0);
-      for (int k = 0; k < nr; ++k) {
-        const float sg = (k == 2) ? s.dof_sign3[i] : 1.0f;
-        const v3 axis = qrot(qmul(rpj, rj), V(k == 0 ? 1.0f : 0.0f, k == 1 ? 1.0f : 0.0f, k == 2 ? 1.0f : 0.0f)) * sg;
-        wj = wj + axis * m.at(d0 + ns + k);
-        rj = qmul(rj, qaxis(k, sg * m.at(q0 + ns + k)));
-      }
-      const qt rl = qmul(qmul(jr, rj), qconj(jr));  // joint rotation in child coordinates
-      const v3 a = f3(s.joint_pos[i]);
-      v3 lpos = f3(s.link_pos[i]) + qrot(lrot, a - qrot(rl, a));
-      v3 slide_vel = V(0, 0, 0);
-      for (int k = 0; k < ns; ++k) {
-        const v3 ax = f3(s.slide_axis[i][k]);
-        lpos = lpos + ax * m.at(q0 + k);
-        slide_vel = slide_vel + qrot(bp.r, ax) * m.at(d0 + k);
-      }
-      rot = qmul(bp.r, qmul(lrot, rl));
-      o = o_p + qrot(bp.r, lpos);
-      const v3 anchor_w = o + qrot(rot, a);
-      ang = bp.w + wj;
-      vel = ov_p + cross(bp.w, o - o_p) + slide_vel + cross(wj, o - anchor_w);
+        for (int cc = 0; cc < 3; ++cc) {
+          float v = e[r][0] * I0 * e[cc][0];
+          v += e[r][1] * I1 * e[cc][1];
+          v += e[r][2] * I2 * e[cc][2];
+          v += mi * ((r == cc ? dd : 0.0f) - dc[r] * dc[cc]);
+          m.at(k++) = v;
+        }
+      m.at(k) = mi;
+      k = e0 + 10 * L + 6 * i;
+      const float f = mi / M;
+      m.at(k) = f * b.v.x; m.at(k + 1) = f * b.v.y; m.at(k + 2) = f * b.v.z;
+      m.at(k + 3) = b.w.x; m.at(k + 4) = b.w.y; m.at(k + 5) = b.w.z;
     }
-    const int fr = m.lay.force + 6 * i;
-    m.at(fr) = o.x; m.at(fr + 1) = o.y; m.at(fr + 2) = o.z;
-    m.at(fr + 3) = vel.x; m.at(fr + 4) = vel.y; m.at(fr + 5) = vel.z;
-    const v3 c = qrot(rot, f3(s.com[i]));
-    Body b;
-    b.r = rot;
-    b.w = ang;
-    b.p = o + c;
-    b.v = vel + cross(ang, c);
-    m.put(i, b);
+  }
+  if (s.obs_extended && go) {
+    const int k0 = m.lay.io + qd0 + s.n_dof + 16 * L;
+    for (int d = m.sub; d < s.n_dof; d += kSub) m.at(k0 + d) = zero_frc ? 0.0f : m.at(m.lay.tau + d);
+  }
+  phase_sync();
+}
+
+// kinematics.forward + com.from_world from (q, qd) held in the io staging rows (q at rows
+// [0, n_q), qd at rows [n_q, n_q + n_dof)); writes the state rows.  The tree is walked level by
+// level (links of one depth in parallel); link-frame origins and their velocities are kept in
+// the wrench rows (free at this point).  Wavefront-uniform call; `go`: envs that take part.
+__device__ __noinline__ void forward_kinematics(const carl_brax_sys_t& s, const Topo& tp, const Lds& m, bool go) {
+  for (int lvl = 0; lvl <= tp.max_depth; ++lvl) {
+    for (int i = m.sub; i < s.n_links; i += kSub) {
+      if (!go || tp.depth[i] != lvl) continue;
+      const int P = s.parent[i];
+      qt rot;
+      v3 o, vel, ang;
+      const int q0 = m.lay.io + s.q_start[i], d0 = m.lay.io + s.n_q + s.dof_start[i];
+      if (is_free_root(s, i)) {
+        rot = qnormalize(qt{m.at(q0 + 3), m.at(q0 + 4), m.at(q0 + 5), m.at(q0 + 6)});
+        o = V(m.at(q0), m.at(q0 + 1), m.at(q0 + 2));
+        vel = V(m.at(d0), m.at(d0 + 1), m.at(d0 + 2));
+        ang = V(m.at(d0 + 3), m.at(d0 + 4), m.at(d0 + 5));
+      } else {
+        const Body bp = (P < 0) ? world_body() : m.body(P);
+        const v3 o_p = (P < 0) ? V(0, 0, 0) : m.get3(m.lay.wrench + 12 * P);
+        const v3 ov_p = (P < 0) ? V(0, 0, 0) : m.get3(m.lay.wrench + 12 * P + 3);
+        const int ns = s.n_slide[i], nr = s.n_link_dof[i] - ns;
+        const qt jr = f4(s.joint_rot[i]), lrot = f4(s.link_rot[i]);
+        const qt rpj = qmul(qmul(bp.r, lrot), jr);  // parent-side joint frame in the world
+        // hinges stack intrinsically about the joint frame's x, y, +-z
+        qt rj{1.0f, 0.0f, 0.0f, 0.0f};
+        v3 wj = V(0, 0, 0);
+        for (int k = 0; k < nr; ++k) {
+          const float sg = (k == 2) ? s.dof_sign3[i] : 1.0f;
+          const v3 axis =
+              qrot(qmul(rpj, rj), V(k == 0 ? 1.0f : 0.0f, k == 1 ? 1.0f : 0.0f, k == 2 ? 1.0f : 0.0f)) * sg;
+          wj = wj + axis * m.at(d0 + ns + k);
+          rj = qmul(rj, qaxis(k, sg * m.at(q0 + ns + k)));
+        }
+        const qt rl = qmul(qmul(jr, rj), qconj(jr));  // joint rotation in child coordinates
+        const v3 a = f3(s.joint_pos[i]);
+        v3 lpos = f3(s.link_pos[i]) + qrot(lrot, a - qrot(rl, a));
+        v3 slide_vel = V(0, 0, 0);
+        for (int k = 0; k < ns; ++k) {
+          const v3 ax = f3(s.slide_axis[i][k]);
+          lpos = lpos + ax * m.at(q0 + k);
+          slide_vel = slide_vel + qrot(bp.r, ax) * m.at(d0 + k);
+        }
+        rot = qmul(bp.r, qmul(lrot, rl));
+        o = o_p + qrot(bp.r, lpos);
+        const v3 anchor_w = o + qrot(rot, a);
+        ang = bp.w + wj;
+        vel = ov_p + cross(bp.w, o - o_p) + slide_vel + cross(wj, o - anchor_w);
+      }
+      m.put3(m.lay.wrench + 12 * i, o);
+      m.put3(m.lay.wrench + 12 * i + 3, vel);
+      const v3 c = qrot(rot, f3(s.com[i]));
+      Body b;
+      b.r = rot;
+      b.w = ang;
+      b.p = o + c;
+      b.v = vel + cross(ang, c);
+      m.put(i, b);
+    }
+    phase_sync();
   }
 }
 
-// brax.envs.<env>.reset: q = init_q + U(-noise, noise), qd = vel_scale * N(0, 1).
-// Draw k uses word (k mod 4) of Philox block k / 4 on sub-stream 0x80000000 | block.
+// brax.envs.<env>.reset: q = init_q + U(-noise, noise), qd = vel_scale * N(0, 1) (humanoid:
+// U(-scale, scale)).  Draw k uses word (k mod 4) of Philox block k / 4 on sub-stream
+// 0x80000000 | block; normals are Box-Muller pairs from two consecutive draws.
 __device__ __forceinline__ float draw_u(uint64_t seed, uint64_t g, uint32_t ep, int k) {
   const u32x4 w = lane_words(seed, g, ep, 0x80000000u | (uint32_t)(k >> 2));
   const uint32_t x = (k & 3) == 0 ? w.x : (k & 3) == 1 ? w.y : (k & 3) == 2 ? w.z : w.w;
   return u01(x);
 }
 
-__device__ __noinline__ void reset_state(const carl_brax_sys_t& s, const carl_batch_t& b, const Lds& m,
-                                         uint64_t glane, uint32_t episode) {
-  int k = 0;
-  u32x4 w{};
-  for (int i = 0; i < s.n_q; ++i, ++k) {
-    if ((k & 3) == 0) w = lane_words(b.seed, glane, episode, 0x80000000u | (uint32_t)(k >> 2));
-    const uint32_t x = (k & 3) == 0 ? w.x : (k & 3) == 1 ? w.y : (k & 3) == 2 ? w.z : w.w;
-    m.at(m.lay.io + i) = s.init_q[i] + s.reset_noise_scale * (2.0f * u01(x) - 1.0f);
+// wavefront-uniform call; `go`: envs that are reset
+__device__ __noinline__ void reset_state(const carl_brax_sys_t& s, const Topo& tp, const carl_batch_t& b, const Lds& m,
+                                         uint64_t genv, uint32_t episode, bool go) {
+  if (go) {
+    for (int i = m.sub; i < s.n_q; i += kSub)
+      m.at(m.lay.io + i) = s.init_q[i] + s.reset_noise_scale * (2.0f * draw_u(b.seed, genv, episode, i) - 1.0f);
+    if (s.reset_vel_uniform) {
+      for (int i = m.sub; i < s.n_dof; i += kSub)
+        m.at(m.lay.io + s.n_q + i) = s.reset_vel_scale * (2.0f * draw_u(b.seed, genv, episode, s.n_q + i) - 1.0f);
+    } else {
+      for (int i = 2 * m.sub; i < s.n_dof; i += 2 * kSub) {  // one Box-Muller pair per lane
+        const int k = s.n_q + i;
+        const float u1 = draw_u(b.seed, genv, episode, k), u2 = draw_u(b.seed, genv, episode, k + 1);
+        const float rad = sqrtf(-2.0f * logf(1.0f - u1));
+        float sn, cs;
+        sincos_fast(2.0f * kPiF * u2, sn, cs);
+        m.at(m.lay.io + s.n_q + i) = s.reset_vel_scale * rad * cs;
+        if (i + 1 < s.n_dof) m.at(m.lay.io + s.n_q + i + 1) = s.reset_vel_scale * rad * sn;
+      }
+    }
   }
-  if (s.reset_vel_uniform) {  // brax.envs.humanoid: qvel = U(-scale, scale)
-    for (int i = 0; i < s.n_dof; ++i, ++k)
-      m.at(m.lay.io + s.n_q + i) = s.reset_vel_scale * (2.0f * draw_u(b.seed, glane, episode, k) - 1.0f);
-  } else
-  for (int i = 0; i < s.n_dof; i += 2, k += 2) {
-    const float u1 = draw_u(b.seed, glane, episode, k), u2 = draw_u(b.seed, glane, episode, k + 1);
-    const float rad = sqrtf(-2.0f * logf(1.0f - u1));
-    float sn, cs;
-    sincos_fast(2.0f * kPiF * u2, sn, cs);
-    m.at(m.lay.io + s.n_q + i) = s.reset_vel_scale * rad * cs;
-    if (i + 1 < s.n_dof) m.at(m.lay.io + s.n_q + i + 1) = s.reset_vel_scale * rad * sn;
-  }
-  forward_kinematics(s, m);
+  phase_sync();
+  forward_kinematics(s, tp, m, go);
 }
 
-__device__ __forceinline__ LaneCtx load_ctx(const carl_brax_sys_t& s, const carl_batch_t& b, const Lds& m, int c) {
+// context scalars of the env + its mass rows (wavefront-uniform call; ends with a phase_sync)
+__device__ __forceinline__ LaneCtx load_ctx(const carl_brax_sys_t& s, const carl_batch_t& b, const Lds& m, int c,
+                                            bool go) {
   const carl_brax_ctx_map_t& cm = s.ctx;
   auto get = [&](int row, float dflt) { return row >= 0 ? b.ctx_table[(size_t)row * b.ctx_stride + c] : dflt; };
-  LaneCtx lc;
-  lc.gravity_z = get(cm.gravity, s.gravity_z);
-  lc.friction = get(cm.friction, s.friction);
-  lc.elasticity = get(cm.elasticity, s.elasticity);
-  lc.ang_damping = get(cm.ang_damping, s.ang_damping);
-  lc.stiffness_scale = get(cm.joint_stiffness_scale, 1.0f);
-  for (int i = 0; i < s.n_links; ++i) m.at(m.lay.mass + i) = s.mass[i];
-  for (int k = 0; k < cm.n_mass; ++k)
-    m.at(m.lay.mass + cm.mass_link[k]) =
-        s.mass[cm.mass_link[k]] * (b.ctx_table[(size_t)cm.mass_row[k] * b.ctx_stride + c] / cm.mass_nominal[k]);
+  LaneCtx lc{};
+  if (go) {
+    lc.gravity_z = get(cm.gravity, s.gravity_z);
+    lc.friction = get(cm.friction, s.friction);
+    lc.elasticity = get(cm.elasticity, s.elasticity);
+    lc.ang_damping = get(cm.ang_damping, s.ang_damping);
+    lc.stiffness_scale = get(cm.joint_stiffness_scale, 1.0f);
+    for (int i = m.sub; i < s.n_links; i += kSub) m.at(m.lay.mass + i) = s.mass[i];
+  }
+  phase_sync();
+  if (go)
+    for (int k = m.sub; k < cm.n_mass; k += kSub)
+      m.at(m.lay.mass + cm.mass_link[k]) =
+          s.mass[cm.mass_link[k]] * (b.ctx_table[(size_t)cm.mass_row[k] * b.ctx_stride + c] / cm.mass_nominal[k]);
+  phase_sync();
   return lc;
 }
 
-// lane-major records <-> LDS staging rows.  HBM side: 64 lanes x W floats contiguous.
-__device__ __forceinline__ void stage_in(const float* __restrict__ src, size_t lane_base, int n_lanes, int W,
-                                         const Lds& m) {
-  // element e of the block (lane = e / W, k = e % W) -> LDS row k, column lane
-  const int total = W * kLanes;
-  for (int e = m.tid; e < total; e += kLanes) {
-    const int lane = e / W, k = e - lane * W;
-    if ((int)lane_base + lane < n_lanes) m.base[(m.lay.io + k) * kLanes + lane] = src[lane_base * W + e];
-  }
-  __syncthreads();
+// env-major records (W floats per env) <-> the env's io staging rows; each env's 8 lanes move
+// their own record (32-byte segments per env; L2 merges them into full lines)
+__device__ __forceinline__ void record_in(const float* __restrict__ src, size_t env, int W, const Lds& m, bool go) {
+  if (go)
+    for (int k = m.sub; k < W; k += kSub) m.at(m.lay.io + k) = src[env * W + k];
+  phase_sync();
 }
-// `only_flagged`: copy only lanes whose flag (first `count` row, free outside substep) is set
-__device__ __forceinline__ void stage_out(float* __restrict__ dst, size_t lane_base, int n_lanes, int W,
-                                          const Lds& m, bool only_flagged = false) {
-  __syncthreads();
-  const int total = W * kLanes;
-  for (int e = m.tid; e < total; e += kLanes) {
-    const int lane = e / W, k = e - lane * W;
-    if ((int)lane_base + lane < n_lanes && (!only_flagged || m.base[m.lay.count * kLanes + lane] != 0.0f))
-      dst[lane_base * W + e] = m.base[(m.lay.io + k) * kLanes + lane];
-  }
-  __syncthreads();
+__device__ __forceinline__ void record_out(float* __restrict__ dst, size_t env, int W, const Lds& m, bool go) {
+  if (go)
+    for (int k = m.sub; k < W; k += kSub) dst[env * W + k] = m.at(m.lay.io + k);
 }
 
 struct LaneState {
@@ -567,12 +627,19 @@ __device__ __forceinline__ void load_goal(const carl_brax_sys_t& s, const carl_b
   r.goal_y = dy * dist;
 }
 
+__device__ __forceinline__ void write_ctx_obs(const carl_batch_t& b, const Lds& m, size_t n, int env, int cidx) {
+  if (b.ctx_obs != nullptr)
+    for (int k = m.sub; k < b.n_ctx_obs; k += kSub)
+      b.ctx_obs[(size_t)k * n + env] = b.ctx_table[(size_t)b.ctx_obs_feat[k] * b.ctx_stride + cidx];
+}
+
 // mode 0: reset (mask optional), mode 1: n_steps env steps (1 = per call, T = fused rollout)
 template <int MODE>
 __global__ void __launch_bounds__(kLanes) brax_kernel(const carl_batch_t b, const carl_brax_sys_t* __restrict__ sys_dev,
                                                       const carl_step_io_t io, const uint8_t* __restrict__ mask,
                                                       float* __restrict__ reset_obs, const int n_steps) {
   __shared__ carl_brax_sys_t s;
+  __shared__ Topo tp;
   extern __shared__ float lds_dyn[];
   {  // model table -> LDS, once per workgroup
     const uint32_t* src = reinterpret_cast<const uint32_t*>(sys_dev);
@@ -580,125 +647,128 @@ __global__ void __launch_bounds__(kLanes) brax_kernel(const carl_batch_t b, cons
     for (int k = threadIdx.x; k < (int)(sizeof(carl_brax_sys_t) / 4); k += kLanes) dst[k] = src[k];
   }
   __syncthreads();
-  Lds m{lds_dyn, Layout::make(s.n_links, s.n_dof, s.n_act, s.obs_dim > s.n_q + s.n_dof ? s.obs_dim : s.n_q + s.n_dof),
-        (int)threadIdx.x};
-  const size_t lane_base = (size_t)blockIdx.x * kLanes;
-  const int lane = (int)lane_base + (int)threadIdx.x;
-  const bool active = lane < b.n_lanes;
-  const uint64_t glane = (uint64_t)(b.lane_offset + lane);
+  if (threadIdx.x == 0) build_topo(s, tp);
+  __syncthreads();
+  const Lds m{lds_dyn, Layout::make(s.n_links, s.n_dof, io_rows_of(s)), (int)threadIdx.x / kSub, (int)threadIdx.x % kSub};
+  const int env = (int)blockIdx.x * kEnvs + m.env;
+  const bool active = env < b.n_lanes;
+  const bool lead = active && m.sub == 0;  // the lane that writes the env's scalars
+  const uint64_t genv = (uint64_t)(b.lane_offset + env);
   const size_t n = (size_t)b.n_lanes;
   const int S = CARL_BRAX_LINK_STATE * s.n_links;
   LaneState r{};
   const bool goal = s.goal_mode != 0 && b.goal_pos != nullptr;
   if (active) {
-    r.cidx = b.ctx_idx[lane];
-    r.episode = b.episode[lane];
-    r.elapsed = b.elapsed[lane];
-    r.ep_return = b.ep_return[lane];
+    r.cidx = b.ctx_idx[env];
+    r.episode = b.episode[env];
+    r.elapsed = b.elapsed[env];
+    r.ep_return = b.ep_return[env];
   }
 
   if constexpr (MODE == 0) {
-    const bool go = active && (mask == nullptr || mask[lane] != 0);
+    const bool go = active && (mask == nullptr || mask[env] != 0);
+    if (__ballot(go) == 0ull) return;
+    if (go) r.cidx = select_context(b, r.cidx, genv, r.episode);
+    reset_state(s, tp, b, m, genv, r.episode, go);
+    r.episode += 1u;
     if (go) {
-      r.cidx = select_context(b, r.cidx, glane, r.episode);
-      reset_state(s, b, m, glane, r.episode);
-      r.episode += 1u;
-      for (int k = 0; k < S; ++k) b.state[(size_t)k * n + lane] = m.at(m.lay.state + k);
-      b.elapsed[lane] = 0;
-      b.ep_return[lane] = 0.0f;
-      b.ctx_idx[lane] = r.cidx;
-      b.episode[lane] = r.episode;
-      b.n_calls[lane] += 1;
-      if (goal) {  // wrapper reset: position = (0, 0)
-        b.goal_pos[lane] = 0.0f;
-        b.goal_pos[n + lane] = 0.0f;
+      for (int k = m.sub; k < S; k += kSub) b.state[(size_t)k * n + env] = m.at(m.lay.state + k);
+      if (m.sub == 0) {
+        b.elapsed[env] = 0;
+        b.ep_return[env] = 0.0f;
+        b.ctx_idx[env] = r.cidx;
+        b.episode[env] = r.episode;
+        b.n_calls[env] += 1;
+        if (goal) {  // wrapper reset: position = (0, 0)
+          b.goal_pos[env] = 0.0f;
+          b.goal_pos[n + env] = 0.0f;
+        }
       }
-      if (b.ctx_obs != nullptr)
-        for (int k = 0; k < b.n_ctx_obs; ++k)
-          b.ctx_obs[(size_t)k * n + lane] = b.ctx_table[(size_t)b.ctx_obs_feat[k] * b.ctx_stride + r.cidx];
-      if (s.obs_extended) load_ctx(s, b, m, r.cidx);  // com inertia / velocity use the lane's masses
-      observe(s, m, true);
-      if (reset_obs != nullptr)  // masked resets write only their own rows (no block staging)
-        for (int k = 0; k < s.obs_dim; ++k) reset_obs[(size_t)lane * s.obs_dim + k] = m.at(m.lay.io + k);
+      write_ctx_obs(b, m, n, env, r.cidx);
     }
+    if (s.obs_extended) load_ctx(s, b, m, r.cidx, go);  // com inertia / velocity use the env's masses
+    observe(s, m, go, true);
+    if (reset_obs != nullptr) record_out(reset_obs, (size_t)env, s.obs_dim, m, go);
     return;
   } else {
-    if (active) {
-      for (int k = 0; k < S; ++k) m.at(m.lay.state + k) = b.state[(size_t)k * n + lane];
-      r.ctx = load_ctx(s, b, m, r.cidx);
-      if (goal) {
-        load_goal(s, b, r.cidx, r);
-        r.pos_x = b.goal_pos[lane];
-        r.pos_y = b.goal_pos[n + lane];
-      }
+    if (active)
+      for (int k = m.sub; k < S; k += kSub) m.at(m.lay.state + k) = b.state[(size_t)k * n + env];
+    r.ctx = load_ctx(s, b, m, r.cidx, active);
+    if (goal && active) {
+      load_goal(s, b, r.cidx, r);
+      r.pos_x = b.goal_pos[env];
+      r.pos_y = b.goal_pos[n + env];
     }
     const float dt_env = s.dt * (float)s.n_frames;
     for (int t = 0; t < n_steps; ++t) {
       const size_t step_off = (size_t)t * n;
-      stage_in(static_cast<const float*>(io.action) + step_off * s.n_act, lane_base, b.n_lanes, s.n_act, m);
-      bool done = false, terminated = false, truncated = false;
-      float reward = 0.0f;
-      if (active) {
-        for (int d = 0; d < s.n_dof; ++d) m.at(m.lay.tau + d) = 0.0f;
-        float ctrl = 0.0f;
-        for (int k = 0; k < s.n_act; ++k) {  // actuator.to_tau
-          const float u = m.at(m.lay.io + k);
-          ctrl += u * u;
-          m.at(m.lay.tau + s.act_dof[k]) += s.act_gear[k] * fminf(fmaxf(u, s.act_lo[k]), s.act_hi[k]);
-        }
-        const Body b0 = m.body(0);
-        float msum;
-        const float x0 = s.reward_on_com ? system_com(s, m, &msum).x : b0.p.x - qrot(b0.r, f3(s.com[0])).x;
-        for (int f = 0; f < s.n_frames; ++f) substep(s, r.ctx, m);
-        const Body b1 = m.body(0);
-        const v3 c1 = qrot(b1.r, f3(s.com[0]));
-        const float x1 = s.reward_on_com ? system_com(s, m, &msum).x : b1.p.x - c1.x, z1 = b1.p.z - c1.z;
-        const bool healthy = (z1 >= s.healthy_z_lo) && (z1 <= s.healthy_z_hi);
-        reward = s.forward_reward_weight * (x1 - x0) / dt_env +
-                 (s.terminate_when_unhealthy ? s.healthy_reward : (healthy ? s.healthy_reward : 0.0f)) -
-                 s.ctrl_cost_weight * ctrl;
-        terminated = s.terminate_when_unhealthy && !healthy;
-        r.elapsed += 1;
-        truncated = (b.max_episode_steps > 0) && (r.elapsed >= b.max_episode_steps);
-        observe(s, m);
-        if (goal) {  // brax_walker_goal_wrapper.py:124-140: progress reward replaces the env reward
-          const float nx = r.pos_x + m.at(m.lay.io + s.goal_obs_idx[0]) * s.goal_dt;
-          const float ny = r.pos_y + m.at(m.lay.io + s.goal_obs_idx[1]) * s.goal_dt;
-          const float cur = sqrtf((r.goal_x - nx) * (r.goal_x - nx) + (r.goal_y - ny) * (r.goal_y - ny));
-          const float prev = sqrtf((r.goal_x - r.pos_x) * (r.goal_x - r.pos_x) + (r.goal_y - r.pos_y) * (r.goal_y - r.pos_y));
-          r.pos_x = nx;
-          r.pos_y = ny;
-          const bool ok = cur <= r.goal_radius;
-          terminated = terminated | ok;
-          reward = fmaxf(0.0f, prev - cur);
-          if (b.success != nullptr) b.success[step_off + lane] = (uint8_t)ok;
-        }
-        r.ep_return += reward;
-        done = terminated | truncated;
-        io.reward[step_off + lane] = reward;
-        io.terminated[step_off + lane] = (uint8_t)terminated;
-        io.truncated[step_off + lane] = (uint8_t)truncated;
+      record_in(static_cast<const float*>(io.action) + step_off * s.n_act, (size_t)env, s.n_act, m, active);
+      // actuator.to_tau: tau = 0, then every actuator adds gear * clip(action) to its dof
+      float ctrl = 0.0f;
+      for (int k = 0; k < s.n_act; ++k) {
+        const float u = m.at(m.lay.io + k);
+        ctrl += u * u;
       }
-      const unsigned long long any_done = __ballot(done);
-      if (any_done != 0ull) {
+      for (int d = m.sub; d < s.n_dof; d += kSub) m.at(m.lay.tau + d) = 0.0f;
+      phase_sync();
+      for (int k = m.sub; k < s.n_act; k += kSub)  // act_dof entries are distinct (checked by the host)
+        m.at(m.lay.tau + s.act_dof[k]) += s.act_gear[k] * fminf(fmaxf(m.at(m.lay.io + k), s.act_lo[k]), s.act_hi[k]);
+      phase_sync();
+      const Body b0 = m.body(0);
+      float msum;
+      const float x0 = s.reward_on_com ? system_com(s, m, &msum).x : b0.p.x - qrot(b0.r, f3(s.com[0])).x;
+      for (int f = 0; f < s.n_frames; ++f) substep(s, tp, r.ctx, m);
+      const Body b1 = m.body(0);
+      const v3 c1 = qrot(b1.r, f3(s.com[0]));
+      const float x1 = s.reward_on_com ? system_com(s, m, &msum).x : b1.p.x - c1.x, z1 = b1.p.z - c1.z;
+      const bool healthy = (z1 >= s.healthy_z_lo) && (z1 <= s.healthy_z_hi);
+      float reward = s.forward_reward_weight * (x1 - x0) / dt_env +
+                     (s.terminate_when_unhealthy ? s.healthy_reward : (healthy ? s.healthy_reward : 0.0f)) -
+                     s.ctrl_cost_weight * ctrl;
+      bool terminated = s.terminate_when_unhealthy && !healthy;
+      r.elapsed += 1;
+      const bool truncated = (b.max_episode_steps > 0) && (r.elapsed >= b.max_episode_steps);
+      observe(s, m, active, false);
+      if (goal) {  // brax_walker_goal_wrapper.py:124-140: progress reward replaces the env reward
+        const float nx = r.pos_x + m.at(m.lay.io + s.goal_obs_idx[0]) * s.goal_dt;
+        const float ny = r.pos_y + m.at(m.lay.io + s.goal_obs_idx[1]) * s.goal_dt;
+        const float cur = sqrtf((r.goal_x - nx) * (r.goal_x - nx) + (r.goal_y - ny) * (r.goal_y - ny));
+        const float prev = sqrtf((r.goal_x - r.pos_x) * (r.goal_x - r.pos_x) + (r.goal_y - r.pos_y) * (r.goal_y - r.pos_y));
+        r.pos_x = nx;
+        r.pos_y = ny;
+        const bool ok = cur <= r.goal_radius;
+        terminated = terminated | ok;
+        reward = fmaxf(0.0f, prev - cur);
+        if (lead && b.success != nullptr) b.success[step_off + env] = (uint8_t)ok;
+      }
+      r.ep_return += reward;
+      const bool done = active && (terminated | truncated);
+      if (lead) {
+        io.reward[step_off + env] = reward;
+        io.terminated[step_off + env] = (uint8_t)terminated;
+        io.truncated[step_off + env] = (uint8_t)truncated;
+      }
+      if (__ballot(done) != 0ull) {
         const float fin_ret = r.ep_return;
         const int fin_len = r.elapsed;
         if (done) {
-          if (b.last_return) b.last_return[lane] = fin_ret;
-          if (b.last_length) b.last_length[lane] = fin_len;
+          if (m.sub == 0) {
+            if (b.last_return) b.last_return[env] = fin_ret;
+            if (b.last_length) b.last_length[env] = fin_len;
+          }
           r.n_new_episodes += 1;
         }
-        log_finished(b, done, glane, fin_ret, fin_len);
+        log_finished(b, done && m.sub == 0, genv, fin_ret, fin_len);
         if (b.flags & CARL_FLAG_AUTORESET) {
-          if (io.final_obs != nullptr) {  // terminal observation, done lanes only
-            m.at(m.lay.count) = done ? 1.0f : 0.0f;
-            stage_out(io.final_obs + step_off * s.obs_dim, lane_base, b.n_lanes, s.obs_dim, m, true);
-          }
+          if (io.final_obs != nullptr)  // terminal observation, done envs only
+            record_out(io.final_obs + step_off * s.obs_dim, (size_t)env, s.obs_dim, m, done);
+          phase_sync();  // the io rows are rewritten below
+          if (done) r.cidx = select_context(b, r.cidx, genv, r.episode);
+          reset_state(s, tp, b, m, genv, r.episode, done);
+          const LaneCtx nc = load_ctx(s, b, m, r.cidx, done);
           if (done) {
-            r.cidx = select_context(b, r.cidx, glane, r.episode);
-            reset_state(s, b, m, glane, r.episode);
             r.episode += 1u;
-            r.ctx = load_ctx(s, b, m, r.cidx);
+            r.ctx = nc;
             if (goal) {
               load_goal(s, b, r.cidx, r);
               r.pos_x = r.pos_y = 0.0f;
@@ -706,28 +776,29 @@ __global__ void __launch_bounds__(kLanes) brax_kernel(const carl_batch_t b, cons
             r.elapsed = 0;
             r.ep_return = 0.0f;
             r.n_new_calls += 1;
-            if (b.ctx_obs != nullptr)
-              for (int k = 0; k < b.n_ctx_obs; ++k)
-                b.ctx_obs[(size_t)k * n + lane] = b.ctx_table[(size_t)b.ctx_obs_feat[k] * b.ctx_stride + r.cidx];
-            observe(s, m, true);
+            write_ctx_obs(b, m, n, env, r.cidx);
           }
+          observe(s, m, done, true);
         }
       }
-      stage_out(io.obs + step_off * s.obs_dim, lane_base, b.n_lanes, s.obs_dim, m);
+      record_out(io.obs + step_off * s.obs_dim, (size_t)env, s.obs_dim, m, active);
+      phase_sync();  // the next step's actions overwrite the io rows
     }
     if (active) {
-      for (int k = 0; k < S; ++k) b.state[(size_t)k * n + lane] = m.at(m.lay.state + k);
-      b.elapsed[lane] = r.elapsed;
-      b.ep_return[lane] = r.ep_return;
-      if (goal) {
-        b.goal_pos[lane] = r.pos_x;
-        b.goal_pos[n + lane] = r.pos_y;
-      }
-      if (r.n_new_episodes != 0 && b.episodes_done != nullptr) b.episodes_done[lane] += r.n_new_episodes;
-      if (r.n_new_calls != 0) {
-        b.ctx_idx[lane] = r.cidx;
-        b.episode[lane] = r.episode;
-        b.n_calls[lane] += r.n_new_calls;
+      for (int k = m.sub; k < S; k += kSub) b.state[(size_t)k * n + env] = m.at(m.lay.state + k);
+      if (m.sub == 0) {
+        b.elapsed[env] = r.elapsed;
+        b.ep_return[env] = r.ep_return;
+        if (goal) {
+          b.goal_pos[env] = r.pos_x;
+          b.goal_pos[n + env] = r.pos_y;
+        }
+        if (r.n_new_episodes != 0 && b.episodes_done != nullptr) b.episodes_done[env] += r.n_new_episodes;
+        if (r.n_new_calls != 0) {
+          b.ctx_idx[env] = r.cidx;
+          b.episode[env] = r.episode;
+          b.n_calls[env] += r.n_new_calls;
+        }
       }
     }
   }

@@ -185,6 +185,13 @@ int validate_brax(const carl_batch_t* b, const carl_brax_sys_t* sd, const carl_b
     if (!free_root && n_rot == 3 && sh->dof_sign3[i] != 1.0f && sh->dof_sign3[i] != -1.0f)
       return fail(CARL_ERR_INVALID_ARGUMENT, "%s: link %d: dof_sign3 must be +1 or -1", who, i);
   }
+  for (int k = 0; k < sh->n_act; ++k) {
+    if (sh->act_dof[k] < 0 || sh->act_dof[k] >= sh->n_dof)
+      return fail(CARL_ERR_INVALID_ARGUMENT, "%s: actuator %d drives dof %d (of %d)", who, k, sh->act_dof[k], sh->n_dof);
+    for (int j = 0; j < k; ++j)
+      if (sh->act_dof[j] == sh->act_dof[k])  // the kernel adds actuator torques to their dofs in parallel
+        return fail(CARL_ERR_UNSUPPORTED, "%s: actuators %d and %d drive the same dof", who, j, k);
+  }
   {
     const int base = sh->n_q - sh->exclude_current_positions + sh->n_dof;
     const int want = sh->obs_extended ? base + 16 * sh->n_links + sh->n_dof : base;
@@ -201,11 +208,10 @@ int launch_brax(const carl_batch_t* b, const carl_brax_sys_t* sd, const carl_bra
                        const carl_step_io_t* io, const uint8_t* mask, float* reset_obs, int n_steps, hipStream_t st,
                        const char* who) {
   if (b->n_lanes == 0 || (MODE == 1 && n_steps == 0)) return 0;
-  const int qrows = sh->n_q + sh->n_dof;
-  const carl::brax::Layout lay =
-      carl::brax::Layout::make(sh->n_links, sh->n_dof, sh->n_act, sh->obs_dim > qrows ? sh->obs_dim : qrows);
-  const size_t sh_bytes = (size_t)lay.total * carl::brax::kLanes * sizeof(float);
-  if (sh_bytes + sizeof(carl_brax_sys_t) > 160 * 1024)
+  // one wavefront = kEnvs envs x kSub lanes; LDS rows are kEnvs floats wide
+  const carl::brax::Layout lay = carl::brax::Layout::make(sh->n_links, sh->n_dof, carl::brax::io_rows_of(*sh));
+  const size_t sh_bytes = (size_t)lay.total * carl::brax::kEnvs * sizeof(float);
+  if (sh_bytes + sizeof(carl_brax_sys_t) + sizeof(carl::brax::Topo) > 160 * 1024)
     return fail(CARL_ERR_UNSUPPORTED, "%s: model needs %zu B of LDS per wavefront", who, sh_bytes);
   auto kern = carl::brax::brax_kernel<MODE>;
   if (sh_bytes > 48 * 1024) {
@@ -213,7 +219,7 @@ int launch_brax(const carl_batch_t* b, const carl_brax_sys_t* sd, const carl_bra
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_bytes);
     if (e != hipSuccess) return fail((int)e, "%s: hipFuncSetAttribute: %s", who, hipGetErrorString(e));
   }
-  const int grid = (b->n_lanes + carl::brax::kLanes - 1) / carl::brax::kLanes;
+  const int grid = (b->n_lanes + carl::brax::kEnvs - 1) / carl::brax::kEnvs;
   carl_step_io_t io_v{};
   if (io != nullptr) io_v = *io;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(carl::brax::kLanes), sh_bytes, st, *b, sd, io_v, mask, reset_obs, n_steps);
