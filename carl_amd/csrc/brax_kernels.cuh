@@ -7,7 +7,8 @@
 // specification implemented here is written out in oracle/brax_spring.c's header and
 // DESIGN.md; PARITY UNPINNED].
 //
-// Mapping: one env = a group of kSub = 8 adjacent lanes; one wavefront (= one workgroup) = 8 envs.
+// Mapping: one env = a group of kSub adjacent lanes (4, 8 or 16; 8 below); one wavefront (= one
+// workgroup) = 64 / kSub envs.
 // Within an env the lanes split the work by link: lane `sub` owns joints / bodies sub, sub + 8,
 // ... (Ant: 8 joints in one round, 9 bodies in two; Halfcheetah 7 / 7 in one round each;
 // Humanoid 10 / 11 in two).  32 768 envs are 4 096 wavefronts = 4 per SIMD, where the earlier
@@ -35,9 +36,9 @@
 namespace carl {
 namespace brax {
 
-constexpr int kSub = 8;                 // lanes per env
-constexpr int kLanes = 64;              // lanes per workgroup = one wavefront
-constexpr int kEnvs = kLanes / kSub;    // envs per workgroup
+constexpr int kLanes = 64;  // lanes per workgroup = one wavefront
+// kSub = lanes per env is a template parameter of everything below (Group<kSub>): 4, 8 or 16,
+// chosen per model and batch size by the host (carl_amd.hip: brax_lanes_per_env)
 constexpr float kPiF = 3.14159265358979323846f;
 
 struct v3 {
@@ -142,6 +143,40 @@ __device__ inline void build_topo(const carl_brax_sys_t& s, Topo& t) {
   t.first_joint = (s.parent[0] < 0 && s.n_link_dof[0] == 6) ? 1 : 0;
 }
 
+// per-link constants derived from the model table once per workgroup
+struct Derived {
+  float ac[CARL_BRAX_MAX_LINKS][3];   // joint anchor relative to the child's COM (child frame)
+  float ap[CARL_BRAX_MAX_LINKS][3];   // ... relative to the parent's COM (parent frame; world: origin), zero slide
+  float rpl[CARL_BRAX_MAX_LINKS][4];  // parent-side joint frame in the parent frame: link_rot (x) joint_rot
+  float reach[CARL_BRAX_MAX_LINKS];   // max over the link's spheres of |centre - COM| + radius (-1: none)
+  uint8_t iso[CARL_BRAX_MAX_LINKS];   // isotropic inertia: R diag(c) R^T = c
+};
+
+__device__ inline void build_derived(const carl_brax_sys_t& s, Derived& d, int i) {
+  const int P = s.parent[i];
+  const v3 a = f3(s.joint_pos[i]);
+  const qt lrot = f4(s.link_rot[i]);
+  const v3 com_p = (P < 0) ? V(0, 0, 0) : f3(s.com[P]);
+  const v3 ac = a - f3(s.com[i]);
+  const v3 ap = f3(s.link_pos[i]) + qrot(lrot, a) - com_p;
+  const qt rpl = qmul(lrot, f4(s.joint_rot[i]));
+  d.ac[i][0] = ac.x; d.ac[i][1] = ac.y; d.ac[i][2] = ac.z;
+  d.ap[i][0] = ap.x; d.ap[i][1] = ap.y; d.ap[i][2] = ap.z;
+  d.rpl[i][0] = rpl.w; d.rpl[i][1] = rpl.x; d.rpl[i][2] = rpl.y; d.rpl[i][3] = rpl.z;
+  float reach = -1.0f;
+  for (int k = 0; k < s.n_coll; ++k)
+    if (s.coll_link[k] == i) {
+      const v3 c = f3(s.coll_pos[k]) - f3(s.com[i]);
+      reach = fmaxf(reach, sqrtf(dot(c, c)) + s.coll_radius[k]);
+    }
+  d.reach[i] = reach;
+  d.iso[i] = (s.inv_inertia[i][0] == s.inv_inertia[i][1] && s.inv_inertia[i][1] == s.inv_inertia[i][2]) ? 1 : 0;
+}
+
+template <int kSub>
+struct Group {
+static constexpr int kEnvs = kLanes / kSub;  // envs per workgroup
+
 struct Lds {
   float* base;
   Layout lay;
@@ -172,57 +207,64 @@ struct Lds {
 
 // hand-over between lockstep phases: the workgroup is ONE wavefront, so this is an LDS
 // drain (s_waitcnt) plus a compiler fence; s_barrier itself is trivially satisfied
-__device__ __forceinline__ void phase_sync() { __syncthreads(); }
+static __device__ __forceinline__ void phase_sync() { __syncthreads(); }
 
-__device__ __forceinline__ v3 apply_inv_inertia(const carl_brax_sys_t& s, int i, qt r, v3 t) {
+static __device__ __forceinline__ v3 apply_inv_inertia(const carl_brax_sys_t& s, int i, qt r, v3 t, bool iso) {
+  if (iso) return t * s.inv_inertia[i][0];  // every shipped model: spring_inertia_scale = 1
   const v3 l = qrot(qconj(r), t);
   return qrot(r, V(l.x * s.inv_inertia[i][0], l.y * s.inv_inertia[i][1], l.z * s.inv_inertia[i][2]));
 }
 
+// first column of the rotation matrix of q = q rotating e_x
+static __device__ __forceinline__ v3 xaxis(qt q) {
+  return V(1.0f - 2.0f * (q.y * q.y + q.z * q.z), 2.0f * (q.x * q.y + q.w * q.z), 2.0f * (q.x * q.z - q.w * q.y));
+}
+
 // the static world as a parent body (planar roots are jointed to it)
-__device__ __forceinline__ Body world_body() {
+static __device__ __forceinline__ Body world_body() {
   return Body{V(0, 0, 0), qt{1, 0, 0, 0}, V(0, 0, 0), V(0, 0, 0)};
 }
 
-__device__ __forceinline__ bool is_free_root(const carl_brax_sys_t& s, int i) {
+static __device__ __forceinline__ bool is_free_root(const carl_brax_sys_t& s, int i) {
   return s.parent[i] < 0 && s.n_link_dof[i] == 6;
 }
 
 // joint geometry shared by joints.resolve and inverse kinematics
 struct JointGeom {
+  v3 rc_off, rp_off;      // anchor relative to the child's / parent's COM, world frame
   v3 A_c, A_p, vA_c, vA_p, x_c, x_p, wrel;
   float theta, thetadot;  // single hinge
   v3 axis[3];             // 2-3 stacked hinges: current world axes ...
   float ang[3], rate[3];  // ... Euler x-y-z angles (third signed by dof_sign3) and their rates
 };
 
-__device__ __forceinline__ JointGeom joint_geometry(const carl_brax_sys_t& s, int i, const Body& bc, const Body& bp) {
+// MULTI: the model has links with 2-3 stacked hinges (Humanoid); false compiles the Euler-angle
+// path out (Ant, Halfcheetah: fewer registers, shorter joint phase)
+template <bool MULTI>
+static __device__ __forceinline__ JointGeom joint_geometry(const carl_brax_sys_t& s, const Derived& dv, int i, const Body& bc,
+                                                    const Body& bp) {
   JointGeom g;
-  const int P = s.parent[i];
-  const v3 a = f3(s.joint_pos[i]);
-  const qt lrot = f4(s.link_rot[i]), jr = f4(s.joint_rot[i]);
-  const v3 com_p = (P < 0) ? V(0, 0, 0) : f3(s.com[P]);
-  const v3 o_c = bc.p - qrot(bc.r, f3(s.com[i]));
-  const v3 o_p = bp.p - qrot(bp.r, com_p);
-  g.A_c = o_c + qrot(bc.r, a);
-  g.A_p = o_p + qrot(bp.r, f3(s.link_pos[i]) + qrot(lrot, a));  // at zero slide
-  g.vA_c = bc.v + cross(bc.w, g.A_c - bc.p);
-  g.vA_p = bp.v + cross(bp.w, g.A_p - bp.p);
-  const qt rc = qmul(bc.r, jr);
-  const qt rp = qmul(qmul(bp.r, lrot), jr);
-  g.x_c = qrot(rc, V(1, 0, 0));
-  g.x_p = qrot(rp, V(1, 0, 0));
+  g.rc_off = qrot(bc.r, f3(dv.ac[i]));
+  g.rp_off = qrot(bp.r, f3(dv.ap[i]));
+  g.A_c = bc.p + g.rc_off;
+  g.A_p = bp.p + g.rp_off;  // at zero slide
+  g.vA_c = bc.v + cross(bc.w, g.rc_off);
+  g.vA_p = bp.v + cross(bp.w, g.rp_off);
+  const qt rc = qmul(bc.r, f4(s.joint_rot[i]));
+  const qt rp = qmul(bp.r, f4(dv.rpl[i]));
+  g.x_c = xaxis(rc);
+  g.x_p = xaxis(rp);
   qt rel = qmul(qconj(rp), rc);
   if (rel.w < 0.0f) { rel.w = -rel.w; rel.x = -rel.x; }
-  g.theta = 2.0f * atan2f(rel.x, rel.w);  // twist about the hinge (joint frame x)
+  g.theta = 2.0f * atan2_fast(rel.x, rel.w);  // twist about the hinge (joint frame x)
   g.wrel = bc.w - bp.w;
   g.thetadot = dot(g.x_c, g.wrel);
-  const int nr = s.n_link_dof[i] - s.n_slide[i];
-  if (nr >= 2) {  // rel = Rx(al) Ry(be) Rz(ga): decompose, ga = sign * theta_3
+  const int nr = MULTI ? s.n_link_dof[i] - s.n_slide[i] : 1;
+  if (MULTI && nr >= 2) {  // rel = Rx(al) Ry(be) Rz(ga): decompose, ga = sign * theta_3
     const float R00 = 1.0f - 2.0f * (rel.y * rel.y + rel.z * rel.z), R01 = 2.0f * (rel.x * rel.y - rel.w * rel.z);
     const float R02 = fminf(fmaxf(2.0f * (rel.x * rel.z + rel.w * rel.y), -1.0f), 1.0f);
     const float R12 = 2.0f * (rel.y * rel.z - rel.w * rel.x), R22 = 1.0f - 2.0f * (rel.x * rel.x + rel.y * rel.y);
-    const float al = atan2f(-R12, R22), be = asinf(R02), ga = atan2f(-R01, R00);
+    const float al = atan2_fast(-R12, R22), be = asinf(R02), ga = atan2_fast(-R01, R00);
     const float sg = s.dof_sign3[i];
     g.ang[0] = al; g.ang[1] = be; g.ang[2] = sg * ga;
     g.axis[0] = g.x_p;
@@ -244,7 +286,9 @@ __device__ __forceinline__ JointGeom joint_geometry(const carl_brax_sys_t& s, in
 }
 
 // ---- one brax.spring.pipeline.step ---------------------------------------------------------
-__device__ __forceinline__ void substep(const carl_brax_sys_t& s, const Topo& tp, const LaneCtx& c, const Lds& m) {
+template <bool MULTI>
+static __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const Topo& tp, const Derived& dv, const LaneCtx& c,
+                                        const Lds& m) {
   const int L = s.n_links;
   // phase A -- spring.joints.resolve, one joint per lane
   for (int i = tp.first_joint + m.sub; i < L; i += kSub) {
@@ -252,7 +296,7 @@ __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const Topo& tp
     if (is_free_root(s, i)) continue;
     const Body bc = m.body(i);
     const Body bp = (P < 0) ? world_body() : m.body(P);
-    const JointGeom g = joint_geometry(s, i, bc, bp);
+    const JointGeom g = joint_geometry<MULTI>(s, dv, i, bc, bp);
     const float kp = s.k_pos[i] * c.stiffness_scale;
     v3 e = g.A_p - g.A_c, ev = g.vA_p - g.vA_c;
     v3 f = V(0, 0, 0);
@@ -266,8 +310,8 @@ __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const Topo& tp
     }
     f = f + e * kp + ev * s.k_vel[i];
     v3 t;
-    const int d = d0 + ns, nr = s.n_link_dof[i] - ns;
-    if (nr == 1) {
+    const int d = d0 + ns, nr = MULTI ? s.n_link_dof[i] - ns : 1;
+    if (!MULTI || nr == 1) {
       t = cross(g.x_c, g.x_p) * kp;  // keep the hinge axes aligned
       float ta = m.at(m.lay.tau + d) - s.dof_damping[d] * g.thetadot - s.dof_stiffness[d] * g.theta;
       if (g.theta < s.dof_lo[d]) ta += s.k_limit[i] * (s.dof_lo[d] - g.theta);
@@ -293,9 +337,9 @@ __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const Topo& tp
     t = t - g.wrel * s.k_ang_damp[i];
     const int wr = m.lay.wrench + 12 * i;
     m.put3(wr, f);
-    m.put3(wr + 3, cross(g.A_c - bc.p, f) + t);
+    m.put3(wr + 3, cross(g.rc_off, f) + t);
     m.put3(wr + 6, f * -1.0f);
-    m.put3(wr + 9, (cross(g.A_p - bp.p, f) + t) * -1.0f);
+    m.put3(wr + 9, (cross(g.rp_off, f) + t) * -1.0f);
   }
   phase_sync();
   // phase B -- per body: wrench sum, semi-implicit Euler, its contacts, integrate
@@ -315,20 +359,22 @@ __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const Topo& tp
     }
     const float inv_m = 1.0f / m.at(m.lay.mass + i);
     b.v = b.v + (F * inv_m + V(0, 0, c.gravity_z)) * s.dt;
-    b.w = b.w + apply_inv_inertia(s, i, b.r, T) * s.dt;
+    b.w = b.w + apply_inv_inertia(s, i, b.r, T, dv.iso[i] != 0) * s.dt;
     // spring.collisions.resolve: this body's spheres vs the plane z = 0
-    v3 dv = V(0, 0, 0), dw = V(0, 0, 0);
+    v3 cdv = V(0, 0, 0), cdw = V(0, 0, 0);
     float cnt = 0.0f;
-    const v3 org = b.p - qrot(b.r, f3(s.com[i]));
-    for (int kk = tp.coll_begin[i]; kk < tp.coll_begin[i + 1]; ++kk) {
+    const bool iso = dv.iso[i] != 0;
+    // no sphere of this link can reach the plane while its COM is higher than the farthest sphere surface
+    const int k_end = (b.p.z < dv.reach[i]) ? tp.coll_begin[i + 1] : 0;
+    for (int kk = tp.coll_begin[i]; kk < k_end; ++kk) {
       const int k = tp.coll_idx[kk];
-      const v3 ctr = org + qrot(b.r, f3(s.coll_pos[k]));
+      const v3 ctr = b.p + qrot(b.r, f3(s.coll_pos[k]) - f3(s.com[i]));
       const float depth = s.coll_radius[k] - ctr.z;
       if (!(depth > 0.0f)) continue;
       const v3 r = V(ctr.x, ctr.y, ctr.z - s.coll_radius[k]) - b.p;
       const v3 rel = b.v + cross(b.w, r);
       const float vn = dot(n, rel);
-      const float ang = dot(n, cross(apply_inv_inertia(s, i, b.r, cross(r, n)), r));
+      const float ang = dot(n, cross(apply_inv_inertia(s, i, b.r, cross(r, n), iso), r));
       const float imp = (-(1.0f + c.elasticity) * vn + s.baumgarte_erp * depth / s.dt) / (inv_m + ang);
       if (!(imp > 0.0f) || !(vn < 0.0f)) continue;
       v3 J = n * imp;
@@ -336,12 +382,12 @@ __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const Topo& tp
       const float vt_len = sqrtf(dot(vt, vt));
       if (vt_len > 1e-9f) {
         const v3 dir = vt * (1.0f / vt_len);
-        const float ang_d = dot(dir, cross(apply_inv_inertia(s, i, b.r, cross(r, dir)), r));
+        const float ang_d = dot(dir, cross(apply_inv_inertia(s, i, b.r, cross(r, dir), iso), r));
         const float imp_d = fminf(vt_len / (inv_m + ang_d), c.friction * imp);
         J = J - dir * imp_d;
       }
-      dv = dv + J * inv_m;
-      dw = dw + apply_inv_inertia(s, i, b.r, cross(r, J));
+      cdv = cdv + J * inv_m;
+      cdw = cdw + apply_inv_inertia(s, i, b.r, cross(r, J), iso);
       cnt += 1.0f;
     }
     // spring.integrator.integrate
@@ -349,8 +395,8 @@ __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const Topo& tp
     b.w = b.w * da;
     if (cnt > 0.0f) {
       const float ic = 1.0f / cnt;
-      b.v = b.v + dv * ic;
-      b.w = b.w + dw * ic;
+      b.v = b.v + cdv * ic;
+      b.w = b.w + cdw * ic;
     }
     b.p = b.p + b.v * s.dt;
     const qt dq = qmul(qt{0.0f, b.w.x, b.w.y, b.w.z}, b.r);
@@ -362,7 +408,7 @@ __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const Topo& tp
 }
 
 // whole-body centre of mass (brax.envs.humanoid.Humanoid._com); *mass_sum = total mass
-__device__ __forceinline__ v3 system_com(const carl_brax_sys_t& s, const Lds& m, float* mass_sum) {
+static __device__ __forceinline__ v3 system_com(const carl_brax_sys_t& s, const Lds& m, float* mass_sum) {
   v3 com = V(0, 0, 0);
   float M = 0.0f;
   for (int i = 0; i < s.n_links; ++i) {
@@ -378,7 +424,9 @@ __device__ __forceinline__ v3 system_com(const carl_brax_sys_t& s, const Lds& m,
 // link per lane; obs_extended (humanoid) appends com inertia (L x 10), com velocity (L x 6) and
 // qfrc_actuator (the tau rows; `zero_frc`: reset observations see a zero action).  `go`: envs
 // that take part (the calls are wavefront-uniform).  Ends with a phase_sync.
-__device__ __forceinline__ void observe(const carl_brax_sys_t& s, const Lds& m, bool go, bool zero_frc) {
+template <bool MULTI>
+static __device__ __forceinline__ void observe(const carl_brax_sys_t& s, const Derived& dv, const Lds& m, bool go,
+                                        bool zero_frc) {
   const int skip = s.exclude_current_positions;
   const int qd0 = s.n_q - skip;  // first qd row in the observation
   const int L = s.n_links;
@@ -402,15 +450,15 @@ __device__ __forceinline__ void observe(const carl_brax_sys_t& s, const Lds& m, 
       for (int k = 0; k < 6; ++k) m.at(m.lay.io + qd0 + s.dof_start[i] + k) = dvv[k];
     } else {
       const Body bp = (P < 0) ? world_body() : m.body(P);
-      const JointGeom g = joint_geometry(s, i, b, bp);
+      const JointGeom g = joint_geometry<MULTI>(s, dv, i, b, bp);
       const int ns = s.n_slide[i];
       for (int k = 0; k < ns; ++k) {
         const v3 ax = qrot(bp.r, f3(s.slide_axis[i][k]));
         if (s.q_start[i] + k >= skip) m.at(m.lay.io + s.q_start[i] + k - skip) = dot(g.A_c - g.A_p, ax);
         m.at(m.lay.io + qd0 + s.dof_start[i] + k) = dot(g.vA_c - g.vA_p, ax);
       }
-      const int nr = s.n_link_dof[i] - ns;
-      if (nr == 1) {
+      const int nr = MULTI ? s.n_link_dof[i] - ns : 1;
+      if (!MULTI || nr == 1) {
         if (s.q_start[i] + ns >= skip) m.at(m.lay.io + s.q_start[i] + ns - skip) = g.theta;
         m.at(m.lay.io + qd0 + s.dof_start[i] + ns) = g.thetadot;
       } else {
@@ -459,7 +507,7 @@ __device__ __forceinline__ void observe(const carl_brax_sys_t& s, const Lds& m, 
 // [0, n_q), qd at rows [n_q, n_q + n_dof)); writes the state rows.  The tree is walked level by
 // level (links of one depth in parallel); link-frame origins and their velocities are kept in
 // the wrench rows (free at this point).  Wavefront-uniform call; `go`: envs that take part.
-__device__ __noinline__ void forward_kinematics(const carl_brax_sys_t& s, const Topo& tp, const Lds& m, bool go) {
+static __device__ __noinline__ void forward_kinematics(const carl_brax_sys_t& s, const Topo& tp, const Lds& m, bool go) {
   for (int lvl = 0; lvl <= tp.max_depth; ++lvl) {
     for (int i = m.sub; i < s.n_links; i += kSub) {
       if (!go || tp.depth[i] != lvl) continue;
@@ -521,14 +569,14 @@ __device__ __noinline__ void forward_kinematics(const carl_brax_sys_t& s, const 
 // brax.envs.<env>.reset: q = init_q + U(-noise, noise), qd = vel_scale * N(0, 1) (humanoid:
 // U(-scale, scale)).  Draw k uses word (k mod 4) of Philox block k / 4 on sub-stream
 // 0x80000000 | block; normals are Box-Muller pairs from two consecutive draws.
-__device__ __forceinline__ float draw_u(uint64_t seed, uint64_t g, uint32_t ep, int k) {
+static __device__ __forceinline__ float draw_u(uint64_t seed, uint64_t g, uint32_t ep, int k) {
   const u32x4 w = lane_words(seed, g, ep, 0x80000000u | (uint32_t)(k >> 2));
   const uint32_t x = (k & 3) == 0 ? w.x : (k & 3) == 1 ? w.y : (k & 3) == 2 ? w.z : w.w;
   return u01(x);
 }
 
 // wavefront-uniform call; `go`: envs that are reset
-__device__ __noinline__ void reset_state(const carl_brax_sys_t& s, const Topo& tp, const carl_batch_t& b, const Lds& m,
+static __device__ __noinline__ void reset_state(const carl_brax_sys_t& s, const Topo& tp, const carl_batch_t& b, const Lds& m,
                                          uint64_t genv, uint32_t episode, bool go) {
   if (go) {
     for (int i = m.sub; i < s.n_q; i += kSub)
@@ -553,7 +601,7 @@ __device__ __noinline__ void reset_state(const carl_brax_sys_t& s, const Topo& t
 }
 
 // context scalars of the env + its mass rows (wavefront-uniform call; ends with a phase_sync)
-__device__ __forceinline__ LaneCtx load_ctx(const carl_brax_sys_t& s, const carl_batch_t& b, const Lds& m, int c,
+static __device__ __forceinline__ LaneCtx load_ctx(const carl_brax_sys_t& s, const carl_batch_t& b, const Lds& m, int c,
                                             bool go) {
   const carl_brax_ctx_map_t& cm = s.ctx;
   auto get = [&](int row, float dflt) { return row >= 0 ? b.ctx_table[(size_t)row * b.ctx_stride + c] : dflt; };
@@ -577,12 +625,12 @@ __device__ __forceinline__ LaneCtx load_ctx(const carl_brax_sys_t& s, const carl
 
 // env-major records (W floats per env) <-> the env's io staging rows; each env's 8 lanes move
 // their own record (32-byte segments per env; L2 merges them into full lines)
-__device__ __forceinline__ void record_in(const float* __restrict__ src, size_t env, int W, const Lds& m, bool go) {
+static __device__ __forceinline__ void record_in(const float* __restrict__ src, size_t env, int W, const Lds& m, bool go) {
   if (go)
     for (int k = m.sub; k < W; k += kSub) m.at(m.lay.io + k) = src[env * W + k];
   phase_sync();
 }
-__device__ __forceinline__ void record_out(float* __restrict__ dst, size_t env, int W, const Lds& m, bool go) {
+static __device__ __forceinline__ void record_out(float* __restrict__ dst, size_t env, int W, const Lds& m, bool go) {
   if (go)
     for (int k = m.sub; k < W; k += kSub) dst[env * W + k] = m.at(m.lay.io + k);
 }
@@ -597,7 +645,7 @@ struct LaneState {
 
 // BraxWalkerGoalWrapper (carl/envs/brax/brax_walker_goal_wrapper.py:69-121): compass code ->
 // goal position = direction * target_distance; radius
-__device__ __forceinline__ void load_goal(const carl_brax_sys_t& s, const carl_batch_t& b, int c, LaneState& r) {
+static __device__ __forceinline__ void load_goal(const carl_brax_sys_t& s, const carl_batch_t& b, int c, LaneState& r) {
   const carl_brax_ctx_map_t& cm = s.ctx;
   const int code = __float2int_rn(b.ctx_table[(size_t)cm.target_direction * b.ctx_stride + c]);
   const float dist = b.ctx_table[(size_t)cm.target_distance * b.ctx_stride + c];
@@ -627,19 +675,20 @@ __device__ __forceinline__ void load_goal(const carl_brax_sys_t& s, const carl_b
   r.goal_y = dy * dist;
 }
 
-__device__ __forceinline__ void write_ctx_obs(const carl_batch_t& b, const Lds& m, size_t n, int env, int cidx) {
+static __device__ __forceinline__ void write_ctx_obs(const carl_batch_t& b, const Lds& m, size_t n, int env, int cidx) {
   if (b.ctx_obs != nullptr)
     for (int k = m.sub; k < b.n_ctx_obs; k += kSub)
       b.ctx_obs[(size_t)k * n + env] = b.ctx_table[(size_t)b.ctx_obs_feat[k] * b.ctx_stride + cidx];
 }
 
 // mode 0: reset (mask optional), mode 1: n_steps env steps (1 = per call, T = fused rollout)
-template <int MODE>
-__global__ void __launch_bounds__(kLanes) brax_kernel(const carl_batch_t b, const carl_brax_sys_t* __restrict__ sys_dev,
-                                                      const carl_step_io_t io, const uint8_t* __restrict__ mask,
-                                                      float* __restrict__ reset_obs, const int n_steps) {
+template <int MODE, bool MULTI>
+static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_brax_sys_t* __restrict__ sys_dev,
+                                           const carl_step_io_t& io, const uint8_t* __restrict__ mask,
+                                           float* __restrict__ reset_obs, const int n_steps) {
   __shared__ carl_brax_sys_t s;
   __shared__ Topo tp;
+  __shared__ Derived dv;
   extern __shared__ float lds_dyn[];
   {  // model table -> LDS, once per workgroup
     const uint32_t* src = reinterpret_cast<const uint32_t*>(sys_dev);
@@ -648,6 +697,7 @@ __global__ void __launch_bounds__(kLanes) brax_kernel(const carl_batch_t b, cons
   }
   __syncthreads();
   if (threadIdx.x == 0) build_topo(s, tp);
+  if ((int)threadIdx.x < s.n_links) build_derived(s, dv, (int)threadIdx.x);
   __syncthreads();
   const Lds m{lds_dyn, Layout::make(s.n_links, s.n_dof, io_rows_of(s)), (int)threadIdx.x / kSub, (int)threadIdx.x % kSub};
   const int env = (int)blockIdx.x * kEnvs + m.env;
@@ -687,7 +737,7 @@ __global__ void __launch_bounds__(kLanes) brax_kernel(const carl_batch_t b, cons
       write_ctx_obs(b, m, n, env, r.cidx);
     }
     if (s.obs_extended) load_ctx(s, b, m, r.cidx, go);  // com inertia / velocity use the env's masses
-    observe(s, m, go, true);
+    observe<MULTI>(s, dv, m, go, true);
     if (reset_obs != nullptr) record_out(reset_obs, (size_t)env, s.obs_dim, m, go);
     return;
   } else {
@@ -717,7 +767,7 @@ __global__ void __launch_bounds__(kLanes) brax_kernel(const carl_batch_t b, cons
       const Body b0 = m.body(0);
       float msum;
       const float x0 = s.reward_on_com ? system_com(s, m, &msum).x : b0.p.x - qrot(b0.r, f3(s.com[0])).x;
-      for (int f = 0; f < s.n_frames; ++f) substep(s, tp, r.ctx, m);
+      for (int f = 0; f < s.n_frames; ++f) substep<MULTI>(s, tp, dv, r.ctx, m);
       const Body b1 = m.body(0);
       const v3 c1 = qrot(b1.r, f3(s.com[0]));
       const float x1 = s.reward_on_com ? system_com(s, m, &msum).x : b1.p.x - c1.x, z1 = b1.p.z - c1.z;
@@ -728,7 +778,7 @@ __global__ void __launch_bounds__(kLanes) brax_kernel(const carl_batch_t b, cons
       bool terminated = s.terminate_when_unhealthy && !healthy;
       r.elapsed += 1;
       const bool truncated = (b.max_episode_steps > 0) && (r.elapsed >= b.max_episode_steps);
-      observe(s, m, active, false);
+      observe<MULTI>(s, dv, m, active, false);
       if (goal) {  // brax_walker_goal_wrapper.py:124-140: progress reward replaces the env reward
         const float nx = r.pos_x + m.at(m.lay.io + s.goal_obs_idx[0]) * s.goal_dt;
         const float ny = r.pos_y + m.at(m.lay.io + s.goal_obs_idx[1]) * s.goal_dt;
@@ -778,7 +828,7 @@ __global__ void __launch_bounds__(kLanes) brax_kernel(const carl_batch_t b, cons
             r.n_new_calls += 1;
             write_ctx_obs(b, m, n, env, r.cidx);
           }
-          observe(s, m, done, true);
+          observe<MULTI>(s, dv, m, done, true);
         }
       }
       record_out(io.obs + step_off * s.obs_dim, (size_t)env, s.obs_dim, m, active);
@@ -802,6 +852,15 @@ __global__ void __launch_bounds__(kLanes) brax_kernel(const carl_batch_t b, cons
       }
     }
   }
+}
+
+};  // struct Group
+
+template <int MODE, bool MULTI, int K>
+__global__ void __launch_bounds__(kLanes) brax_kernel(const carl_batch_t b, const carl_brax_sys_t* __restrict__ sys_dev,
+                                                      const carl_step_io_t io, const uint8_t* __restrict__ mask,
+                                                      float* __restrict__ reset_obs, const int n_steps) {
+  Group<K>::template run<MODE, MULTI>(b, sys_dev, io, mask, reset_obs, n_steps);
 }
 
 }  // namespace brax

@@ -203,23 +203,56 @@ int validate_brax(const carl_batch_t* b, const carl_brax_sys_t* sd, const carl_b
   return 0;
 }
 
+// Lanes per env (the kernels' kSub).  One lane per joint keeps a substep to one joint round and
+// one or two body rounds -- the kernel is bound by the serial instruction stream of a wavefront,
+// not by lane utilisation (measured, profiles/r01g: Ant 8 > 4, 16; Humanoid 16 > 8 > 4) -- except
+// for the smallest model, where 4 lanes and 16 envs per wavefront won (Halfcheetah 4 > 8 > 16).
+// Small batches are widened so that the launch has at least two wavefronts per SIMD.
+// CARL_AMD_BRAX_SUB=4|8|16 overrides (experiments).
+int brax_lanes_per_env(int n_joints, int n_lanes) {
+  const char* env = getenv("CARL_AMD_BRAX_SUB");  // read per call: tests switch it
+  if (env != nullptr) {
+    const int k = atoi(env);
+    if (k == 4 || k == 8 || k == 16) return k;
+  }
+  int k = n_joints <= 7 ? 4 : n_joints <= 8 ? 8 : 16;
+  while (k < 16 && (long long)n_lanes * k / carl::brax::kLanes < 2048) k *= 2;
+  return k;
+}
+
 template <int MODE>
 int launch_brax(const carl_batch_t* b, const carl_brax_sys_t* sd, const carl_brax_sys_t* sh,
                        const carl_step_io_t* io, const uint8_t* mask, float* reset_obs, int n_steps, hipStream_t st,
                        const char* who) {
   if (b->n_lanes == 0 || (MODE == 1 && n_steps == 0)) return 0;
-  // one wavefront = kEnvs envs x kSub lanes; LDS rows are kEnvs floats wide
+  bool multi = false;  // any link with 2-3 stacked hinges?
+  int n_joints = 0;
+  for (int i = 0; i < sh->n_links; ++i) {
+    const bool free_root = sh->parent[i] < 0 && sh->n_link_dof[i] == 6;
+    multi |= !free_root && sh->n_link_dof[i] - sh->n_slide[i] >= 2;
+    n_joints += free_root ? 0 : 1;
+  }
+  const int K = brax_lanes_per_env(n_joints, b->n_lanes);
+  const int envs = carl::brax::kLanes / K;  // one wavefront = envs x K lanes; LDS rows are `envs` floats wide
   const carl::brax::Layout lay = carl::brax::Layout::make(sh->n_links, sh->n_dof, carl::brax::io_rows_of(*sh));
-  const size_t sh_bytes = (size_t)lay.total * carl::brax::kEnvs * sizeof(float);
-  if (sh_bytes + sizeof(carl_brax_sys_t) + sizeof(carl::brax::Topo) > 160 * 1024)
+  const size_t sh_bytes = (size_t)lay.total * envs * sizeof(float);
+  if (sh_bytes + sizeof(carl_brax_sys_t) + sizeof(carl::brax::Topo) + sizeof(carl::brax::Derived) > 160 * 1024)
     return fail(CARL_ERR_UNSUPPORTED, "%s: model needs %zu B of LDS per wavefront", who, sh_bytes);
-  auto kern = carl::brax::brax_kernel<MODE>;
+  using kern_t = void (*)(carl_batch_t, const carl_brax_sys_t*, carl_step_io_t, const uint8_t*, float*, int);
+  kern_t kern = nullptr;
+#define CARL_PICK(KK)                                                                              \
+  kern = multi ? static_cast<kern_t>(carl::brax::brax_kernel<MODE, true, KK>)                       \
+               : static_cast<kern_t>(carl::brax::brax_kernel<MODE, false, KK>)
+  if (K == 4) CARL_PICK(4);
+  else if (K == 8) CARL_PICK(8);
+  else CARL_PICK(16);
+#undef CARL_PICK
   if (sh_bytes > 48 * 1024) {
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_bytes);
     if (e != hipSuccess) return fail((int)e, "%s: hipFuncSetAttribute: %s", who, hipGetErrorString(e));
   }
-  const int grid = (b->n_lanes + carl::brax::kEnvs - 1) / carl::brax::kEnvs;
+  const int grid = (b->n_lanes + envs - 1) / envs;
   carl_step_io_t io_v{};
   if (io != nullptr) io_v = *io;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(carl::brax::kLanes), sh_bytes, st, *b, sd, io_v, mask, reset_obs, n_steps);

@@ -473,3 +473,49 @@ def test_humanoid_rollout_equals_step_and_env_api(device):
     assert o["obs"].shape == (244,)
     o, r, te, tr, _ = single.step(np.zeros(17, np.float32))
     assert te is False and tr is False and 4.0 < r < 6.5  # healthy reward 5 + small forward term
+
+
+# ------------------------------------------------------------------ lanes-per-env variants
+@pytest.mark.parametrize("lanes_per_env", [4, 8, 16])
+@pytest.mark.parametrize("model", ["ant", "halfcheetah", "humanoid"])
+def test_every_lane_group_width_matches_oracle(device, model, lanes_per_env, monkeypatch):
+    """The host picks 4, 8 or 16 lanes per env from the model and the batch size
+    (carl_amd.hip: brax_lanes_per_env); CARL_AMD_BRAX_SUB pins it so that every instantiation is
+    checked on every model, with a ragged last wavefront and auto-reset inside the window."""
+    from carl_amd.brax_engine import BraxVecEngine
+
+    monkeypatch.setenv("CARL_AMD_BRAX_SUB", str(lanes_per_env))
+    if model == "ant":
+        s, names, default = ant_sys(NAMES), NAMES, DEFAULT
+    elif model == "halfcheetah":
+        s, names, default = _cheetah()
+    else:
+        s, names, default = _humanoid()
+    rng = np.random.default_rng(100 + lanes_per_env)
+    n = 203
+    rows = np.tile(default, (n, 1))
+    rows[:, names.index("gravity")] = rng.uniform(-15, -5, n)
+    rows = rows.astype(np.float32).astype(np.float64)
+    kw = dict(selector=O.SEL_STATIC, seed=9, ctx_idx0=np.arange(n))
+    eng = BraxVecEngine(s, len(names), rows, n, device, max_episode_steps=4, **kw)
+    ora = B.Engine(s, rows, n, max_steps=4, **kw)
+    obs = eng.reset().cpu().numpy()
+    assert rel_err(obs, ora.reset()).max() < 5e-6
+    lo = float(s.act_lo[0])
+    errs = []
+    for t in range(9):
+        ora.state[:] = eng.state.t().cpu().numpy()
+        a = rng.uniform(lo, -lo, (n, s.n_act)).astype(np.float32)
+        o, rew, term, trunc = eng.step(torch.as_tensor(a))
+        out = ora.step(a)
+        np.testing.assert_array_equal(trunc.cpu().numpy(), out.truncated)
+        np.testing.assert_array_equal(term.cpu().numpy(), out.terminated)
+        done = (term.cpu().numpy() | trunc.cpu().numpy()) != 0
+        got = np.where(done[:, None], eng.final_obs.cpu().numpy(), o.cpu().numpy())
+        wnt = np.where(done[:, None], out.final_obs, out.obs)
+        errs.append(np.maximum(rel_err(got, wnt).max(1), rel_err(rew.cpu().numpy(), out.reward)))
+        # the observation returned on a done step is the reset observation of the next episode
+        assert rel_err(o.cpu().numpy()[done], out.obs[done]).max(initial=0.0) < 5e-6
+        np.testing.assert_array_equal(eng.elapsed.cpu().numpy(), ora.elapsed)
+    e = np.concatenate(errs)
+    assert np.percentile(e, 50) <= 3e-5 and np.percentile(e, 99) <= 5e-4, np.percentile(e, [50, 99, 100])
