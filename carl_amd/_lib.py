@@ -15,7 +15,7 @@ import torch  # noqa: F401  (must precede the CDLL load, see module docstring)
 
 from carl_amd import build as _build
 
-CARL_ABI_VERSION = 2
+CARL_ABI_VERSION = 3
 CARL_MAX_CTX_OBS = 32
 
 # carl_family_t
@@ -185,4 +185,24 @@ EXPORTS.update({
     "carl_brax_reset": (C.c_int, [C.POINTER(Batch), _vp, C.POINTER(BraxSys), _vp, _vp, _vp]),
     "carl_brax_step": (C.c_int, [C.POINTER(Batch), _vp, C.POINTER(BraxSys), C.POINTER(StepIO), _vp]),
     "carl_brax_rollout": (C.c_int, [C.POINTER(Batch), _vp, C.POINTER(BraxSys), C.POINTER(StepIO), C.c_int32, _vp]),
+})
+
+
+# ---- context sets on the device (include/carl_amd.h: carl_feature_spec_t) --------------------
+MAX_CHOICES = 32
+FEAT_CONSTANT, FEAT_UNIFORM_FLOAT, FEAT_NORMAL_FLOAT, FEAT_UNIFORM_INT, FEAT_CATEGORICAL = range(5)
+
+
+class FeatureSpec(C.Structure):
+    _fields_ = [
+        ("kind", _i), ("n_choices", _i), ("log_scale", _i), ("reserved", _i),
+        ("lower", _f), ("upper", _f), ("mu", _f), ("sigma", _f), ("value", _f), ("reserved_f", _f),
+        ("choices", _f * MAX_CHOICES),
+    ]
+
+
+EXPORTS.update({
+    "carl_sample_contexts": (C.c_int, [_vp, C.POINTER(FeatureSpec), C.c_int32, C.c_int32, C.c_int32, C.c_int64,
+                                       C.c_uint64, _vp, _vp]),
+    "carl_verify_contexts": (C.c_int, [_vp, C.POINTER(FeatureSpec), C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp]),
 })

@@ -21,6 +21,7 @@ class ContextSampler(ConfigurationSpace):
     def __init__(self, context_distributions, context_space: ContextSpace, seed: int,
                  name: str | None = None):
         self.context_distributions = context_distributions
+        self._device_seed = 0 if seed is None else int(seed)
         super().__init__(name=name, seed=seed)
 
         if isinstance(context_distributions, list):
@@ -68,3 +69,11 @@ class ContextSampler(ConfigurationSpace):
         for j, n in enumerate(names):
             out[:, j] = np.asarray(cols[n], dtype=np.float64) if n in cols else float(base[n])
         return ContextTable(names, out)
+
+    def sample_context_table_device(self, n_contexts: int, device="cuda", context_offset: int = 0):
+        """The same kind of context set, produced directly in HBM by ``carl_sample_contexts``
+        (Philox stream keyed by this sampler's seed; see carl_amd/context/device_sampler.py)."""
+        from carl_amd.context.device_sampler import sample_context_table_device
+
+        return sample_context_table_device(self.context_space, self.get_context_features(), n_contexts,
+                                           self._device_seed, device, context_offset)

@@ -10,6 +10,7 @@
 #include "../../include/carl_amd.h"
 #include "brax_kernels.cuh"
 #include "classic_control.cuh"
+#include "context_kernels.cuh"
 #include "engine_kernels.cuh"
 
 namespace {
@@ -259,6 +260,33 @@ int launch_brax(const carl_batch_t* b, const carl_brax_sys_t* sd, const carl_bra
   return check_launch(who);
 }
 
+int validate_specs(const carl_feature_spec_t* sd, const carl_feature_spec_t* sh, int n_features, int n_contexts,
+                   int ctx_stride, const void* table, const char* who) {
+  if (sd == nullptr || sh == nullptr || table == nullptr)
+    return fail(CARL_ERR_INVALID_ARGUMENT, "%s: specs / table pointer is NULL", who);
+  if (n_features < 1 || n_features > 256)
+    return fail(CARL_ERR_INVALID_ARGUMENT, "%s: n_features %d out of range [1, 256]", who, n_features);
+  if (n_contexts < 0 || ctx_stride < n_contexts)
+    return fail(CARL_ERR_INVALID_ARGUMENT, "%s: n_contexts %d / ctx_stride %d invalid", who, n_contexts, ctx_stride);
+  for (int f = 0; f < n_features; ++f) {
+    const carl_feature_spec_t& s = sh[f];
+    if (s.kind < CARL_FEAT_CONSTANT || s.kind > CARL_FEAT_CATEGORICAL)
+      return fail(CARL_ERR_INVALID_ARGUMENT, "%s: feature %d: unknown kind %d", who, f, s.kind);
+    if (s.kind == CARL_FEAT_CATEGORICAL && (s.n_choices < 1 || s.n_choices > CARL_MAX_CHOICES))
+      return fail(CARL_ERR_INVALID_ARGUMENT, "%s: feature %d: n_choices %d out of range", who, f, s.n_choices);
+    if (s.kind != CARL_FEAT_CONSTANT && s.kind != CARL_FEAT_CATEGORICAL && !(s.lower <= s.upper))
+      return fail(CARL_ERR_INVALID_ARGUMENT, "%s: feature %d: lower %g > upper %g", who, f, s.lower, s.upper);
+    if ((s.kind == CARL_FEAT_UNIFORM_FLOAT || s.kind == CARL_FEAT_UNIFORM_INT) &&
+        !(s.lower > -3.0e38f && s.upper < 3.0e38f))
+      return fail(CARL_ERR_INVALID_ARGUMENT, "%s: feature %d: a uniform distribution needs finite bounds", who, f);
+    if (s.kind == CARL_FEAT_UNIFORM_FLOAT && s.log_scale && !(s.lower > 0.0f))
+      return fail(CARL_ERR_INVALID_ARGUMENT, "%s: feature %d: log-uniform needs lower > 0", who, f);
+    if (s.kind == CARL_FEAT_NORMAL_FLOAT && !(s.sigma >= 0.0f))
+      return fail(CARL_ERR_INVALID_ARGUMENT, "%s: feature %d: sigma %g < 0", who, f, s.sigma);
+  }
+  return 0;
+}
+
 int validate_brax_io(const carl_step_io_t* io, const char* who) {
   if (io == nullptr) return fail(CARL_ERR_INVALID_ARGUMENT, "%s: io is NULL", who);
   if (!io->action || !io->obs || !io->reward || !io->terminated || !io->truncated)
@@ -362,6 +390,35 @@ int carl_brax_rollout(const carl_batch_t* batch, const carl_brax_sys_t* sys_dev,
   if (n_steps < 0) return fail(CARL_ERR_INVALID_ARGUMENT, "carl_brax_rollout: n_steps %d < 0", n_steps);
   return launch_brax<1>(batch, sys_dev, sys_host, io, nullptr, nullptr, n_steps, (hipStream_t)stream,
                         "carl_brax_rollout");
+}
+
+int carl_sample_contexts(const carl_feature_spec_t* specs_dev, const carl_feature_spec_t* specs_host,
+                         int32_t n_features, int32_t n_contexts, int32_t ctx_stride, int64_t context_offset,
+                         uint64_t seed, float* ctx_table, void* stream) {
+  if (int e = validate_specs(specs_dev, specs_host, n_features, n_contexts, ctx_stride, ctx_table,
+                             "carl_sample_contexts"))
+    return e;
+  if (n_contexts == 0) return 0;
+  const size_t sh = (size_t)n_features * sizeof(carl_feature_spec_t);
+  hipLaunchKernelGGL(carl::sample_contexts_kernel, dim3((n_contexts + 255) / 256), dim3(256), sh, (hipStream_t)stream,
+                     specs_dev, n_features, n_contexts, ctx_stride, (long long)context_offset, seed, ctx_table);
+  return check_launch("carl_sample_contexts");
+}
+
+int carl_verify_contexts(const carl_feature_spec_t* specs_dev, const carl_feature_spec_t* specs_host,
+                         int32_t n_features, int32_t n_contexts, int32_t ctx_stride, const float* ctx_table,
+                         int32_t* n_bad_out, void* stream) {
+  if (int e = validate_specs(specs_dev, specs_host, n_features, n_contexts, ctx_stride, ctx_table,
+                             "carl_verify_contexts"))
+    return e;
+  if (n_bad_out == nullptr) return fail(CARL_ERR_INVALID_ARGUMENT, "carl_verify_contexts: n_bad_out is NULL");
+  const hipError_t z = hipMemsetAsync(n_bad_out, 0, sizeof(int32_t), (hipStream_t)stream);
+  if (z != hipSuccess) return fail((int)z, "carl_verify_contexts: hipMemsetAsync: %s", hipGetErrorString(z));
+  if (n_contexts == 0) return 0;
+  const size_t sh = (size_t)n_features * sizeof(carl_feature_spec_t);
+  hipLaunchKernelGGL(carl::verify_contexts_kernel, dim3((n_contexts + 255) / 256), dim3(256), sh, (hipStream_t)stream,
+                     specs_dev, n_features, n_contexts, ctx_stride, ctx_table, n_bad_out);
+  return check_launch("carl_verify_contexts");
 }
 
 }  // extern "C"

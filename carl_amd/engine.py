@@ -152,6 +152,28 @@ class VecEngine:
         if hasattr(self, "_io"):
             self._sync_pointers()
 
+    def set_contexts_device(self, table_fc, ctx_idx0=None) -> None:
+        """Adopt a context table that already lives on this device as feature-major ``[F][C]``
+        float32 (``carl_sample_contexts`` output, carl_amd/context/device_sampler.py): no copy."""
+        t = table_fc
+        if not torch.is_tensor(t) or t.ndim != 2 or t.shape[0] != self.F:
+            raise ValueError(f"device context table must be a [{self.F}, C] tensor")
+        if t.dtype != torch.float32 or t.device != self.device or not t.is_contiguous():
+            t = t.to(device=self.device, dtype=torch.float32).contiguous()
+        C_ = int(t.shape[1])
+        if C_ < 1:
+            raise ValueError("empty context set")
+        self.ctx_table = t
+        self.b.n_contexts = C_
+        self.b.ctx_stride = C_
+        if ctx_idx0 is None:
+            idx = self.default_ctx_idx(C_)
+        else:
+            idx = torch.as_tensor(ctx_idx0).to(torch.int32).reshape(self.n)
+        self.ctx_idx = idx.to(self.device).contiguous()
+        if hasattr(self, "_io"):
+            self._sync_pointers()
+
     def set_ctx_idx(self, idx) -> None:
         """Host-driven context switch (``context_id`` setter, carl_env.py:139-157)."""
         idx = torch.as_tensor(idx).to(torch.int32).reshape(self.n)

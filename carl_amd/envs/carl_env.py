@@ -150,7 +150,10 @@ class CARLEnv(abc.ABC):
                 if n in self._table.names and self._table.names.index(n) < eng.F]
         eng.ctx_obs_rows = rows
         eng.ctx_obs = torch.zeros((len(rows), eng.n), dtype=torch.float32, device=eng.device)
-        eng.set_contexts(self._table.values_2d[:, : eng.F])
+        if hasattr(self._table, "tensor"):  # DeviceContextTable: already [F][C] in HBM
+            eng.set_contexts_device(self._table.tensor[: eng.F])
+        else:
+            eng.set_contexts(self._table.values_2d[:, : eng.F])
         eng._sync_pointers()
 
     # ------------------------------------------------------------------ properties
@@ -163,7 +166,12 @@ class CARLEnv(abc.ABC):
         """Fill every context with defaults (reference: carl_env.py:122-137) and keep
         the dense form the engine uploads."""
         space = self.get_context_space()
-        if isinstance(contexts, ContextTable):
+        if hasattr(contexts, "tensor"):  # DeviceContextTable (carl_amd/context/device_sampler.py)
+            if list(contexts.names) != list(space.context_feature_names):
+                raise ValueError("a device context table must hold the env's context features in table order")
+            self._table = contexts
+            self._contexts = contexts
+        elif isinstance(contexts, ContextTable):
             self._table = space.to_table(contexts)
             self._contexts = self._table
         else:

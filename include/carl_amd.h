@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define CARL_ABI_VERSION 2
+#define CARL_ABI_VERSION 3
 #define CARL_MAX_CTX_OBS 32
 
 #define CARL_ERR_INVALID_ARGUMENT (-1)
@@ -290,6 +290,54 @@ int carl_brax_step(const carl_batch_t* batch, const carl_brax_sys_t* sys_dev, co
                    const carl_step_io_t* io, void* stream);
 int carl_brax_rollout(const carl_batch_t* batch, const carl_brax_sys_t* sys_dev, const carl_brax_sys_t* sys_host,
                       const carl_step_io_t* io, int32_t n_steps, void* stream);
+
+/* ======================= context sets on the device =======================
+ * Replaces ContextSampler.sample_contexts (carl/context/sampler.py:45-61: per-feature draws from
+ * the distributions, defaults filled for every other feature) and ContextSpace.verify_context
+ * (carl/context/context_space.py:54-59) for dense context sets: the [F][C] table the step kernels
+ * read is produced (and bounds-checked) in HBM instead of as C Python dicts.
+ * Draws are Philox4x32-10 keyed (seed; global context id, feature index, attempt): a pure function
+ * of (seed, context id, feature) -- independent of sharding -- and NOT the reference's NumPy
+ * MT19937 stream (carl_amd.context.sampler reproduces that one on the host, pinned by the
+ * reference's notebook outputs; this entry point is the one that scales).
+ *   CONSTANT       value                                   (features without a distribution: default)
+ *   UNIFORM_FLOAT  fma(upper - lower, u, lower); log_scale: exp of the same between the logs
+ *   NORMAL_FLOAT   mu + sigma * z (Box-Muller), redrawn while outside [lower, upper] (<= 32 times,
+ *                  then clipped) -- ConfigSpace NormalFloat with bounds
+ *   UNIFORM_INT    lower + floor(u * (upper - lower + 1))
+ *   CATEGORICAL    choices[floor(u * n_choices)] (numeric choices, e.g. Brax target_direction) */
+#define CARL_MAX_CHOICES 32
+typedef enum {
+  CARL_FEAT_CONSTANT = 0,
+  CARL_FEAT_UNIFORM_FLOAT = 1,
+  CARL_FEAT_NORMAL_FLOAT = 2,
+  CARL_FEAT_UNIFORM_INT = 3,
+  CARL_FEAT_CATEGORICAL = 4
+} carl_feature_kind_t;
+
+typedef struct {
+  int32_t kind;       /* carl_feature_kind_t */
+  int32_t n_choices;  /* CATEGORICAL */
+  int32_t log_scale;  /* UNIFORM_FLOAT */
+  int32_t reserved;
+  float lower, upper; /* bounds: sampling range and carl_verify_contexts (+-inf allowed) */
+  float mu, sigma;    /* NORMAL_FLOAT */
+  float value;        /* CONSTANT */
+  float reserved_f;
+  float choices[CARL_MAX_CHOICES];
+} carl_feature_spec_t;
+
+/* ctx_table[f * ctx_stride + c] for c in [0, n_contexts), f in [0, n_features); context c is the
+ * global context `context_offset + c`.  specs_dev / specs_host: the same n_features specs on the
+ * device and on the host (validation). */
+int carl_sample_contexts(const carl_feature_spec_t* specs_dev, const carl_feature_spec_t* specs_host,
+                         int32_t n_features, int32_t n_contexts, int32_t ctx_stride, int64_t context_offset,
+                         uint64_t seed, float* ctx_table, void* stream);
+/* n_bad_out[0] (device int32) = number of table entries outside their feature's bounds (or not one
+ * of a categorical feature's choices, or NaN) */
+int carl_verify_contexts(const carl_feature_spec_t* specs_dev, const carl_feature_spec_t* specs_host,
+                         int32_t n_features, int32_t n_contexts, int32_t ctx_stride, const float* ctx_table,
+                         int32_t* n_bad_out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -67,7 +67,8 @@ def default_row(family: int) -> np.ndarray:
 
 def build(force: bool = False) -> str:
     """Compile the C oracle with gcc (oracle/Makefile)."""
-    srcs = [os.path.join(_HERE, f) for f in ("carl_oracle.c", "classic_control.inc", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("carl_oracle.c", "classic_control.inc", "brax_spring.c",
+                                              "context_sampler.c", "Makefile")]
     if force or not os.path.exists(_SO) or any(
         os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs
     ):
@@ -222,3 +223,23 @@ class Engine:
             _p(rew), _p(term), _p(trunc), _p(final_obs), _p(self.last_return),
             _p(self.last_length), _p(self.episodes_done))
         return StepOut(self.obs.copy(), rew, term, trunc, final_obs)
+
+
+# ---- device context sampler restatement (oracle/context_sampler.c) -------------------------
+def sample_contexts(specs, n_contexts: int, seed: int, context_offset: int = 0) -> np.ndarray:
+    """[F][C] float32 table from an array of carl_amd._lib.FeatureSpec (ctypes array)."""
+    n_features = len(specs)
+    out = np.empty((n_features, n_contexts), dtype=np.float32)
+    fn = lib().oracle_sample_contexts
+    fn.restype = None
+    fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_uint64, C.c_void_p]
+    fn(C.addressof(specs), n_features, n_contexts, n_contexts, context_offset, seed & (2**64 - 1), _p(out))
+    return out
+
+
+def verify_contexts(specs, table: np.ndarray) -> int:
+    table = np.ascontiguousarray(table, dtype=np.float32)
+    fn = lib().oracle_verify_contexts
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    return int(fn(C.addressof(specs), table.shape[0], table.shape[1], table.shape[1], _p(table)))
