@@ -17,6 +17,9 @@ _LAZY = {
     "CARLBraxAnt": "carl_amd.envs.brax",
     "CARLBraxHalfcheetah": "carl_amd.envs.brax",
     "CARLBraxHumanoid": "carl_amd.envs.brax",
+    "CARLBraxHopper": "carl_amd.envs.brax",
+    "CARLBraxWalker2d": "carl_amd.envs.brax",
+    "CARLBraxInvertedPendulum": "carl_amd.envs.brax",
     "VecEngine": "carl_amd.engine",
 }
 

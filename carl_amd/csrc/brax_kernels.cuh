@@ -238,7 +238,7 @@ struct JointGeom {
   float ang[3], rate[3];  // ... Euler x-y-z angles (third signed by dof_sign3) and their rates
 };
 
-// MULTI: the model has links with 2-3 stacked hinges (Humanoid); false compiles the Euler-angle
+// MULTI: the model has links with 0, 2 or 3 hinges (Humanoid; a pure slider); false compiles the Euler-angle
 // path out (Ant, Halfcheetah: fewer registers, shorter joint phase)
 template <bool MULTI>
 static __device__ __forceinline__ JointGeom joint_geometry(const carl_brax_sys_t& s, const Derived& dv, int i, const Body& bc,
@@ -260,12 +260,12 @@ static __device__ __forceinline__ JointGeom joint_geometry(const carl_brax_sys_t
   g.wrel = bc.w - bp.w;
   g.thetadot = dot(g.x_c, g.wrel);
   const int nr = MULTI ? s.n_link_dof[i] - s.n_slide[i] : 1;
-  if (MULTI && nr >= 2) {  // rel = Rx(al) Ry(be) Rz(ga): decompose, ga = sign * theta_3
+  if (MULTI && nr != 1) {  // rel = Rx(al) Ry(be) Rz(ga): decompose, ga = sign * theta_3 (nr = 0: all locked)
     const float R00 = 1.0f - 2.0f * (rel.y * rel.y + rel.z * rel.z), R01 = 2.0f * (rel.x * rel.y - rel.w * rel.z);
     const float R02 = fminf(fmaxf(2.0f * (rel.x * rel.z + rel.w * rel.y), -1.0f), 1.0f);
     const float R12 = 2.0f * (rel.y * rel.z - rel.w * rel.x), R22 = 1.0f - 2.0f * (rel.x * rel.x + rel.y * rel.y);
     const float al = atan2_fast(-R12, R22), be = asinf(R02), ga = atan2_fast(-R01, R00);
-    const float sg = s.dof_sign3[i];
+    const float sg = (nr == 3) ? s.dof_sign3[i] : 1.0f;
     g.ang[0] = al; g.ang[1] = be; g.ang[2] = sg * ga;
     g.axis[0] = g.x_p;
     const qt rpx = qmul(rp, qaxis(0, al));
@@ -306,7 +306,10 @@ static __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const T
       const float qk = -dot(e, ax), qdk = -dot(ev, ax);
       e = e + ax * qk;
       ev = ev + ax * qdk;
-      f = f + ax * (m.at(m.lay.tau + d0 + k) - s.dof_damping[d0 + k] * qdk - s.dof_stiffness[d0 + k] * qk);
+      float fa = m.at(m.lay.tau + d0 + k) - s.dof_damping[d0 + k] * qdk - s.dof_stiffness[d0 + k] * qk;
+      if (qk < s.dof_lo[d0 + k]) fa += s.k_limit[i] * (s.dof_lo[d0 + k] - qk);  // range of the slide
+      if (qk > s.dof_hi[d0 + k]) fa -= s.k_limit[i] * (qk - s.dof_hi[d0 + k]);
+      f = f + ax * fa;
     }
     f = f + e * kp + ev * s.k_vel[i];
     v3 t;
@@ -430,6 +433,8 @@ static __device__ __forceinline__ void observe(const carl_brax_sys_t& s, const D
   const int skip = s.exclude_current_positions;
   const int qd0 = s.n_q - skip;  // first qd row in the observation
   const int L = s.n_links;
+  const float clipv = s.obs_qd_clip > 0.0f ? s.obs_qd_clip : 3.0e38f;  // hopper / walker2d clip velocities
+  auto vel = [&](float v) { return fminf(fmaxf(v, -clipv), clipv); };
   float M = 1.0f;
   v3 com = V(0, 0, 0);
   if (s.obs_extended && go) com = system_com(s, m, &M);
@@ -440,14 +445,14 @@ static __device__ __forceinline__ void observe(const carl_brax_sys_t& s, const D
     if (is_free_root(s, i)) {
       const v3 c = qrot(b.r, f3(s.com[i]));
       const v3 o = b.p - c;
-      const v3 vel = b.v - cross(b.w, c);
+      const v3 vl = b.v - cross(b.w, c);
       const float qv[7] = {o.x, o.y, o.z, b.r.w, b.r.x, b.r.y, b.r.z};
 #pragma unroll
       for (int k = 0; k < 7; ++k)
         if (s.q_start[i] + k >= skip) m.at(m.lay.io + s.q_start[i] + k - skip) = qv[k];
-      const float dvv[6] = {vel.x, vel.y, vel.z, b.w.x, b.w.y, b.w.z};
+      const float dvv[6] = {vl.x, vl.y, vl.z, b.w.x, b.w.y, b.w.z};
 #pragma unroll
-      for (int k = 0; k < 6; ++k) m.at(m.lay.io + qd0 + s.dof_start[i] + k) = dvv[k];
+      for (int k = 0; k < 6; ++k) m.at(m.lay.io + qd0 + s.dof_start[i] + k) = vel(dvv[k]);
     } else {
       const Body bp = (P < 0) ? world_body() : m.body(P);
       const JointGeom g = joint_geometry<MULTI>(s, dv, i, b, bp);
@@ -455,18 +460,18 @@ static __device__ __forceinline__ void observe(const carl_brax_sys_t& s, const D
       for (int k = 0; k < ns; ++k) {
         const v3 ax = qrot(bp.r, f3(s.slide_axis[i][k]));
         if (s.q_start[i] + k >= skip) m.at(m.lay.io + s.q_start[i] + k - skip) = dot(g.A_c - g.A_p, ax);
-        m.at(m.lay.io + qd0 + s.dof_start[i] + k) = dot(g.vA_c - g.vA_p, ax);
+        m.at(m.lay.io + qd0 + s.dof_start[i] + k) = vel(dot(g.vA_c - g.vA_p, ax));
       }
       const int nr = MULTI ? s.n_link_dof[i] - ns : 1;
       if (!MULTI || nr == 1) {
         if (s.q_start[i] + ns >= skip) m.at(m.lay.io + s.q_start[i] + ns - skip) = g.theta;
-        m.at(m.lay.io + qd0 + s.dof_start[i] + ns) = g.thetadot;
+        m.at(m.lay.io + qd0 + s.dof_start[i] + ns) = vel(g.thetadot);
       } else {
 #pragma unroll
         for (int k = 0; k < 3; ++k)
           if (k < nr) {
             if (s.q_start[i] + ns + k >= skip) m.at(m.lay.io + s.q_start[i] + ns + k - skip) = g.ang[k];
-            m.at(m.lay.io + qd0 + s.dof_start[i] + ns + k) = g.rate[k];
+            m.at(m.lay.io + qd0 + s.dof_start[i] + ns + k) = vel(g.rate[k]);
           }
       }
     }
@@ -771,14 +776,18 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
       const Body b1 = m.body(0);
       const v3 c1 = qrot(b1.r, f3(s.com[0]));
       const float x1 = s.reward_on_com ? system_com(s, m, &msum).x : b1.p.x - c1.x, z1 = b1.p.z - c1.z;
-      const bool healthy = (z1 >= s.healthy_z_lo) && (z1 <= s.healthy_z_hi);
+      bool healthy = (z1 >= s.healthy_z_lo) && (z1 <= s.healthy_z_hi);
+      r.elapsed += 1;
+      const bool truncated = (b.max_episode_steps > 0) && (r.elapsed >= b.max_episode_steps);
+      observe<MULTI>(s, dv, m, active, false);
+      if (s.healthy_q_index >= 0) {  // torso pitch (hopper, walker2d) / pole angle: read from the observation
+        const float qa = m.at(m.lay.io + s.healthy_q_index - s.exclude_current_positions);
+        healthy = healthy && (qa >= s.healthy_q_lo) && (qa <= s.healthy_q_hi);
+      }
       float reward = s.forward_reward_weight * (x1 - x0) / dt_env +
                      (s.terminate_when_unhealthy ? s.healthy_reward : (healthy ? s.healthy_reward : 0.0f)) -
                      s.ctrl_cost_weight * ctrl;
       bool terminated = s.terminate_when_unhealthy && !healthy;
-      r.elapsed += 1;
-      const bool truncated = (b.max_episode_steps > 0) && (r.elapsed >= b.max_episode_steps);
-      observe<MULTI>(s, dv, m, active, false);
       if (goal) {  // brax_walker_goal_wrapper.py:124-140: progress reward replaces the env reward
         const float nx = r.pos_x + m.at(m.lay.io + s.goal_obs_idx[0]) * s.goal_dt;
         const float ny = r.pos_y + m.at(m.lay.io + s.goal_obs_idx[1]) * s.goal_dt;

@@ -179,10 +179,10 @@ int validate_brax(const carl_batch_t* b, const carl_brax_sys_t* sd, const carl_b
   for (int i = 0; i < sh->n_links; ++i) {
     const bool free_root = sh->parent[i] < 0 && sh->n_link_dof[i] == 6;
     const int n_rot = sh->n_link_dof[i] - sh->n_slide[i];
-    const bool hinge = sh->n_slide[i] >= 0 && sh->n_slide[i] <= 2 && n_rot >= 1 && n_rot <= 3;
+    const bool hinge = sh->n_slide[i] >= 0 && sh->n_slide[i] <= 2 && n_rot >= 0 && n_rot <= 3 && sh->n_link_dof[i] >= 1;
     if (sh->parent[i] >= i || !(free_root || hinge))
       return fail(CARL_ERR_UNSUPPORTED,
-                  "%s: link %d: supported joints are a free root, or 0-2 prismatic dofs + 1-3 stacked hinges", who, i);
+                  "%s: link %d: supported joints are a free root, or 0-2 prismatic dofs + 0-3 stacked hinges", who, i);
     if (!free_root && n_rot == 3 && sh->dof_sign3[i] != 1.0f && sh->dof_sign3[i] != -1.0f)
       return fail(CARL_ERR_INVALID_ARGUMENT, "%s: link %d: dof_sign3 must be +1 or -1", who, i);
   }
@@ -193,6 +193,10 @@ int validate_brax(const carl_batch_t* b, const carl_brax_sys_t* sd, const carl_b
       if (sh->act_dof[j] == sh->act_dof[k])  // the kernel adds actuator torques to their dofs in parallel
         return fail(CARL_ERR_UNSUPPORTED, "%s: actuators %d and %d drive the same dof", who, j, k);
   }
+  if (sh->healthy_q_index >= 0 &&
+      (sh->healthy_q_index < sh->exclude_current_positions || sh->healthy_q_index >= sh->n_q))
+    return fail(CARL_ERR_INVALID_ARGUMENT, "%s: healthy_q_index %d must be an observed coordinate", who,
+                sh->healthy_q_index);
   {
     const int base = sh->n_q - sh->exclude_current_positions + sh->n_dof;
     const int want = sh->obs_extended ? base + 16 * sh->n_links + sh->n_dof : base;
@@ -226,11 +230,11 @@ int launch_brax(const carl_batch_t* b, const carl_brax_sys_t* sd, const carl_bra
                        const carl_step_io_t* io, const uint8_t* mask, float* reset_obs, int n_steps, hipStream_t st,
                        const char* who) {
   if (b->n_lanes == 0 || (MODE == 1 && n_steps == 0)) return 0;
-  bool multi = false;  // any link with 2-3 stacked hinges?
+  bool multi = false;  // any link with 0, 2 or 3 hinges (Euler-angle path)?
   int n_joints = 0;
   for (int i = 0; i < sh->n_links; ++i) {
     const bool free_root = sh->parent[i] < 0 && sh->n_link_dof[i] == 6;
-    multi |= !free_root && sh->n_link_dof[i] - sh->n_slide[i] >= 2;
+    multi |= !free_root && sh->n_link_dof[i] - sh->n_slide[i] != 1;
     n_joints += free_root ? 0 : 1;
   }
   const int K = brax_lanes_per_env(n_joints, b->n_lanes);

@@ -48,6 +48,7 @@ def ant_sys(feature_names: list[str] | None = None, reference_compat: bool = Fal
     what the reference effectively simulates (SURVEY.md Quirk B1)."""
     s = _lib.BraxSys()
     s.env_kind = _lib.BRAX_ANT
+    s.healthy_q_index = -1
     s.n_links, s.n_q, s.n_dof, s.n_act = 9, 15, 14, 8
     s.n_frames, s.obs_dim = 10, 27
     s.max_episode_steps = 1000
@@ -163,6 +164,7 @@ def halfcheetah_sys(feature_names: list[str] | None = None, reference_compat: bo
     joint_stiffness 15000 for Halfcheetah).  PARITY UNPINNED."""
     s = _lib.BraxSys()
     s.env_kind = _lib.BRAX_HALFCHEETAH
+    s.healthy_q_index = -1
     s.n_links, s.n_q, s.n_dof, s.n_act = 7, 9, 9, 6
     s.n_frames, s.obs_dim = 16, 17
     s.max_episode_steps = 1000
@@ -204,6 +206,8 @@ def halfcheetah_sys(feature_names: list[str] | None = None, reference_compat: bo
                 for c in range(3):
                     s.slide_axis[i][k][c] = ax[c]
             lo, hi = -1e9, 1e9  # rooty is unlimited
+            for k in range(ns):  # ... and so are the root slides
+                s.dof_lo[di + k], s.dof_hi[di + k] = -1e9, 1e9
         else:
             lo, hi = rng
         d = di + ns
@@ -295,6 +299,7 @@ def humanoid_sys(feature_names: list[str] | None = None, reference_compat: bool 
     (``dof_sign3``); the spring-constraint constants are this build's choice.  PARITY UNPINNED."""
     s = _lib.BraxSys()
     s.env_kind = _lib.BRAX_HUMANOID
+    s.healthy_q_index = -1
     s.n_links, s.n_q, s.n_dof, s.n_act = 11, 24, 23, 17
     s.n_frames = 10
     s.max_episode_steps = 1000
@@ -416,5 +421,181 @@ def humanoid_sys(feature_names: list[str] | None = None, reference_compat: bool 
     s.goal_obs_idx[0], s.goal_obs_idx[1], s.goal_dt = 22, 23, 0.003
     return s
 
+def _planar_chain(s, links, *, k_pos, k_vel, k_limit, k_ang_damp):
+    """Fill link / joint / collider arrays of a planar (x-z) model: the first link is jointed to the
+    world by slides along x and z plus a hinge about y (MuJoCo's rootx / rootz / rooty), every other
+    link by one hinge.  ``links``: (name, parent, body pos, hinge axis, (lo, hi) rad, stiffness,
+    damping, geoms[(end0, end1, radius)]) with capsule ends in the link frame."""
+    ident = (1.0, 0.0, 0.0, 0.0)
+    coll, link_ids, joint_dof = [], {}, {}
+    qi = di = 0
+    for i, (name, parent, pos, axis, rng, stiff, damp, geoms) in enumerate(links):
+        link_ids[name] = i
+        s.parent[i] = parent
+        _set3(s.link_pos, i, pos)
+        _set3(s.link_rot, i, ident)
+        _set3(s.joint_rot, i, _axis_quat(axis))
+        ns = 2 if parent < 0 else 0
+        s.n_slide[i], s.n_link_dof[i] = ns, ns + 1
+        s.q_start[i], s.dof_start[i] = qi, di
+        s.dof_sign3[i] = 1.0
+        if ns:
+            for k, ax in enumerate([(1.0, 0.0, 0.0), (0.0, 0.0, 1.0)]):
+                for c in range(3):
+                    s.slide_axis[i][k][c] = ax[c]
+                s.dof_lo[di + k], s.dof_hi[di + k] = -1e9, 1e9
+            lo, hi = -1e9, 1e9
+        else:
+            lo, hi = rng
+        d = di + ns
+        s.dof_lo[d], s.dof_hi[d] = lo, hi
+        s.dof_stiffness[d], s.dof_damping[d] = float(stiff), float(damp)
+        joint_dof[name] = d
+        vols, ctrs = [], []
+        for e0, e1, r in geoms:
+            vols.append(_vol("capsule", e0, e1, r))
+            ctrs.append((np.asarray(e0, dtype=np.float64) + np.asarray(e1, dtype=np.float64)) / 2)
+            coll += [(i, e0, r), (i, e1, r)]
+        _set3(s.com, i, sum(v * c for v, c in zip(vols, ctrs)) / sum(vols))
+        s.mass[i] = 1.0
+        _set3(s.inv_inertia, i, (1.0, 1.0, 1.0))
+        s.k_pos[i], s.k_vel[i], s.k_limit[i], s.k_ang_damp[i] = k_pos, k_vel, k_limit, k_ang_damp
+        qi, di = qi + ns + 1, di + ns + 1
+    s.n_coll = len(coll)
+    assert s.n_coll <= _lib.BRAX_MAX_COLL
+    for k, (link, pos, rad) in enumerate(coll):
+        s.coll_link[k], s.coll_radius[k] = link, rad
+        _set3(s.coll_pos, k, pos)
+    return link_ids, joint_dof
 
-SYSTEMS = {"ant": ant_sys, "halfcheetah": halfcheetah_sys, "humanoid": humanoid_sys}
+
+def _walker_common(s):
+    s.max_episode_steps = 1000
+    s.terminate_when_unhealthy = 1
+    s.exclude_current_positions = 1
+    s.reset_vel_uniform = 1
+    s.dt, s.n_frames = 0.001, 8
+    s.gravity_z, s.vel_damping, s.ang_damping = -9.81, 0.0, 0.0
+    s.baumgarte_erp, s.elasticity, s.friction = 0.1, 0.0, 1.0
+    s.healthy_reward, s.ctrl_cost_weight, s.forward_reward_weight = 1.0, 1e-3, 1.0
+    s.reset_noise_scale, s.reset_vel_scale = 5e-3, 5e-3
+    s.obs_qd_clip = 10.0
+    s.healthy_q_index = 2  # rooty: the torso pitch
+
+
+def hopper_sys(feature_names: list[str] | None = None, reference_compat: bool = False) -> _lib.BraxSys:
+    """Hopper: planar torso + thigh / leg / foot hinges (about -y); q 6, qd 6, 3 motors (gear 200),
+    obs 11 = q[1:] ++ clip(qd, +-10).  Healthy while z >= 0.7 and |pitch| <= 0.2; reward = forward
+    velocity + 1 - 1e-3 |a|^2; reset noise U(+-5e-3) on q and qd.  Geometry and ranges restated from
+    upstream memory of brax's ``hopper.xml`` (a Gym-Hopper derivative) and ``brax/envs/hopper.py``;
+    dt 0.001 x 8 frames and the spring constants are this build's choice.  PARITY UNPINNED."""
+    s = _lib.BraxSys()
+    s.env_kind = _lib.BRAX_HOPPER
+    _walker_common(s)
+    s.n_links, s.n_q, s.n_dof, s.n_act = 4, 6, 6, 3
+    s.obs_dim = 11
+    s.healthy_z_lo, s.healthy_z_hi = 0.7, 1e9
+    s.healthy_q_lo, s.healthy_q_hi = -0.2, 0.2
+    ny = (0, -1, 0)
+    links = [
+        ("torso", -1, (0, 0, 0), (0, 1, 0), None, 0, 0, [((0, 0, 0.2), (0, 0, -0.2), 0.05)]),
+        ("thigh", 0, (0, 0, -0.2), ny, (math.radians(-150), 0.0), 0, 1, [((0, 0, 0), (0, 0, -0.45), 0.05)]),
+        ("leg", 1, (0, 0, -0.45), ny, (math.radians(-150), 0.0), 0, 1, [((0, 0, 0), (0, 0, -0.5), 0.04)]),
+        ("foot", 2, (0, 0, -0.5), ny, (math.radians(-45), math.radians(45)), 0, 1,
+         [((-0.13, 0, 0), (0.26, 0, 0), 0.06)]),
+    ]
+    link_ids, joint_dof = _planar_chain(s, links, k_pos=20000.0, k_vel=100.0, k_limit=1000.0, k_ang_damp=20.0)
+    s.init_q[1] = 1.25  # rootz carries MuJoCo's ref = 1.25: q[1] (and obs[0]) is the torso height
+    for k, name in enumerate(["thigh", "leg", "foot"]):
+        s.act_dof[k], s.act_gear[k], s.act_lo[k], s.act_hi[k] = joint_dof[name], 200.0, -1.0, 1.0
+    _wire_context(s, feature_names, reference_compat, link_ids,
+                  {"mass_torso": 10.0, "mass_thigh": 4.0578904, "mass_leg": 2.7813568, "mass_foot": 5.3155746})
+    # STATE_INDICES["hopper"] = [5, 6] (brax_walker_goal_wrapper.py:10), hopper.xml timestep 0.002
+    s.goal_obs_idx[0], s.goal_obs_idx[1], s.goal_dt = 5, 6, 0.002
+    return s
+
+
+def walker2d_sys(feature_names: list[str] | None = None, reference_compat: bool = False) -> _lib.BraxSys:
+    """Walker2d: planar torso + two (thigh, leg, foot) chains; q 9, qd 9, 6 motors (gear 100), obs 17.
+    Healthy while 0.8 <= z <= 2 and |pitch| <= 1.  Restated from upstream memory of brax's
+    ``walker2d.xml`` / ``brax/envs/walker2d.py``; PARITY UNPINNED."""
+    s = _lib.BraxSys()
+    s.env_kind = _lib.BRAX_WALKER2D
+    _walker_common(s)
+    s.n_links, s.n_q, s.n_dof, s.n_act = 7, 9, 9, 6
+    s.obs_dim = 17
+    s.healthy_z_lo, s.healthy_z_hi = 0.8, 2.0
+    s.healthy_q_lo, s.healthy_q_hi = -1.0, 1.0
+    ny = (0, -1, 0)
+    leg_rng = (math.radians(-150), 0.0)
+    foot_rng = (math.radians(-45), math.radians(45))
+    links = [("torso", -1, (0, 0, 0), (0, 1, 0), None, 0, 0, [((0, 0, 0.2), (0, 0, -0.2), 0.05)])]
+    for suffix in ("", "_left"):
+        base = len(links)
+        links += [
+            ("thigh" + suffix, 0, (0, 0, -0.2), ny, leg_rng, 0, 0.1, [((0, 0, 0), (0, 0, -0.45), 0.05)]),
+            ("leg" + suffix, base, (0, 0, -0.45), ny, leg_rng, 0, 0.1, [((0, 0, 0), (0, 0, -0.5), 0.04)]),
+            ("foot" + suffix, base + 1, (0, 0, -0.5), ny, foot_rng, 0, 0.1, [((0.0, 0, 0), (0.2, 0, 0), 0.06)]),
+        ]
+    link_ids, joint_dof = _planar_chain(s, links, k_pos=20000.0, k_vel=100.0, k_limit=1000.0, k_ang_damp=20.0)
+    s.init_q[1] = 1.25  # rootz ref, as for the hopper
+    for k, name in enumerate(["thigh", "leg", "foot", "thigh_left", "leg_left", "foot_left"]):
+        s.act_dof[k], s.act_gear[k], s.act_lo[k], s.act_hi[k] = joint_dof[name], 100.0, -1.0, 1.0
+    _wire_context(s, feature_names, reference_compat, link_ids,
+                  {"mass_torso": 10.0, "mass_thigh": 4.0578904, "mass_leg": 2.7813568, "mass_foot": 3.1667254,
+                   "mass_thigh_left": 4.0578904, "mass_leg_left": 2.7813568, "mass_foot_left": 3.1667254})
+    # STATE_INDICES["walker2d"] = [8, 9] (brax_walker_goal_wrapper.py:11), walker2d.xml timestep 0.002
+    s.goal_obs_idx[0], s.goal_obs_idx[1], s.goal_dt = 8, 9, 0.002
+    return s
+
+
+def inverted_pendulum_sys(feature_names: list[str] | None = None, reference_compat: bool = False) -> _lib.BraxSys:
+    """InvertedPendulum: a cart on a slider (x, range +-1; no hinge: all three rotations locked by the
+    joint) carrying a pole on a hinge about y; q 2, qd 2, one motor on the slider (gear 100, ctrl +-3),
+    obs 4, reward 1 per step, done when |pole angle| > 0.2; no contacts.  Restated from upstream memory
+    of brax's ``inverted_pendulum.xml`` / ``brax/envs/inverted_pendulum.py``; dt 0.005 x 8 frames and
+    the spring constants are this build's choice.  PARITY UNPINNED."""
+    s = _lib.BraxSys()
+    s.env_kind = _lib.BRAX_INVERTED_PENDULUM
+    s.n_links, s.n_q, s.n_dof, s.n_act = 2, 2, 2, 1
+    s.obs_dim = 4
+    s.max_episode_steps = 1000
+    s.terminate_when_unhealthy = 1
+    s.exclude_current_positions = 0
+    s.reset_vel_uniform = 1
+    s.dt, s.n_frames = 0.005, 8
+    s.gravity_z, s.vel_damping, s.ang_damping = -9.81, 0.0, 0.0
+    s.baumgarte_erp, s.elasticity, s.friction = 0.1, 0.0, 1.0
+    s.healthy_z_lo, s.healthy_z_hi = -1e9, 1e9
+    s.healthy_q_index, s.healthy_q_lo, s.healthy_q_hi = 1, -0.2, 0.2
+    s.healthy_reward, s.ctrl_cost_weight, s.forward_reward_weight = 1.0, 0.0, 0.0
+    s.reset_noise_scale, s.reset_vel_scale = 0.01, 0.01
+    ident = (1.0, 0.0, 0.0, 0.0)
+    # cart: slide along x against the world, no rotational dof
+    s.parent[0], s.n_slide[0], s.n_link_dof[0], s.q_start[0], s.dof_start[0] = -1, 1, 1, 0, 0
+    _set3(s.link_rot, 0, ident)
+    _set3(s.joint_rot, 0, ident)
+    for c, v in enumerate((1.0, 0.0, 0.0)):
+        s.slide_axis[0][0][c] = v
+    s.dof_lo[0], s.dof_hi[0] = -1.0, 1.0
+    s.dof_damping[0] = 1.0
+    # pole: hinge about y at the cart's origin, capsule (0,0,0)-(0.001,0,0.6)
+    s.parent[1], s.n_slide[1], s.n_link_dof[1], s.q_start[1], s.dof_start[1] = 0, 0, 1, 1, 1
+    _set3(s.link_rot, 1, ident)
+    _set3(s.joint_rot, 1, _axis_quat((0, 1, 0)))
+    _set3(s.com, 1, (0.0005, 0.0, 0.3))
+    s.dof_lo[1], s.dof_hi[1] = math.radians(-90), math.radians(90)
+    s.dof_damping[1] = 1.0
+    for i in range(2):
+        s.dof_sign3[i] = 1.0
+        s.mass[i] = 1.0
+        _set3(s.inv_inertia, i, (1.0, 1.0, 1.0))
+        s.k_pos[i], s.k_vel[i], s.k_limit[i], s.k_ang_damp[i] = 10000.0, 100.0, 1000.0, 10.0
+    s.act_dof[0], s.act_gear[0], s.act_lo[0], s.act_hi[0] = 0, 100.0, -3.0, 3.0
+    s.n_coll = 0
+    _wire_context(s, feature_names, reference_compat, {"cart": 0, "pole": 1}, {"mass_cart": 1.0, "mass_pole": 1.0})
+    return s
+
+
+SYSTEMS = {"ant": ant_sys, "halfcheetah": halfcheetah_sys, "humanoid": humanoid_sys, "hopper": hopper_sys,
+           "walker2d": walker2d_sys, "inverted_pendulum": inverted_pendulum_sys}

@@ -240,7 +240,7 @@ typedef struct carl_brax_sys {
   float reset_noise_scale, reset_vel_scale;
   /* links, topological order, parent < child */
   int32_t parent[CARL_BRAX_MAX_LINKS];      /* -1: free root */
-  int32_t n_link_dof[CARL_BRAX_MAX_LINKS];  /* 6 = free root; else n_slide prismatic dofs followed by 1..3
+  int32_t n_link_dof[CARL_BRAX_MAX_LINKS];  /* 6 = free root; else n_slide prismatic dofs followed by 0..3
                                                revolute dofs turning, in order, about the joint frame's x, y,
                                                +-z axes (each carried by the preceding ones: MuJoCo's stacking of
                                                several hinges in one body).  parent -1 with n_link_dof < 6 =
@@ -271,7 +271,12 @@ typedef struct carl_brax_sys {
   int32_t reset_vel_uniform;                   /* qd noise: 1 = U(-scale, scale) (humanoid), 0 = scale * N(0,1) */
   int32_t reward_on_com;                       /* forward velocity of the whole-body centre of mass (humanoid) */
   int32_t obs_extended;                        /* append com inertia (L x 10), com velocity (L x 6), qfrc_actuator */
-  int32_t reserved2;
+  int32_t healthy_q_index;                     /* >= 0: the env is healthy only while q[index] is inside
+                                                * [healthy_q_lo, healthy_q_hi] (hopper / walker2d torso pitch,
+                                                * inverted-pendulum pole angle); -1: no such check */
+  float healthy_q_lo, healthy_q_hi;
+  float obs_qd_clip;                           /* > 0: velocities in the observation are clipped to +-this */
+  float reserved3;
   float slide_axis[CARL_BRAX_MAX_LINKS][2][3]; /* unit axes in the PARENT frame, mutually orthogonal */
   carl_brax_ctx_map_t ctx;
 } carl_brax_sys_t;

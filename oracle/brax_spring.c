@@ -223,14 +223,14 @@ static joint_geom joint_geometry(const carl_brax_sys_t* s, int i, const body* bc
   g.wrel = vsub(bc->w, bp->w);
   g.thetadot = vdot(g.x_c, g.wrel);
   const int nr = s->n_link_dof[i] - s->n_slide[i];
-  if (nr >= 2) { /* rel = Rx(al) Ry(be) Rz(ga): decompose, ga = sign * theta_3 */
+  if (nr != 1) { /* rel = Rx(al) Ry(be) Rz(ga): decompose, ga = sign * theta_3 (nr = 0: all three locked) */
     const double R00 = 1 - 2 * (rel.y * rel.y + rel.z * rel.z), R01 = 2 * (rel.x * rel.y - rel.w * rel.z);
     double R02 = 2 * (rel.x * rel.z + rel.w * rel.y);
     const double R12 = 2 * (rel.y * rel.z - rel.w * rel.x), R22 = 1 - 2 * (rel.x * rel.x + rel.y * rel.y);
     if (R02 > 1) R02 = 1;
     if (R02 < -1) R02 = -1;
     const double al = atan2(-R12, R22), be = asin(R02), ga = atan2(-R01, R00);
-    const double sg = s->dof_sign3[i];
+    const double sg = (nr == 3) ? s->dof_sign3[i] : 1.0;
     g.ang[0] = al; g.ang[1] = be; g.ang[2] = sg * ga;
     g.axis[0] = g.x_p;
     const qt rx = qaxis(0, al);
@@ -312,7 +312,10 @@ static void substep(const carl_brax_sys_t* s, const lane_ctx* c, const double* t
       const double qk = -vdot(e, ax), qdk = -vdot(ev, ax);
       e = vadd(e, vscale(ax, qk));
       ev = vadd(ev, vscale(ax, qdk));
-      f = vadd(f, vscale(ax, tau[d0 + k] - s->dof_damping[d0 + k] * qdk - s->dof_stiffness[d0 + k] * qk));
+      double fa = tau[d0 + k] - s->dof_damping[d0 + k] * qdk - s->dof_stiffness[d0 + k] * qk;
+      if (qk < s->dof_lo[d0 + k]) fa += s->k_limit[i] * (s->dof_lo[d0 + k] - qk); /* range of the slide */
+      if (qk > s->dof_hi[d0 + k]) fa -= s->k_limit[i] * (qk - s->dof_hi[d0 + k]);
+      f = vadd(f, vscale(ax, fa));
     }
     f = vadd(f, vadd(vscale(e, kp), vscale(ev, s->k_vel[i])));
     F[i] = vadd(F[i], f);
@@ -422,7 +425,11 @@ static void observe(const carl_brax_sys_t* s, const lane_ctx* c, const body* b, 
   inverse_kinematics(s, b, q, qd);
   int k = 0;
   for (int i = s->exclude_current_positions; i < s->n_q; ++i) obs[k++] = (float)q[i];
-  for (int i = 0; i < s->n_dof; ++i) obs[k++] = (float)qd[i];
+  for (int i = 0; i < s->n_dof; ++i) {
+    float v = (float)qd[i];
+    if (s->obs_qd_clip > 0.0f) v = v > s->obs_qd_clip ? s->obs_qd_clip : (v < -s->obs_qd_clip ? -s->obs_qd_clip : v);
+    obs[k++] = v;
+  }
   if (!s->obs_extended) return;
   double M;
   const v3 com = system_com(s, c, b, &M);
@@ -600,7 +607,13 @@ void obx_engine_step(const carl_brax_sys_t* s, const oracle_cfg_t* cfg, const do
     const double x1 = s->reward_on_com ? system_com(s, &c, b, &M).x : b[0].p.x - c1.x;
     const double z1 = b[0].p.z - c1.z;
     const double dt_env = (double)s->dt * s->n_frames;
-    const int healthy = (z1 >= s->healthy_z_lo) && (z1 <= s->healthy_z_hi);
+    int healthy = (z1 >= s->healthy_z_lo) && (z1 <= s->healthy_z_hi);
+    if (s->healthy_q_index >= 0) { /* hopper / walker2d torso pitch, inverted-pendulum pole angle */
+      double q[CARL_BRAX_MAX_Q], qd[CARL_BRAX_MAX_DOF];
+      inverse_kinematics(s, b, q, qd);
+      const float qa = (float)q[s->healthy_q_index]; /* the kernel checks the float32 observation entry */
+      healthy = healthy && (qa >= s->healthy_q_lo) && (qa <= s->healthy_q_hi);
+    }
     const double r = s->forward_reward_weight * (x1 - x0) / dt_env +
                      (s->terminate_when_unhealthy ? s->healthy_reward : s->healthy_reward * healthy) -
                      s->ctrl_cost_weight * ctrl;

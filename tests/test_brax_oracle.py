@@ -305,3 +305,81 @@ def test_humanoid_mass_context_changes_com_terms(humanoid):
     obs = e.reset()
     assert obs[0, 45 + 9] == pytest.approx(1.0) and obs[1, 45 + 9] == pytest.approx(2.0)  # effective mass, link 0
     assert obs[1, 45 + 19] == pytest.approx(1.0)                                           # link 1 untouched
+
+
+# ------------------------------------------------------------------ Hopper / Walker2d / InvertedPendulum
+from carl_amd.envs.brax.models import hopper_sys, inverted_pendulum_sys, walker2d_sys  # noqa: E402
+
+
+def _features(cls_name):
+    import importlib
+
+    cls = getattr(importlib.import_module("carl_amd.envs.brax"), cls_name)
+    feats = cls.get_context_features()
+    return list(feats), np.array([float(f.default_value) for f in feats.values()])
+
+
+@pytest.mark.parametrize("cls_name,fn,shape", [
+    ("CARLBraxHopper", hopper_sys, (4, 6, 6, 3, 11)),
+    ("CARLBraxWalker2d", walker2d_sys, (7, 9, 9, 6, 17)),
+    ("CARLBraxInvertedPendulum", inverted_pendulum_sys, (2, 2, 2, 1, 4)),
+])
+def test_planar_family_tables_and_kinematics(cls_name, fn, shape):
+    names, default = _features(cls_name)
+    s = fn(names)
+    assert (s.n_links, s.n_q, s.n_dof, s.n_act, s.obs_dim) == shape
+    assert s.ctx.n_mass == sum(n.startswith("mass_") for n in names)
+    rng = np.random.default_rng(1)
+    for _ in range(10):
+        q = np.array(s.init_q[:s.n_q], dtype=np.float64) + rng.uniform(-0.15, 0.15, s.n_q)
+        qd = rng.normal(0, 1, s.n_dof)
+        st = B.forward_kinematics(s, q, qd)
+        q2, qd2 = B.inverse_kinematics(s, st)
+        np.testing.assert_allclose(q2, q, atol=2e-6)
+        np.testing.assert_allclose(qd2, qd, atol=5e-6)
+        assert np.abs(st.reshape(s.n_links, 13)[:, 1]).max() < 1e-9  # planar: y = 0
+
+
+def test_hopper_health_rule_and_velocity_clip():
+    names, default = _features("CARLBraxHopper")
+    s = hopper_sys(names)
+    n = 4
+    e = B.Engine(s, default[None], n, selector=O.SEL_STATIC, seed=3)
+    obs = e.reset()
+    np.testing.assert_allclose(obs[:, 0], 1.25, atol=6e-3)  # rootz carries ref = 1.25
+    # pitch the torso beyond 0.2 rad: the step must terminate although z is still healthy
+    st = e.state.reshape(n, 4, 13).copy()
+    q = np.array(s.init_q[:6], dtype=np.float64)
+    q[2] = 0.25
+    qd = np.zeros(6)
+    qd[0] = 50.0  # and a forward velocity beyond the +-10 clip of the observation
+    e.state[0] = B.forward_kinematics(s, q, qd).reshape(-1)
+    out = e.step(np.zeros((n, 3), np.float32))
+    assert out.terminated[0] == 1 and not out.terminated[1:].any()
+    assert out.final_obs[0, 0] > 0.7 and abs(out.final_obs[0, 1]) > 0.2
+    assert out.final_obs[0, 5] == 10.0  # clipped qd[0]
+    assert out.reward[0] > 40  # the reward uses the unclipped forward velocity
+
+
+def test_inverted_pendulum_rules():
+    names, default = _features("CARLBraxInvertedPendulum")
+    s = inverted_pendulum_sys(names)
+    n = 3
+    e = B.Engine(s, default[None], n, selector=O.SEL_STATIC, seed=5)
+    obs = e.reset()
+    assert obs.shape == (n, 4) and np.abs(obs).max() <= 0.0100001
+    # constant push: the slider's +-1 range holds the cart (limit spring), reward is 1 per step
+    total, done_at = 0, None
+    for t in range(120):
+        out = e.step(np.full((n, 1), 3.0, np.float32))
+        assert np.all(out.reward == 1.0) and np.isfinite(out.obs).all()
+        x = np.where(out.terminated[:, None] != 0, out.final_obs, out.obs)[:, 0]
+        assert np.all(x < 1.6)
+        if out.terminated.any() and done_at is None:
+            done_at = t
+            ang = out.final_obs[out.terminated != 0, 1]
+            assert np.all(np.abs(ang) > 0.2)
+    assert done_at is not None and done_at < 60  # pushing the cart tips the pole over
+    # the cart is carried by its joint against gravity: z stays 0, no rotation
+    st = e.state.reshape(n, 2, 13)
+    assert np.abs(st[:, 0, 2]).max() < 5e-3 and np.abs(st[:, 0, 4:7]).max() < 5e-3

@@ -476,8 +476,18 @@ def test_humanoid_rollout_equals_step_and_env_api(device):
 
 
 # ------------------------------------------------------------------ lanes-per-env variants
+def _planar(cls_name, fn_name):
+    import importlib
+
+    cls = getattr(importlib.import_module("carl_amd.envs"), cls_name)
+    fn = getattr(importlib.import_module("carl_amd.envs.brax.models"), fn_name)
+    feats = cls.get_context_features()
+    names = list(feats)
+    return fn(names), names, np.array([float(f.default_value) for f in feats.values()])
+
+
 @pytest.mark.parametrize("lanes_per_env", [4, 8, 16])
-@pytest.mark.parametrize("model", ["ant", "halfcheetah", "humanoid"])
+@pytest.mark.parametrize("model", ["ant", "halfcheetah", "humanoid", "hopper", "walker2d", "inverted_pendulum"])
 def test_every_lane_group_width_matches_oracle(device, model, lanes_per_env, monkeypatch):
     """The host picks 4, 8 or 16 lanes per env from the model and the batch size
     (carl_amd.hip: brax_lanes_per_env); CARL_AMD_BRAX_SUB pins it so that every instantiation is
@@ -489,8 +499,14 @@ def test_every_lane_group_width_matches_oracle(device, model, lanes_per_env, mon
         s, names, default = ant_sys(NAMES), NAMES, DEFAULT
     elif model == "halfcheetah":
         s, names, default = _cheetah()
-    else:
+    elif model == "humanoid":
         s, names, default = _humanoid()
+    elif model == "hopper":
+        s, names, default = _planar("CARLBraxHopper", "hopper_sys")
+    elif model == "walker2d":
+        s, names, default = _planar("CARLBraxWalker2d", "walker2d_sys")
+    else:
+        s, names, default = _planar("CARLBraxInvertedPendulum", "inverted_pendulum_sys")
     rng = np.random.default_rng(100 + lanes_per_env)
     n = 203
     rows = np.tile(default, (n, 1))
@@ -519,3 +535,43 @@ def test_every_lane_group_width_matches_oracle(device, model, lanes_per_env, mon
         np.testing.assert_array_equal(eng.elapsed.cpu().numpy(), ora.elapsed)
     e = np.concatenate(errs)
     assert np.percentile(e, 50) <= 3e-5 and np.percentile(e, 99) <= 5e-4, np.percentile(e, [50, 99, 100])
+
+
+def test_new_planar_families_env_api_and_rules(device):
+    """CARLBraxHopper / Walker2d / InvertedPendulum through the CARL-shaped API: spaces, context
+    observation, the pitch / pole-angle health rule and the velocity clip against the oracle."""
+    from carl_amd.brax_engine import BraxVecEngine
+    from carl_amd.envs import CARLBraxHopper, CARLBraxInvertedPendulum, CARLBraxWalker2d
+
+    for cls, dims in ((CARLBraxHopper, (11, 3)), (CARLBraxWalker2d, (17, 6)), (CARLBraxInvertedPendulum, (4, 1))):
+        env = cls(batch_size=64, device=device)
+        obs, info = env.reset(seed=0)
+        assert obs["obs"].shape == (64, dims[0]) and env.action_space.shape == (64, dims[1])
+        o, r, te, tr, info = env.step(torch.zeros((64, dims[1]), device=device))
+        assert torch.isfinite(o["obs"]).all() and not te.any()
+        single = cls()
+        o, _ = single.reset()
+        assert o["obs"].shape == (dims[0],)
+    # hopper: a pitched, fast torso terminates and shows a clipped velocity, exactly like the oracle
+    s, names, default = _planar("CARLBraxHopper", "hopper_sys")
+    n = 64
+    kw = dict(selector=O.SEL_STATIC, seed=3)
+    eng = BraxVecEngine(s, len(names), default[None], n, device, **kw)
+    ora = B.Engine(s, default[None], n, **kw)
+    eng.reset()
+    ora.reset()
+    q = np.array(s.init_q[:6], dtype=np.float64)
+    q[2] = 0.25
+    qd = np.zeros(6)
+    qd[0] = 50.0
+    st = eng.state.t().cpu().numpy().copy()
+    st[::2] = B.forward_kinematics(s, q, qd).reshape(-1)
+    eng.state.copy_(torch.as_tensor(st.T.astype(np.float32)))
+    ora.state[:] = eng.state.t().cpu().numpy()
+    a = np.zeros((n, 3), np.float32)
+    o, r, te, tr = eng.step(torch.as_tensor(a))
+    out = ora.step(a)
+    np.testing.assert_array_equal(te.cpu().numpy(), out.terminated)
+    assert te.cpu().numpy()[::2].all() and not te.cpu().numpy()[1::2].any()
+    fo = eng.final_obs.cpu().numpy()
+    assert np.all(fo[::2, 5] == 10.0) and rel_err(fo[::2], out.final_obs[::2]).max() < 1e-4
