@@ -51,3 +51,87 @@ class FlattenObservation:
 
     def __getattr__(self, name):
         return getattr(self.env, name)
+
+
+class SB3VecEnv:
+    """stable-baselines3 ``VecEnv``-shaped facade over a batched CARL env (SURVEY.md section 8f rank 4;
+    reference flow: examples/carl_with_sb3.py:22-36 = ``FlattenObservation`` -> ``DummyVecEnv`` ->
+    ``PPO``).  SB3's protocol is NumPy on the host: ``reset() -> obs``, ``step_async(actions)`` /
+    ``step_wait() -> (obs, rewards, dones, infos)`` with ``infos[i]["terminal_observation"]`` and
+    ``infos[i]["TimeLimit.truncated"]`` for envs that finished, the returned obs being the first
+    observation of the next episode.  That is the engine's auto-reset contract, so the facade only
+    moves tensors to the host (one device->host copy per output per step) and fills info dicts for
+    the finished envs (ballot-compacted ``carl_done_compact`` list, not a Python scan of N flags).
+    stable-baselines3 is not installed in this image: the class is duck-typed (no base class), which
+    SB3's algorithms accept through ``VecEnvWrapper``-style attribute access."""
+
+    _EMPTY: dict = {}
+
+    def __init__(self, env, flatten: bool = True):
+        if getattr(env, "_scalar_api", False) or env.num_envs < 2:
+            raise ValueError("SB3VecEnv wraps a batched env (num_envs > 1)")
+        self.env = FlattenObservation(env) if flatten else env
+        self.carl_env = env
+        self.num_envs = env.num_envs
+        self.observation_space = self.env.single_observation_space
+        self.action_space = env.single_action_space
+        self._actions = None
+        self.reset_infos = [dict() for _ in range(self.num_envs)]
+
+    # ---- VecEnv protocol -------------------------------------------------------------
+    def reset(self):
+        obs, _ = self.env.reset()
+        return self._host(obs)
+
+    def seed(self, seed=None):
+        if seed is not None:
+            self.carl_env.env.seed(int(seed))
+        return [seed] * self.num_envs
+
+    def step_async(self, actions) -> None:
+        self._actions = actions
+
+    def step_wait(self):
+        eng = self.carl_env.env
+        a = torch.as_tensor(np.asarray(self._actions), device=eng.device)
+        obs, reward, term, trunc, info = self.env.step(a)
+        done = term | trunc
+        infos = [self._EMPTY] * self.num_envs
+        idx, count = eng.done_compact()  # ascending ids of finished envs, built on the device
+        idx = idx[: int(count.item())]
+        if idx.numel():
+            ids = idx.cpu().numpy()
+            final = info["final_observation"][idx.long()].cpu().numpy()
+            tr = trunc[idx.long()].cpu().numpy()
+            te = term[idx.long()].cpu().numpy()
+            for k, i in enumerate(ids):
+                infos[i] = {"terminal_observation": final[k], "TimeLimit.truncated": bool(tr[k] and not te[k])}
+        return self._host(obs), reward.cpu().numpy(), done.cpu().numpy(), infos
+
+    def step(self, actions):
+        self.step_async(actions)
+        return self.step_wait()
+
+    def close(self) -> None:
+        self.carl_env.close()
+
+    def env_is_wrapped(self, wrapper_class, indices=None):
+        return [False] * self.num_envs
+
+    def get_attr(self, attr_name, indices=None):
+        n = self.num_envs if indices is None else len(np.atleast_1d(indices))
+        return [getattr(self.carl_env, attr_name)] * n
+
+    def set_attr(self, attr_name, value, indices=None) -> None:
+        setattr(self.carl_env, attr_name, value)
+
+    def env_method(self, method_name, *args, indices=None, **kwargs):
+        n = self.num_envs if indices is None else len(np.atleast_1d(indices))
+        return [getattr(self.carl_env, method_name)(*args, **kwargs)] * n
+
+    @staticmethod
+    def _host(obs):
+        if torch.is_tensor(obs):
+            return obs.cpu().numpy()
+        return {k: (SB3VecEnv._host(v) if not isinstance(v, dict) else {kk: vv.cpu().numpy() for kk, vv in v.items()})
+                for k, v in obs.items()}
