@@ -1,5 +1,6 @@
 """CARLBraxHumanoid: context-feature table of the reference
-(carl/envs/brax/carl_humanoid.py:14-85; feature order preserved).  Model:
+(carl/envs/brax/carl_humanoid.py:14-85; feature order preserved) + the ``joint_stiffness``
+extension BASELINE config 5 asks for (SURVEY.md Quirk B4; appended, default 1).  Model:
 ``models.humanoid_sys`` (11 links, multi-dof waist / hip / shoulder joints, 244-dim obs)."""
 from __future__ import annotations
 
@@ -35,4 +36,6 @@ class CARLBraxHumanoid(CARLBraxEnv):
         feats["target_distance"] = U("target_distance", lower=0, upper=np.inf, default_value=100)
         feats["target_direction"] = CategoricalContextFeature("target_direction", choices=directions, default_value=1)
         feats["target_radius"] = U("target_radius", lower=0.1, upper=np.inf, default_value=5)
+        # extension, appended so that the reference's feature order is a prefix
+        feats["joint_stiffness"] = U("joint_stiffness", lower=0.01, upper=100, default_value=1.0)
         return feats

@@ -575,3 +575,48 @@ def test_new_planar_families_env_api_and_rules(device):
     assert te.cpu().numpy()[::2].all() and not te.cpu().numpy()[1::2].any()
     fo = eng.final_obs.cpu().numpy()
     assert np.all(fo[::2, 5] == 10.0) and rel_err(fo[::2], out.final_obs[::2]).max() < 1e-4
+
+
+def test_config5_full_size_properties(device):
+    """BASELINE config 5 shape on one GPU: Halfcheetah + Humanoid, 32 768 contexts each (65 536
+    together) with joint_stiffness variation; episodic returns gathered with the reporting helper
+    (an RCCL all-gather under torchrun, the identity in one process)."""
+    from carl_amd.brax_engine import BraxVecEngine
+    from carl_amd.distributed import all_gather_episode_stats, reduce_episode_summary
+
+    n, T = 32768, 24
+    rng = np.random.default_rng(50)
+    for make, n_act, lo in ((_cheetah, 6, 1.0), (_humanoid, 17, 0.4)):
+        s, names, default = make()
+        rows = np.tile(default, (n, 1))
+        js = names.index("joint_stiffness")
+        rows[:, js] = rng.uniform(0.5, 2.0, n)
+        rows[:, names.index("gravity")] = rng.uniform(-15, -5, n)
+        rows = rows.astype(np.float32).astype(np.float64)
+        eng = BraxVecEngine(s, len(names), rows, n, device, selector=O.SEL_STATIC, seed=0, ctx_idx0=np.arange(n),
+                            max_episode_steps=16)
+        eng.reset()
+        acts = torch.as_tensor(rng.uniform(-lo, lo, (T, n, n_act)).astype(np.float32), device=device)
+        out = eng.rollout(acts)
+        assert torch.isfinite(out["obs"]).all() and torch.isfinite(out["reward"]).all()
+        done = (out["terminated"] | out["truncated"]).bool()
+        assert torch.equal(done.sum(0).to(torch.int32), eng.episodes_done)
+        assert int(out["truncated"][15].sum()) >= int(0.5 * n)  # TimeLimit(16) fires at step index 15 for survivors
+        # the per-env joint_stiffness context acts: softer constraint springs let the joints separate
+        # more under the same load -> larger anchor gap (measured on the final state, non-root joints)
+        st = eng.state.view(s.n_links, 13, n).permute(2, 0, 1).double().cpu().numpy()
+        soft, stiff = rows[:, js] < 0.7, rows[:, js] > 1.6
+        gaps = []
+        for sel in (soft, stiff):
+            idx = np.nonzero(sel)[0][:256]
+            g = []
+            for e in idx:
+                q, qd = B.inverse_kinematics(s, st[e].reshape(-1))
+                re = B.forward_kinematics(s, q, qd).reshape(s.n_links, 13)  # the nearest consistent pose
+                g.append(np.abs(re[:, :3] - st[e][:, :3]).max())
+            gaps.append(np.mean(g))
+        assert gaps[0] > 1.3 * gaps[1], gaps
+        stats = all_gather_episode_stats(eng)
+        assert stats["last_return"].shape == (n,) and int(stats["episodes_done"].sum()) == int(done.sum())
+        summary = reduce_episode_summary(eng)
+        assert summary["episodes"] == float(done.sum()) and summary["mean_length"] <= 16
