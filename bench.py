@@ -58,8 +58,8 @@ BRAX_ENVS = ("ant", "halfcheetah", "humanoid")
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=2000)
-    p.add_argument("--warmup", type=int, default=200)
+    p.add_argument("--steps", type=int, default=50000)
+    p.add_argument("--warmup", type=int, default=5000)
     p.add_argument("--env", default="pendulum", choices=list(BYTES_8D))
     p.add_argument("--lanes", type=int, default=65536, help="lanes (= contexts) per GPU")
     p.add_argument("--chunk", type=int, default=250, help="env steps per fused launch")

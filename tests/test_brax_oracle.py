@@ -383,3 +383,31 @@ def test_inverted_pendulum_rules():
     # the cart is carried by its joint against gravity: z stays 0, no rotation
     st = e.state.reshape(n, 2, 13)
     assert np.abs(st[:, 0, 2]).max() < 5e-3 and np.abs(st[:, 0, 4:7]).max() < 5e-3
+
+
+def test_reference_recorded_ant_first_step_is_typical_for_this_restatement(golden_dir):
+    """The ONE Brax transition the reference records (examples/brax_with_goals.ipynb cell 3: obs and
+    reward of CARLBraxAnt after reset + one random step; fixture made by
+    tests/golden/make_notebook_brax_golden.py).  Action and PRNG state are unknown, so this cannot
+    pin the arithmetic -- it checks that the recorded vector is an ordinary draw of OUR reset + one
+    step under random actions, dimension by dimension: observation layout (z, quaternion, joint
+    angles, velocities), initial pose, reset-noise scale, velocity scale after one control step, and
+    that the goal wrapper's reward 0 (no progress) is a common outcome."""
+    import json
+    import os
+
+    g = json.load(open(os.path.join(golden_dir, "notebook_brax_ant_first_step.json")))
+    names = list(g["context"])
+    row = np.array([g["context"][k] for k in names], dtype=np.float64)
+    s = ant_sys(names)
+    s.goal_mode = 1
+    n = 4096
+    e = B.Engine(s, row[None], n, selector=O.SEL_STATIC, seed=0)
+    e.reset()
+    out = e.step(np.random.default_rng(0).uniform(-1, 1, (n, 8)).astype(np.float32))
+    ref = np.array(g["obs"])
+    assert ref.shape == (27,) == out.obs.shape[1:]
+    z = (ref - out.obs.mean(0)) / out.obs.std(0)
+    assert np.abs(z).max() < 3.0, z
+    assert np.all(ref >= out.obs.min(0)) and np.all(ref <= out.obs.max(0))
+    assert g["reward"] == 0.0 and 0.2 < (out.reward == 0).mean() < 0.8
