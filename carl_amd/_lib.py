@@ -176,7 +176,7 @@ class BraxSys(C.Structure):
         ("goal_mode", _i), ("goal_obs_idx", _i * 2), ("goal_dt", _f),
         ("n_slide", _i * BRAX_MAX_LINKS), ("dof_sign3", _f * BRAX_MAX_LINKS),
         ("reset_vel_uniform", _i), ("reward_on_com", _i), ("obs_extended", _i), ("healthy_q_index", _i),
-        ("healthy_q_lo", _f), ("healthy_q_hi", _f), ("obs_qd_clip", _f), ("reserved3", _f),
+        ("healthy_q_lo", _f), ("healthy_q_hi", _f), ("obs_qd_clip", _f), ("lanes_per_env", _i),
         ("slide_axis", ((_f * 3) * 2) * BRAX_MAX_LINKS),
         ("ctx", BraxCtxMap),
     ]
@@ -186,6 +186,7 @@ EXPORTS.update({
     "carl_brax_reset": (C.c_int, [C.POINTER(Batch), _vp, C.POINTER(BraxSys), _vp, _vp, _vp]),
     "carl_brax_step": (C.c_int, [C.POINTER(Batch), _vp, C.POINTER(BraxSys), C.POINTER(StepIO), _vp]),
     "carl_brax_rollout": (C.c_int, [C.POINTER(Batch), _vp, C.POINTER(BraxSys), C.POINTER(StepIO), C.c_int32, _vp]),
+    "carl_brax_lane_widths": (C.c_int, [C.POINTER(BraxSys), _vp, C.c_int32]),
 })
 
 

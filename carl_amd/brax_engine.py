@@ -76,6 +76,52 @@ class BraxVecEngine(VecEngine):
         finally:
             self.b.success = self.success.data_ptr()
 
+    # ------------------------------------------------------------------ launch-shape autotuning
+    def lane_widths(self) -> list[int]:
+        """Lane-group widths (lanes sharing one env) the library can launch for this model."""
+        out = (C.c_int32 * 16)()
+        n = self.lib.carl_brax_lane_widths(C.byref(self.sys), out, 16)
+        return [int(out[i]) for i in range(n)]
+
+    def autotune(self, n_steps: int = 2, reps: int = 2) -> int:
+        """Time ``carl_brax_rollout`` on THIS batch for every launchable lane-group width and keep
+        the fastest (``sys.lanes_per_env``).  The width is a pure scheduling choice -- results are
+        bit-identical across widths (tests/test_gpu_brax.py) -- but the best one depends on the
+        batch size: workgroups live for the whole launch, so what matters is how evenly
+        ceil(N / envs_per_wave) workgroups fill the 2 048 resident wave slots of the chip as well as
+        the instruction count per wave.  All engine state is saved and restored around the probe."""
+        saved = {k: getattr(self, k).clone() for k in ("state", "elapsed", "ctx_idx", "episode", "n_calls", "ep_return",
+                                                      "last_return", "last_length", "episodes_done", "obs", "ctx_obs")}
+        if self.goal_pos is not None:
+            saved["goal_pos"] = self.goal_pos.clone()
+        if getattr(self, "fin_count", None) is not None:
+            saved["fin_count"] = self.fin_count.clone()
+        lo, hi = float(min(self.sys.act_lo[: self.sys.n_act])), float(max(self.sys.act_hi[: self.sys.n_act]))
+        acts = torch.rand((n_steps, self.n, self.sys.n_act), device=self.device) * (hi - lo) + lo
+        out = self.alloc_rollout(n_steps)
+        if int(self.episode.max()) == 0:  # never reset: give the probe a valid state
+            self.reset()
+        best, best_ms = 0, float("inf")
+        timings = {}
+        for w in self.lane_widths():
+            self.sys.lanes_per_env = w
+            self.rollout(acts, out)  # warm-up (code object load)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                self.rollout(acts, out)
+            e1.record()
+            torch.cuda.synchronize(self.device)
+            ms = e0.elapsed_time(e1) / reps
+            timings[w] = ms
+            if ms < best_ms:
+                best, best_ms = w, ms
+        for k, v in saved.items():
+            getattr(self, k).copy_(v)
+        self.sys.lanes_per_env = best
+        self.autotune_ms = timings
+        return best
+
     def reset_indexed(self, idx, count):
         raise NotImplementedError("Brax families reset through a lane mask (reset(mask)) or in-kernel auto-reset")
 

@@ -7,11 +7,13 @@
 // specification implemented here is written out in oracle/brax_spring.c's header and
 // DESIGN.md; PARITY UNPINNED].
 //
-// Mapping: one env = a group of kSub adjacent lanes (4, 8 or 16; 8 below); one wavefront (= one
-// workgroup) = 64 / kSub envs.
-// Within an env the lanes split the work by link: lane `sub` owns joints / bodies sub, sub + 8,
-// ... (Ant: 8 joints in one round, 9 bodies in two; Halfcheetah 7 / 7 in one round each;
-// Humanoid 10 / 11 in two).  32 768 envs are 4 096 wavefronts = 4 per SIMD, where the earlier
+// Mapping: one env = a group of kSub adjacent lanes -- normally one lane per link (Ant 9, Halfcheetah
+// and Walker2d 7, Humanoid 11, Hopper 4), 16 for small batches; one wavefront (= one workgroup) =
+// floor(64 / kSub) envs, spare lanes idle.
+// Within an env the lanes split the work by link: lane `sub` owns joint / body sub (and sub + kSub,
+// ... when kSub < n_links).  The kernel is bound by the instruction stream a wavefront issues, so a
+// second round with one busy lane per env costs a whole round: one lane per link keeps every phase
+// to a single round.  32 768 Ant envs are 4 682 wavefronts = 4.6 per SIMD, where the earlier
 // one-lane-per-env kernel (r01c) had 512 wavefronts for 1 024 SIMDs, each walking all links
 // serially through LDS.  An env's maximal-coordinate state (13 floats per link), the per-joint
 // wrenches, masses, joint torques and the action / observation record live in LDS for the whole
@@ -37,8 +39,8 @@ namespace carl {
 namespace brax {
 
 constexpr int kLanes = 64;  // lanes per workgroup = one wavefront
-// kSub = lanes per env is a template parameter of everything below (Group<kSub>): 4, 8 or 16,
-// chosen per model and batch size by the host (carl_amd.hip: brax_lanes_per_env)
+// kSub = lanes per env is a template parameter of everything below (Group<kSub>): 2, 4, 7, 9, 11 or
+// 16, chosen per model and batch size by the host (carl_amd.hip: brax_lanes_per_env)
 constexpr float kPiF = 3.14159265358979323846f;
 
 struct v3 {
@@ -704,9 +706,14 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
   if (threadIdx.x == 0) build_topo(s, tp);
   if ((int)threadIdx.x < s.n_links) build_derived(s, dv, (int)threadIdx.x);
   __syncthreads();
-  const Lds m{lds_dyn, Layout::make(s.n_links, s.n_dof, io_rows_of(s)), (int)threadIdx.x / kSub, (int)threadIdx.x % kSub};
+  // kSub need not divide 64 (one lane per link: 7, 9, 11): the wavefront's spare lanes idle -- they
+  // point at the last env's column, own no link (sub beyond every loop bound) and are never active
+  const int tid = (int)threadIdx.x;
+  const bool lane_ok = tid < kEnvs * kSub;
+  const Lds m{lds_dyn, Layout::make(s.n_links, s.n_dof, io_rows_of(s)), lane_ok ? tid / kSub : kEnvs - 1,
+              lane_ok ? tid % kSub : kLanes};
   const int env = (int)blockIdx.x * kEnvs + m.env;
-  const bool active = env < b.n_lanes;
+  const bool active = lane_ok && env < b.n_lanes;
   const bool lead = active && m.sub == 0;  // the lane that writes the env's scalars
   const uint64_t genv = (uint64_t)(b.lane_offset + env);
   const size_t n = (size_t)b.n_lanes;

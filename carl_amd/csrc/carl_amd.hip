@@ -208,20 +208,54 @@ int validate_brax(const carl_batch_t* b, const carl_brax_sys_t* sd, const carl_b
   return 0;
 }
 
-// Lanes per env (the kernels' kSub).  One lane per joint keeps a substep to one joint round and
-// one or two body rounds -- the kernel is bound by the serial instruction stream of a wavefront,
-// not by lane utilisation (measured, profiles/r01g: Ant 8 > 4, 16; Humanoid 16 > 8 > 4) -- except
-// for the smallest model, where 4 lanes and 16 envs per wavefront won (Halfcheetah 4 > 8 > 16).
-// Small batches are widened so that the launch has at least two wavefronts per SIMD.
-// CARL_AMD_BRAX_SUB=4|8|16 overrides (experiments).
-int brax_lanes_per_env(int n_joints, int n_lanes) {
-  const char* env = getenv("CARL_AMD_BRAX_SUB");  // read per call: tests switch it
-  if (env != nullptr) {
-    const int k = atoi(env);
-    if (k == 4 || k == 8 || k == 16) return k;
+// Lanes per env (the kernels' kSub).  The Brax kernel is bound by the instruction stream a
+// wavefront issues (~4.3 cycles per wavefront instruction with two resident waves per SIMD,
+// profiles/r01g), so a joint or body round with one busy lane per env costs as much as a full one:
+// the width is the number of links (every phase = one round), rounded up to an instantiated
+// (width, MULTI) pair, and widened for small batches so that the launch has at least two
+// wavefronts per SIMD.  CARL_AMD_BRAX_SUB=<width> overrides (tests, experiments).
+constexpr int kBraxWidths[] = {2, 4, 7, 8, 9, 11, 16};
+constexpr bool brax_instantiated(int k, bool multi) {
+  return multi ? (k == 2 || k == 11 || k == 16) : (k == 4 || k == 7 || k == 8 || k == 9 || k == 16);
+}
+bool brax_is_multi(const carl_brax_sys_t* sh) {  // any link with 0, 2 or 3 hinges (Euler-angle path)?
+  bool multi = false;
+  for (int i = 0; i < sh->n_links; ++i) {
+    const bool free_root = sh->parent[i] < 0 && sh->n_link_dof[i] == 6;
+    multi |= !free_root && sh->n_link_dof[i] - sh->n_slide[i] != 1;
   }
-  int k = n_joints <= 7 ? 4 : n_joints <= 8 ? 8 : 16;
-  while (k < 16 && (long long)n_lanes * k / carl::brax::kLanes < 2048) k *= 2;
+  return multi;
+}
+int brax_lanes_per_env(int n_links, bool multi, int n_lanes, int hint) {
+  int want = n_links;
+  bool pinned = false;
+  if (hint > 0) {  // sys.lanes_per_env (autotuned by the caller)
+    want = hint;
+    pinned = true;
+  }
+  if (const char* env = getenv("CARL_AMD_BRAX_SUB")) {  // read per call: tests switch it
+    const int k = atoi(env);
+    if (k >= 1 && k <= 16) {
+      want = k;
+      pinned = true;
+    }
+  }
+  int k = 16;
+  for (int w : kBraxWidths)
+    if (w >= want && brax_instantiated(w, multi)) {
+      k = w;
+      break;
+    }
+  if (!pinned)
+    while (k < 16 && ((long long)n_lanes + 64 / k - 1) / (64 / k) < 2048) {
+      int next = 16;
+      for (int w : kBraxWidths)
+        if (w > k && brax_instantiated(w, multi)) {
+          next = w;
+          break;
+        }
+      k = next;
+    }
   return k;
 }
 
@@ -230,14 +264,8 @@ int launch_brax(const carl_batch_t* b, const carl_brax_sys_t* sd, const carl_bra
                        const carl_step_io_t* io, const uint8_t* mask, float* reset_obs, int n_steps, hipStream_t st,
                        const char* who) {
   if (b->n_lanes == 0 || (MODE == 1 && n_steps == 0)) return 0;
-  bool multi = false;  // any link with 0, 2 or 3 hinges (Euler-angle path)?
-  int n_joints = 0;
-  for (int i = 0; i < sh->n_links; ++i) {
-    const bool free_root = sh->parent[i] < 0 && sh->n_link_dof[i] == 6;
-    multi |= !free_root && sh->n_link_dof[i] - sh->n_slide[i] != 1;
-    n_joints += free_root ? 0 : 1;
-  }
-  const int K = brax_lanes_per_env(n_joints, b->n_lanes);
+  const bool multi = brax_is_multi(sh);
+  const int K = brax_lanes_per_env(sh->n_links, multi, b->n_lanes, sh->lanes_per_env);
   const int envs = carl::brax::kLanes / K;  // one wavefront = envs x K lanes; LDS rows are `envs` floats wide
   const carl::brax::Layout lay = carl::brax::Layout::make(sh->n_links, sh->n_dof, carl::brax::io_rows_of(*sh));
   const size_t sh_bytes = (size_t)lay.total * envs * sizeof(float);
@@ -245,13 +273,18 @@ int launch_brax(const carl_batch_t* b, const carl_brax_sys_t* sd, const carl_bra
     return fail(CARL_ERR_UNSUPPORTED, "%s: model needs %zu B of LDS per wavefront", who, sh_bytes);
   using kern_t = void (*)(carl_batch_t, const carl_brax_sys_t*, carl_step_io_t, const uint8_t*, float*, int);
   kern_t kern = nullptr;
-#define CARL_PICK(KK)                                                                              \
-  kern = multi ? static_cast<kern_t>(carl::brax::brax_kernel<MODE, true, KK>)                       \
-               : static_cast<kern_t>(carl::brax::brax_kernel<MODE, false, KK>)
-  if (K == 4) CARL_PICK(4);
-  else if (K == 8) CARL_PICK(8);
-  else CARL_PICK(16);
+#define CARL_PICK(KK, MM) \
+  if (K == KK && multi == MM) kern = static_cast<kern_t>(carl::brax::brax_kernel<MODE, MM, KK>)
+  CARL_PICK(2, true);
+  CARL_PICK(11, true);
+  CARL_PICK(16, true);
+  CARL_PICK(4, false);
+  CARL_PICK(7, false);
+  CARL_PICK(8, false);
+  CARL_PICK(9, false);
+  CARL_PICK(16, false);
 #undef CARL_PICK
+  if (kern == nullptr) return fail(CARL_ERR_UNSUPPORTED, "%s: no kernel for %d lanes per env", who, K);
   if (sh_bytes > 48 * 1024) {
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_bytes);
@@ -423,6 +456,18 @@ int carl_verify_contexts(const carl_feature_spec_t* specs_dev, const carl_featur
   hipLaunchKernelGGL(carl::verify_contexts_kernel, dim3((n_contexts + 255) / 256), dim3(256), sh, (hipStream_t)stream,
                      specs_dev, n_features, n_contexts, ctx_stride, ctx_table, n_bad_out);
   return check_launch("carl_verify_contexts");
+}
+
+int carl_brax_lane_widths(const carl_brax_sys_t* sys_host, int32_t* widths_out, int32_t cap) {
+  if (sys_host == nullptr || widths_out == nullptr || cap < 1) {
+    fail(CARL_ERR_INVALID_ARGUMENT, "carl_brax_lane_widths: NULL argument");
+    return 0;
+  }
+  const bool multi = brax_is_multi(sys_host);
+  int n = 0;
+  for (int w : kBraxWidths)
+    if (brax_instantiated(w, multi) && n < cap) widths_out[n++] = w;
+  return n;
 }
 
 }  // extern "C"

@@ -64,6 +64,7 @@ class CARLBraxEnv(CARLEnv):
         lane_offset: int = 0,
         reference_compat: bool = False,
         fin_capacity: int = 0,
+        autotune: bool | None = None,
         **kwargs,
     ) -> None:
         """Reference parameters (carl_brax_env.py:119-131) plus the lane-engine ones.
@@ -104,6 +105,10 @@ class CARLBraxEnv(CARLEnv):
             context_selector_kwargs=context_selector_kwargs,
             **kwargs,
         )
+        # launch shape: time the launchable lane-group widths on this batch once (results do not
+        # depend on the width); small batches keep the library's heuristic
+        if (autotune if autotune is not None else batch_size >= 4096) and hasattr(self.env, "autotune"):
+            self.env.autotune()
 
     def _base_observation_space(self) -> spaces.Space:
         obs = np.inf * np.ones(self.env.D, dtype=np.float32)

@@ -276,7 +276,9 @@ typedef struct carl_brax_sys {
                                                 * inverted-pendulum pole angle); -1: no such check */
   float healthy_q_lo, healthy_q_hi;
   float obs_qd_clip;                           /* > 0: velocities in the observation are clipped to +-this */
-  float reserved3;
+  int32_t lanes_per_env;                       /* HOST-side launch hint: lanes that share one env (rounded up
+                                                * to an instantiated width, carl_brax_lane_widths); 0 = chosen
+                                                * by the library from the model and the batch size */
   float slide_axis[CARL_BRAX_MAX_LINKS][2][3]; /* unit axes in the PARENT frame, mutually orthogonal */
   carl_brax_ctx_map_t ctx;
 } carl_brax_sys_t;
@@ -295,6 +297,10 @@ int carl_brax_step(const carl_batch_t* batch, const carl_brax_sys_t* sys_dev, co
                    const carl_step_io_t* io, void* stream);
 int carl_brax_rollout(const carl_batch_t* batch, const carl_brax_sys_t* sys_dev, const carl_brax_sys_t* sys_host,
                       const carl_step_io_t* io, int32_t n_steps, void* stream);
+/* the lane-group widths (values for sys.lanes_per_env) this library can launch for the model,
+ * ascending; returns their number (<= cap).  Results do not depend on the width: it is a pure
+ * scheduling choice (carl_amd.brax_engine.BraxVecEngine.autotune times them on the real batch). */
+int carl_brax_lane_widths(const carl_brax_sys_t* sys_host, int32_t* widths_out, int32_t cap);
 
 /* ======================= context sets on the device =======================
  * Replaces ContextSampler.sample_contexts (carl/context/sampler.py:45-61: per-feature draws from

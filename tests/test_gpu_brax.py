@@ -486,10 +486,11 @@ def _planar(cls_name, fn_name):
     return fn(names), names, np.array([float(f.default_value) for f in feats.values()])
 
 
-@pytest.mark.parametrize("lanes_per_env", [4, 8, 16])
+@pytest.mark.parametrize("lanes_per_env", [2, 4, 7, 9, 11, 16])
 @pytest.mark.parametrize("model", ["ant", "halfcheetah", "humanoid", "hopper", "walker2d", "inverted_pendulum"])
 def test_every_lane_group_width_matches_oracle(device, model, lanes_per_env, monkeypatch):
-    """The host picks 4, 8 or 16 lanes per env from the model and the batch size
+    """The host picks the lanes per env (one per link, rounded up to an instantiated width: 2, 4, 7,
+    9, 11, 16) from the model and the batch size
     (carl_amd.hip: brax_lanes_per_env); CARL_AMD_BRAX_SUB pins it so that every instantiation is
     checked on every model, with a ragged last wavefront and auto-reset inside the window."""
     from carl_amd.brax_engine import BraxVecEngine
@@ -620,3 +621,37 @@ def test_config5_full_size_properties(device):
         assert stats["last_return"].shape == (n,) and int(stats["episodes_done"].sum()) == int(done.sum())
         summary = reduce_episode_summary(eng)
         assert summary["episodes"] == float(done.sum()) and summary["mean_length"] <= 16
+
+
+def test_lane_width_is_a_pure_scheduling_choice_and_autotune_restores_state(device):
+    """Every launchable lane-group width produces bit-identical transitions (same per-link
+    arithmetic, same summation order), so ``BraxVecEngine.autotune`` may pick by time alone; the
+    probe must leave all engine state untouched."""
+    from carl_amd.brax_engine import BraxVecEngine
+
+    s, names, default = _humanoid()
+    rng = np.random.default_rng(77)
+    n, T = 333, 6
+    rows = _humanoid_rows(rng, n, default, names)
+    acts = torch.as_tensor(rng.uniform(-0.4, 0.4, (T, n, 17)).astype(np.float32), device=device)
+    ref = None
+    for hint in [0] + BraxVecEngine(s, len(names), rows, n, device).lane_widths():
+        eng = BraxVecEngine(s, len(names), rows, n, device, selector=O.SEL_STATIC, seed=3, ctx_idx0=np.arange(n),
+                            max_episode_steps=4)
+        eng.sys.lanes_per_env = hint
+        eng.reset()
+        out = eng.rollout(acts)
+        cur = (out["obs"].clone(), out["reward"].clone(), out["terminated"].clone(), eng.state.clone())
+        if ref is None:
+            ref = cur
+        else:
+            assert all(torch.equal(a, b) for a, b in zip(ref, cur)), hint
+    s2 = ant_sys(NAMES)
+    eng = engine(s2, context_rows(rng, 512), 512, device, selector=O.SEL_STATIC, seed=1, ctx_idx0=np.arange(512))
+    assert eng.lane_widths() == [4, 7, 8, 9, 16]
+    eng.reset()
+    eng.step(torch.zeros((512, 8), device=device))
+    before = {k: getattr(eng, k).clone() for k in ("state", "elapsed", "episode", "n_calls", "ep_return", "obs")}
+    best = eng.autotune()
+    assert best in eng.lane_widths() and eng.sys.lanes_per_env == best and set(eng.autotune_ms) == set(eng.lane_widths())
+    assert all(torch.equal(v, getattr(eng, k)) for k, v in before.items())
