@@ -16,7 +16,8 @@ LIB_DIR = os.path.join(_HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libcarl_amd.so")
 ARCH = "gfx950"
 
-SOURCES = ["carl_amd.hip"]
+# translation unit -> extra compile flags (see the header comment of carl_brax.hip)
+SOURCES = {"carl_amd.hip": [], "carl_brax.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc() -> str:
@@ -30,7 +31,7 @@ def _deps() -> list[str]:
     out = []
     for root in (CSRC, os.path.join(os.path.dirname(_HERE), "include")):
         for f in sorted(os.listdir(root)):
-            if f.endswith((".hip", ".cuh", ".h")):
+            if f.endswith((".hip", ".cuh", ".h", ".hpp")):
                 out.append(os.path.join(root, f))
     return out
 
@@ -46,16 +47,25 @@ def build(force: bool = False, verbose: bool = False, extra_flags: list[str] | N
     if not force and not needs_build():
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [
-        _hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
-        "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
-        *(extra_flags or []),
-        *[os.path.join(CSRC, s) for s in SOURCES],
-        "-o", LIB_PATH,
-    ]
+    obj_dir = os.path.join(LIB_DIR, "obj")
+    os.makedirs(obj_dir, exist_ok=True)
+    common = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
+              *(extra_flags or [])]
+    procs, objs = [], []
+    for src, flags in SOURCES.items():  # the translation units compile side by side
+        obj = os.path.join(obj_dir, src.replace(".hip", ".o"))
+        cmd = [_hipcc(), *common, *flags, "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((cmd, subprocess.Popen(cmd)))
+        objs.append(obj)
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    link = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-fno-gpu-rdc", *objs, "-o", LIB_PATH]
     if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True)
+        print(" ".join(link), flush=True)
+    subprocess.run(link, check=True)
     return LIB_PATH
 
 

@@ -1,4 +1,5 @@
-// carl_amd.hip -- C-ABI entry points (include/carl_amd.h) and kernel dispatch.
+// carl_amd.hip -- C-ABI entry points (include/carl_amd.h) and kernel dispatch: classic control,
+// context sets, done compaction.  The Brax entry points live in carl_brax.hip (own compile flags).
 // gfx950 only.  No persistent device allocations, no global mutable state.
 #include <hip/hip_runtime.h>
 
@@ -8,12 +9,12 @@
 #include <cstring>
 
 #include "../../include/carl_amd.h"
-#include "brax_kernels.cuh"
 #include "classic_control.cuh"
 #include "context_kernels.cuh"
 #include "engine_kernels.cuh"
+#include "host_common.hpp"
 
-namespace {
+namespace carl_host {
 
 thread_local char g_err[512] = "";
 
@@ -30,6 +31,13 @@ int check_launch(const char* what) {
   if (e != hipSuccess) return fail((int)e, "%s: %s", what, hipGetErrorString(e));
   return 0;
 }
+
+}  // namespace carl_host
+
+namespace {
+
+using carl_host::check_launch;
+using carl_host::fail;
 
 const carl_family_info_t kInfo[CARL_N_FAMILIES] = {
     /* state obs feat adim disc nact max_steps rsv lo hi */
@@ -163,140 +171,6 @@ int launch_step(const carl_batch_t* b, const carl_step_io_t* io, int n_steps, hi
   }
 
 // ---------------------------- Brax-locomotion families -----------------------------------
-int validate_brax(const carl_batch_t* b, const carl_brax_sys_t* sd, const carl_brax_sys_t* sh, const char* who) {
-  if (b == nullptr || sd == nullptr || sh == nullptr)
-    return fail(CARL_ERR_INVALID_ARGUMENT, "%s: batch / sys pointer is NULL", who);
-  if (b->n_lanes < 0) return fail(CARL_ERR_INVALID_ARGUMENT, "%s: n_lanes %d < 0", who, b->n_lanes);
-  if (b->n_contexts <= 0 || b->ctx_stride < b->n_contexts)
-    return fail(CARL_ERR_INVALID_ARGUMENT, "%s: n_contexts %d / ctx_stride %d invalid", who, b->n_contexts,
-                b->ctx_stride);
-  if (!b->state || !b->elapsed || !b->ctx_idx || !b->episode || !b->n_calls || !b->ep_return || !b->ctx_table)
-    return fail(CARL_ERR_INVALID_ARGUMENT, "%s: a required batch pointer is NULL", who);
-  if (sh->n_links < 1 || sh->n_links > CARL_BRAX_MAX_LINKS || sh->n_dof > CARL_BRAX_MAX_DOF ||
-      sh->n_q > CARL_BRAX_MAX_Q || sh->n_act > CARL_BRAX_MAX_ACT || sh->n_coll > CARL_BRAX_MAX_COLL ||
-      sh->n_frames < 1 || sh->obs_dim < 1)
-    return fail(CARL_ERR_INVALID_ARGUMENT, "%s: model table out of range", who);
-  for (int i = 0; i < sh->n_links; ++i) {
-    const bool free_root = sh->parent[i] < 0 && sh->n_link_dof[i] == 6;
-    const int n_rot = sh->n_link_dof[i] - sh->n_slide[i];
-    const bool hinge = sh->n_slide[i] >= 0 && sh->n_slide[i] <= 2 && n_rot >= 0 && n_rot <= 3 && sh->n_link_dof[i] >= 1;
-    if (sh->parent[i] >= i || !(free_root || hinge))
-      return fail(CARL_ERR_UNSUPPORTED,
-                  "%s: link %d: supported joints are a free root, or 0-2 prismatic dofs + 0-3 stacked hinges", who, i);
-    if (!free_root && n_rot == 3 && sh->dof_sign3[i] != 1.0f && sh->dof_sign3[i] != -1.0f)
-      return fail(CARL_ERR_INVALID_ARGUMENT, "%s: link %d: dof_sign3 must be +1 or -1", who, i);
-  }
-  for (int k = 0; k < sh->n_act; ++k) {
-    if (sh->act_dof[k] < 0 || sh->act_dof[k] >= sh->n_dof)
-      return fail(CARL_ERR_INVALID_ARGUMENT, "%s: actuator %d drives dof %d (of %d)", who, k, sh->act_dof[k], sh->n_dof);
-    for (int j = 0; j < k; ++j)
-      if (sh->act_dof[j] == sh->act_dof[k])  // the kernel adds actuator torques to their dofs in parallel
-        return fail(CARL_ERR_UNSUPPORTED, "%s: actuators %d and %d drive the same dof", who, j, k);
-  }
-  if (sh->healthy_q_index >= 0 &&
-      (sh->healthy_q_index < sh->exclude_current_positions || sh->healthy_q_index >= sh->n_q))
-    return fail(CARL_ERR_INVALID_ARGUMENT, "%s: healthy_q_index %d must be an observed coordinate", who,
-                sh->healthy_q_index);
-  {
-    const int base = sh->n_q - sh->exclude_current_positions + sh->n_dof;
-    const int want = sh->obs_extended ? base + 16 * sh->n_links + sh->n_dof : base;
-    if (sh->obs_dim != want)
-      return fail(CARL_ERR_INVALID_ARGUMENT, "%s: obs_dim %d does not match the model (%d)", who, sh->obs_dim, want);
-  }
-  if (b->fin_count != nullptr && (b->fin_capacity <= 0 || !b->fin_lane || !b->fin_return || !b->fin_length))
-    return fail(CARL_ERR_INVALID_ARGUMENT, "%s: finished-episode log is incomplete", who);
-  return 0;
-}
-
-// Lanes per env (the kernels' kSub).  The Brax kernel is bound by the instruction stream a
-// wavefront issues (~4.3 cycles per wavefront instruction with two resident waves per SIMD,
-// profiles/r01g), so a joint or body round with one busy lane per env costs as much as a full one:
-// the width is the number of links (every phase = one round), rounded up to an instantiated
-// (width, MULTI) pair, and widened for small batches so that the launch has at least two
-// wavefronts per SIMD.  CARL_AMD_BRAX_SUB=<width> overrides (tests, experiments).
-constexpr int kBraxWidths[] = {2, 4, 7, 8, 9, 11, 16};
-constexpr bool brax_instantiated(int k, bool multi) {
-  return multi ? (k == 2 || k == 11 || k == 16) : (k == 4 || k == 7 || k == 8 || k == 9 || k == 16);
-}
-bool brax_is_multi(const carl_brax_sys_t* sh) {  // any link with 0, 2 or 3 hinges (Euler-angle path)?
-  bool multi = false;
-  for (int i = 0; i < sh->n_links; ++i) {
-    const bool free_root = sh->parent[i] < 0 && sh->n_link_dof[i] == 6;
-    multi |= !free_root && sh->n_link_dof[i] - sh->n_slide[i] != 1;
-  }
-  return multi;
-}
-int brax_lanes_per_env(int n_links, bool multi, int n_lanes, int hint) {
-  int want = n_links;
-  bool pinned = false;
-  if (hint > 0) {  // sys.lanes_per_env (autotuned by the caller)
-    want = hint;
-    pinned = true;
-  }
-  if (const char* env = getenv("CARL_AMD_BRAX_SUB")) {  // read per call: tests switch it
-    const int k = atoi(env);
-    if (k >= 1 && k <= 16) {
-      want = k;
-      pinned = true;
-    }
-  }
-  int k = 16;
-  for (int w : kBraxWidths)
-    if (w >= want && brax_instantiated(w, multi)) {
-      k = w;
-      break;
-    }
-  if (!pinned)
-    while (k < 16 && ((long long)n_lanes + 64 / k - 1) / (64 / k) < 2048) {
-      int next = 16;
-      for (int w : kBraxWidths)
-        if (w > k && brax_instantiated(w, multi)) {
-          next = w;
-          break;
-        }
-      k = next;
-    }
-  return k;
-}
-
-template <int MODE>
-int launch_brax(const carl_batch_t* b, const carl_brax_sys_t* sd, const carl_brax_sys_t* sh,
-                       const carl_step_io_t* io, const uint8_t* mask, float* reset_obs, int n_steps, hipStream_t st,
-                       const char* who) {
-  if (b->n_lanes == 0 || (MODE == 1 && n_steps == 0)) return 0;
-  const bool multi = brax_is_multi(sh);
-  const int K = brax_lanes_per_env(sh->n_links, multi, b->n_lanes, sh->lanes_per_env);
-  const int envs = carl::brax::kLanes / K;  // one wavefront = envs x K lanes; LDS rows are `envs` floats wide
-  const carl::brax::Layout lay = carl::brax::Layout::make(sh->n_links, sh->n_dof, carl::brax::io_rows_of(*sh));
-  const size_t sh_bytes = (size_t)lay.total * envs * sizeof(float);
-  if (sh_bytes + sizeof(carl_brax_sys_t) + sizeof(carl::brax::Topo) + sizeof(carl::brax::Derived) > 160 * 1024)
-    return fail(CARL_ERR_UNSUPPORTED, "%s: model needs %zu B of LDS per wavefront", who, sh_bytes);
-  using kern_t = void (*)(carl_batch_t, const carl_brax_sys_t*, carl_step_io_t, const uint8_t*, float*, int);
-  kern_t kern = nullptr;
-#define CARL_PICK(KK, MM) \
-  if (K == KK && multi == MM) kern = static_cast<kern_t>(carl::brax::brax_kernel<MODE, MM, KK>)
-  CARL_PICK(2, true);
-  CARL_PICK(11, true);
-  CARL_PICK(16, true);
-  CARL_PICK(4, false);
-  CARL_PICK(7, false);
-  CARL_PICK(8, false);
-  CARL_PICK(9, false);
-  CARL_PICK(16, false);
-#undef CARL_PICK
-  if (kern == nullptr) return fail(CARL_ERR_UNSUPPORTED, "%s: no kernel for %d lanes per env", who, K);
-  if (sh_bytes > 48 * 1024) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_bytes);
-    if (e != hipSuccess) return fail((int)e, "%s: hipFuncSetAttribute: %s", who, hipGetErrorString(e));
-  }
-  const int grid = (b->n_lanes + envs - 1) / envs;
-  carl_step_io_t io_v{};
-  if (io != nullptr) io_v = *io;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(carl::brax::kLanes), sh_bytes, st, *b, sd, io_v, mask, reset_obs, n_steps);
-  return check_launch(who);
-}
-
 int validate_specs(const carl_feature_spec_t* sd, const carl_feature_spec_t* sh, int n_features, int n_contexts,
                    int ctx_stride, const void* table, const char* who) {
   if (sd == nullptr || sh == nullptr || table == nullptr)
@@ -324,23 +198,13 @@ int validate_specs(const carl_feature_spec_t* sd, const carl_feature_spec_t* sh,
   return 0;
 }
 
-int validate_brax_io(const carl_step_io_t* io, const char* who) {
-  if (io == nullptr) return fail(CARL_ERR_INVALID_ARGUMENT, "%s: io is NULL", who);
-  if (!io->action || !io->obs || !io->reward || !io->terminated || !io->truncated)
-    return fail(CARL_ERR_INVALID_ARGUMENT, "%s: a required io pointer is NULL", who);
-  if (io->action_dtype != CARL_ACTION_F32)
-    return fail(CARL_ERR_INVALID_ARGUMENT, "%s: Brax families take float32 actions", who);
-  return 0;
-}
-
-
 }  // namespace
 
 extern "C" {
 
 int carl_abi_version(void) { return CARL_ABI_VERSION; }
 
-const char* carl_last_error(void) { return g_err; }
+const char* carl_last_error(void) { return carl_host::g_err; }
 
 int carl_family_info(int family, carl_family_info_t* out) {
   if (out == nullptr) return fail(CARL_ERR_INVALID_ARGUMENT, "carl_family_info: out is NULL");
@@ -407,28 +271,6 @@ int carl_done_compact(const uint8_t* terminated, const uint8_t* truncated, int32
   return check_launch("carl_done_compact");
 }
 
-int carl_brax_reset(const carl_batch_t* batch, const carl_brax_sys_t* sys_dev, const carl_brax_sys_t* sys_host,
-                    const uint8_t* mask, float* obs, void* stream) {
-  if (int e = validate_brax(batch, sys_dev, sys_host, "carl_brax_reset")) return e;
-  return launch_brax<0>(batch, sys_dev, sys_host, nullptr, mask, obs, 0, (hipStream_t)stream, "carl_brax_reset");
-}
-
-int carl_brax_step(const carl_batch_t* batch, const carl_brax_sys_t* sys_dev, const carl_brax_sys_t* sys_host,
-                   const carl_step_io_t* io, void* stream) {
-  if (int e = validate_brax(batch, sys_dev, sys_host, "carl_brax_step")) return e;
-  if (int e = validate_brax_io(io, "carl_brax_step")) return e;
-  return launch_brax<1>(batch, sys_dev, sys_host, io, nullptr, nullptr, 1, (hipStream_t)stream, "carl_brax_step");
-}
-
-int carl_brax_rollout(const carl_batch_t* batch, const carl_brax_sys_t* sys_dev, const carl_brax_sys_t* sys_host,
-                      const carl_step_io_t* io, int32_t n_steps, void* stream) {
-  if (int e = validate_brax(batch, sys_dev, sys_host, "carl_brax_rollout")) return e;
-  if (int e = validate_brax_io(io, "carl_brax_rollout")) return e;
-  if (n_steps < 0) return fail(CARL_ERR_INVALID_ARGUMENT, "carl_brax_rollout: n_steps %d < 0", n_steps);
-  return launch_brax<1>(batch, sys_dev, sys_host, io, nullptr, nullptr, n_steps, (hipStream_t)stream,
-                        "carl_brax_rollout");
-}
-
 int carl_sample_contexts(const carl_feature_spec_t* specs_dev, const carl_feature_spec_t* specs_host,
                          int32_t n_features, int32_t n_contexts, int32_t ctx_stride, int64_t context_offset,
                          uint64_t seed, float* ctx_table, void* stream) {
@@ -456,18 +298,6 @@ int carl_verify_contexts(const carl_feature_spec_t* specs_dev, const carl_featur
   hipLaunchKernelGGL(carl::verify_contexts_kernel, dim3((n_contexts + 255) / 256), dim3(256), sh, (hipStream_t)stream,
                      specs_dev, n_features, n_contexts, ctx_stride, ctx_table, n_bad_out);
   return check_launch("carl_verify_contexts");
-}
-
-int carl_brax_lane_widths(const carl_brax_sys_t* sys_host, int32_t* widths_out, int32_t cap) {
-  if (sys_host == nullptr || widths_out == nullptr || cap < 1) {
-    fail(CARL_ERR_INVALID_ARGUMENT, "carl_brax_lane_widths: NULL argument");
-    return 0;
-  }
-  const bool multi = brax_is_multi(sys_host);
-  int n = 0;
-  for (int w : kBraxWidths)
-    if (brax_instantiated(w, multi) && n < cap) widths_out[n++] = w;
-  return n;
 }
 
 }  // extern "C"
