@@ -349,6 +349,7 @@ static __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const T
   phase_sync();
   // phase B -- per body: wrench sum, semi-implicit Euler, its contacts, integrate
   const float dl = __expf(s.vel_damping * s.dt), da = __expf(c.ang_damping * s.dt);
+  const float inv_dt = __builtin_amdgcn_rcpf(s.dt);
   const v3 n = V(0, 0, 1);
   for (int i = m.sub; i < L; i += kSub) {
     Body b = m.body(i);
@@ -362,7 +363,7 @@ static __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const T
       F = F + m.get3(wr + 6);
       T = T + m.get3(wr + 9);
     }
-    const float inv_m = 1.0f / m.at(m.lay.mass + i);
+    const float inv_m = __builtin_amdgcn_rcpf(m.at(m.lay.mass + i));  // v_rcp_f32 (1 ulp): the phase is issue-bound
     b.v = b.v + (F * inv_m + V(0, 0, c.gravity_z)) * s.dt;
     b.w = b.w + apply_inv_inertia(s, i, b.r, T, dv.iso[i] != 0) * s.dt;
     // spring.collisions.resolve: this body's spheres vs the plane z = 0
@@ -380,15 +381,15 @@ static __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const T
       const v3 rel = b.v + cross(b.w, r);
       const float vn = dot(n, rel);
       const float ang = dot(n, cross(apply_inv_inertia(s, i, b.r, cross(r, n), iso), r));
-      const float imp = (-(1.0f + c.elasticity) * vn + s.baumgarte_erp * depth / s.dt) / (inv_m + ang);
+      const float imp = div_fast(-(1.0f + c.elasticity) * vn + s.baumgarte_erp * depth * inv_dt, inv_m + ang);
       if (!(imp > 0.0f) || !(vn < 0.0f)) continue;
       v3 J = n * imp;
       const v3 vt = rel - n * vn;
       const float vt_len = sqrtf(dot(vt, vt));
       if (vt_len > 1e-9f) {
-        const v3 dir = vt * (1.0f / vt_len);
+        const v3 dir = vt * __builtin_amdgcn_rcpf(vt_len);
         const float ang_d = dot(dir, cross(apply_inv_inertia(s, i, b.r, cross(r, dir), iso), r));
-        const float imp_d = fminf(vt_len / (inv_m + ang_d), c.friction * imp);
+        const float imp_d = fminf(div_fast(vt_len, inv_m + ang_d), c.friction * imp);
         J = J - dir * imp_d;
       }
       cdv = cdv + J * inv_m;
@@ -399,7 +400,7 @@ static __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const T
     b.v = b.v * dl;
     b.w = b.w * da;
     if (cnt > 0.0f) {
-      const float ic = 1.0f / cnt;
+      const float ic = __builtin_amdgcn_rcpf(cnt);
       b.v = b.v + cdv * ic;
       b.w = b.w + cdw * ic;
     }
