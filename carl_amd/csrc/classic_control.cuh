@@ -216,8 +216,9 @@ struct AcrobotT {
     float noise_max;
     float ia_lo, ia_hi, iv_lo, iv_hi;
   };
-  struct Aux {  // cos/sin of theta1, theta2 of the current state (for the observation)
-    float c0, s0, c1, s1;
+  struct Aux {
+    float c0, s0, c1, s1;  // cos/sin of theta1, theta2 of the unrounded new angles (observation)
+    Real ks0, kc0, ks1, kc1;  // ... of the STORED (float32) angles: the next step's first RK4 stage
   };
 
   template <class Ctx>
@@ -241,8 +242,10 @@ struct AcrobotT {
   }
 
   __device__ static __forceinline__ void prepare(const float (&s)[S], Aux& a) {
-    sincos_fast(s[0], a.s0, a.c0);
-    sincos_fast(s[1], a.s1, a.c1);
+    sincos_fast((Real)s[0], a.ks0, a.kc0);
+    sincos_fast((Real)s[1], a.ks1, a.kc1);
+    a.s0 = (float)a.ks0; a.c0 = (float)a.kc0;
+    a.s1 = (float)a.ks1; a.c1 = (float)a.kc1;
   }
 
   struct Deriv {
@@ -256,11 +259,16 @@ struct AcrobotT {
   // one sincos + two cos.
   __device__ static __forceinline__ Deriv dsdt(const Params& p, Real theta1, Real theta2, Real dtheta1,
                                                Real dtheta2, Real a) {
-    const Real m1 = p.m1, m2 = p.m2, l1 = p.l1, lc1 = p.lc1, lc2 = p.lc2, I1 = p.moi, I2 = p.moi;
-    const Real g = (Real)9.8;
     Real s1, c1, s2, c2;
     sincos_fast(theta1, s1, c1);
     sincos_fast(theta2, s2, c2);
+    return dsdt_trig(p, s1, c1, s2, c2, dtheta1, dtheta2, a);
+  }
+
+  __device__ static __forceinline__ Deriv dsdt_trig(const Params& p, Real s1, Real c1, Real s2, Real c2, Real dtheta1,
+                                                    Real dtheta2, Real a) {
+    const Real m1 = p.m1, m2 = p.m2, l1 = p.l1, lc1 = p.lc1, lc2 = p.lc2, I1 = p.moi, I2 = p.moi;
+    const Real g = (Real)9.8;
     const Real s12 = s1 * c2 + c1 * s2;
     const Real d1 = p.m1lc1sq + m2 * (l1 * l1 + lc2 * lc2 + (Real)2.0 * l1 * lc2 * c2) + I1 + I2;
     const Real d2 = m2 * (lc2 * lc2 + l1 * lc2 * c2) + I2;
@@ -289,7 +297,8 @@ struct AcrobotT {
     const Real dt = (Real)0.2, dt2 = dt / (Real)2.0;
     const Real a = (Real)((float)(action - 1) + noise);
     const Real y0 = s[0], y1 = s[1], y2 = s[2], y3 = s[3];
-    const Deriv k1 = dsdt(p, y0, y1, y2, y3, a);
+    // first stage at the stored state: its trig was carried over from the previous step / reset
+    const Deriv k1 = dsdt_trig(p, aux.ks0, aux.kc0, aux.ks1, aux.kc1, y2, y3, a);
     const Deriv k2 = dsdt(p, y0 + dt2 * k1.d0, y1 + dt2 * k1.d1, y2 + dt2 * k1.d2, y3 + dt2 * k1.d3, a);
     const Deriv k3 = dsdt(p, y0 + dt2 * k2.d0, y1 + dt2 * k2.d1, y2 + dt2 * k2.d2, y3 + dt2 * k2.d3, a);
     const Deriv k4 = dsdt(p, y0 + dt * k3.d0, y1 + dt * k3.d1, y2 + dt * k3.d2, y3 + dt * k3.d3, a);
@@ -312,7 +321,11 @@ struct AcrobotT {
     sincos_fast(n0, s0r, c0r);
     sincos_fast(n1, s1r, c1r);
     const bool terminated = (-c0r - (c0r * c1r - s0r * s1r)) > (Real)1.0;
-    aux = Aux{(float)c0r, (float)s0r, (float)c1r, (float)s1r};
+    // trig of the ROUNDED angles for the next step's first stage: sin(x + d) = sin x + d cos x to
+    // O(d^2) with |d| <= 2e-7 (the float32 rounding of an angle in [-pi, pi]) -> error < 2e-14
+    const Real d0 = (Real)s[0] - n0, d1 = (Real)s[1] - n1;
+    aux = Aux{(float)c0r, (float)s0r, (float)c1r, (float)s1r,
+              s0r + d0 * c0r, c0r - d0 * s0r, s1r + d1 * c1r, c1r - d1 * s1r};
     reward = terminated ? 0.0f : -1.0f;
     return terminated;
   }
