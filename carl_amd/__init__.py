@@ -20,6 +20,7 @@ _LAZY = {
     "CARLBraxHopper": "carl_amd.envs.brax",
     "CARLBraxWalker2d": "carl_amd.envs.brax",
     "CARLBraxInvertedPendulum": "carl_amd.envs.brax",
+    "CARLBraxHumanoidStandup": "carl_amd.envs.brax",
     "VecEngine": "carl_amd.engine",
 }
 

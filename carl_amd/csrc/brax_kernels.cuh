@@ -792,7 +792,7 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
         const float qa = m.at(m.lay.io + s.healthy_q_index - s.exclude_current_positions);
         healthy = healthy && (qa >= s.healthy_q_lo) && (qa <= s.healthy_q_hi);
       }
-      float reward = s.forward_reward_weight * (x1 - x0) / dt_env +
+      float reward = s.forward_reward_weight * (s.reward_height ? z1 : (x1 - x0)) / dt_env +
                      (s.terminate_when_unhealthy ? s.healthy_reward : (healthy ? s.healthy_reward : 0.0f)) -
                      s.ctrl_cost_weight * ctrl;
       bool terminated = s.terminate_when_unhealthy && !healthy;

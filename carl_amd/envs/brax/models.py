@@ -597,5 +597,23 @@ def inverted_pendulum_sys(feature_names: list[str] | None = None, reference_comp
     return s
 
 
-SYSTEMS = {"ant": ant_sys, "halfcheetah": halfcheetah_sys, "humanoid": humanoid_sys, "hopper": hopper_sys,
+def humanoidstandup_sys(feature_names: list[str] | None = None, reference_compat: bool = False) -> _lib.BraxSys:
+    """HumanoidStandup: the Humanoid model lying on its back (root rotated -90 deg about y, torso
+    0.105 above the ground); reward = torso height / dt_env (uph_cost) + 1 - 0.1 |a|^2, never
+    terminates, observation as for Humanoid.  Restated from upstream memory of brax's
+    ``humanoidstandup.xml`` / ``brax/envs/humanoidstandup.py`` (a Gym-HumanoidStandup derivative);
+    PARITY UNPINNED."""
+    s = humanoid_sys(feature_names, reference_compat)
+    s.env_kind = _lib.BRAX_HUMANOIDSTANDUP
+    s.terminate_when_unhealthy = 0
+    s.healthy_z_lo, s.healthy_z_hi = -1e9, 1e9
+    s.healthy_reward, s.ctrl_cost_weight, s.forward_reward_weight = 1.0, 0.1, 1.0
+    s.reward_height, s.reward_on_com = 1, 0
+    h = math.sqrt(0.5)
+    for i, v in enumerate([0.0, 0.0, 0.105, h, 0.0, -h, 0.0]):
+        s.init_q[i] = v
+    return s
+
+
+SYSTEMS = {"humanoidstandup": humanoidstandup_sys, "ant": ant_sys, "halfcheetah": halfcheetah_sys, "humanoid": humanoid_sys, "hopper": hopper_sys,
            "walker2d": walker2d_sys, "inverted_pendulum": inverted_pendulum_sys}

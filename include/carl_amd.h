@@ -279,6 +279,9 @@ typedef struct carl_brax_sys {
   int32_t lanes_per_env;                       /* HOST-side launch hint: lanes that share one env (rounded up
                                                 * to an instantiated width, carl_brax_lane_widths); 0 = chosen
                                                 * by the library from the model and the batch size */
+  int32_t reward_height;                       /* 1: the "forward" term is weight * (root z) / dt_env
+                                                * (humanoidstandup's uph_cost) instead of weight * dx / dt_env */
+  int32_t reserved4;
   float slide_axis[CARL_BRAX_MAX_LINKS][2][3]; /* unit axes in the PARENT frame, mutually orthogonal */
   carl_brax_ctx_map_t ctx;
 } carl_brax_sys_t;

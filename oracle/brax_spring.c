@@ -614,7 +614,7 @@ void obx_engine_step(const carl_brax_sys_t* s, const oracle_cfg_t* cfg, const do
       const float qa = (float)q[s->healthy_q_index]; /* the kernel checks the float32 observation entry */
       healthy = healthy && (qa >= s->healthy_q_lo) && (qa <= s->healthy_q_hi);
     }
-    const double r = s->forward_reward_weight * (x1 - x0) / dt_env +
+    const double r = s->forward_reward_weight * (s->reward_height ? z1 : (x1 - x0)) / dt_env +
                      (s->terminate_when_unhealthy ? s->healthy_reward : s->healthy_reward * healthy) -
                      s->ctrl_cost_weight * ctrl;
     int term = s->terminate_when_unhealthy ? !healthy : 0;

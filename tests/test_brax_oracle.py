@@ -411,3 +411,25 @@ def test_reference_recorded_ant_first_step_is_typical_for_this_restatement(golde
     assert np.abs(z).max() < 3.0, z
     assert np.all(ref >= out.obs.min(0)) and np.all(ref <= out.obs.max(0))
     assert g["reward"] == 0.0 and 0.2 < (out.reward == 0).mean() < 0.8
+
+
+def test_humanoidstandup_lies_down_and_rewards_height():
+    from carl_amd.envs.brax.models import humanoidstandup_sys
+
+    names, default = _features("CARLBraxHumanoidStandup")
+    assert "target_distance" not in names and len(names) == 16
+    s = humanoidstandup_sys(names)
+    n = 4
+    e = B.Engine(s, default[None], n, selector=O.SEL_STATIC, seed=0)
+    obs = e.reset()
+    assert obs.shape == (n, 244) and np.all(np.abs(obs[:, 0] - 0.105) <= 0.0101)
+    np.testing.assert_allclose(np.abs(obs[:, 1]), np.sqrt(0.5), atol=0.02)  # root rotated -90 deg about y
+    rng = np.random.default_rng(0)
+    for t in range(50):
+        a = rng.uniform(-0.4, 0.4, (n, 17)).astype(np.float32)
+        out = e.step(a)
+        assert not out.terminated.any() and np.isfinite(out.obs).all()
+        z = out.obs[:, 0].astype(np.float64)
+        want = z / 0.015 + 1.0 - 0.1 * (a.astype(np.float64) ** 2).sum(1)  # uph_cost + 1 - quad_ctrl_cost
+        np.testing.assert_allclose(out.reward, want, rtol=1e-5, atol=1e-4)
+    assert np.all(out.obs[:, 0] < 0.3)  # random torques do not stand it up
