@@ -36,17 +36,47 @@ def _deps() -> list[str]:
     return out
 
 
-def needs_build() -> bool:
-    if not os.path.exists(LIB_PATH):
+HASH_PATH = os.path.join(LIB_DIR, "build.sha256")
+
+
+def _source_hash(extra_flags: list[str] | None = None) -> str:
+    """Content hash of every source / header and of the flags.  File times do not survive a copy
+    of the tree (the GPU boxes receive a snapshot), so staleness is decided on content."""
+    import hashlib
+
+    h = hashlib.sha256()
+    root = os.path.dirname(_HERE)
+    for d in _deps():
+        h.update(os.path.relpath(d, root).encode())
+        with open(d, "rb") as f:
+            h.update(f.read())
+    h.update(repr(sorted(SOURCES.items())).encode())
+    h.update(repr(extra_flags or []).encode())
+    return h.hexdigest()
+
+
+def needs_build(extra_flags: list[str] | None = None) -> bool:
+    if not os.path.exists(LIB_PATH) or not os.path.exists(HASH_PATH):
         return True
-    t = os.path.getmtime(LIB_PATH)
-    return any(os.path.getmtime(d) > t for d in _deps())
+    with open(HASH_PATH) as f:
+        return f.read().strip() != _source_hash(extra_flags)
 
 
 def build(force: bool = False, verbose: bool = False, extra_flags: list[str] | None = None) -> str:
-    if not force and not needs_build():
+    if not force and not needs_build(extra_flags):
         return LIB_PATH
+    import fcntl
+
     os.makedirs(LIB_DIR, exist_ok=True)
+    # one builder at a time: the ranks of a multi-GPU launch import the package simultaneously
+    with open(os.path.join(LIB_DIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and not needs_build(extra_flags):  # another process built it while we waited
+            return LIB_PATH
+        return _build_locked(verbose, extra_flags)
+
+
+def _build_locked(verbose: bool, extra_flags: list[str] | None) -> str:
     obj_dir = os.path.join(LIB_DIR, "obj")
     os.makedirs(obj_dir, exist_ok=True)
     common = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
@@ -62,10 +92,14 @@ def build(force: bool = False, verbose: bool = False, extra_flags: list[str] | N
     for cmd, p in procs:
         if p.wait() != 0:
             raise subprocess.CalledProcessError(p.returncode, cmd)
-    link = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-fno-gpu-rdc", *objs, "-o", LIB_PATH]
+    tmp = LIB_PATH + f".tmp{os.getpid()}"
+    link = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-fno-gpu-rdc", *objs, "-o", tmp]
     if verbose:
         print(" ".join(link), flush=True)
     subprocess.run(link, check=True)
+    os.replace(tmp, LIB_PATH)  # atomic: a concurrent loader never maps a half-written file
+    with open(HASH_PATH, "w") as f:
+        f.write(_source_hash(extra_flags) + "\n")
     return LIB_PATH
 
 
