@@ -2,7 +2,7 @@
 the CPU restatement of the kernel (oracle/context_sampler.c).  The device stream is a new
 (Philox) stream, so what is checked here is the distribution family per feature type, default
 fill, determinism and shard invariance -- the reference's exact NumPy draws are pinned for the
-host sampler in tests/test_sampler.py."""
+host sampler in tests/test_context_sampler.py."""
 import ctypes as C
 import os
 import subprocess
