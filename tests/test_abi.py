@@ -107,3 +107,40 @@ def test_product_never_imports_the_oracle():
     code = "import sys; import carl_amd.envs, carl_amd.engine, carl_amd.distributed; " \
            "assert not [m for m in sys.modules if m == 'oracle' or m.startswith('oracle.')]"
     subprocess.run([sys.executable, "-c", code], check=True, cwd=ROOT)
+
+
+def test_missing_library_fails_loudly():
+    """the product path has no fallback: without the HIP library every entry point is an error"""
+    code = ("import os; os.environ['CARL_AMD_LIB_PATH'] = '/nonexistent/libcarl_amd.so'\n"
+            "from carl_amd import _lib\n"
+            "try:\n    _lib.load()\nexcept _lib.CarlHipError as e:\n    print('LOUD', e)\n")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, check=True).stdout
+    assert "LOUD" in out and "not found" in out
+    code = ("import os; os.environ['CARL_AMD_LIB_PATH'] = '/nonexistent/libcarl_amd.so'\n"
+            "from carl_amd.envs import CARLPendulum\n"
+            "try:\n    CARLPendulum()\nexcept Exception as e:\n    print(type(e).__name__)\n")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, check=True).stdout
+    assert "CarlHipError" in out
+
+
+def test_brax_and_sampler_entry_points_validate_arguments():
+    from carl_amd import _lib
+    from carl_amd.envs.brax.models import ant_sys
+
+    lib = _lib.load()
+    assert lib.carl_brax_reset(None, None, None, None, None, None) == -1
+    s = ant_sys()
+    b = _lib.Batch()
+    b.n_lanes, b.n_contexts, b.ctx_stride = 4, 1, 1
+    assert lib.carl_brax_step(C.byref(b), None, C.byref(s), None, None) == -1  # sys_dev NULL
+    widths = (C.c_int32 * 16)()
+    n = lib.carl_brax_lane_widths(C.byref(s), widths, 16)
+    assert [widths[i] for i in range(n)] == [4, 7, 8, 9, 16]
+    assert lib.carl_brax_lane_widths(None, widths, 16) == 0
+    spec = (_lib.FeatureSpec * 1)()
+    spec[0].kind = 99
+    assert lib.carl_sample_contexts(C.addressof(spec), spec, 1, 4, 4, 0, 0, 1, None) == -1  # table "pointer" 1, kind 99
+    assert b"unknown kind" in lib.carl_last_error()
+    spec[0].kind, spec[0].lower, spec[0].upper = _lib.FEAT_UNIFORM_FLOAT, 2.0, 1.0
+    assert lib.carl_sample_contexts(C.addressof(spec), spec, 1, 4, 4, 0, 0, 1, None) == -1
+    assert b"lower" in lib.carl_last_error()
