@@ -63,6 +63,9 @@ def parse():
     p.add_argument("--env", default="pendulum", choices=list(BYTES_8D))
     p.add_argument("--lanes", type=int, default=65536, help="lanes (= contexts) per GPU")
     p.add_argument("--chunk", type=int, default=250, help="env steps per fused launch")
+    p.add_argument("--strong", action="store_true",
+                   help="strong scaling: --lanes is the TOTAL number of contexts, split over the GPUs "
+                        "(default: weak scaling, --lanes per GPU)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-per-call", action="store_true")
     p.add_argument("--cpu-envs-per-core", type=int, default=256)
@@ -94,7 +97,7 @@ def make_env(args, rank, world, device):
         "halfcheetah": [U("joint_stiffness", 0.5, 2.0), U("gravity", -15, -5), U("mass_torso", 5, 15)],
         "humanoid": [U("mass_torso", 5, 15), U("gravity", -15, -5), U("friction", 0.3, 1.5)],
     }[args.env]
-    n = args.lanes
+    n = args.lanes // world if args.strong else args.lanes
     # one global context set (seed 0), each rank uploads only its lanes' rows
     table = ContextSampler(dists, cls.get_context_space(), seed=0).sample_context_table(n * world)
     from carl_amd.context.table import ContextTable
@@ -390,7 +393,7 @@ def main():
         line = {
             "metric": "env-steps/sec (whole node) at 65k parallel contexts per GPU",
             "value": n * world * K / elapsed, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"CARL{args.env} x {n} contexts/GPU, StaticSelector "
                                    f"lane<->context, auto-reset, fused carl_rollout in launches of {T} steps, "
