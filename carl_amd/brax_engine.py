@@ -34,6 +34,11 @@ class BraxVecEngine(VecEngine):
         kw.pop("cartpole_recompute", None)
         self.goal_pos = self.success = None
         super().__init__(-1, ctx_table, n_lanes, device, **kw)
+        # Brax state is env-major in HBM ([N][13 L], one contiguous record per env: include/carl_amd.h);
+        # ``self.state`` stays the [13 L, N] VIEW the classic-control engine exposes (same indexing).
+        self._state_storage = torch.zeros((self.n, self.S), dtype=torch.float32, device=self.device)
+        self.state = self._state_storage.t()
+        self._sync_pointers()
         if self.sys.goal_mode:  # BraxWalkerGoalWrapper state: integrated (x, y) + per-step success flag
             self.goal_pos = torch.zeros((2, self.n), dtype=torch.float32, device=self.device)
             self.success = torch.zeros(self.n, dtype=torch.uint8, device=self.device)

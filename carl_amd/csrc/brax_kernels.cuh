@@ -125,24 +125,43 @@ struct Topo {
   int first_joint;  // 1 when link 0 is a free root (it has no joint), else 0
 };
 
-__device__ inline void build_topo(const carl_brax_sys_t& s, Topo& t) {
-  const int L = s.n_links;
-  int nc = 0, nk = 0, md = 0;
-  for (int i = 0; i < L; ++i) {
-    t.child_begin[i] = (uint8_t)nc;
+// Built by the workgroup in three small parallel steps (one lane per link): a single lane
+// walking all (link, link) and (link, collider) pairs through LDS took ~55 us per launch -- a third of a
+// per-call carl_brax_step.  `scratch`: 2 * CARL_BRAX_MAX_LINKS ints of LDS.
+__device__ inline void build_topo(const carl_brax_sys_t& s, Topo& t, int* scratch) {
+  const int L = s.n_links, i = (int)threadIdx.x;
+  if (i < L) {
+    int nc = 0, nk = 0, d = 0;
+    for (int c = i + 1; c < L; ++c) nc += (s.parent[c] == i) ? 1 : 0;
+    for (int k = 0; k < s.n_coll; ++k) nk += (s.coll_link[k] == i) ? 1 : 0;
+    for (int p = s.parent[i]; p >= 0; p = s.parent[p]) ++d;
+    scratch[i] = nc;
+    scratch[CARL_BRAX_MAX_LINKS + i] = nk;
+    t.depth[i] = (uint8_t)d;
+  }
+  __syncthreads();
+  if (i == 0) {
+    int nc = 0, nk = 0, md = 0;
+    for (int j = 0; j < L; ++j) {
+      t.child_begin[j] = (uint8_t)nc;
+      t.coll_begin[j] = (uint8_t)nk;
+      nc += scratch[j];
+      nk += scratch[CARL_BRAX_MAX_LINKS + j];
+      md = t.depth[j] > md ? t.depth[j] : md;
+    }
+    t.child_begin[L] = (uint8_t)nc;
+    t.coll_begin[L] = (uint8_t)nk;
+    t.max_depth = md;
+    t.first_joint = (s.parent[0] < 0 && s.n_link_dof[0] == 6) ? 1 : 0;
+  }
+  __syncthreads();
+  if (i < L) {  // ascending child / collider lists: the oracle's summation order
+    int nc = t.child_begin[i], nk = t.coll_begin[i];
     for (int c = i + 1; c < L; ++c)
       if (s.parent[c] == i) t.child_idx[nc++] = (uint8_t)c;
-    t.coll_begin[i] = (uint8_t)nk;
     for (int k = 0; k < s.n_coll; ++k)
       if (s.coll_link[k] == i) t.coll_idx[nk++] = (uint8_t)k;
-    const int d = s.parent[i] < 0 ? 0 : t.depth[s.parent[i]] + 1;
-    t.depth[i] = (uint8_t)d;
-    md = d > md ? d : md;
   }
-  t.child_begin[L] = (uint8_t)nc;
-  t.coll_begin[L] = (uint8_t)nk;
-  t.max_depth = md;
-  t.first_joint = (s.parent[0] < 0 && s.n_link_dof[0] == 6) ? 1 : 0;
 }
 
 // per-link constants derived from the model table once per workgroup
@@ -698,13 +717,27 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
   __shared__ Topo tp;
   __shared__ Derived dv;
   extern __shared__ float lds_dyn[];
-  {  // model table -> LDS, once per workgroup
+  {  // model table -> LDS, once per workgroup: every load in flight before the first LDS write (a
+     // load-store loop paid one HBM/L2 round trip per 256 bytes: ~15 us of a per-call step)
+    constexpr int kWords = (int)(sizeof(carl_brax_sys_t) / 4);
+    constexpr int kPer = (kWords + kLanes - 1) / kLanes;
     const uint32_t* src = reinterpret_cast<const uint32_t*>(sys_dev);
     uint32_t* dst = reinterpret_cast<uint32_t*>(&s);
-    for (int k = threadIdx.x; k < (int)(sizeof(carl_brax_sys_t) / 4); k += kLanes) dst[k] = src[k];
+    uint32_t tmp[kPer];
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+      const int k = j * kLanes + (int)threadIdx.x;
+      tmp[j] = (k < kWords) ? src[k] : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+      const int k = j * kLanes + (int)threadIdx.x;
+      if (k < kWords) dst[k] = tmp[j];
+    }
   }
   __syncthreads();
-  if (threadIdx.x == 0) build_topo(s, tp);
+  __shared__ int topo_scratch[2 * CARL_BRAX_MAX_LINKS];
+  build_topo(s, tp, topo_scratch);
   if ((int)threadIdx.x < s.n_links) build_derived(s, dv, (int)threadIdx.x);
   __syncthreads();
   // kSub need not divide 64 (one lane per link: 7, 9, 11): the wavefront's spare lanes idle -- they
@@ -735,7 +768,7 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
     reset_state(s, tp, b, m, genv, r.episode, go);
     r.episode += 1u;
     if (go) {
-      for (int k = m.sub; k < S; k += kSub) b.state[(size_t)k * n + env] = m.at(m.lay.state + k);
+      for (int k = m.sub; k < S; k += kSub) b.state[(size_t)env * S + k] = m.at(m.lay.state + k);
       if (m.sub == 0) {
         b.elapsed[env] = 0;
         b.ep_return[env] = 0.0f;
@@ -755,7 +788,7 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
     return;
   } else {
     if (active)
-      for (int k = m.sub; k < S; k += kSub) m.at(m.lay.state + k) = b.state[(size_t)k * n + env];
+      for (int k = m.sub; k < S; k += kSub) m.at(m.lay.state + k) = b.state[(size_t)env * S + k];
     r.ctx = load_ctx(s, b, m, r.cidx, active);
     if (goal && active) {
       load_goal(s, b, r.cidx, r);
@@ -852,7 +885,7 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
       phase_sync();  // the next step's actions overwrite the io rows
     }
     if (active) {
-      for (int k = m.sub; k < S; k += kSub) b.state[(size_t)k * n + env] = m.at(m.lay.state + k);
+      for (int k = m.sub; k < S; k += kSub) b.state[(size_t)env * S + k] = m.at(m.lay.state + k);
       if (m.sub == 0) {
         b.elapsed[env] = r.elapsed;
         b.ep_return[env] = r.ep_return;

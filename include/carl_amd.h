@@ -291,7 +291,9 @@ typedef struct carl_brax_sys {
 #define CARL_BRAX_LINK_STATE 13
 
 /* carl_batch_t is reused: family = CARL_N_FAMILIES + env_kind is ignored here (sys decides),
- * state is [13 * n_links][n_lanes], ctx_table rows follow the CARL class's feature table.
+ * state is [n_lanes][13 * n_links] (env-major: the lanes that share an env move its 13 L floats as one
+ * contiguous record; the classic-control families keep [S][n_lanes]), ctx_table rows follow the CARL
+ * class's feature table.
  * action is float32 [n_lanes][n_act] (lane-major, like obs).  `sys` is a DEVICE pointer to
  * one carl_brax_sys_t.  */
 int carl_brax_reset(const carl_batch_t* batch, const carl_brax_sys_t* sys_dev, const carl_brax_sys_t* sys_host,
