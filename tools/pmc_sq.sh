@@ -16,7 +16,7 @@ for sub in ("a", "b"):
     for f in glob.glob(f"{root}/{sub}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
-            if "rollout" not in k and "step_kernel" not in k:
+            if "rollout" not in k and "step_kernel" not in k and "brax_kernel<1" not in k:
                 continue
             a = acc[k[:70]][r["Counter_Name"]]
             a[0] += 1; a[1] += float(r["Counter_Value"])
