@@ -294,7 +294,7 @@ def main():
     bytes_per_step = IO_PER_STEP[args.env] + PER_LAUNCH[args.env] / T
     achieved = bytes_per_step * n * T / avg_launch_s / 1e9
     kernel_name = ("brax_kernel<1>" if args.env in BRAX_ENVS else
-                   "rollout_staged_kernel" if n % 256 == 0 else "rollout_kernel")
+                   "rollout_staged_kernel" if n % 16 == 0 else "rollout_kernel")
     roofline = {
         "bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBS, "traffic": None,

@@ -138,10 +138,10 @@ int launch_step(const carl_batch_t* b, const carl_step_io_t* io, int n_steps, hi
     CARL_LAUNCH(step_kernel, *b, *io);
     return check_launch("carl_step");
   }
-  // full workgroups + global context table: records are staged in LDS and written out by the
+  // n_lanes % 16 == 0 + global context table: records are staged in LDS and written out by the
   // workgroup's storer wave with 16-byte stores (see rollout_staged_kernel)
   static const bool no_staged = getenv("CARL_AMD_NO_STAGED") != nullptr;
-  if (!lds && !no_staged && b->n_lanes % carl::kRolloutLanes == 0) {
+  if (!lds && !no_staged && b->n_lanes % 16 == 0) {  // 16-byte pieces of every output row stay inside the batch
     const size_t sh_staged = carl::rollout_staged_lds_bytes<Fam>();
     const void* fn = a64 ? reinterpret_cast<const void*>(carl::rollout_staged_kernel<Fam, true>)
                          : reinterpret_cast<const void*>(carl::rollout_staged_kernel<Fam, false>);

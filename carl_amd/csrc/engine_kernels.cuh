@@ -36,7 +36,7 @@ __device__ __forceinline__ ctx_t<LDS> make_ctx(const carl_batch_t& b, float* lds
 template <class Fam, class Ctx>
 __device__ __forceinline__ bool reset_lane(const carl_batch_t& b, const Ctx& ctx, int lane, uint64_t glane,
                                            int& cidx, uint32_t& episode, typename Fam::Params& p,
-                                           float (&s)[Fam::S], bool force) {
+                                           float (&s)[Fam::S], bool force, bool valid = true) {
   const int old = cidx;
   cidx = select_context(b, cidx, glane, episode);
   const bool changed = force || (cidx != old);
@@ -48,7 +48,7 @@ __device__ __forceinline__ bool reset_lane(const carl_batch_t& b, const Ctx& ctx
     // statistics just stored (a full store round trip per reset; CartPole under a random policy
     // resets some lane of nearly every wave on nearly every step: 983 -> 852 ns/step, A/B on one box)
     settle(p);
-    if (b.ctx_obs != nullptr) {
+    if (b.ctx_obs != nullptr && valid) {
       for (int k = 0; k < b.n_ctx_obs; ++k)
         b.ctx_obs[(size_t)k * b.n_lanes + lane] = ctx.get(b.ctx_obs_feat[k], cidx);
     }
@@ -108,6 +108,8 @@ struct LaneRegs {
   bool episode_valid;
   int n_new_calls;      // resets performed in this launch
   int n_new_episodes;   // episodes finished in this launch
+  bool valid;           // false: a padding lane of a ragged last workgroup (a register-only clone of
+                        // the batch's last lane: it computes, but nothing it does reaches global memory)
   typename Fam::Params p;
   typename Fam::Aux aux;  // derived from s: shared by this step's obs and the next step
 };
@@ -183,20 +185,20 @@ __device__ __forceinline__ void finish_episodes(const carl_batch_t& b, const Ctx
                                                 LaneRegs<Fam>& r) {
   const float fin_ret = r.ep_return;
   const int fin_len = r.elapsed;
-  if (done) {
+  if (done && r.valid) {
     if (b.last_return) b.last_return[lane] = fin_ret;
     if (b.last_length) b.last_length[lane] = fin_len;
     r.n_new_episodes += 1;
   }
-  log_finished(b, done, glane, fin_ret, fin_len);
+  log_finished(b, done && r.valid, glane, fin_ret, fin_len);
   if ((b.flags & CARL_FLAG_AUTORESET) && done) {
     if (final_obs != nullptr) store_obs<Fam::D>(final_obs, 0, o);
-    if (!r.episode_valid) {
+    if (!r.episode_valid) {  // (never on a padding lane: the rollout kernels preload the counter)
       r.episode = b.episode[lane];
       r.episode_valid = true;
       settle(r.episode);  // wait here, inside the branch (see reset_lane)
     }
-    reset_lane<Fam>(b, ctx, lane, glane, r.cidx, r.episode, r.p, r.s, false);
+    reset_lane<Fam>(b, ctx, lane, glane, r.cidx, r.episode, r.p, r.s, false, r.valid);
     r.elapsed = 0;
     r.ep_return = 0.0f;
     r.n_new_calls += 1;
@@ -270,6 +272,7 @@ __device__ __forceinline__ void load_lane(const carl_batch_t& b, const Ctx& ctx,
   if constexpr (Fam::kNeedsStepNoise) r.episode = b.episode[lane];
   r.n_new_calls = 0;
   r.n_new_episodes = 0;
+  r.valid = true;
   r.p = Fam::load(ctx, r.cidx, b.flags);
   Fam::prepare(r.s, r.aux);
   // have all of it in registers NOW (see finish_episodes): the first use must not leave
@@ -376,12 +379,23 @@ __device__ __forceinline__ void stage_actions(Action* buf, const AStore* __restr
       return;
     }
   }
-#pragma unroll 1
-  for (int u = 0; u < CHUNK && t0 + u < n_steps; ++u) {  // ragged tail / int64 actions
+  // ragged workgroup / unaligned rows / ragged tail / int64 actions: element loads, predicated instead
+  // of loop-bounded so that the loop unrolls completely -- every load of the chunk is in flight before
+  // the first LDS write (a load-then-store loop paid one memory round trip per step and made the
+  // ragged last workgroup 3x slower than the others, which is what the whole launch then waits for)
+  Action tmp[CHUNK][4];
+#pragma unroll
+  for (int u = 0; u < CHUNK; ++u) {
     const AStore* row = act + (size_t)(t0 + u) * n;
+    const bool row_ok = t0 + u < n_steps;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) tmp[u][k] = (row_ok && first + k < (int)n) ? (Action)row[first + k] : Action{};
+  }
+#pragma unroll
+  for (int u = 0; u < CHUNK; ++u) {
     Action* dst = buf + u * kRolloutLanes + 4 * l;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) dst[k] = (first + k < (int)n) ? (Action)row[first + k] : Action{};
+    for (int k = 0; k < 4; ++k) dst[k] = tmp[u][k];
   }
 }
 
@@ -488,68 +502,90 @@ __host__ __device__ constexpr size_t rollout_staged_lds_bytes() {
 }
 
 // A chunk of actions in flight: issue() starts the HBM loads into registers, commit() writes
-// them to the LDS buffer the compute waves will read.  Chunks that are ragged (tail of the
-// rollout) or need conversion (int64 actions) are loaded at commit time instead.
+// them to the LDS buffer the compute waves will read.  int64 actions (torch's default integer type)
+// travel as two 16-byte vectors per lane-row and are narrowed at commit time.
 template <class AStore, class Action, int CHUNK>
 struct ActionPipe {
-  static_assert(CHUNK == 8, "the in-flight chunk is held in eight named registers quads");
+  static_assert(CHUNK == 8, "the in-flight chunk is held in eight named register groups");
+  static constexpr bool kSame = std::is_same_v<AStore, Action>;
   // native 16-byte vectors in named members: first-class register values.  (A float4 array
   // member that is live across the chunk loop stayed a private-memory object -> scratch.)
   typedef float vf4 __attribute__((ext_vector_type(4)));
   typedef int vi4 __attribute__((ext_vector_type(4)));
   using V = std::conditional_t<std::is_same_v<Action, float>, vf4, vi4>;
-  V a0, a1, a2, a3, a4, a5, a6, a7;
-  bool fast;
+  struct Wide {  // four int64 actions: little-endian, values fit 32 bits
+    vi4 lo, hi;
+  };
+  using R = std::conditional_t<kSame, V, Wide>;
+  R a0, a1, a2, a3, a4, a5, a6, a7;
   int t0;
-  // l: lane of the loader wave (0..63); workgroup fully inside the batch, n % 4 == 0
+  bool in_range;  // this lane's four actions are inside the batch (n % 4 == 0: all or none)
+
+  __device__ static __forceinline__ R load_row(const AStore* __restrict__ p) {
+#ifndef CARL_EXP_TEMPORAL
+#define CARL_LD(q) __builtin_nontemporal_load(q)  // read once
+#else
+#define CARL_LD(q) (*(q))
+#endif
+    if constexpr (kSame) {
+      return CARL_LD(reinterpret_cast<const V*>(p));
+    } else {
+      const vi4* q = reinterpret_cast<const vi4*>(p);
+      return Wide{CARL_LD(q), CARL_LD(q + 1)};
+    }
+#undef CARL_LD
+  }
+  __device__ static __forceinline__ V narrow(const R& r) {
+    if constexpr (kSame) {
+      return r;
+    } else {
+      return V{r.lo.x, r.lo.z, r.hi.x, r.hi.z};
+    }
+  }
+
+  bool fast;  // full chunk: its loads are in flight in a0..a7; else (the rollout's last, ragged chunk)
+              // commit() loads it itself
+
+  // l: lane of the loader wave (0..63).  ONE unconditional basic block of eight loads: per-row
+  // branches (a predicated tail in the same function) made the register allocator spill the in-flight
+  // rows and wait for each load before issuing the next.  Lanes past the end of a ragged last
+  // workgroup load the batch's last four actions instead (valid memory) and skip the commit.
   __device__ __forceinline__ void issue(const AStore* __restrict__ act, size_t n, int lane_base, int l, int t0_,
                                         int n_steps) {
     t0 = t0_;
-    fast = false;
-    if constexpr (std::is_same_v<AStore, Action>) {
-      fast = t0 + CHUNK <= n_steps;
-      if (fast) {
-        const V* src = reinterpret_cast<const V*>(act + (size_t)t0 * n + lane_base + 4 * l);
-        const size_t row_v = n / 4;
-#ifndef CARL_EXP_TEMPORAL
-#define CARL_LD(p) __builtin_nontemporal_load(p)  // read once
-#else
-#define CARL_LD(p) (*(p))
-#endif
-        a0 = CARL_LD(src);
-        a1 = CARL_LD(src + row_v);
-        a2 = CARL_LD(src + 2 * row_v);
-        a3 = CARL_LD(src + 3 * row_v);
-        a4 = CARL_LD(src + 4 * row_v);
-        a5 = CARL_LD(src + 5 * row_v);
-        a6 = CARL_LD(src + 6 * row_v);
-        a7 = CARL_LD(src + 7 * row_v);
-#undef CARL_LD
-      }
-    }
+    in_range = lane_base + 4 * l < (int)n;
+    fast = t0 + CHUNK <= n_steps;
+    if (!fast) return;
+    const AStore* src = act + (size_t)t0 * n + min(lane_base + 4 * l, (int)n - 4);
+    a0 = load_row(src);
+    a1 = load_row(src + n);
+    a2 = load_row(src + 2 * n);
+    a3 = load_row(src + 3 * n);
+    a4 = load_row(src + 4 * n);
+    a5 = load_row(src + 5 * n);
+    a6 = load_row(src + 6 * n);
+    a7 = load_row(src + 7 * n);
   }
   __device__ __forceinline__ void commit(Action* buf, const AStore* __restrict__ act, size_t n, int lane_base, int l,
                                          int n_steps) const {
+    if (!in_range) return;
+    V* dst = reinterpret_cast<V*>(buf + 4 * l);
+    constexpr int row = kRolloutLanes / 4;
     if (fast) {
-      V* dst = reinterpret_cast<V*>(buf + 4 * l);
-      constexpr int row = kRolloutLanes / 4;
-      dst[0] = a0;
-      dst[row] = a1;
-      dst[2 * row] = a2;
-      dst[3 * row] = a3;
-      dst[4 * row] = a4;
-      dst[5 * row] = a5;
-      dst[6 * row] = a6;
-      dst[7 * row] = a7;
+      dst[0] = narrow(a0);
+      dst[row] = narrow(a1);
+      dst[2 * row] = narrow(a2);
+      dst[3 * row] = narrow(a3);
+      dst[4 * row] = narrow(a4);
+      dst[5 * row] = narrow(a5);
+      dst[6 * row] = narrow(a6);
+      dst[7 * row] = narrow(a7);
       return;
     }
+    // last, ragged chunk of the rollout (once per launch): a plain row loop
+    const AStore* src = act + (size_t)t0 * n + lane_base + 4 * l;
 #pragma unroll 1
-    for (int u = 0; u < CHUNK && t0 + u < n_steps; ++u) {  // ragged tail / int64 actions
-      const AStore* row = act + (size_t)(t0 + u) * n + lane_base + 4 * l;
-      Action* dst = buf + u * kRolloutLanes + 4 * l;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) dst[k] = (Action)row[k];
-    }
+    for (int u = 0; u < CHUNK && t0 + u < n_steps; ++u) dst[u * row] = narrow(load_row(src + (size_t)u * n));
   }
 };
 
@@ -559,6 +595,9 @@ template <class Fam>
 __device__ __forceinline__ void drain_records(char* buf, const carl_step_io_t& io, size_t n, int lane_base, int l,
                                               int which, int t0, int steps) {
   using SK = LdsSink<Fam>;
+  // lanes of this workgroup inside the batch: 256, or a multiple of 16 in the ragged last workgroup
+  // (n % 16 == 0), so every 16-byte piece below is entirely inside or entirely outside
+  const int valid = min(kRolloutLanes, (int)n - lane_base);
   typedef float vf4 __attribute__((ext_vector_type(4)));
   // streamed once, never re-read by this kernel: non-temporal stores (CARL_EXP_TEMPORAL: ablation)
   auto put = [](char* dst, const char* src) {
@@ -574,12 +613,14 @@ __device__ __forceinline__ void drain_records(char* buf, const carl_step_io_t& i
     const size_t row = (size_t)(t0 + u) * n + lane_base;
     char* g_obs = reinterpret_cast<char*>(io.obs + row * Fam::D);
 #pragma unroll
-    for (int off = 0; off < SK::kObsBytes; off += 1024) put(g_obs + off + 16 * l, rec + off + 16 * l);
-    put(reinterpret_cast<char*>(io.reward + row) + 16 * l, rec + SK::kObsBytes + 16 * l);
+    for (int off = 0; off < SK::kObsBytes; off += 1024)
+      if (off + 16 * l < valid * Fam::D * 4) put(g_obs + off + 16 * l, rec + off + 16 * l);
+    if (16 * l < valid * 4) put(reinterpret_cast<char*>(io.reward + row) + 16 * l, rec + SK::kObsBytes + 16 * l);
     if (l < 32) {  // [256] term | [256] trunc are contiguous in the record: 16 lanes each
       char* fl = rec + SK::kFlagOff + 16 * l;
-      uint8_t* dst = (l < 16) ? io.terminated + row + 16 * l : io.truncated + row + 16 * (l - 16);
-      put(reinterpret_cast<char*>(dst), fl);
+      const int fl_lane = 16 * (l & 15);
+      uint8_t* dst = (l < 16) ? io.terminated + row + fl_lane : io.truncated + row + fl_lane;
+      if (fl_lane < valid) put(reinterpret_cast<char*>(dst), fl);
       *reinterpret_cast<vf4*>(fl) = vf4{0.0f, 0.0f, 0.0f, 0.0f};  // LdsSink::kLazyFlags
     }
   }
@@ -595,7 +636,8 @@ __device__ __forceinline__ void zero_flag_rows(char* out_buf, int l, int which) 
       *reinterpret_cast<vf4*>(out_buf + (size_t)u * SK::kStepBytes + SK::kFlagOff + 16 * l) = vf4{0.0f, 0.0f, 0.0f, 0.0f};
 }
 
-// Preconditions (checked by the host): n_lanes % 256 == 0, global context table.
+// Preconditions (checked by the host): n_lanes % 16 == 0 (the last workgroup may be ragged), global
+// context table.
 template <class Fam, bool A64>
 __global__ void __launch_bounds__(kStagedThreads) rollout_staged_kernel(const carl_batch_t b, const carl_step_io_t io,
                                                                         const int n_steps) {
@@ -616,6 +658,7 @@ __global__ void __launch_bounds__(kStagedThreads) rollout_staged_kernel(const ca
   const int hl = threadIdx.x % kWave;    // lane within a helper wave
   const int lane_base = blockIdx.x * kRolloutLanes;
   const int lane = lane_base + (compute ? (int)threadIdx.x : 0);
+  const bool active = compute && lane < b.n_lanes;
   const uint64_t glane = (uint64_t)(b.lane_offset + lane);
   const size_t n = (size_t)b.n_lanes;
   const int max_steps = b.max_episode_steps;
@@ -623,19 +666,23 @@ __global__ void __launch_bounds__(kStagedThreads) rollout_staged_kernel(const ca
   constexpr int kBufActs = kStageChunk * kRolloutLanes;
   LaneRegs<Fam> r{};
   ActionPipe<AStore, Action, kStageChunk> pipe;
-  float* const final_base = (io.final_obs != nullptr && compute) ? io.final_obs + (size_t)lane * Fam::D : nullptr;
+  float* const final_base = (io.final_obs != nullptr && active) ? io.final_obs + (size_t)lane * Fam::D : nullptr;
   if (!compute && !loader) zero_flag_rows<Fam>(out_buf, hl, storer);
   if (loader) {
     pipe.issue(act, n, lane_base, hl, 0, n_steps);
     pipe.commit(act_buf, act, n, lane_base, hl, n_steps);
     pipe.issue(act, n, lane_base, hl, kStageChunk, n_steps);  // in flight across the barrier
   } else if (compute) {
-    load_lane<Fam>(b, ctx, lane, r);
+    // padding lanes of a ragged last workgroup run as register-only clones of the batch's last lane
+    // (valid numbers, so the step loop needs no per-lane predicate and takes no slow math path)
+    const int src = min(lane, b.n_lanes - 1);
+    load_lane<Fam>(b, ctx, src, r);
     if (!r.episode_valid) {
-      r.episode = b.episode[lane];
+      r.episode = b.episode[src];
       r.episode_valid = true;
       settle(r.episode);
     }
+    r.valid = active;
   }
   __syncthreads();
   int buf = 0;
@@ -668,7 +715,7 @@ __global__ void __launch_bounds__(kStagedThreads) rollout_staged_kernel(const ca
     __syncthreads();
   }
   if (compute) {
-    store_lane<Fam>(b, lane, r);
+    if (active) store_lane<Fam>(b, lane, r);
   } else if (!loader) {  // records of the last chunk
     const int last_t0 = ((n_steps - 1) / kStageChunk) * kStageChunk;
     drain_records<Fam>(out_buf + (size_t)(buf ^ 1) * kStageChunk * SK::kStepBytes, io, n, lane_base, hl, storer,

@@ -317,13 +317,14 @@ def test_rollout_equals_repeated_step_bit_exact(fam, device):
 
 
 @pytest.mark.parametrize("fam", range(5), ids=O.FAMILY_NAMES)
-@pytest.mark.parametrize("T", [1, 7, 8, 9, 37])
-def test_staged_rollout_equals_repeated_step_bit_exact(fam, T, device):
-    """n % 256 == 0 takes the LDS-staged-output kernel (records drained by the loader/storer
-    wave with 16-byte stores); chunk boundaries (8 steps) and ragged tails must not matter.
+@pytest.mark.parametrize("T,n", [(1, 1024), (7, 1024), (8, 1024), (9, 1024), (37, 1024), (9, 1008), (17, 272), (8, 16)])
+def test_staged_rollout_equals_repeated_step_bit_exact(fam, T, n, device):
+    """n % 16 == 0 takes the LDS-staged-output kernel (records drained by the storer waves with
+    16-byte stores); chunk boundaries (8 steps), ragged step tails and a ragged LAST WORKGROUP
+    (n % 256 != 0) must not matter, and nothing may be written past a row's n entries.
     int64 actions exercise the converting loader path."""
     rng = np.random.default_rng(fam * 10 + T)
-    n, n_ctx = 1024, 1024  # lane <-> context identity, global table
+    n_ctx = n  # lane <-> context identity, global table
     table = random_table(fam, rng, n_ctx)
     a_np = random_actions(fam, rng, (T, n))
     acts = torch.as_tensor(a_np, device=device)
@@ -334,13 +335,20 @@ def test_staged_rollout_equals_repeated_step_bit_exact(fam, T, device):
     e2 = _engine(fam, table, n, device, **kw)
     e1.reset()
     e2.reset()
-    out = e1.rollout(acts, e1.alloc_rollout(T, final_obs=True))
+    buf = e1.alloc_rollout(T + 1, final_obs=True)  # one sentinel row behind the last step
+    buf["obs"][T].fill_(-7.0)
+    buf["reward"][T].fill_(-7.0)
+    buf["terminated"][T].fill_(9)
+    buf["truncated"][T].fill_(9)
+    out = e1.rollout(acts, buf)
     for t in range(T):
         obs, rew, term, trunc = e2.step(acts[t])
         assert torch.equal(out["obs"][t], obs) and torch.equal(out["reward"][t], rew)
         assert torch.equal(out["terminated"][t], term) and torch.equal(out["truncated"][t], trunc)
         d = (term | trunc).bool()
         assert torch.equal(out["final_obs"][t][d], e2.final_obs[d])
+    assert bool((buf["obs"][T] == -7.0).all()) and bool((buf["reward"][T] == -7.0).all())
+    assert bool((buf["terminated"][T] == 9).all()) and bool((buf["truncated"][T] == 9).all())
     for name in ("state", "elapsed", "ctx_idx", "episode", "n_calls", "ep_return", "episodes_done"):
         assert torch.equal(getattr(e1, name), getattr(e2, name)), name
 
