@@ -141,7 +141,9 @@ int launch_step(const carl_batch_t* b, const carl_step_io_t* io, int n_steps, hi
   // n_lanes % 16 == 0 + global context table: records are staged in LDS and written out by the
   // workgroup's storer wave with 16-byte stores (see rollout_staged_kernel)
   static const bool no_staged = getenv("CARL_AMD_NO_STAGED") != nullptr;
-  if (!lds && !no_staged && b->n_lanes % 16 == 0) {  // 16-byte pieces of every output row stay inside the batch
+  // (also for tables small enough for LDS: a fused rollout gathers parameters once per launch and on
+  // resets, so the global table costs nothing there; the LDS copy pays off in the per-call kernel)
+  if (!no_staged && b->n_lanes % 16 == 0) {  // 16-byte pieces of every output row stay inside the batch
     const size_t sh_staged = carl::rollout_staged_lds_bytes<Fam>();
     const void* fn = a64 ? reinterpret_cast<const void*>(carl::rollout_staged_kernel<Fam, true>)
                          : reinterpret_cast<const void*>(carl::rollout_staged_kernel<Fam, false>);

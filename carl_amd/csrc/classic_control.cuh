@@ -286,8 +286,13 @@ struct AcrobotT {
   __device__ static __forceinline__ Real wrap_pi(Real x) {
     const Real pi = (Real)3.14159265358979323846;
     const Real diff = pi - (-pi);
-    while (x > pi) x = x - diff;
-    while (x < -pi) x = x + diff;
+    // the reference's loops, bounded: a step moves an angle by at most a few turns (velocities are
+    // clipped), so eight iterations reproduce them exactly; an absurd input (e.g. an action far
+    // outside Discrete(3), which gymnasium would reject with an assert) must not spin a wavefront
+    // for millions of iterations -- it is reduced in one go instead
+    for (int it = 0; it < 8 && x > pi; ++it) x = x - diff;
+    for (int it = 0; it < 8 && x < -pi; ++it) x = x + diff;
+    if (!(x <= pi && x >= -pi) && x == x && (x - x) == (Real)0) x = x - diff * floor((x + pi) / diff);
     return x;
   }
 

@@ -519,7 +519,6 @@ struct ActionPipe {
   using R = std::conditional_t<kSame, V, Wide>;
   R a0, a1, a2, a3, a4, a5, a6, a7;
   int t0;
-  bool in_range;  // this lane's four actions are inside the batch (n % 4 == 0: all or none)
 
   __device__ static __forceinline__ R load_row(const AStore* __restrict__ p) {
 #ifndef CARL_EXP_TEMPORAL
@@ -549,11 +548,10 @@ struct ActionPipe {
   // l: lane of the loader wave (0..63).  ONE unconditional basic block of eight loads: per-row
   // branches (a predicated tail in the same function) made the register allocator spill the in-flight
   // rows and wait for each load before issuing the next.  Lanes past the end of a ragged last
-  // workgroup load the batch's last four actions instead (valid memory) and skip the commit.
+  // workgroup load the batch's last four actions instead (valid memory, valid actions).
   __device__ __forceinline__ void issue(const AStore* __restrict__ act, size_t n, int lane_base, int l, int t0_,
                                         int n_steps) {
     t0 = t0_;
-    in_range = lane_base + 4 * l < (int)n;
     fast = t0 + CHUNK <= n_steps;
     if (!fast) return;
     const AStore* src = act + (size_t)t0 * n + min(lane_base + 4 * l, (int)n - 4);
@@ -568,7 +566,9 @@ struct ActionPipe {
   }
   __device__ __forceinline__ void commit(Action* buf, const AStore* __restrict__ act, size_t n, int lane_base, int l,
                                          int n_steps) const {
-    if (!in_range) return;
+    // padding lanes of a ragged last workgroup must see VALID actions too (they run as clones of the
+    // last lane; a garbage torque sent the Acrobot's angle to 1e7 rad and its wrap loop with it):
+    // they get the batch's last four actions (fast path: what issue() loaded) or zeros (tail chunk)
     V* dst = reinterpret_cast<V*>(buf + 4 * l);
     constexpr int row = kRolloutLanes / 4;
     if (fast) {
@@ -583,7 +583,7 @@ struct ActionPipe {
       return;
     }
     // last, ragged chunk of the rollout (once per launch): a plain row loop
-    const AStore* src = act + (size_t)t0 * n + lane_base + 4 * l;
+    const AStore* src = act + (size_t)t0 * n + min(lane_base + 4 * l, (int)n - 4);
 #pragma unroll 1
     for (int u = 0; u < CHUNK && t0 + u < n_steps; ++u) dst[u * row] = narrow(load_row(src + (size_t)u * n));
   }

@@ -285,11 +285,15 @@ def test_short_free_running_rollout(fam, device):
     assert rel_err(obs.cpu().numpy(), out.obs).max() <= 1e-3
 
 
+@pytest.mark.parametrize("n", [3000, 3008], ids=["generic-kernel", "staged-kernel"])
 @pytest.mark.parametrize("fam", range(5), ids=O.FAMILY_NAMES)
-def test_rollout_equals_repeated_step_bit_exact(fam, device):
-    """the fused T-step kernel and T per-call launches are the same arithmetic"""
+def test_rollout_equals_repeated_step_bit_exact(fam, n, device):
+    """the fused T-step kernel and T per-call launches are the same arithmetic: round-robin context
+    switches on reset (parameter re-gather, ctx_obs rewrite), the finished-episode log and terminal
+    observations, through the direct-store kernel (n % 16 != 0) and the LDS-staged one (ragged
+    last workgroup)"""
     rng = np.random.default_rng(fam + 50)
-    n, T, n_ctx = 3000, 70, 13
+    T, n_ctx = 70, 13
     table = random_table(fam, rng, n_ctx)
     acts = torch.as_tensor(random_actions(fam, rng, (T, n)), device=device)
     kw = dict(selector=O.SEL_ROUND_ROBIN, seed=3, max_episode_steps=23, fin_capacity=1 << 16)
@@ -503,3 +507,24 @@ def test_full_size_config3_mixed_batch_properties(device):
         # elapsed + sum of finished lengths = T for every lane
         total = torch.zeros(n, dtype=torch.int64, device=device).index_add_(0, lanes, lens.long())
         assert torch.equal(total + eng.elapsed.long(), torch.full((n,), T, device=device))
+
+
+def test_absurd_actions_do_not_spin_the_acrobot(device):
+    """an action far outside Discrete(3) (gymnasium asserts on it) sends the angle to ~1e9 rad; the
+    reference's `while` wrap loops would spin a wavefront for minutes -- the kernel reduces such an
+    angle in one go"""
+    import time
+
+    fam = O.ACROBOT
+    n = 512
+    e = _engine(fam, random_table(fam, np.random.default_rng(0), n), n, device, selector=O.SEL_STATIC, seed=0,
+                ctx_idx0=np.arange(n))
+    e.reset()
+    acts = torch.full((40, n), 1_000_000_000, dtype=torch.int32, device=device)
+    t0 = time.perf_counter()
+    out = e.rollout(acts)
+    torch.cuda.synchronize()
+    assert time.perf_counter() - t0 < 5.0  # (values are garbage in, garbage out -- possibly non-finite)
+    e.reset()                               # ... and the engine is usable afterwards
+    out = e.rollout(torch.ones((10, n), dtype=torch.int32, device=device))
+    assert torch.isfinite(out["obs"]).all()
