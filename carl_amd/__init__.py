@@ -21,6 +21,7 @@ _LAZY = {
     "CARLBraxWalker2d": "carl_amd.envs.brax",
     "CARLBraxInvertedPendulum": "carl_amd.envs.brax",
     "CARLBraxHumanoidStandup": "carl_amd.envs.brax",
+    "CARLBraxInvertedDoublePendulum": "carl_amd.envs.brax",
     "VecEngine": "carl_amd.engine",
 }
 

@@ -134,7 +134,7 @@ def family_info(family: int) -> FamilyInfo:
 
 # ---- Brax-locomotion families (carl_brax_sys_t, include/carl_amd.h) ----------------------
 BRAX_MAX_LINKS, BRAX_MAX_DOF, BRAX_MAX_Q, BRAX_MAX_ACT, BRAX_MAX_COLL, BRAX_MAX_CTX_MASS = 16, 24, 32, 24, 32, 16
-(BRAX_ANT, BRAX_HALFCHEETAH, BRAX_HUMANOID, BRAX_HOPPER, BRAX_WALKER2D, BRAX_INVERTED_PENDULUM, BRAX_HUMANOIDSTANDUP) = range(7)
+(BRAX_ANT, BRAX_HALFCHEETAH, BRAX_HUMANOID, BRAX_HOPPER, BRAX_WALKER2D, BRAX_INVERTED_PENDULUM, BRAX_HUMANOIDSTANDUP, BRAX_INVERTED_DOUBLE_PENDULUM) = range(8)
 BRAX_LINK_STATE = 13
 _f, _i = C.c_float, C.c_int32
 
@@ -177,7 +177,9 @@ class BraxSys(C.Structure):
         ("n_slide", _i * BRAX_MAX_LINKS), ("dof_sign3", _f * BRAX_MAX_LINKS),
         ("reset_vel_uniform", _i), ("reward_on_com", _i), ("obs_extended", _i), ("healthy_q_index", _i),
         ("healthy_q_lo", _f), ("healthy_q_hi", _f), ("obs_qd_clip", _f), ("lanes_per_env", _i),
-        ("reward_height", _i), ("reserved4", _i),
+        ("reward_height", _i), ("obs_trig_from", _i),
+        ("tip_link", _i), ("tip_offset", _f * 3), ("tip_x_weight", _f), ("tip_height", _f), ("tip_min_height", _f),
+        ("tip_vel_weight", _f * 2), ("tip_vel_dof", _i * 2),
         ("slide_axis", ((_f * 3) * 2) * BRAX_MAX_LINKS),
         ("ctx", BraxCtxMap),
     ]

@@ -453,10 +453,17 @@ template <bool MULTI>
 static __device__ __forceinline__ void observe(const carl_brax_sys_t& s, const Derived& dv, const Lds& m, bool go,
                                         bool zero_frc) {
   const int skip = s.exclude_current_positions;
-  const int qd0 = s.n_q - skip;  // first qd row in the observation
+  // q[from:] as sin ++ cos (inverted double pendulum): the raw angles are written to the sin rows and
+  // converted in a second pass below; everything behind them moves back by n_trig rows
+  const int n_trig = s.obs_trig_from > 0 ? s.n_q - s.obs_trig_from : 0;
+  const int qd0 = s.n_q - skip + n_trig;  // first qd row in the observation
   const int L = s.n_links;
   const float clipv = s.obs_qd_clip > 0.0f ? s.obs_qd_clip : 3.0e38f;  // hopper / walker2d clip velocities
-  auto vel = [&](float v) { return fminf(fmaxf(v, -clipv), clipv); };
+  const bool keep_raw = s.tip_link > 0;  // the tip reward uses unclipped rates: parked in the wrench rows
+  auto put_qd = [&](int dof, float v) {
+    m.at(m.lay.io + qd0 + dof) = fminf(fmaxf(v, -clipv), clipv);
+    if (keep_raw) m.at(m.lay.wrench + dof) = v;
+  };
   float M = 1.0f;
   v3 com = V(0, 0, 0);
   if (s.obs_extended && go) com = system_com(s, m, &M);
@@ -474,7 +481,7 @@ static __device__ __forceinline__ void observe(const carl_brax_sys_t& s, const D
         if (s.q_start[i] + k >= skip) m.at(m.lay.io + s.q_start[i] + k - skip) = qv[k];
       const float dvv[6] = {vl.x, vl.y, vl.z, b.w.x, b.w.y, b.w.z};
 #pragma unroll
-      for (int k = 0; k < 6; ++k) m.at(m.lay.io + qd0 + s.dof_start[i] + k) = vel(dvv[k]);
+      for (int k = 0; k < 6; ++k) put_qd(s.dof_start[i] + k, dvv[k]);
     } else {
       const Body bp = (P < 0) ? world_body() : m.body(P);
       const JointGeom g = joint_geometry<MULTI>(s, dv, i, b, bp);
@@ -482,18 +489,18 @@ static __device__ __forceinline__ void observe(const carl_brax_sys_t& s, const D
       for (int k = 0; k < ns; ++k) {
         const v3 ax = qrot(bp.r, f3(s.slide_axis[i][k]));
         if (s.q_start[i] + k >= skip) m.at(m.lay.io + s.q_start[i] + k - skip) = dot(g.A_c - g.A_p, ax);
-        m.at(m.lay.io + qd0 + s.dof_start[i] + k) = vel(dot(g.vA_c - g.vA_p, ax));
+        put_qd(s.dof_start[i] + k, dot(g.vA_c - g.vA_p, ax));
       }
       const int nr = MULTI ? s.n_link_dof[i] - ns : 1;
       if (!MULTI || nr == 1) {
         if (s.q_start[i] + ns >= skip) m.at(m.lay.io + s.q_start[i] + ns - skip) = g.theta;
-        m.at(m.lay.io + qd0 + s.dof_start[i] + ns) = vel(g.thetadot);
+        put_qd(s.dof_start[i] + ns, g.thetadot);
       } else {
 #pragma unroll
         for (int k = 0; k < 3; ++k)
           if (k < nr) {
             if (s.q_start[i] + ns + k >= skip) m.at(m.lay.io + s.q_start[i] + ns + k - skip) = g.ang[k];
-            m.at(m.lay.io + qd0 + s.dof_start[i] + ns + k) = vel(g.rate[k]);
+            put_qd(s.dof_start[i] + ns + k, g.rate[k]);
           }
       }
     }
@@ -528,6 +535,16 @@ static __device__ __forceinline__ void observe(const carl_brax_sys_t& s, const D
     for (int d = m.sub; d < s.n_dof; d += kSub) m.at(k0 + d) = zero_frc ? 0.0f : m.at(m.lay.tau + d);
   }
   phase_sync();
+  if (n_trig > 0) {  // wavefront-uniform
+    if (go)
+      for (int i = s.obs_trig_from + m.sub; i < s.n_q; i += kSub) {
+        float sn, cs;
+        sincos_fast(m.at(m.lay.io + i - skip), sn, cs);
+        m.at(m.lay.io + i - skip) = sn;
+        m.at(m.lay.io + i - skip + n_trig) = cs;
+      }
+    phase_sync();
+  }
 }
 
 // kinematics.forward + com.from_world from (q, qd) held in the io staging rows (q at rows
@@ -829,6 +846,15 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
                      (s.terminate_when_unhealthy ? s.healthy_reward : (healthy ? s.healthy_reward : 0.0f)) -
                      s.ctrl_cost_weight * ctrl;
       bool terminated = s.terminate_when_unhealthy && !healthy;
+      if (s.tip_link > 0) {  // brax.envs.inverted_double_pendulum: alive bonus - distance - velocity penalties
+        const Body bt = m.body(s.tip_link);
+        const v3 tip = bt.p + qrot(bt.r, f3(s.tip_offset) - f3(s.com[s.tip_link]));
+        const float dz = tip.z - s.tip_height;
+        const float v0 = m.at(m.lay.wrench + s.tip_vel_dof[0]), v1 = m.at(m.lay.wrench + s.tip_vel_dof[1]);
+        reward = s.healthy_reward - (s.tip_x_weight * tip.x * tip.x + dz * dz) -
+                 (s.tip_vel_weight[0] * v0 * v0 + s.tip_vel_weight[1] * v1 * v1);
+        terminated = tip.z <= s.tip_min_height;
+      }
       if (goal) {  // brax_walker_goal_wrapper.py:124-140: progress reward replaces the env reward
         const float nx = r.pos_x + m.at(m.lay.io + s.goal_obs_idx[0]) * s.goal_dt;
         const float ny = r.pos_y + m.at(m.lay.io + s.goal_obs_idx[1]) * s.goal_dt;

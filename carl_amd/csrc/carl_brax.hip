@@ -40,6 +40,15 @@ int validate_brax(const carl_batch_t* b, const carl_brax_sys_t* sd, const carl_b
     if (!free_root && n_rot == 3 && sh->dof_sign3[i] != 1.0f && sh->dof_sign3[i] != -1.0f)
       return fail(CARL_ERR_INVALID_ARGUMENT, "%s: link %d: dof_sign3 must be +1 or -1", who, i);
   }
+  if (sh->obs_trig_from < 0 || sh->obs_trig_from >= sh->n_q ||
+      (sh->obs_trig_from > 0 && sh->obs_trig_from < sh->exclude_current_positions))
+    return fail(CARL_ERR_INVALID_ARGUMENT, "%s: obs_trig_from %d out of range", who, sh->obs_trig_from);
+  if (sh->tip_link < 0 || sh->tip_link >= sh->n_links)
+    return fail(CARL_ERR_INVALID_ARGUMENT, "%s: tip_link %d out of range", who, sh->tip_link);
+  if (sh->tip_link > 0)
+    for (int k = 0; k < 2; ++k)
+      if (sh->tip_vel_dof[k] < 0 || sh->tip_vel_dof[k] >= sh->n_dof)
+        return fail(CARL_ERR_INVALID_ARGUMENT, "%s: tip_vel_dof[%d] = %d out of range", who, k, sh->tip_vel_dof[k]);
   for (int k = 0; k < sh->n_act; ++k) {
     if (sh->act_dof[k] < 0 || sh->act_dof[k] >= sh->n_dof)
       return fail(CARL_ERR_INVALID_ARGUMENT, "%s: actuator %d drives dof %d (of %d)", who, k, sh->act_dof[k], sh->n_dof);
@@ -52,7 +61,8 @@ int validate_brax(const carl_batch_t* b, const carl_brax_sys_t* sd, const carl_b
     return fail(CARL_ERR_INVALID_ARGUMENT, "%s: healthy_q_index %d must be an observed coordinate", who,
                 sh->healthy_q_index);
   {
-    const int base = sh->n_q - sh->exclude_current_positions + sh->n_dof;
+    const int base = sh->n_q - sh->exclude_current_positions + sh->n_dof +
+                     (sh->obs_trig_from > 0 ? sh->n_q - sh->obs_trig_from : 0);
     const int want = sh->obs_extended ? base + 16 * sh->n_links + sh->n_dof : base;
     if (sh->obs_dim != want)
       return fail(CARL_ERR_INVALID_ARGUMENT, "%s: obs_dim %d does not match the model (%d)", who, sh->obs_dim, want);

@@ -615,5 +615,65 @@ def humanoidstandup_sys(feature_names: list[str] | None = None, reference_compat
     return s
 
 
-SYSTEMS = {"humanoidstandup": humanoidstandup_sys, "ant": ant_sys, "halfcheetah": halfcheetah_sys, "humanoid": humanoid_sys, "hopper": hopper_sys,
+def inverted_double_pendulum_sys(feature_names: list[str] | None = None, reference_compat: bool = False) -> _lib.BraxSys:
+    """InvertedDoublePendulum: cart on a slider (x, range +-1) + two poles of length 0.6 on hinges about
+    y; q 3, qd 3, one motor on the slider (gear 500, ctrl +-1).  Observation (8) = cart x ++ sin(q[1:])
+    ++ cos(q[1:]) ++ clip(qd, +-10); reward = 10 - (0.01 x_tip^2 + (z_tip - 2)^2) - (1e-3 qd1^2 +
+    5e-3 qd2^2); done when the tip of the second pole is at z <= 1; reset q + U(+-0.01), qd = 0.1 N(0,1).
+    Restated from upstream memory of brax's ``inverted_double_pendulum.xml`` /
+    ``brax/envs/inverted_double_pendulum.py``; dt 0.0025 x 20 frames and the spring constants are this
+    build's choice.  PARITY UNPINNED."""
+    s = _lib.BraxSys()
+    s.env_kind = _lib.BRAX_INVERTED_DOUBLE_PENDULUM
+    s.n_links, s.n_q, s.n_dof, s.n_act = 3, 3, 3, 1
+    s.obs_trig_from = 1
+    s.obs_dim = 1 + 2 + 2 + 3
+    s.max_episode_steps = 1000
+    s.terminate_when_unhealthy = 0  # the tip rule below decides
+    s.exclude_current_positions = 0
+    s.dt, s.n_frames = 0.0025, 20  # at 0.005 the gear-500 slider drives the spring joints unstable
+    s.gravity_z, s.vel_damping, s.ang_damping = -9.81, 0.0, 0.0
+    s.baumgarte_erp, s.elasticity, s.friction = 0.1, 0.0, 1.0
+    s.healthy_z_lo, s.healthy_z_hi = -1e9, 1e9
+    s.healthy_q_index = -1
+    s.healthy_reward, s.ctrl_cost_weight, s.forward_reward_weight = 10.0, 0.0, 0.0
+    s.reset_noise_scale, s.reset_vel_scale = 0.01, 0.1
+    s.obs_qd_clip = 10.0
+    s.tip_link = 2
+    for c, v in enumerate((0.0, 0.0, 0.6)):
+        s.tip_offset[c] = v
+    s.tip_x_weight, s.tip_height, s.tip_min_height = 0.01, 2.0, 1.0
+    s.tip_vel_weight[0], s.tip_vel_weight[1] = 1e-3, 5e-3
+    s.tip_vel_dof[0], s.tip_vel_dof[1] = 1, 2
+    ident = (1.0, 0.0, 0.0, 0.0)
+    hinge_y = _axis_quat((0, 1, 0))
+    # cart: slide along x against the world, no rotational dof
+    s.parent[0], s.n_slide[0], s.n_link_dof[0], s.q_start[0], s.dof_start[0] = -1, 1, 1, 0, 0
+    _set3(s.link_rot, 0, ident)
+    _set3(s.joint_rot, 0, ident)
+    for c, v in enumerate((1.0, 0.0, 0.0)):
+        s.slide_axis[0][0][c] = v
+    s.dof_lo[0], s.dof_hi[0] = -1.0, 1.0
+    s.dof_damping[0] = 0.05
+    for i, (parent, pos) in enumerate([(0, (0.0, 0.0, 0.0)), (1, (0.0, 0.0, 0.6))], start=1):
+        s.parent[i], s.n_slide[i], s.n_link_dof[i], s.q_start[i], s.dof_start[i] = parent, 0, 1, i, i
+        _set3(s.link_pos, i, pos)
+        _set3(s.link_rot, i, ident)
+        _set3(s.joint_rot, i, hinge_y)
+        _set3(s.com, i, (0.0, 0.0, 0.3))
+        s.dof_lo[i], s.dof_hi[i] = -1e9, 1e9
+        s.dof_damping[i] = 0.05
+    for i in range(3):
+        s.dof_sign3[i] = 1.0
+        s.mass[i] = 1.0
+        _set3(s.inv_inertia, i, (1.0, 1.0, 1.0))
+        s.k_pos[i], s.k_vel[i], s.k_limit[i], s.k_ang_damp[i] = 10000.0, 100.0, 1000.0, 10.0
+    s.act_dof[0], s.act_gear[0], s.act_lo[0], s.act_hi[0] = 0, 500.0, -1.0, 1.0
+    s.n_coll = 0
+    _wire_context(s, feature_names, reference_compat, {"cart": 0, "pole": 1, "pole2": 2},
+                  {"mass_cart": 1.0, "mass_pole": 1.0, "mass_pole2": 1.0})
+    return s
+
+
+SYSTEMS = {"inverted_double_pendulum": inverted_double_pendulum_sys, "humanoidstandup": humanoidstandup_sys, "ant": ant_sys, "halfcheetah": halfcheetah_sys, "humanoid": humanoid_sys, "hopper": hopper_sys,
            "walker2d": walker2d_sys, "inverted_pendulum": inverted_pendulum_sys}

@@ -281,7 +281,18 @@ typedef struct carl_brax_sys {
                                                 * by the library from the model and the batch size */
   int32_t reward_height;                       /* 1: the "forward" term is weight * (root z) / dt_env
                                                 * (humanoidstandup's uph_cost) instead of weight * dx / dt_env */
-  int32_t reserved4;
+  int32_t obs_trig_from;                       /* > 0: coordinates q[obs_trig_from:] appear in the observation as
+                                                * sin(q[from:]) ++ cos(q[from:]) instead of q[from:]
+                                                * (inverted double pendulum); 0: plain q */
+  /* tip reward / termination (brax.envs.inverted_double_pendulum): with tip = frame origin of
+   * tip_link + R * tip_offset, reward = healthy_reward - (tip_x_weight * tip.x^2 + (tip.z -
+   * tip_height)^2) - (tip_vel_weight[k] * qd[tip_vel_dof[k]]^2, k = 0, 1); done when tip.z <=
+   * tip_min_height.  tip_link = 0: not used (the root is never the tip) */
+  int32_t tip_link;
+  float tip_offset[3];
+  float tip_x_weight, tip_height, tip_min_height;
+  float tip_vel_weight[2];
+  int32_t tip_vel_dof[2];
   float slide_axis[CARL_BRAX_MAX_LINKS][2][3]; /* unit axes in the PARENT frame, mutually orthogonal */
   carl_brax_ctx_map_t ctx;
 } carl_brax_sys_t;

@@ -424,6 +424,11 @@ static void observe(const carl_brax_sys_t* s, const lane_ctx* c, const body* b, 
   double q[CARL_BRAX_MAX_Q], qd[CARL_BRAX_MAX_DOF];
   inverse_kinematics(s, b, q, qd);
   int k = 0;
+  if (s->obs_trig_from > 0) { /* q[:from] ++ sin(q[from:]) ++ cos(q[from:]) */
+    for (int i = s->exclude_current_positions; i < s->obs_trig_from; ++i) obs[k++] = (float)q[i];
+    for (int i = s->obs_trig_from; i < s->n_q; ++i) obs[k++] = (float)sin((double)(float)q[i]);
+    for (int i = s->obs_trig_from; i < s->n_q; ++i) obs[k++] = (float)cos((double)(float)q[i]);
+  } else
   for (int i = s->exclude_current_positions; i < s->n_q; ++i) obs[k++] = (float)q[i];
   for (int i = 0; i < s->n_dof; ++i) {
     float v = (float)qd[i];
@@ -614,10 +619,21 @@ void obx_engine_step(const carl_brax_sys_t* s, const oracle_cfg_t* cfg, const do
       const float qa = (float)q[s->healthy_q_index]; /* the kernel checks the float32 observation entry */
       healthy = healthy && (qa >= s->healthy_q_lo) && (qa <= s->healthy_q_hi);
     }
-    const double r = s->forward_reward_weight * (s->reward_height ? z1 : (x1 - x0)) / dt_env +
-                     (s->terminate_when_unhealthy ? s->healthy_reward : s->healthy_reward * healthy) -
-                     s->ctrl_cost_weight * ctrl;
+    double r = s->forward_reward_weight * (s->reward_height ? z1 : (x1 - x0)) / dt_env +
+               (s->terminate_when_unhealthy ? s->healthy_reward : s->healthy_reward * healthy) -
+               s->ctrl_cost_weight * ctrl;
     int term = s->terminate_when_unhealthy ? !healthy : 0;
+    if (s->tip_link > 0) { /* brax.envs.inverted_double_pendulum: alive bonus - distance - velocity penalties */
+      const int tl = s->tip_link;
+      const v3 o = vsub(b[tl].p, qrot(b[tl].r, f3(s->com[tl])));
+      const v3 tip = vadd(o, qrot(b[tl].r, f3(s->tip_offset)));
+      double q[CARL_BRAX_MAX_Q], qd[CARL_BRAX_MAX_DOF];
+      inverse_kinematics(s, b, q, qd);
+      const double dist = s->tip_x_weight * tip.x * tip.x + (tip.z - s->tip_height) * (tip.z - s->tip_height);
+      const double v0 = qd[s->tip_vel_dof[0]], v1 = qd[s->tip_vel_dof[1]];
+      r = s->healthy_reward - dist - (s->tip_vel_weight[0] * v0 * v0 + s->tip_vel_weight[1] * v1 * v1);
+      term = tip.z <= s->tip_min_height;
+    }
     double r_out = r;
     elapsed[i] += 1;
     const int trunc = elapsed[i] >= cfg->max_steps;

@@ -433,3 +433,43 @@ def test_humanoidstandup_lies_down_and_rewards_height():
         want = z / 0.015 + 1.0 - 0.1 * (a.astype(np.float64) ** 2).sum(1)  # uph_cost + 1 - quad_ctrl_cost
         np.testing.assert_allclose(out.reward, want, rtol=1e-5, atol=1e-4)
     assert np.all(out.obs[:, 0] < 0.3)  # random torques do not stand it up
+
+
+def test_inverted_double_pendulum_observation_and_tip_reward():
+    from carl_amd.envs.brax.models import inverted_double_pendulum_sys
+
+    names, default = _features("CARLBraxInvertedDoublePendulum")
+    assert names == ["gravity", "friction", "elasticity", "mass_cart", "mass_pole", "mass_pole2", "ang_damping",
+                     "viscosity"]
+    s = inverted_double_pendulum_sys(names)
+    assert (s.n_links, s.n_q, s.n_dof, s.n_act, s.obs_dim) == (3, 3, 3, 1, 8) and s.ctx.n_mass == 3
+    n = 6
+    e = B.Engine(s, default[None], n, selector=O.SEL_STATIC, seed=0)
+    obs = e.reset()
+    # cart x, sin(q1), sin(q2), cos(q1), cos(q2), qd: upright + U(+-0.01) noise
+    assert np.abs(obs[:, 0:3]).max() <= 0.0101 and np.all(obs[:, 3:5] > 0.9999)
+    np.testing.assert_allclose(obs[:, 1] ** 2 + obs[:, 3] ** 2, 1.0, atol=1e-6)
+    rng = np.random.default_rng(0)
+    seen_done = False
+    for t in range(120):
+        out = e.step(rng.uniform(-1, 1, (n, 1)).astype(np.float32))
+        live = out.terminated == 0
+        # live envs: the true tip from the stored state of link 2 (COM p, rotation r): origin + R (0, 0, 0.6)
+        st = e.state.reshape(n, 3, 13)[live, 2]
+        w, x_, y_, z_ = st[:, 3], st[:, 4], st[:, 5], st[:, 6]
+        zx = 2 * (x_ * z_ + w * y_)                 # R e_z, x component
+        zz = 1 - 2 * (x_ * x_ + y_ * y_)           # R e_z, z component
+        tip_x = st[:, 0] + zx * (0.6 - 0.3)        # COM is at 0.3 along the pole
+        tip_z = st[:, 2] + zz * (0.6 - 0.3)
+        o = out.obs[live].astype(np.float64)
+        unclipped = np.abs(o[:, 6:8]).max(1) < 10.0  # the penalty uses the unclipped rates
+        want = 10.0 - (0.01 * tip_x**2 + (tip_z - 2.0) ** 2) - (1e-3 * o[:, 6] ** 2 + 5e-3 * o[:, 7] ** 2)
+        np.testing.assert_allclose(out.reward[live][unclipped], want[unclipped], rtol=1e-5, atol=2e-4)
+        assert np.all(tip_z > 1.0)
+        # finished envs: the terminal observation shows a tip near or below the threshold (rigid-geometry
+        # estimate from its own sines / cosines; the spring joints stretch by centimetres under the motor)
+        f = out.final_obs[~live].astype(np.float64)
+        zf = 0.6 * f[:, 3] + 0.6 * (f[:, 3] * f[:, 4] - f[:, 1] * f[:, 2])
+        assert np.all(zf < 1.2)
+        seen_done |= bool(out.terminated.any())
+    assert seen_done and not out.truncated.any()

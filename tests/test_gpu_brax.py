@@ -488,7 +488,7 @@ def _planar(cls_name, fn_name):
 
 @pytest.mark.parametrize("lanes_per_env", [2, 4, 7, 9, 11, 16])
 @pytest.mark.parametrize("model", ["ant", "halfcheetah", "humanoid", "hopper", "walker2d", "inverted_pendulum",
-                                   "humanoidstandup"])
+                                   "humanoidstandup", "inverted_double_pendulum"])
 def test_every_lane_group_width_matches_oracle(device, model, lanes_per_env, monkeypatch):
     """The host picks the lanes per env (one per link, rounded up to an instantiated width: 2, 4, 7,
     9, 11, 16) from the model and the batch size
@@ -509,6 +509,8 @@ def test_every_lane_group_width_matches_oracle(device, model, lanes_per_env, mon
         s, names, default = _planar("CARLBraxWalker2d", "walker2d_sys")
     elif model == "humanoidstandup":
         s, names, default = _planar("CARLBraxHumanoidStandup", "humanoidstandup_sys")
+    elif model == "inverted_double_pendulum":
+        s, names, default = _planar("CARLBraxInvertedDoublePendulum", "inverted_double_pendulum_sys")
     else:
         s, names, default = _planar("CARLBraxInvertedPendulum", "inverted_pendulum_sys")
     rng = np.random.default_rng(100 + lanes_per_env)
