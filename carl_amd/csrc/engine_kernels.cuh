@@ -554,15 +554,24 @@ struct ActionPipe {
     t0 = t0_;
     fast = t0 + CHUNK <= n_steps;
     if (!fast) return;
-    const AStore* src = act + (size_t)t0 * n + min(lane_base + 4 * l, (int)n - 4);
-    a0 = load_row(src);
-    a1 = load_row(src + n);
-    a2 = load_row(src + 2 * n);
-    a3 = load_row(src + 3 * n);
-    a4 = load_row(src + 4 * n);
-    a5 = load_row(src + 5 * n);
-    a6 = load_row(src + 6 * n);
-    a7 = load_row(src + 7 * n);
+    // uniform row base + 32-bit lane offset: the loads take the scalar-base addressing form
+    const int lane4 = min(lane_base + 4 * l, (int)n - 4);
+    const AStore* row = act + (size_t)t0 * n;
+    a0 = load_row(row + lane4);
+    row += n;
+    a1 = load_row(row + lane4);
+    row += n;
+    a2 = load_row(row + lane4);
+    row += n;
+    a3 = load_row(row + lane4);
+    row += n;
+    a4 = load_row(row + lane4);
+    row += n;
+    a5 = load_row(row + lane4);
+    row += n;
+    a6 = load_row(row + lane4);
+    row += n;
+    a7 = load_row(row + lane4);
   }
   __device__ __forceinline__ void commit(Action* buf, const AStore* __restrict__ act, size_t n, int lane_base, int l,
                                          int n_steps) const {
@@ -612,17 +621,24 @@ __device__ __forceinline__ void drain_records(char* buf, const carl_step_io_t& i
     char* rec = buf + (size_t)u * SK::kStepBytes;
     const size_t row = (size_t)(t0 + u) * n + lane_base;
     char* g_obs = reinterpret_cast<char*>(io.obs + row * Fam::D);
+    char* fl = rec + SK::kFlagOff + 16 * l;  // [256] term | [256] trunc are contiguous in the record
+    const int fl_lane = 16 * (l & 15);
+    uint8_t* fl_dst = (l < 16) ? io.terminated + row + fl_lane : io.truncated + row + fl_lane;
+    if (valid == kRolloutLanes) {  // full workgroup (wave-uniform): straight-line, the LDS reads of a
+                                   // step issue together and the stores follow as they arrive
 #pragma unroll
-    for (int off = 0; off < SK::kObsBytes; off += 1024)
-      if (off + 16 * l < valid * Fam::D * 4) put(g_obs + off + 16 * l, rec + off + 16 * l);
-    if (16 * l < valid * 4) put(reinterpret_cast<char*>(io.reward + row) + 16 * l, rec + SK::kObsBytes + 16 * l);
-    if (l < 32) {  // [256] term | [256] trunc are contiguous in the record: 16 lanes each
-      char* fl = rec + SK::kFlagOff + 16 * l;
-      const int fl_lane = 16 * (l & 15);
-      uint8_t* dst = (l < 16) ? io.terminated + row + fl_lane : io.truncated + row + fl_lane;
-      if (fl_lane < valid) put(reinterpret_cast<char*>(dst), fl);
-      *reinterpret_cast<vf4*>(fl) = vf4{0.0f, 0.0f, 0.0f, 0.0f};  // LdsSink::kLazyFlags
+      for (int off = 0; off < SK::kObsBytes; off += 1024) put(g_obs + off + 16 * l, rec + off + 16 * l);
+      put(reinterpret_cast<char*>(io.reward + row) + 16 * l, rec + SK::kObsBytes + 16 * l);
+      if (l < 32) put(reinterpret_cast<char*>(fl_dst), fl);
+    } else {  // ragged last workgroup: per-piece guards (each guard is its own block with its own LDS wait:
+              // slower, but only this one workgroup pays it)
+#pragma unroll
+      for (int off = 0; off < SK::kObsBytes; off += 1024)
+        if (off + 16 * l < valid * Fam::D * 4) put(g_obs + off + 16 * l, rec + off + 16 * l);
+      if (16 * l < valid * 4) put(reinterpret_cast<char*>(io.reward + row) + 16 * l, rec + SK::kObsBytes + 16 * l);
+      if (l < 32 && fl_lane < valid) put(reinterpret_cast<char*>(fl_dst), fl);
     }
+    if (l < 32) *reinterpret_cast<vf4*>(fl) = vf4{0.0f, 0.0f, 0.0f, 0.0f};  // LdsSink::kLazyFlags
   }
 }
 

@@ -15,7 +15,7 @@ else:
     print(f"{n:28s} launch_ms {r['avg_launch_ms']:.4f}  ns/step {r['avg_launch_ms']*1e6/d['config']['chunk']:.1f}")
 PY
 }
-for rep in 1 2; do
+for rep in $(seq 1 ${REPS:-2}); do
 for v in ${VARIANTS}; do
   CARL_AMD_LIB_PATH=$PWD/gpurun_in/libcarl_$v.so run ${v}_r$rep --env ${ENV:-pendulum} $ARGS
 done
