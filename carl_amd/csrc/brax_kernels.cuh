@@ -49,24 +49,24 @@ struct v3 {
 struct qt {
   float w, x, y, z;
 };
-__device__ __forceinline__ v3 V(float x, float y, float z) { return v3{x, y, z}; }
-__device__ __forceinline__ v3 operator+(v3 a, v3 b) { return V(a.x + b.x, a.y + b.y, a.z + b.z); }
-__device__ __forceinline__ v3 operator-(v3 a, v3 b) { return V(a.x - b.x, a.y - b.y, a.z - b.z); }
-__device__ __forceinline__ v3 operator*(v3 a, float s) { return V(a.x * s, a.y * s, a.z * s); }
-__device__ __forceinline__ float dot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
-__device__ __forceinline__ v3 cross(v3 a, v3 b) {
+__host__ __device__ __forceinline__ v3 V(float x, float y, float z) { return v3{x, y, z}; }
+__host__ __device__ __forceinline__ v3 operator+(v3 a, v3 b) { return V(a.x + b.x, a.y + b.y, a.z + b.z); }
+__host__ __device__ __forceinline__ v3 operator-(v3 a, v3 b) { return V(a.x - b.x, a.y - b.y, a.z - b.z); }
+__host__ __device__ __forceinline__ v3 operator*(v3 a, float s) { return V(a.x * s, a.y * s, a.z * s); }
+__host__ __device__ __forceinline__ float dot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__host__ __device__ __forceinline__ v3 cross(v3 a, v3 b) {
   return V(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
-__device__ __forceinline__ qt qmul(qt a, qt b) {
+__host__ __device__ __forceinline__ qt qmul(qt a, qt b) {
   return qt{a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z, a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
             a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x, a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w};
 }
-__device__ __forceinline__ qt qconj(qt a) { return qt{a.w, -a.x, -a.y, -a.z}; }
+__host__ __device__ __forceinline__ qt qconj(qt a) { return qt{a.w, -a.x, -a.y, -a.z}; }
 __device__ __forceinline__ qt qnormalize(qt a) {
   const float inv = rsqrtf(a.w * a.w + a.x * a.x + a.y * a.y + a.z * a.z);
   return qt{a.w * inv, a.x * inv, a.y * inv, a.z * inv};
 }
-__device__ __forceinline__ v3 qrot(qt q, v3 v) {
+__host__ __device__ __forceinline__ v3 qrot(qt q, v3 v) {
   const v3 u = V(q.x, q.y, q.z);
   const v3 t = cross(u, v) * 2.0f;
   return v + t * q.w + cross(u, t);
@@ -76,8 +76,8 @@ __device__ __forceinline__ qt qaxis(int k, float angle) {
   sincos_fast(0.5f * angle, s, c);
   return qt{c, k == 0 ? s : 0.0f, k == 1 ? s : 0.0f, k == 2 ? s : 0.0f};
 }
-__device__ __forceinline__ v3 f3(const float* p) { return V(p[0], p[1], p[2]); }
-__device__ __forceinline__ qt f4(const float* p) { return qt{p[0], p[1], p[2], p[3]}; }
+__host__ __device__ __forceinline__ v3 f3(const float* p) { return V(p[0], p[1], p[2]); }
+__host__ __device__ __forceinline__ qt f4(const float* p) { return qt{p[0], p[1], p[2], p[3]}; }
 
 struct Body {
   v3 p;
@@ -125,46 +125,31 @@ struct Topo {
   int first_joint;  // 1 when link 0 is a free root (it has no joint), else 0
 };
 
-// Built by the workgroup in three small parallel steps (one lane per link): a single lane
-// walking all (link, link) and (link, collider) pairs through LDS took ~55 us per launch -- a third of a
-// per-call carl_brax_step.  `scratch`: 2 * CARL_BRAX_MAX_LINKS ints of LDS.
-__device__ inline void build_topo(const carl_brax_sys_t& s, Topo& t, int* scratch) {
-  const int L = s.n_links, i = (int)threadIdx.x;
-  if (i < L) {
-    int nc = 0, nk = 0, d = 0;
-    for (int c = i + 1; c < L; ++c) nc += (s.parent[c] == i) ? 1 : 0;
-    for (int k = 0; k < s.n_coll; ++k) nk += (s.coll_link[k] == i) ? 1 : 0;
-    for (int p = s.parent[i]; p >= 0; p = s.parent[p]) ++d;
-    scratch[i] = nc;
-    scratch[CARL_BRAX_MAX_LINKS + i] = nk;
-    t.depth[i] = (uint8_t)d;
-  }
-  __syncthreads();
-  if (i == 0) {
-    int nc = 0, nk = 0, md = 0;
-    for (int j = 0; j < L; ++j) {
-      t.child_begin[j] = (uint8_t)nc;
-      t.coll_begin[j] = (uint8_t)nk;
-      nc += scratch[j];
-      nk += scratch[CARL_BRAX_MAX_LINKS + j];
-      md = t.depth[j] > md ? t.depth[j] : md;
-    }
-    t.child_begin[L] = (uint8_t)nc;
-    t.coll_begin[L] = (uint8_t)nk;
-    t.max_depth = md;
-    t.first_joint = (s.parent[0] < 0 && s.n_link_dof[0] == 6) ? 1 : 0;
-  }
-  __syncthreads();
-  if (i < L) {  // ascending child / collider lists: the oracle's summation order
-    int nc = t.child_begin[i], nk = t.coll_begin[i];
+// Built ONCE PER LAUNCH ON THE HOST (a few hundred integer operations) and passed to the kernel by value
+// with the derived constants below: building them in the kernel -- by one lane ~55 us, by the
+// workgroup in three parallel steps ~5 us -- sat on the critical path of every workgroup of every
+// launch, which is what a per-call carl_brax_step pays in full.
+inline void build_topo_host(const carl_brax_sys_t& s, Topo& t) {
+  const int L = s.n_links;
+  int nc = 0, nk = 0, md = 0;
+  for (int i = 0; i < L; ++i) {
+    t.child_begin[i] = (uint8_t)nc;
     for (int c = i + 1; c < L; ++c)
-      if (s.parent[c] == i) t.child_idx[nc++] = (uint8_t)c;
+      if (s.parent[c] == i) t.child_idx[nc++] = (uint8_t)c;  // ascending: the oracle's summation order
+    t.coll_begin[i] = (uint8_t)nk;
     for (int k = 0; k < s.n_coll; ++k)
       if (s.coll_link[k] == i) t.coll_idx[nk++] = (uint8_t)k;
+    const int d = s.parent[i] < 0 ? 0 : t.depth[s.parent[i]] + 1;
+    t.depth[i] = (uint8_t)d;
+    md = d > md ? d : md;
   }
+  t.child_begin[L] = (uint8_t)nc;
+  t.coll_begin[L] = (uint8_t)nk;
+  t.max_depth = md;
+  t.first_joint = (s.parent[0] < 0 && s.n_link_dof[0] == 6) ? 1 : 0;
 }
 
-// per-link constants derived from the model table once per workgroup
+// per-link constants derived from the model table (on the host, once per launch)
 struct Derived {
   float ac[CARL_BRAX_MAX_LINKS][3];   // joint anchor relative to the child's COM (child frame)
   float ap[CARL_BRAX_MAX_LINKS][3];   // ... relative to the parent's COM (parent frame; world: origin), zero slide
@@ -173,7 +158,7 @@ struct Derived {
   uint8_t iso[CARL_BRAX_MAX_LINKS];   // isotropic inertia: R diag(c) R^T = c
 };
 
-__device__ inline void build_derived(const carl_brax_sys_t& s, Derived& d, int i) {
+inline void build_derived_host(const carl_brax_sys_t& s, Derived& d, int i) {
   const int P = s.parent[i];
   const v3 a = f3(s.joint_pos[i]);
   const qt lrot = f4(s.link_rot[i]);
@@ -188,11 +173,18 @@ __device__ inline void build_derived(const carl_brax_sys_t& s, Derived& d, int i
   for (int k = 0; k < s.n_coll; ++k)
     if (s.coll_link[k] == i) {
       const v3 c = f3(s.coll_pos[k]) - f3(s.com[i]);
-      reach = fmaxf(reach, sqrtf(dot(c, c)) + s.coll_radius[k]);
+      const float rk = sqrtf(dot(c, c)) + s.coll_radius[k];
+      reach = rk > reach ? rk : reach;
     }
   d.reach[i] = reach;
   d.iso[i] = (s.inv_inertia[i][0] == s.inv_inertia[i][1] && s.inv_inertia[i][1] == s.inv_inertia[i][2]) ? 1 : 0;
 }
+
+// what the host precomputes per launch (kernel argument, ~830 bytes)
+struct Prepared {
+  Topo topo;
+  Derived derived;
+};
 
 template <int kSub>
 struct Group {
@@ -728,8 +720,9 @@ static __device__ __forceinline__ void write_ctx_obs(const carl_batch_t& b, cons
 // mode 0: reset (mask optional), mode 1: n_steps env steps (1 = per call, T = fused rollout)
 template <int MODE, bool MULTI>
 static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_brax_sys_t* __restrict__ sys_dev,
-                                           const carl_step_io_t& io, const uint8_t* __restrict__ mask,
-                                           float* __restrict__ reset_obs, const int n_steps) {
+                                           const Prepared& prep, const carl_step_io_t& io,
+                                           const uint8_t* __restrict__ mask, float* __restrict__ reset_obs,
+                                           const int n_steps) {
   __shared__ carl_brax_sys_t s;
   __shared__ Topo tp;
   __shared__ Derived dv;
@@ -753,9 +746,16 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
     }
   }
   __syncthreads();
-  __shared__ int topo_scratch[2 * CARL_BRAX_MAX_LINKS];
-  build_topo(s, tp, topo_scratch);
-  if ((int)threadIdx.x < s.n_links) build_derived(s, dv, (int)threadIdx.x);
+  {  // topology + derived constants: kernel argument -> LDS (per-lane indexed in the phases)
+    constexpr int kWordsT = (int)(sizeof(Topo) / 4), kWordsD = (int)(sizeof(Derived) / 4);
+    static_assert(sizeof(Topo) % 4 == 0 && sizeof(Derived) % 4 == 0, "word copies");
+    const uint32_t* st = reinterpret_cast<const uint32_t*>(&prep.topo);
+    const uint32_t* sd = reinterpret_cast<const uint32_t*>(&prep.derived);
+    uint32_t* dt = reinterpret_cast<uint32_t*>(&tp);
+    uint32_t* dd = reinterpret_cast<uint32_t*>(&dv);
+    for (int k = (int)threadIdx.x; k < kWordsT; k += kLanes) dt[k] = st[k];
+    for (int k = (int)threadIdx.x; k < kWordsD; k += kLanes) dd[k] = sd[k];
+  }
   __syncthreads();
   // kSub need not divide 64 (one lane per link: 7, 9, 11): the wavefront's spare lanes idle -- they
   // point at the last env's column, own no link (sub beyond every loop bound) and are never active
@@ -934,9 +934,10 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
 
 template <int MODE, bool MULTI, int K>
 __global__ void __launch_bounds__(kLanes) brax_kernel(const carl_batch_t b, const carl_brax_sys_t* __restrict__ sys_dev,
-                                                      const carl_step_io_t io, const uint8_t* __restrict__ mask,
-                                                      float* __restrict__ reset_obs, const int n_steps) {
-  Group<K>::template run<MODE, MULTI>(b, sys_dev, io, mask, reset_obs, n_steps);
+                                                      const Prepared prep, const carl_step_io_t io,
+                                                      const uint8_t* __restrict__ mask, float* __restrict__ reset_obs,
+                                                      const int n_steps) {
+  Group<K>::template run<MODE, MULTI>(b, sys_dev, prep, io, mask, reset_obs, n_steps);
 }
 
 }  // namespace brax

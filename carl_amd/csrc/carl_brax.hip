@@ -133,9 +133,10 @@ int launch_brax(const carl_batch_t* b, const carl_brax_sys_t* sd, const carl_bra
   const int envs = carl::brax::kLanes / K;  // one wavefront = envs x K lanes; LDS rows are `envs` floats wide
   const carl::brax::Layout lay = carl::brax::Layout::make(sh->n_links, sh->n_dof, carl::brax::io_rows_of(*sh));
   const size_t sh_bytes = (size_t)lay.total * envs * sizeof(float);
-  if (sh_bytes + sizeof(carl_brax_sys_t) + sizeof(carl::brax::Topo) + sizeof(carl::brax::Derived) > 160 * 1024)
+  if (sh_bytes + sizeof(carl_brax_sys_t) + sizeof(carl::brax::Prepared) > 160 * 1024)
     return fail(CARL_ERR_UNSUPPORTED, "%s: model needs %zu B of LDS per wavefront", who, sh_bytes);
-  using kern_t = void (*)(carl_batch_t, const carl_brax_sys_t*, carl_step_io_t, const uint8_t*, float*, int);
+  using kern_t = void (*)(carl_batch_t, const carl_brax_sys_t*, carl::brax::Prepared, carl_step_io_t, const uint8_t*,
+                          float*, int);
   kern_t kern = nullptr;
 #define CARL_PICK(KK, MM) \
   if (K == KK && multi == MM) kern = static_cast<kern_t>(carl::brax::brax_kernel<MODE, MM, KK>)
@@ -157,7 +158,11 @@ int launch_brax(const carl_batch_t* b, const carl_brax_sys_t* sd, const carl_bra
   const int grid = (b->n_lanes + envs - 1) / envs;
   carl_step_io_t io_v{};
   if (io != nullptr) io_v = *io;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(carl::brax::kLanes), sh_bytes, st, *b, sd, io_v, mask, reset_obs, n_steps);
+  carl::brax::Prepared prep{};  // topology + derived per-link constants, host-side (microseconds)
+  carl::brax::build_topo_host(*sh, prep.topo);
+  for (int i = 0; i < sh->n_links; ++i) carl::brax::build_derived_host(*sh, prep.derived, i);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(carl::brax::kLanes), sh_bytes, st, *b, sd, prep, io_v, mask, reset_obs,
+                     n_steps);
   return check_launch(who);
 }
 
