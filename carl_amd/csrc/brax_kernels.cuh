@@ -804,8 +804,23 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
     if (reset_obs != nullptr) record_out(reset_obs, (size_t)env, s.obs_dim, m, go);
     return;
   } else {
-    if (active)
-      for (int k = m.sub; k < S; k += kSub) m.at(m.lay.state + k) = b.state[(size_t)env * S + k];
+    if (active) {  // the env's state record -> LDS, eight loads in flight at a time (a load-store loop pays
+                   // one memory round trip per element: 13 per lane for Ant)
+      const float* src = b.state + (size_t)env * S;
+      for (int k0 = m.sub; k0 < S; k0 += 8 * kSub) {
+        float tmp[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int k = k0 + j * kSub;
+          tmp[j] = (k < S) ? src[k] : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int k = k0 + j * kSub;
+          if (k < S) m.at(m.lay.state + k) = tmp[j];
+        }
+      }
+    }
     r.ctx = load_ctx(s, b, m, r.cidx, active);
     if (goal && active) {
       load_goal(s, b, r.cidx, r);
