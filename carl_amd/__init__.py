@@ -22,6 +22,7 @@ _LAZY = {
     "CARLBraxInvertedPendulum": "carl_amd.envs.brax",
     "CARLBraxHumanoidStandup": "carl_amd.envs.brax",
     "CARLBraxInvertedDoublePendulum": "carl_amd.envs.brax",
+    "CARLBraxReacher": "carl_amd.envs.brax",
     "VecEngine": "carl_amd.engine",
 }
 

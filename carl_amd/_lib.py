@@ -134,7 +134,8 @@ def family_info(family: int) -> FamilyInfo:
 
 # ---- Brax-locomotion families (carl_brax_sys_t, include/carl_amd.h) ----------------------
 BRAX_MAX_LINKS, BRAX_MAX_DOF, BRAX_MAX_Q, BRAX_MAX_ACT, BRAX_MAX_COLL, BRAX_MAX_CTX_MASS = 16, 24, 32, 24, 32, 16
-(BRAX_ANT, BRAX_HALFCHEETAH, BRAX_HUMANOID, BRAX_HOPPER, BRAX_WALKER2D, BRAX_INVERTED_PENDULUM, BRAX_HUMANOIDSTANDUP, BRAX_INVERTED_DOUBLE_PENDULUM) = range(8)
+(BRAX_ANT, BRAX_HALFCHEETAH, BRAX_HUMANOID, BRAX_HOPPER, BRAX_WALKER2D, BRAX_INVERTED_PENDULUM, BRAX_HUMANOIDSTANDUP, BRAX_INVERTED_DOUBLE_PENDULUM,
+ BRAX_REACHER) = range(9)
 BRAX_LINK_STATE = 13
 _f, _i = C.c_float, C.c_int32
 
@@ -180,6 +181,7 @@ class BraxSys(C.Structure):
         ("reward_height", _i), ("obs_trig_from", _i),
         ("tip_link", _i), ("tip_offset", _f * 3), ("tip_x_weight", _f), ("tip_height", _f), ("tip_min_height", _f),
         ("tip_vel_weight", _f * 2), ("tip_vel_dof", _i * 2),
+        ("target_link", _i), ("target_max_dist", _f),
         ("slide_axis", ((_f * 3) * 2) * BRAX_MAX_LINKS),
         ("ctx", BraxCtxMap),
     ]

@@ -451,7 +451,7 @@ static __device__ __forceinline__ void observe(const carl_brax_sys_t& s, const D
   const int qd0 = s.n_q - skip + n_trig;  // first qd row in the observation
   const int L = s.n_links;
   const float clipv = s.obs_qd_clip > 0.0f ? s.obs_qd_clip : 3.0e38f;  // hopper / walker2d clip velocities
-  const bool keep_raw = s.tip_link > 0;  // the tip reward uses unclipped rates: parked in the wrench rows
+  const bool keep_raw = s.tip_link > 0 && s.target_link == 0;  // the tip reward uses unclipped rates: parked in the wrench rows
   auto put_qd = [&](int dof, float v) {
     m.at(m.lay.io + qd0 + dof) = fminf(fmaxf(v, -clipv), clipv);
     if (keep_raw) m.at(m.lay.wrench + dof) = v;
@@ -537,6 +537,30 @@ static __device__ __forceinline__ void observe(const carl_brax_sys_t& s, const D
       }
     phase_sync();
   }
+  if (s.target_link > 0) {  // reach task: the rows q ++ qd written above are parked in the wrench rows (free
+                            // here) and laid out again as cos ++ sin ++ goal q ++ arm qd ++ (tip - goal)
+    const int tq = s.q_start[s.target_link], td = s.dof_start[s.target_link], nq = s.n_q;
+    if (go)
+      for (int i = m.sub; i < nq + td; i += kSub) m.at(m.lay.wrench + i) = m.at(m.lay.io + i);
+    phase_sync();
+    if (go) {
+      for (int i = m.sub; i < tq; i += kSub) {
+        float sn, cs;
+        sincos_fast(m.at(m.lay.wrench + i), sn, cs);
+        m.at(m.lay.io + i) = cs;
+        m.at(m.lay.io + tq + i) = sn;
+      }
+      for (int i = tq + m.sub; i < nq; i += kSub) m.at(m.lay.io + tq + i) = m.at(m.lay.wrench + i);
+      for (int i = m.sub; i < td; i += kSub) m.at(m.lay.io + tq + nq + i) = m.at(m.lay.wrench + nq + i);
+      if (m.sub == 0) {
+        const Body bt = m.body(s.tip_link), bg = m.body(s.target_link);
+        const v3 tip = bt.p + qrot(bt.r, f3(s.tip_offset) - f3(s.com[s.tip_link]));
+        const v3 d = tip - (bg.p - qrot(bg.r, f3(s.com[s.target_link])));
+        m.put3(m.lay.io + tq + nq + td, d);
+      }
+    }
+    phase_sync();
+  }
 }
 
 // kinematics.forward + com.from_world from (q, qd) held in the io staging rows (q at rows
@@ -615,11 +639,22 @@ static __device__ __forceinline__ float draw_u(uint64_t seed, uint64_t g, uint32
 static __device__ __noinline__ void reset_state(const carl_brax_sys_t& s, const Topo& tp, const carl_batch_t& b, const Lds& m,
                                          uint64_t genv, uint32_t episode, bool go) {
   if (go) {
-    for (int i = m.sub; i < s.n_q; i += kSub)
-      m.at(m.lay.io + i) = s.init_q[i] + s.reset_noise_scale * (2.0f * draw_u(b.seed, genv, episode, i) - 1.0f);
+    const int tq = s.target_link > 0 ? s.q_start[s.target_link] : s.n_q;     // reach task: the goal's
+    const int td = s.target_link > 0 ? s.dof_start[s.target_link] : s.n_dof;  // coordinates / rates start here
+    for (int i = m.sub; i < s.n_q; i += kSub) {
+      float v = s.init_q[i] + s.reset_noise_scale * (2.0f * draw_u(b.seed, genv, episode, i) - 1.0f);
+      if (i >= tq) {  // brax.envs.reacher._random_target: uniform distance and bearing
+        const float dist = s.target_max_dist * draw_u(b.seed, genv, episode, s.n_q + s.n_dof);
+        float sn, cs;
+        sincos_fast(2.0f * kPiF * draw_u(b.seed, genv, episode, s.n_q + s.n_dof + 1), sn, cs);
+        v = dist * (i == tq ? cs : sn);
+      }
+      m.at(m.lay.io + i) = v;
+    }
     if (s.reset_vel_uniform) {
       for (int i = m.sub; i < s.n_dof; i += kSub)
-        m.at(m.lay.io + s.n_q + i) = s.reset_vel_scale * (2.0f * draw_u(b.seed, genv, episode, s.n_q + i) - 1.0f);
+        m.at(m.lay.io + s.n_q + i) =
+            i >= td ? 0.0f : s.reset_vel_scale * (2.0f * draw_u(b.seed, genv, episode, s.n_q + i) - 1.0f);
     } else {
       for (int i = 2 * m.sub; i < s.n_dof; i += 2 * kSub) {  // one Box-Muller pair per lane
         const int k = s.n_q + i;
@@ -861,7 +896,12 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
                      (s.terminate_when_unhealthy ? s.healthy_reward : (healthy ? s.healthy_reward : 0.0f)) -
                      s.ctrl_cost_weight * ctrl;
       bool terminated = s.terminate_when_unhealthy && !healthy;
-      if (s.tip_link > 0) {  // brax.envs.inverted_double_pendulum: alive bonus - distance - velocity penalties
+      if (s.target_link > 0) {  // brax.envs.reacher: the observation ends with tip - goal
+        const int k = m.lay.io + s.obs_dim - 3;
+        const float dx = m.at(k), dy = m.at(k + 1), dz = m.at(k + 2);
+        reward = -sqrtf(dx * dx + dy * dy + dz * dz) - s.ctrl_cost_weight * ctrl;
+        terminated = false;
+      } else if (s.tip_link > 0) {  // brax.envs.inverted_double_pendulum: alive bonus - distance - velocity penalties
         const Body bt = m.body(s.tip_link);
         const v3 tip = bt.p + qrot(bt.r, f3(s.tip_offset) - f3(s.com[s.tip_link]));
         const float dz = tip.z - s.tip_height;

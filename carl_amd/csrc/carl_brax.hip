@@ -45,7 +45,7 @@ int validate_brax(const carl_batch_t* b, const carl_brax_sys_t* sd, const carl_b
     return fail(CARL_ERR_INVALID_ARGUMENT, "%s: obs_trig_from %d out of range", who, sh->obs_trig_from);
   if (sh->tip_link < 0 || sh->tip_link >= sh->n_links)
     return fail(CARL_ERR_INVALID_ARGUMENT, "%s: tip_link %d out of range", who, sh->tip_link);
-  if (sh->tip_link > 0)
+  if (sh->tip_link > 0 && sh->target_link == 0)
     for (int k = 0; k < 2; ++k)
       if (sh->tip_vel_dof[k] < 0 || sh->tip_vel_dof[k] >= sh->n_dof)
         return fail(CARL_ERR_INVALID_ARGUMENT, "%s: tip_vel_dof[%d] = %d out of range", who, k, sh->tip_vel_dof[k]);
@@ -60,10 +60,22 @@ int validate_brax(const carl_batch_t* b, const carl_brax_sys_t* sd, const carl_b
       (sh->healthy_q_index < sh->exclude_current_positions || sh->healthy_q_index >= sh->n_q))
     return fail(CARL_ERR_INVALID_ARGUMENT, "%s: healthy_q_index %d must be an observed coordinate", who,
                 sh->healthy_q_index);
+  if (sh->target_link != 0) {  // reach task (see carl_brax_sys_t::target_link)
+    const int t = sh->target_link;
+    if (t != sh->n_links - 1 || t < 1 || sh->parent[t] != -1 || sh->n_slide[t] != 2 || sh->n_link_dof[t] != 2)
+      return fail(CARL_ERR_INVALID_ARGUMENT, "%s: target_link must be the last link, on two slides against the world", who);
+    if (sh->tip_link < 1 || sh->tip_link >= t || sh->exclude_current_positions != 0 || sh->obs_trig_from != 0 ||
+        sh->obs_extended || sh->goal_mode || !sh->reset_vel_uniform)
+      return fail(CARL_ERR_INVALID_ARGUMENT,
+                  "%s: the reach task needs a tip link, the plain q ++ qd observation and uniform reset rates", who);
+    if (sh->n_q + sh->dof_start[t] > 12 * sh->n_links)
+      return fail(CARL_ERR_UNSUPPORTED, "%s: reach task: %d coordinates do not fit the staging rows", who, sh->n_q);
+  }
   {
     const int base = sh->n_q - sh->exclude_current_positions + sh->n_dof +
                      (sh->obs_trig_from > 0 ? sh->n_q - sh->obs_trig_from : 0);
-    const int want = sh->obs_extended ? base + 16 * sh->n_links + sh->n_dof : base;
+    int want = sh->obs_extended ? base + 16 * sh->n_links + sh->n_dof : base;
+    if (sh->target_link > 0) want = sh->q_start[sh->target_link] + sh->n_q + sh->dof_start[sh->target_link] + 3;
     if (sh->obs_dim != want)
       return fail(CARL_ERR_INVALID_ARGUMENT, "%s: obs_dim %d does not match the model (%d)", who, sh->obs_dim, want);
   }

@@ -675,5 +675,71 @@ def inverted_double_pendulum_sys(feature_names: list[str] | None = None, referen
     return s
 
 
-SYSTEMS = {"inverted_double_pendulum": inverted_double_pendulum_sys, "humanoidstandup": humanoidstandup_sys, "ant": ant_sys, "halfcheetah": halfcheetah_sys, "humanoid": humanoid_sys, "hopper": hopper_sys,
+def reacher_sys(feature_names: list[str] | None = None, reference_compat: bool = False) -> _lib.BraxSys:
+    """Reacher: a two-link arm in the horizontal plane (body0 on a hinge about z against the world,
+    body1 on a hinge about z, range +-3 rad, 0.1 m further out; fingertip 0.11 m along body1) and a
+    goal marker on two slides (x, y, range +-0.27) against the world; q 4, qd 4, two motors (ctrl +-1).
+    Observation (11) = cos(q[:2]) ++ sin(q[:2]) ++ goal (x, y) ++ arm qd ++ (fingertip - goal);
+    reward = -|fingertip - goal| - |a|^2; never terminates; reset: arm q = U(+-0.1), arm qd =
+    U(+-0.005), goal at a uniform distance (< 0.2) and bearing, at rest.  Restated from upstream memory
+    of brax's ``reacher.xml`` / ``brax/envs/reacher.py`` (spring backend: dt 0.005 x 4 frames, gear 25).
+    Link masses are the reference's defaults (carl/envs/brax/carl_reacher.py:33-38); rotational inertias
+    are 1 (the MJCF's armature = 1 dominates the capsules' 1e-5 kg m^2), the goal marker is given 0.01 kg
+    (its 3e-6 kg sphere cannot be carried by an explicit spring) and the spring constants are sized for
+    these masses -- this build's choices.  PARITY UNPINNED."""
+    s = _lib.BraxSys()
+    s.env_kind = _lib.BRAX_REACHER
+    s.n_links, s.n_q, s.n_dof, s.n_act = 3, 4, 4, 2
+    s.target_link, s.target_max_dist = 2, 0.2
+    s.tip_link = 1
+    for c, v in enumerate((0.11, 0.0, 0.0)):
+        s.tip_offset[c] = v
+    s.obs_dim = 11
+    s.max_episode_steps = 1000
+    s.terminate_when_unhealthy = 0
+    s.exclude_current_positions = 0
+    s.reset_vel_uniform = 1
+    s.dt, s.n_frames = 0.005, 4
+    s.gravity_z, s.vel_damping, s.ang_damping = -9.81, 0.0, 0.0
+    s.baumgarte_erp, s.elasticity, s.friction = 0.1, 0.0, 1.0
+    s.healthy_z_lo, s.healthy_z_hi = -1e9, 1e9
+    s.healthy_q_index = -1
+    s.healthy_reward, s.ctrl_cost_weight, s.forward_reward_weight = 0.0, 1.0, 0.0
+    s.reset_noise_scale, s.reset_vel_scale = 0.1, 0.005
+    ident = (1.0, 0.0, 0.0, 0.0)
+    hinge_z = _axis_quat((0, 0, 1))
+    arm = [(-1, (0.0, 0.0, 0.01), 0.05, 0.03560472, (-1e9, 1e9)),
+           (0, (0.1, 0.0, 0.0), (0.03560472 * 0.05 + 0.00418879 * 0.11) / 0.03979351, 0.03979351, (-3.0, 3.0))]
+    for i, (parent, pos, com_x, mass, rng) in enumerate(arm):
+        s.parent[i], s.n_slide[i], s.n_link_dof[i], s.q_start[i], s.dof_start[i] = parent, 0, 1, i, i
+        _set3(s.link_pos, i, pos)
+        _set3(s.link_rot, i, ident)
+        _set3(s.joint_rot, i, hinge_z)
+        _set3(s.com, i, (com_x, 0.0, 0.0))
+        s.mass[i] = mass
+        s.dof_lo[i], s.dof_hi[i] = rng
+        s.dof_damping[i] = 1.0
+        s.k_pos[i], s.k_vel[i], s.k_limit[i], s.k_ang_damp[i] = 400.0, 1.5, 100.0, 1.0
+        s.act_dof[i], s.act_gear[i], s.act_lo[i], s.act_hi[i] = i, 25.0, -1.0, 1.0
+    # goal marker: two slides against the world, no rotational dof
+    s.parent[2], s.n_slide[2], s.n_link_dof[2], s.q_start[2], s.dof_start[2] = -1, 2, 2, 2, 2
+    _set3(s.link_pos, 2, (0.0, 0.0, 0.01))
+    _set3(s.link_rot, 2, ident)
+    _set3(s.joint_rot, 2, ident)
+    for k, ax in enumerate(((1.0, 0.0, 0.0), (0.0, 1.0, 0.0))):
+        for c, v in enumerate(ax):
+            s.slide_axis[2][k][c] = v
+        s.dof_lo[2 + k], s.dof_hi[2 + k] = -0.27, 0.27
+    s.mass[2] = 0.01
+    s.k_pos[2], s.k_vel[2], s.k_limit[2], s.k_ang_damp[2] = 100.0, 1.0, 100.0, 1.0
+    for i in range(3):
+        s.dof_sign3[i] = 1.0
+        _set3(s.inv_inertia, i, (1.0, 1.0, 1.0))
+    s.n_coll = 0
+    _wire_context(s, feature_names, reference_compat, {"body0": 0, "body1": 1},
+                  {"mass_body0": 0.03560472, "mass_body1": 0.03979351})
+    return s
+
+
+SYSTEMS = {"reacher": reacher_sys, "inverted_double_pendulum": inverted_double_pendulum_sys, "humanoidstandup": humanoidstandup_sys, "ant": ant_sys, "halfcheetah": halfcheetah_sys, "humanoid": humanoid_sys, "hopper": hopper_sys,
            "walker2d": walker2d_sys, "inverted_pendulum": inverted_pendulum_sys}

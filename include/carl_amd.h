@@ -214,7 +214,9 @@ int32_t carl_done_compact_scratch_elems(int32_t n);
 #define CARL_BRAX_MAX_COLL 32
 #define CARL_BRAX_MAX_CTX_MASS 16
 
-enum { CARL_BRAX_ANT = 0, CARL_BRAX_HALFCHEETAH = 1, CARL_BRAX_HUMANOID = 2 };
+enum { CARL_BRAX_ANT = 0, CARL_BRAX_HALFCHEETAH = 1, CARL_BRAX_HUMANOID = 2, CARL_BRAX_HOPPER = 3, CARL_BRAX_WALKER2D = 4,
+       CARL_BRAX_INVERTED_PENDULUM = 5, CARL_BRAX_HUMANOIDSTANDUP = 6, CARL_BRAX_INVERTED_DOUBLE_PENDULUM = 7,
+       CARL_BRAX_REACHER = 8 };
 
 /* context-table rows the physics reads (row index in the family's feature table, -1 =
  * feature absent -> the model default is used) */
@@ -293,6 +295,15 @@ typedef struct carl_brax_sys {
   float tip_x_weight, tip_height, tip_min_height;
   float tip_vel_weight[2];
   int32_t tip_vel_dof[2];
+  /* reach task (brax.envs.reacher; reference class carl/envs/brax/carl_reacher.py:9-39): target_link > 0
+   * names the LAST link, jointed to the world by two slides whose coordinates q[tq : tq + 2]
+   * (tq = q_start[target_link]) are the goal.  reset: q[tq], q[tq + 1] = d cos(a), d sin(a) with
+   * d = target_max_dist * U, a = 2 pi U (draws n_q + n_dof and + 1 of the reset stream), goal rates 0;
+   * observation = cos(q[:tq]) ++ sin(q[:tq]) ++ q[tq:] ++ qd[:dof_start[target_link]] ++ (tip - goal
+   * position), tip = frame origin of tip_link + R * tip_offset; reward = -|tip - goal| -
+   * ctrl_cost_weight * |a|^2; never terminates.  0: not used */
+  int32_t target_link;
+  float target_max_dist;
   float slide_axis[CARL_BRAX_MAX_LINKS][2][3]; /* unit axes in the PARENT frame, mutually orthogonal */
   carl_brax_ctx_map_t ctx;
 } carl_brax_sys_t;

@@ -424,6 +424,18 @@ static void observe(const carl_brax_sys_t* s, const lane_ctx* c, const body* b, 
   double q[CARL_BRAX_MAX_Q], qd[CARL_BRAX_MAX_DOF];
   inverse_kinematics(s, b, q, qd);
   int k = 0;
+  if (s->target_link > 0) { /* brax.envs.reacher._get_obs: cos(theta) ++ sin(theta) ++ goal q ++ arm qd ++ (tip - goal) */
+    const int tl = s->tip_link, g = s->target_link, tq = s->q_start[g], td = s->dof_start[g];
+    for (int i = 0; i < tq; ++i) obs[k++] = (float)cos((double)(float)q[i]);
+    for (int i = 0; i < tq; ++i) obs[k++] = (float)sin((double)(float)q[i]);
+    for (int i = tq; i < s->n_q; ++i) obs[k++] = (float)q[i];
+    for (int i = 0; i < td; ++i) obs[k++] = (float)qd[i];
+    const v3 tip = vadd(vsub(b[tl].p, qrot(b[tl].r, f3(s->com[tl]))), qrot(b[tl].r, f3(s->tip_offset)));
+    const v3 goal = vsub(b[g].p, qrot(b[g].r, f3(s->com[g])));
+    const v3 d = vsub(tip, goal);
+    obs[k++] = (float)d.x; obs[k++] = (float)d.y; obs[k++] = (float)d.z;
+    return;
+  }
   if (s->obs_trig_from > 0) { /* q[:from] ++ sin(q[from:]) ++ cos(q[from:]) */
     for (int i = s->exclude_current_positions; i < s->obs_trig_from; ++i) obs[k++] = (float)q[i];
     for (int i = s->obs_trig_from; i < s->n_q; ++i) obs[k++] = (float)sin((double)(float)q[i]);
@@ -484,6 +496,14 @@ static void reset_lane(const carl_brax_sys_t* s, uint64_t seed, uint64_t g, uint
     const double rad = sqrt(-2.0 * log(1.0 - u1));
     qd[i] = s->reset_vel_scale * rad * cos(2.0 * M_PI * u2);
     if (i + 1 < s->n_dof) qd[i + 1] = s->reset_vel_scale * rad * sin(2.0 * M_PI * u2);
+  }
+  if (s->target_link > 0) { /* brax.envs.reacher._random_target: uniform distance and bearing; goal at rest */
+    const int tq = s->q_start[s->target_link], td = s->dof_start[s->target_link];
+    const double dist = (double)s->target_max_dist * draw_u(seed, g, ep, s->n_q + s->n_dof);
+    const double ang = 2.0 * M_PI * draw_u(seed, g, ep, s->n_q + s->n_dof + 1);
+    q[tq] = dist * cos(ang);
+    q[tq + 1] = dist * sin(ang);
+    for (int i = td; i < s->n_dof; ++i) qd[i] = 0.0;
   }
   forward_kinematics(s, q, qd, b);
 }
@@ -623,7 +643,13 @@ void obx_engine_step(const carl_brax_sys_t* s, const oracle_cfg_t* cfg, const do
                (s->terminate_when_unhealthy ? s->healthy_reward : s->healthy_reward * healthy) -
                s->ctrl_cost_weight * ctrl;
     int term = s->terminate_when_unhealthy ? !healthy : 0;
-    if (s->tip_link > 0) { /* brax.envs.inverted_double_pendulum: alive bonus - distance - velocity penalties */
+    if (s->target_link > 0) { /* brax.envs.reacher: -|tip - goal| - |a|^2 */
+      const int tl = s->tip_link, gl = s->target_link;
+      const v3 tip = vadd(vsub(b[tl].p, qrot(b[tl].r, f3(s->com[tl]))), qrot(b[tl].r, f3(s->tip_offset)));
+      const v3 d = vsub(tip, vsub(b[gl].p, qrot(b[gl].r, f3(s->com[gl]))));
+      r = -sqrt(vdot(d, d)) - s->ctrl_cost_weight * ctrl;
+      term = 0;
+    } else if (s->tip_link > 0) { /* brax.envs.inverted_double_pendulum: alive bonus - distance - velocity penalties */
       const int tl = s->tip_link;
       const v3 o = vsub(b[tl].p, qrot(b[tl].r, f3(s->com[tl])));
       const v3 tip = vadd(o, qrot(b[tl].r, f3(s->tip_offset)));

@@ -473,3 +473,47 @@ def test_inverted_double_pendulum_observation_and_tip_reward():
         assert np.all(zf < 1.2)
         seen_done |= bool(out.terminated.any())
     assert seen_done and not out.truncated.any()
+
+
+def test_reacher_goal_draw_observation_and_reward():
+    """reach task (carl_brax_sys_t::target_link): the goal is drawn inside the 0.2 disc and stays put,
+    the observation is cos ++ sin ++ goal ++ arm rates ++ (fingertip - goal) with the fingertip on the
+    rigid-arm circle, reward = -distance - |a|^2, no termination before the time limit."""
+    from carl_amd.envs.brax.models import reacher_sys
+
+    names, default = _features("CARLBraxReacher")
+    assert names == ["gravity", "friction", "elasticity", "ang_damping", "viscosity", "mass_body0", "mass_body1"]
+    s = reacher_sys(names)
+    assert (s.n_links, s.n_q, s.n_dof, s.n_act, s.obs_dim) == (3, 4, 4, 2, 11) and s.ctx.n_mass == 2
+    n = 64
+    e = B.Engine(s, default[None], n, selector=O.SEL_STATIC, seed=3)
+    obs = e.reset().astype(np.float64)
+    goal0 = obs[:, 4:6].copy()
+    r = np.hypot(goal0[:, 0], goal0[:, 1])
+    assert r.max() <= 0.2 and r.min() >= 0.0 and r.std() > 0.03          # uniform distance
+    assert np.ptp(np.arctan2(goal0[:, 1], goal0[:, 0])) > 5.0             # all bearings
+    np.testing.assert_allclose(obs[:, 0:2] ** 2 + obs[:, 2:4] ** 2, 1.0, atol=1e-6)
+    th = np.arctan2(obs[:, 2:4], obs[:, 0:2])
+    assert np.abs(th).max() <= 0.1001 and np.abs(obs[:, 6:8]).max() <= 0.0051
+    # fingertip of the rigid arm: 0.1 (cos t0, sin t0) + 0.11 (cos(t0+t1), sin(t0+t1))
+    tip = 0.1 * np.stack([np.cos(th[:, 0]), np.sin(th[:, 0])], 1) + \
+        0.11 * np.stack([np.cos(th.sum(1)), np.sin(th.sum(1))], 1)
+    np.testing.assert_allclose(obs[:, 8:10], tip - goal0, atol=1e-6)
+    np.testing.assert_allclose(obs[:, 10], 0.0, atol=1e-6)                # arm and goal both at z = 0.01
+    rng = np.random.default_rng(0)
+    for t in range(150):
+        a = rng.uniform(-1, 1, (n, 2)).astype(np.float32)
+        out = e.step(a)
+        o = out.obs.astype(np.float64)
+        assert np.isfinite(o).all() and not out.terminated.any() and not out.truncated.any()
+        np.testing.assert_allclose(o[:, 4:6], goal0, atol=2e-4)           # the marker does not move
+        want = -np.linalg.norm(o[:, 8:11], axis=1) - (a.astype(np.float64) ** 2).sum(1)
+        np.testing.assert_allclose(out.reward, want, rtol=1e-5, atol=1e-5)
+        th = np.arctan2(o[:, 2:4], o[:, 0:2])
+        tip = 0.1 * np.stack([np.cos(th[:, 0]), np.sin(th[:, 0])], 1) + \
+            0.11 * np.stack([np.cos(th.sum(1)), np.sin(th.sum(1))], 1)
+        # spring joints stretch by millimetres under the motors
+        np.testing.assert_allclose(o[:, 8:10], tip - o[:, 4:6], atol=5e-3)
+        assert np.abs(o[:, 10]).max() < 5e-3                              # gravity sag of the springs
+    assert np.abs(th[:, 1]).max() <= 3.05                                  # elbow range +-3 rad
+    assert np.abs(o[:, 6:8]).max() < 40.0                                  # gear 25 against damping 1

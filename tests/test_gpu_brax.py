@@ -488,7 +488,7 @@ def _planar(cls_name, fn_name):
 
 @pytest.mark.parametrize("lanes_per_env", [2, 4, 7, 9, 11, 16])
 @pytest.mark.parametrize("model", ["ant", "halfcheetah", "humanoid", "hopper", "walker2d", "inverted_pendulum",
-                                   "humanoidstandup", "inverted_double_pendulum"])
+                                   "humanoidstandup", "inverted_double_pendulum", "reacher"])
 def test_every_lane_group_width_matches_oracle(device, model, lanes_per_env, monkeypatch):
     """The host picks the lanes per env (one per link, rounded up to an instantiated width: 2, 4, 7,
     9, 11, 16) from the model and the batch size
@@ -511,6 +511,8 @@ def test_every_lane_group_width_matches_oracle(device, model, lanes_per_env, mon
         s, names, default = _planar("CARLBraxHumanoidStandup", "humanoidstandup_sys")
     elif model == "inverted_double_pendulum":
         s, names, default = _planar("CARLBraxInvertedDoublePendulum", "inverted_double_pendulum_sys")
+    elif model == "reacher":
+        s, names, default = _planar("CARLBraxReacher", "reacher_sys")
     else:
         s, names, default = _planar("CARLBraxInvertedPendulum", "inverted_pendulum_sys")
     rng = np.random.default_rng(100 + lanes_per_env)
@@ -660,3 +662,29 @@ def test_lane_width_is_a_pure_scheduling_choice_and_autotune_restores_state(devi
     best = eng.autotune()
     assert best in eng.lane_widths() and eng.sys.lanes_per_env == best and set(eng.autotune_ms) == set(eng.lane_widths())
     assert all(torch.equal(v, getattr(eng, k)) for k, v in before.items())
+
+
+def test_reacher_env_api_and_goal_stays_put(device):
+    """CARLBraxReacher through the CARL-shaped API (reference class carl/envs/brax/carl_reacher.py:9-39):
+    spaces, goal inside the 0.2 disc and fixed over an episode, reward = -distance - |a|^2, no
+    termination; mass context reaches the physics (a heavier arm swings less under the same torque)."""
+    from carl_amd.envs import CARLBraxReacher
+
+    n = 256
+    env = CARLBraxReacher(batch_size=n, device=device)
+    obs, info = env.reset(seed=0)
+    o0 = obs["obs"].cpu().numpy().astype(np.float64)
+    assert o0.shape == (n, 11) and env.action_space.shape == (n, 2)
+    assert np.hypot(o0[:, 4], o0[:, 5]).max() <= 0.2
+    g = torch.Generator(device="cpu").manual_seed(0)
+    for t in range(30):
+        a = (torch.rand((n, 2), generator=g) * 2 - 1).to(device)
+        o, r, te, tr, info = env.step(a)
+        on = o["obs"].cpu().numpy().astype(np.float64)
+        np.testing.assert_allclose(on[:, 4:6], o0[:, 4:6], atol=2e-4)
+        want = -np.linalg.norm(on[:, 8:11], axis=1) - (a.cpu().numpy().astype(np.float64) ** 2).sum(1)
+        np.testing.assert_allclose(r.cpu().numpy(), want, rtol=1e-5, atol=1e-5)
+        assert not te.any() and not tr.any()
+    single = CARLBraxReacher()
+    o, _ = single.reset()
+    assert o["obs"].shape == (11,)
