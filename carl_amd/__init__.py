@@ -23,6 +23,7 @@ _LAZY = {
     "CARLBraxHumanoidStandup": "carl_amd.envs.brax",
     "CARLBraxInvertedDoublePendulum": "carl_amd.envs.brax",
     "CARLBraxReacher": "carl_amd.envs.brax",
+    "CARLBraxPusher": "carl_amd.envs.brax",
     "VecEngine": "carl_amd.engine",
 }
 

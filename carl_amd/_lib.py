@@ -134,8 +134,9 @@ def family_info(family: int) -> FamilyInfo:
 
 # ---- Brax-locomotion families (carl_brax_sys_t, include/carl_amd.h) ----------------------
 BRAX_MAX_LINKS, BRAX_MAX_DOF, BRAX_MAX_Q, BRAX_MAX_ACT, BRAX_MAX_COLL, BRAX_MAX_CTX_MASS = 16, 24, 32, 24, 32, 16
+BRAX_MAX_PAIR = 8
 (BRAX_ANT, BRAX_HALFCHEETAH, BRAX_HUMANOID, BRAX_HOPPER, BRAX_WALKER2D, BRAX_INVERTED_PENDULUM, BRAX_HUMANOIDSTANDUP, BRAX_INVERTED_DOUBLE_PENDULUM,
- BRAX_REACHER) = range(9)
+ BRAX_REACHER, BRAX_PUSHER) = range(10)
 BRAX_LINK_STATE = 13
 _f, _i = C.c_float, C.c_int32
 
@@ -147,6 +148,7 @@ class BraxCtxMap(C.Structure):
         ("n_mass", _i),
         ("mass_row", _i * BRAX_MAX_CTX_MASS), ("mass_link", _i * BRAX_MAX_CTX_MASS),
         ("mass_nominal", _f * BRAX_MAX_CTX_MASS),
+        ("goal_position", _i * 3),
     ]
 
 
@@ -182,6 +184,10 @@ class BraxSys(C.Structure):
         ("tip_link", _i), ("tip_offset", _f * 3), ("tip_x_weight", _f), ("tip_height", _f), ("tip_min_height", _f),
         ("tip_vel_weight", _f * 2), ("tip_vel_dof", _i * 2),
         ("target_link", _i), ("target_max_dist", _f),
+        ("push_link", _i), ("push_goal", _f * 3), ("push_near_weight", _f), ("push_min_dist", _f),
+        ("push_lo", _f * 2), ("push_hi", _f * 2),
+        ("n_pair", _i), ("pair_link", _i), ("pair_pos", (_f * 3) * BRAX_MAX_PAIR), ("pair_radius", _f * BRAX_MAX_PAIR),
+        ("pair_obj_radius", _f), ("pair_obj_half", _f), ("pair_k", _f), ("pair_c", _f),
         ("slide_axis", ((_f * 3) * 2) * BRAX_MAX_LINKS),
         ("ctx", BraxCtxMap),
     ]

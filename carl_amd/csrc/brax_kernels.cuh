@@ -95,6 +95,7 @@ struct Layout {
   int state;   // 13 * L rows
   int wrench;  // 12 * L rows: per joint (f, t) on the child, (-f, -t') on the parent; reused by FK
   int mass;    // L rows (effective mass per link, context-scaled)
+  int goal;    // 3 rows: push task, the env's goal position (context or model default)
   int tau;     // n_dof rows
   int io;      // staging of the env's action / observation record, and of (q, qd) in reset
   int total;
@@ -103,7 +104,8 @@ struct Layout {
     l.state = 0;
     l.wrench = l.state + 13 * L;
     l.mass = l.wrench + 12 * L;
-    l.tau = l.mass + L;
+    l.goal = l.mass + L;
+    l.tau = l.goal + 3;
     l.io = l.tau + n_dof;
     l.total = l.io + io_rows;
     return l;
@@ -136,6 +138,9 @@ inline void build_topo_host(const carl_brax_sys_t& s, Topo& t) {
     t.child_begin[i] = (uint8_t)nc;
     for (int c = i + 1; c < L; ++c)
       if (s.parent[c] == i) t.child_idx[nc++] = (uint8_t)c;  // ascending: the oracle's summation order
+    // pair contact: the object (last link, jointed to the world) leaves the reaction on the gripper in
+    // its parent-side wrench rows, which the gripper sums like a child's
+    if (s.n_pair > 0 && s.pair_link == i) t.child_idx[nc++] = (uint8_t)s.push_link;
     t.coll_begin[i] = (uint8_t)nk;
     for (int k = 0; k < s.n_coll; ++k)
       if (s.coll_link[k] == i) t.coll_idx[nk++] = (uint8_t)k;
@@ -298,8 +303,43 @@ static __device__ __forceinline__ JointGeom joint_geometry(const carl_brax_sys_t
   return g;
 }
 
+// link-pair contact of the push task (carl_brax_sys_t::n_pair): run by the object's joint lane.  Returns
+// the push on the object and the reaction on the gripper link (force, torque about that link's COM).
+// The object hangs on the world, so its parent-side wrench rows are free: the reaction is parked there,
+// and Topo lists the object among the gripper's children, so phase B sums it in.  Everything goes in
+// and out BY VALUE: reference parameters of a non-inlined call pin their variables to scratch memory in
+// the caller for every model, not only for this one.
+struct PairOut {
+  v3 on_obj, on_a, t_a;
+};
+static __device__ __forceinline__ PairOut pair_contact(const carl_brax_sys_t& s, const Lds& m) {
+  const int a = s.pair_link;
+  const Body ba = m.body(a), bo = m.body(s.push_link);
+  const v3 o = bo.p - qrot(bo.r, f3(s.com[s.push_link]));
+  PairOut r{V(0, 0, 0), V(0, 0, 0), V(0, 0, 0)};
+  for (int k = 0; k < s.n_pair; ++k) {
+    const v3 rel = qrot(ba.r, f3(s.pair_pos[k]) - f3(s.com[a]));
+    const v3 cs = ba.p + rel;
+    const float rk = s.pair_radius[k];
+    if (!(fabsf(cs.z - o.z) < s.pair_obj_half + rk)) continue;
+    const float dx = o.x - cs.x, dy = o.y - cs.y;
+    const float dist = sqrtf(dx * dx + dy * dy);
+    const float depth = rk + s.pair_obj_radius - dist;
+    if (!(depth > 0.0f) || !(dist > 1e-9f)) continue;
+    const v3 n = V(dx / dist, dy / dist, 0.0f);
+    const v3 vs = ba.v + cross(ba.w, rel);
+    const float fm = s.pair_k * depth + s.pair_c * dot(vs - bo.v, n);
+    if (!(fm > 0.0f)) continue;
+    const v3 fc = n * fm;
+    r.on_obj = r.on_obj + fc;
+    r.on_a = r.on_a - fc;
+    r.t_a = r.t_a - cross(rel, fc);
+  }
+  return r;
+}
+
 // ---- one brax.spring.pipeline.step ---------------------------------------------------------
-template <bool MULTI>
+template <bool MULTI, bool TASK>
 static __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const Topo& tp, const Derived& dv, const LaneCtx& c,
                                         const Lds& m) {
   const int L = s.n_links;
@@ -352,10 +392,17 @@ static __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const T
     }
     t = t - g.wrel * s.k_ang_damp[i];
     const int wr = m.lay.wrench + 12 * i;
+    v3 pf = f * -1.0f, pt = (cross(g.rp_off, f) + t) * -1.0f;  // on the parent
+    if (TASK && s.n_pair > 0 && i == s.push_link) {
+      const PairOut po = pair_contact(s, m);
+      f = f + po.on_obj;
+      pf = po.on_a;
+      pt = po.t_a;
+    }
     m.put3(wr, f);
     m.put3(wr + 3, cross(g.rc_off, f) + t);
-    m.put3(wr + 6, f * -1.0f);
-    m.put3(wr + 9, (cross(g.rp_off, f) + t) * -1.0f);
+    m.put3(wr + 6, pf);
+    m.put3(wr + 9, pt);
   }
   phase_sync();
   // phase B -- per body: wrench sum, semi-implicit Euler, its contacts, integrate
@@ -441,7 +488,7 @@ static __device__ __forceinline__ v3 system_com(const carl_brax_sys_t& s, const 
 // link per lane; obs_extended (humanoid) appends com inertia (L x 10), com velocity (L x 6) and
 // qfrc_actuator (the tau rows; `zero_frc`: reset observations see a zero action).  `go`: envs
 // that take part (the calls are wavefront-uniform).  Ends with a phase_sync.
-template <bool MULTI>
+template <bool MULTI, bool TASK>
 static __device__ __forceinline__ void observe(const carl_brax_sys_t& s, const Derived& dv, const Lds& m, bool go,
                                         bool zero_frc) {
   const int skip = s.exclude_current_positions;
@@ -451,7 +498,7 @@ static __device__ __forceinline__ void observe(const carl_brax_sys_t& s, const D
   const int qd0 = s.n_q - skip + n_trig;  // first qd row in the observation
   const int L = s.n_links;
   const float clipv = s.obs_qd_clip > 0.0f ? s.obs_qd_clip : 3.0e38f;  // hopper / walker2d clip velocities
-  const bool keep_raw = s.tip_link > 0 && s.target_link == 0;  // the tip reward uses unclipped rates: parked in the wrench rows
+  const bool keep_raw = s.tip_link > 0 && !(TASK && (s.target_link > 0 || s.push_link > 0));  // the tip reward uses unclipped rates: parked in the wrench rows
   auto put_qd = [&](int dof, float v) {
     m.at(m.lay.io + qd0 + dof) = fminf(fmaxf(v, -clipv), clipv);
     if (keep_raw) m.at(m.lay.wrench + dof) = v;
@@ -537,7 +584,23 @@ static __device__ __forceinline__ void observe(const carl_brax_sys_t& s, const D
       }
     phase_sync();
   }
-  if (s.target_link > 0) {  // reach task: the rows q ++ qd written above are parked in the wrench rows (free
+  if (TASK && s.push_link > 0) {  // push task: arm q ++ arm qd ++ COM of the end effector, the object, the goal
+    const int na = s.q_start[s.push_link], nq = s.n_q;
+    if (go)
+      for (int i = m.sub; i < na; i += kSub) m.at(m.lay.wrench + i) = m.at(m.lay.io + nq + i);
+    phase_sync();
+    if (go) {
+      for (int i = m.sub; i < na; i += kSub) m.at(m.lay.io + na + i) = m.at(m.lay.wrench + i);
+      for (int j = m.sub; j < 3; j += kSub) {
+        const int k = m.lay.io + 2 * na + j;
+        m.at(k) = m.at(m.lay.state + 13 * s.tip_link + j);
+        m.at(k + 3) = m.at(m.lay.state + 13 * s.push_link + j);
+        m.at(k + 6) = m.at(m.lay.goal + j);
+      }
+    }
+    phase_sync();
+  }
+  if (TASK && s.target_link > 0) {  // reach task: the rows q ++ qd written above are parked in the wrench rows (free
                             // here) and laid out again as cos ++ sin ++ goal q ++ arm qd ++ (tip - goal)
     const int tq = s.q_start[s.target_link], td = s.dof_start[s.target_link], nq = s.n_q;
     if (go)
@@ -635,30 +698,57 @@ static __device__ __forceinline__ float draw_u(uint64_t seed, uint64_t g, uint32
   return u01(x);
 }
 
-// wavefront-uniform call; `go`: envs that are reset
-static __device__ __noinline__ void reset_state(const carl_brax_sys_t& s, const Topo& tp, const carl_batch_t& b, const Lds& m,
+// push task: the env's goal position (context rows goal_position_*, else the model's) -> the goal rows
+static __device__ __forceinline__ void put_goal(const carl_brax_sys_t& s, const carl_batch_t& b, const Lds& m, int c, bool go) {
+  if (go)
+    for (int j = m.sub; j < 3; j += kSub) {
+      const int row = s.ctx.goal_position[j];
+      m.at(m.lay.goal + j) = row >= 0 ? b.ctx_table[(size_t)row * b.ctx_stride + c] : s.push_goal[j];
+    }
+}
+
+// wavefront-uniform call; `go`: envs that are reset.  Push task: the caller has put the envs' goal rows
+// (put_goal + phase_sync) -- the batch descriptor stays out of this non-inlined function's arguments: by
+// reference it would have to live in scratch memory for the whole kernel.
+template <bool TASK>
+static __device__ __noinline__ void reset_state(const carl_brax_sys_t& s, const Topo& tp, uint64_t seed, const Lds& m,
                                          uint64_t genv, uint32_t episode, bool go) {
   if (go) {
-    const int tq = s.target_link > 0 ? s.q_start[s.target_link] : s.n_q;     // reach task: the goal's
-    const int td = s.target_link > 0 ? s.dof_start[s.target_link] : s.n_dof;  // coordinates / rates start here
+    const int tl = !TASK ? 0 : s.target_link > 0 ? s.target_link : s.push_link;  // reach / push task: the last link's
+    const int tq = tl > 0 ? s.q_start[tl] : s.n_q;                    // coordinates / rates are set by the
+    const int td = tl > 0 ? s.dof_start[tl] : s.n_dof;                // task, not by the noise
     for (int i = m.sub; i < s.n_q; i += kSub) {
-      float v = s.init_q[i] + s.reset_noise_scale * (2.0f * draw_u(b.seed, genv, episode, i) - 1.0f);
-      if (i >= tq) {  // brax.envs.reacher._random_target: uniform distance and bearing
-        const float dist = s.target_max_dist * draw_u(b.seed, genv, episode, s.n_q + s.n_dof);
-        float sn, cs;
-        sincos_fast(2.0f * kPiF * draw_u(b.seed, genv, episode, s.n_q + s.n_dof + 1), sn, cs);
-        v = dist * (i == tq ? cs : sn);
+      float v = s.init_q[i] + s.reset_noise_scale * (2.0f * draw_u(seed, genv, episode, i) - 1.0f);
+      if (TASK && i >= tq) {
+        const float u0 = draw_u(seed, genv, episode, s.n_q + s.n_dof);
+        const float u1 = draw_u(seed, genv, episode, s.n_q + s.n_dof + 1);
+        if (s.target_link > 0) {  // brax.envs.reacher._random_target: uniform distance and bearing
+          float sn, cs;
+          sincos_fast(2.0f * kPiF * u1, sn, cs);
+          v = s.target_max_dist * u0 * (i == tq ? cs : sn);
+        } else {  // brax.envs.pusher.reset: a box in front of the arm, pushed out of the goal's disc
+          const float gx = m.at(m.lay.goal), gy = m.at(m.lay.goal + 1);
+          float dx = s.link_pos[tl][0] + s.push_lo[0] + (s.push_hi[0] - s.push_lo[0]) * u0 - gx;
+          float dy = s.link_pos[tl][1] + s.push_lo[1] + (s.push_hi[1] - s.push_lo[1]) * u1 - gy;
+          const float nrm = sqrtf(dx * dx + dy * dy);
+          if (nrm < s.push_min_dist) {
+            const float sc = s.push_min_dist / fmaxf(nrm, 1e-12f);
+            dx *= sc;
+            dy *= sc;
+          }
+          v = (i == tq) ? gx + dx - s.link_pos[tl][0] : gy + dy - s.link_pos[tl][1];
+        }
       }
       m.at(m.lay.io + i) = v;
     }
     if (s.reset_vel_uniform) {
       for (int i = m.sub; i < s.n_dof; i += kSub)
         m.at(m.lay.io + s.n_q + i) =
-            i >= td ? 0.0f : s.reset_vel_scale * (2.0f * draw_u(b.seed, genv, episode, s.n_q + i) - 1.0f);
+            (TASK && i >= td) ? 0.0f : s.reset_vel_scale * (2.0f * draw_u(seed, genv, episode, s.n_q + i) - 1.0f);
     } else {
       for (int i = 2 * m.sub; i < s.n_dof; i += 2 * kSub) {  // one Box-Muller pair per lane
         const int k = s.n_q + i;
-        const float u1 = draw_u(b.seed, genv, episode, k), u2 = draw_u(b.seed, genv, episode, k + 1);
+        const float u1 = draw_u(seed, genv, episode, k), u2 = draw_u(seed, genv, episode, k + 1);
         const float rad = sqrtf(-2.0f * logf(1.0f - u1));
         float sn, cs;
         sincos_fast(2.0f * kPiF * u2, sn, cs);
@@ -672,6 +762,7 @@ static __device__ __noinline__ void reset_state(const carl_brax_sys_t& s, const 
 }
 
 // context scalars of the env + its mass rows (wavefront-uniform call; ends with a phase_sync)
+template <bool TASK>
 static __device__ __forceinline__ LaneCtx load_ctx(const carl_brax_sys_t& s, const carl_batch_t& b, const Lds& m, int c,
                                             bool go) {
   const carl_brax_ctx_map_t& cm = s.ctx;
@@ -685,6 +776,7 @@ static __device__ __forceinline__ LaneCtx load_ctx(const carl_brax_sys_t& s, con
     lc.stiffness_scale = get(cm.joint_stiffness_scale, 1.0f);
     for (int i = m.sub; i < s.n_links; i += kSub) m.at(m.lay.mass + i) = s.mass[i];
   }
+  if (TASK && s.push_link > 0) put_goal(s, b, m, c, go);
   phase_sync();
   if (go)
     for (int k = m.sub; k < cm.n_mass; k += kSub)
@@ -753,7 +845,7 @@ static __device__ __forceinline__ void write_ctx_obs(const carl_batch_t& b, cons
 }
 
 // mode 0: reset (mask optional), mode 1: n_steps env steps (1 = per call, T = fused rollout)
-template <int MODE, bool MULTI>
+template <int MODE, bool MULTI, bool TASK>
 static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_brax_sys_t* __restrict__ sys_dev,
                                            const Prepared& prep, const carl_step_io_t& io,
                                            const uint8_t* __restrict__ mask, float* __restrict__ reset_obs,
@@ -817,7 +909,11 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
     const bool go = active && (mask == nullptr || mask[env] != 0);
     if (__ballot(go) == 0ull) return;
     if (go) r.cidx = select_context(b, r.cidx, genv, r.episode);
-    reset_state(s, tp, b, m, genv, r.episode, go);
+    if (TASK && s.push_link > 0) {  // the object is placed relative to the env's goal
+      put_goal(s, b, m, r.cidx, go);
+      phase_sync();
+    }
+    reset_state<TASK>(s, tp, b.seed, m, genv, r.episode, go);
     r.episode += 1u;
     if (go) {
       for (int k = m.sub; k < S; k += kSub) b.state[(size_t)env * S + k] = m.at(m.lay.state + k);
@@ -834,8 +930,8 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
       }
       write_ctx_obs(b, m, n, env, r.cidx);
     }
-    if (s.obs_extended) load_ctx(s, b, m, r.cidx, go);  // com inertia / velocity use the env's masses
-    observe<MULTI>(s, dv, m, go, true);
+    if (s.obs_extended) load_ctx<TASK>(s, b, m, r.cidx, go);  // com inertia / velocity use the env's masses
+    observe<MULTI, TASK>(s, dv, m, go, true);
     if (reset_obs != nullptr) record_out(reset_obs, (size_t)env, s.obs_dim, m, go);
     return;
   } else {
@@ -856,7 +952,7 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
         }
       }
     }
-    r.ctx = load_ctx(s, b, m, r.cidx, active);
+    r.ctx = load_ctx<TASK>(s, b, m, r.cidx, active);
     if (goal && active) {
       load_goal(s, b, r.cidx, r);
       r.pos_x = b.goal_pos[env];
@@ -880,14 +976,14 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
       const Body b0 = m.body(0);
       float msum;
       const float x0 = s.reward_on_com ? system_com(s, m, &msum).x : b0.p.x - qrot(b0.r, f3(s.com[0])).x;
-      for (int f = 0; f < s.n_frames; ++f) substep<MULTI>(s, tp, dv, r.ctx, m);
+      for (int f = 0; f < s.n_frames; ++f) substep<MULTI, TASK>(s, tp, dv, r.ctx, m);
       const Body b1 = m.body(0);
       const v3 c1 = qrot(b1.r, f3(s.com[0]));
       const float x1 = s.reward_on_com ? system_com(s, m, &msum).x : b1.p.x - c1.x, z1 = b1.p.z - c1.z;
       bool healthy = (z1 >= s.healthy_z_lo) && (z1 <= s.healthy_z_hi);
       r.elapsed += 1;
       const bool truncated = (b.max_episode_steps > 0) && (r.elapsed >= b.max_episode_steps);
-      observe<MULTI>(s, dv, m, active, false);
+      observe<MULTI, TASK>(s, dv, m, active, false);
       if (s.healthy_q_index >= 0) {  // torso pitch (hopper, walker2d) / pole angle: read from the observation
         const float qa = m.at(m.lay.io + s.healthy_q_index - s.exclude_current_positions);
         healthy = healthy && (qa >= s.healthy_q_lo) && (qa <= s.healthy_q_hi);
@@ -896,7 +992,13 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
                      (s.terminate_when_unhealthy ? s.healthy_reward : (healthy ? s.healthy_reward : 0.0f)) -
                      s.ctrl_cost_weight * ctrl;
       bool terminated = s.terminate_when_unhealthy && !healthy;
-      if (s.target_link > 0) {  // brax.envs.reacher: the observation ends with tip - goal
+      if (TASK && s.push_link > 0) {  // brax.envs.pusher: the observation ends with end effector, object, goal
+        const int k = m.lay.io + s.obs_dim - 9;
+        const v3 tipc = m.get3(k), obj = m.get3(k + 3), gl = m.get3(k + 6);
+        const v3 d1 = obj - tipc, d2 = obj - gl;
+        reward = -sqrtf(dot(d2, d2)) - s.ctrl_cost_weight * ctrl - s.push_near_weight * sqrtf(dot(d1, d1));
+        terminated = false;
+      } else if (TASK && s.target_link > 0) {  // brax.envs.reacher: the observation ends with tip - goal
         const int k = m.lay.io + s.obs_dim - 3;
         const float dx = m.at(k), dy = m.at(k + 1), dz = m.at(k + 2);
         reward = -sqrtf(dx * dx + dy * dy + dz * dz) - s.ctrl_cost_weight * ctrl;
@@ -945,8 +1047,12 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
             record_out(io.final_obs + step_off * s.obs_dim, (size_t)env, s.obs_dim, m, done);
           phase_sync();  // the io rows are rewritten below
           if (done) r.cidx = select_context(b, r.cidx, genv, r.episode);
-          reset_state(s, tp, b, m, genv, r.episode, done);
-          const LaneCtx nc = load_ctx(s, b, m, r.cidx, done);
+          if (TASK && s.push_link > 0) {
+            put_goal(s, b, m, r.cidx, done);
+            phase_sync();
+          }
+          reset_state<TASK>(s, tp, b.seed, m, genv, r.episode, done);
+          const LaneCtx nc = load_ctx<TASK>(s, b, m, r.cidx, done);
           if (done) {
             r.episode += 1u;
             r.ctx = nc;
@@ -959,7 +1065,7 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
             r.n_new_calls += 1;
             write_ctx_obs(b, m, n, env, r.cidx);
           }
-          observe<MULTI>(s, dv, m, done, true);
+          observe<MULTI, TASK>(s, dv, m, done, true);
         }
       }
       record_out(io.obs + step_off * s.obs_dim, (size_t)env, s.obs_dim, m, active);
@@ -987,12 +1093,15 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
 
 };  // struct Group
 
-template <int MODE, bool MULTI, int K>
+// TASK: the model is a reach / push task (target_link / push_link / pair contacts); false compiles that code
+// out, as MULTI = false does for the Euler-angle joints.  Task models always have a hinge-less last link,
+// so TASK implies MULTI.
+template <int MODE, bool MULTI, int K, bool TASK = false>
 __global__ void __launch_bounds__(kLanes) brax_kernel(const carl_batch_t b, const carl_brax_sys_t* __restrict__ sys_dev,
                                                       const Prepared prep, const carl_step_io_t io,
                                                       const uint8_t* __restrict__ mask, float* __restrict__ reset_obs,
                                                       const int n_steps) {
-  Group<K>::template run<MODE, MULTI>(b, sys_dev, prep, io, mask, reset_obs, n_steps);
+  Group<K>::template run<MODE, MULTI, TASK>(b, sys_dev, prep, io, mask, reset_obs, n_steps);
 }
 
 }  // namespace brax

@@ -45,7 +45,7 @@ int validate_brax(const carl_batch_t* b, const carl_brax_sys_t* sd, const carl_b
     return fail(CARL_ERR_INVALID_ARGUMENT, "%s: obs_trig_from %d out of range", who, sh->obs_trig_from);
   if (sh->tip_link < 0 || sh->tip_link >= sh->n_links)
     return fail(CARL_ERR_INVALID_ARGUMENT, "%s: tip_link %d out of range", who, sh->tip_link);
-  if (sh->tip_link > 0 && sh->target_link == 0)
+  if (sh->tip_link > 0 && sh->target_link == 0 && sh->push_link == 0)
     for (int k = 0; k < 2; ++k)
       if (sh->tip_vel_dof[k] < 0 || sh->tip_vel_dof[k] >= sh->n_dof)
         return fail(CARL_ERR_INVALID_ARGUMENT, "%s: tip_vel_dof[%d] = %d out of range", who, k, sh->tip_vel_dof[k]);
@@ -60,6 +60,21 @@ int validate_brax(const carl_batch_t* b, const carl_brax_sys_t* sd, const carl_b
       (sh->healthy_q_index < sh->exclude_current_positions || sh->healthy_q_index >= sh->n_q))
     return fail(CARL_ERR_INVALID_ARGUMENT, "%s: healthy_q_index %d must be an observed coordinate", who,
                 sh->healthy_q_index);
+  if (sh->push_link != 0) {  // push task (see carl_brax_sys_t::push_link)
+    const int t = sh->push_link;
+    if (t != sh->n_links - 1 || t < 1 || sh->parent[t] != -1 || sh->n_slide[t] != 2 || sh->n_link_dof[t] != 2)
+      return fail(CARL_ERR_INVALID_ARGUMENT, "%s: push_link must be the last link, on two slides against the world", who);
+    if (sh->target_link != 0 || sh->tip_link < 1 || sh->tip_link >= t || sh->exclude_current_positions != 0 ||
+        sh->obs_trig_from != 0 || sh->obs_extended || sh->goal_mode || !sh->reset_vel_uniform)
+      return fail(CARL_ERR_INVALID_ARGUMENT,
+                  "%s: the push task needs an end-effector link, the plain q ++ qd observation and uniform reset rates", who);
+    if (sh->q_start[t] != sh->dof_start[t])
+      return fail(CARL_ERR_UNSUPPORTED, "%s: push task: the arm must be hinges only", who);
+    if (sh->n_pair < 0 || sh->n_pair > CARL_BRAX_MAX_PAIR || (sh->n_pair > 0 && (sh->pair_link < 0 || sh->pair_link >= t)))
+      return fail(CARL_ERR_INVALID_ARGUMENT, "%s: pair contact table out of range", who);
+  } else if (sh->n_pair != 0) {
+    return fail(CARL_ERR_INVALID_ARGUMENT, "%s: pair contacts belong to the push task", who);
+  }
   if (sh->target_link != 0) {  // reach task (see carl_brax_sys_t::target_link)
     const int t = sh->target_link;
     if (t != sh->n_links - 1 || t < 1 || sh->parent[t] != -1 || sh->n_slide[t] != 2 || sh->n_link_dof[t] != 2)
@@ -76,6 +91,7 @@ int validate_brax(const carl_batch_t* b, const carl_brax_sys_t* sd, const carl_b
                      (sh->obs_trig_from > 0 ? sh->n_q - sh->obs_trig_from : 0);
     int want = sh->obs_extended ? base + 16 * sh->n_links + sh->n_dof : base;
     if (sh->target_link > 0) want = sh->q_start[sh->target_link] + sh->n_q + sh->dof_start[sh->target_link] + 3;
+    if (sh->push_link > 0) want = 2 * sh->q_start[sh->push_link] + 9;
     if (sh->obs_dim != want)
       return fail(CARL_ERR_INVALID_ARGUMENT, "%s: obs_dim %d does not match the model (%d)", who, sh->obs_dim, want);
   }
@@ -91,9 +107,11 @@ int validate_brax(const carl_batch_t* b, const carl_brax_sys_t* sd, const carl_b
 // (width, MULTI) pair, and widened for small batches so that the launch has at least two
 // wavefronts per SIMD.  CARL_AMD_BRAX_SUB=<width> overrides (tests, experiments).
 constexpr int kBraxWidths[] = {2, 4, 7, 8, 9, 11, 16};
-constexpr bool brax_instantiated(int k, bool multi) {
+constexpr bool brax_instantiated(int k, bool multi, bool task) {
+  if (task) return k == 4 || k == 8 || k == 16;  // reacher: 3 links, pusher: 8
   return multi ? (k == 2 || k == 11 || k == 16) : (k == 4 || k == 7 || k == 8 || k == 9 || k == 16);
 }
+bool brax_is_task(const carl_brax_sys_t* sh) { return sh->target_link > 0 || sh->push_link > 0; }
 bool brax_is_multi(const carl_brax_sys_t* sh) {  // any link with 0, 2 or 3 hinges (Euler-angle path)?
   bool multi = false;
   for (int i = 0; i < sh->n_links; ++i) {
@@ -102,7 +120,7 @@ bool brax_is_multi(const carl_brax_sys_t* sh) {  // any link with 0, 2 or 3 hing
   }
   return multi;
 }
-int brax_lanes_per_env(int n_links, bool multi, int n_lanes, int hint) {
+int brax_lanes_per_env(int n_links, bool multi, bool task, int n_lanes, int hint) {
   int want = n_links;
   bool pinned = false;
   if (hint > 0) {  // sys.lanes_per_env (autotuned by the caller)
@@ -118,7 +136,7 @@ int brax_lanes_per_env(int n_links, bool multi, int n_lanes, int hint) {
   }
   int k = 16;
   for (int w : kBraxWidths)
-    if (w >= want && brax_instantiated(w, multi)) {
+    if (w >= want && brax_instantiated(w, multi, task)) {
       k = w;
       break;
     }
@@ -126,7 +144,7 @@ int brax_lanes_per_env(int n_links, bool multi, int n_lanes, int hint) {
     while (k < 16 && ((long long)n_lanes + 64 / k - 1) / (64 / k) < 2048) {
       int next = 16;
       for (int w : kBraxWidths)
-        if (w > k && brax_instantiated(w, multi)) {
+        if (w > k && brax_instantiated(w, multi, task)) {
           next = w;
           break;
         }
@@ -140,8 +158,8 @@ int launch_brax(const carl_batch_t* b, const carl_brax_sys_t* sd, const carl_bra
                        const carl_step_io_t* io, const uint8_t* mask, float* reset_obs, int n_steps, hipStream_t st,
                        const char* who) {
   if (b->n_lanes == 0 || (MODE == 1 && n_steps == 0)) return 0;
-  const bool multi = brax_is_multi(sh);
-  const int K = brax_lanes_per_env(sh->n_links, multi, b->n_lanes, sh->lanes_per_env);
+  const bool multi = brax_is_multi(sh), task = brax_is_task(sh);  // task models have a hinge-less last link: multi
+  const int K = brax_lanes_per_env(sh->n_links, multi, task, b->n_lanes, sh->lanes_per_env);
   const int envs = carl::brax::kLanes / K;  // one wavefront = envs x K lanes; LDS rows are `envs` floats wide
   const carl::brax::Layout lay = carl::brax::Layout::make(sh->n_links, sh->n_dof, carl::brax::io_rows_of(*sh));
   const size_t sh_bytes = (size_t)lay.total * envs * sizeof(float);
@@ -151,7 +169,12 @@ int launch_brax(const carl_batch_t* b, const carl_brax_sys_t* sd, const carl_bra
                           float*, int);
   kern_t kern = nullptr;
 #define CARL_PICK(KK, MM) \
-  if (K == KK && multi == MM) kern = static_cast<kern_t>(carl::brax::brax_kernel<MODE, MM, KK>)
+  if (!task && K == KK && multi == MM) kern = static_cast<kern_t>(carl::brax::brax_kernel<MODE, MM, KK>)
+#define CARL_PICK_TASK(KK) \
+  if (task && K == KK) kern = static_cast<kern_t>(carl::brax::brax_kernel<MODE, true, KK, true>)
+  CARL_PICK_TASK(4);
+  CARL_PICK_TASK(8);
+  CARL_PICK_TASK(16);
   CARL_PICK(2, true);
   CARL_PICK(11, true);
   CARL_PICK(16, true);
@@ -161,6 +184,7 @@ int launch_brax(const carl_batch_t* b, const carl_brax_sys_t* sd, const carl_bra
   CARL_PICK(9, false);
   CARL_PICK(16, false);
 #undef CARL_PICK
+#undef CARL_PICK_TASK
   if (kern == nullptr) return fail(CARL_ERR_UNSUPPORTED, "%s: no kernel for %d lanes per env", who, K);
   if (sh_bytes > 48 * 1024) {
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -222,7 +246,7 @@ int carl_brax_lane_widths(const carl_brax_sys_t* sys_host, int32_t* widths_out, 
   const bool multi = brax_is_multi(sys_host);
   int n = 0;
   for (int w : kBraxWidths)
-    if (brax_instantiated(w, multi) && n < cap) widths_out[n++] = w;
+    if (brax_instantiated(w, multi, brax_is_task(sys_host)) && n < cap) widths_out[n++] = w;
   return n;
 }
 

@@ -46,6 +46,9 @@ def check_context(context: dict[str, Any], registered_context_features: list[str
 class CARLBraxEnv(CARLEnv):
     env_name: str
     backend: str = "spring"
+    # features a subclass hands to the task instead of the brax system (CARLBraxPusher removes its goal
+    # position from the context before the system update and sets the env's goal: carl_pusher.py:91-103)
+    task_context_features: tuple = ()
 
     def __init__(
         self,
@@ -131,7 +134,7 @@ class CARLBraxEnv(CARLEnv):
     @contexts.setter
     def contexts(self, contexts: Contexts) -> None:
         for c in contexts.values() if not hasattr(contexts, "names") else []:
-            check_context(c, REGISTERED_CFS)
+            check_context(c, REGISTERED_CFS + list(self.task_context_features))
         CARLEnv.contexts.fset(self, contexts)
 
     def step(self, action: Any):

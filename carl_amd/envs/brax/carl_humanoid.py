@@ -28,7 +28,7 @@ class CARLBraxHumanoid(CARLBraxEnv):
             "gravity": U("gravity", lower=-1000, upper=-1e-6, default_value=-9.8),
             "friction": U("friction", lower=0, upper=100, default_value=1),
             "elasticity": U("elasticity", lower=0, upper=100, default_value=0),
-            "ang_damping": U("ang_damping", lower=-np.inf, upper=np.inf, default_value=-0.0),
+            "ang_damping": U("ang_damping", lower=-np.inf, upper=np.inf, default_value=-0.05),
             "viscosity": U("viscosity", lower=0, upper=np.inf, default_value=0),
         }
         for name, default in HUMANOID_MASSES.items():

@@ -121,6 +121,8 @@ def _wire_context(s, feature_names, reference_compat, link_ids, mass_defaults):
     m.gravity = m.friction = m.elasticity = m.ang_damping = m.joint_stiffness_scale = -1
     m.target_distance = m.target_direction = m.target_radius = -1
     m.n_mass = 0
+    for k in range(3):
+        m.goal_position[k] = -1
     if not feature_names:
         return
     col = {n: i for i, n in enumerate(feature_names)}
@@ -135,6 +137,8 @@ def _wire_context(s, feature_names, reference_compat, link_ids, mass_defaults):
     m.elasticity = col.get("elasticity", -1)
     m.ang_damping = col.get("ang_damping", -1)
     m.joint_stiffness_scale = col.get("joint_stiffness", -1)
+    for k, axis in enumerate("xyz"):  # push task (carl_pusher.py:91-103 hands them to the env as its goal)
+        m.goal_position[k] = col.get(f"goal_position_{axis}", -1)
     for name, i in col.items():
         if name.startswith("mass_"):
             link = name.split("_", 1)[-1]
@@ -741,5 +745,103 @@ def reacher_sys(feature_names: list[str] | None = None, reference_compat: bool =
     return s
 
 
-SYSTEMS = {"reacher": reacher_sys, "inverted_double_pendulum": inverted_double_pendulum_sys, "humanoidstandup": humanoidstandup_sys, "ant": ant_sys, "halfcheetah": halfcheetah_sys, "humanoid": humanoid_sys, "hopper": hopper_sys,
+PUSHER_MASSES = {
+    "mass_r_shoulder_pan_link": 7.2935214, "mass_r_shoulder_lift_link": math.pi, "mass_r_upper_arm_roll_link": 1.7140529,
+    "mass_r_elbow_flex_link": 4.0715042e-01, "mass_r_forearm_roll_link": 9.2818356e-01,
+    "mass_r_wrist_flex_link": 5.0265482e-03, "mass_r_wrist_roll_link": 1.8346901e-01, "mass_object": 1.8325957e-03,
+}
+
+
+def pusher_sys(feature_names: list[str] | None = None, reference_compat: bool = False) -> _lib.BraxSys:
+    """Pusher: a 7-hinge arm (shoulder pan z / lift y / upper-arm roll x, elbow flex y, forearm roll x,
+    wrist flex y / roll x; the jointless upper-arm, forearm and fork bodies are fused into their
+    parents as brax's MJCF loader does) whose U-shaped gripper pushes a puck (radius 0.05, half height
+    0.05, on two damped slides at table height) towards a goal.  q 9, qd 9, 7 motors (gear 1, ctrl +-2),
+    obs 23 = arm q ++ arm qd ++ COM of the gripper link, the puck, the goal; reward = -|puck - goal| -
+    0.1 |a|^2 - 0.5 |puck - gripper|; never terminates; reset: arm at init_q with rates U(+-0.005), puck
+    uniform in [-0.3, 0] x [-0.2, 0.2] about its MJCF position, pushed out of the 0.17 disc around the
+    goal.  Restated from upstream memory of brax's ``pusher.xml`` (a Gym Pusher derivative: gravity
+    0 0 0 in the MJCF, joint damping 1 / 0.1) and ``brax/envs/pusher.py``.  The goal position is the
+    context's ``goal_position_x/y/z`` (carl/envs/brax/carl_pusher.py:80-103 hands it to the env as
+    ``_goal_pos``); without those rows it is the MJCF goal body (0.45, -0.05, -0.323), and brax's goal
+    marker body (two slides, no collisions) is not simulated.  Link masses are the reference's defaults
+    (carl_pusher.py:37-79).  This build's choices: rotational inertias 1 (shoulder) ... 0.05 (wrist) in
+    place of armature 0.04 + geometry; gripper-puck contact = 7 spheres along the fork against the puck
+    (frictionless penalty contact, ``carl_brax_sys_t::n_pair``), no table plane; dt 0.001 x 50 so that
+    the 1.8 g puck and the 5 g wrist link sit on explicit springs.  NOTE the reference's context default
+    gravity = -9.8 applies in the intended form (the MJCF has none): the 2 N m motors do not hold the arm
+    against it.  PARITY UNPINNED."""
+    s = _lib.BraxSys()
+    s.env_kind = _lib.BRAX_PUSHER
+    s.n_links, s.n_q, s.n_dof, s.n_act = 8, 9, 9, 7
+    s.push_link, s.tip_link = 7, 6
+    for c, v in enumerate((0.45, -0.05, -0.323)):
+        s.push_goal[c] = v
+    s.push_near_weight, s.push_min_dist = 0.5, 0.17
+    s.push_lo[0], s.push_hi[0], s.push_lo[1], s.push_hi[1] = -0.3, 0.0, -0.2, 0.2
+    s.obs_dim = 23
+    s.max_episode_steps = 1000
+    s.terminate_when_unhealthy = 0
+    s.exclude_current_positions = 0
+    s.reset_vel_uniform = 1
+    s.dt, s.n_frames = 0.001, 50
+    s.gravity_z, s.vel_damping, s.ang_damping = 0.0, 0.0, 0.0
+    s.baumgarte_erp, s.elasticity, s.friction = 0.1, 0.0, 1.0
+    s.healthy_z_lo, s.healthy_z_hi = -1e9, 1e9
+    s.healthy_q_index = -1
+    s.healthy_reward, s.ctrl_cost_weight, s.forward_reward_weight = 0.0, 0.1, 0.0
+    s.reset_noise_scale, s.reset_vel_scale = 0.0, 0.005
+    ident = (1.0, 0.0, 0.0, 0.0)
+    X, Y, Z = (1, 0, 0), (0, 1, 0), (0, 0, 1)
+    names = ["r_shoulder_pan_link", "r_shoulder_lift_link", "r_upper_arm_roll_link", "r_elbow_flex_link",
+             "r_forearm_roll_link", "r_wrist_flex_link", "r_wrist_roll_link", "object"]
+    # parent, position in the parent, hinge axis, range, damping, COM, inertia, k_pos, k_vel
+    arm = [(-1, (0.0, -0.6, 0.0), Z, (-2.2854, 1.714602), 1.0, (0.0, 0.0, -0.2), 1.0, 20000.0, 200.0),
+           (0, (0.1, 0.0, 0.0), Y, (-0.5236, 1.3963), 1.0, (0.0, 0.0, 0.0), 1.0, 20000.0, 100.0),
+           (1, (0.0, 0.0, 0.0), X, (-1.5, 1.7), 0.1, (0.2, 0.0, 0.0), 0.5, 10000.0, 50.0),
+           (2, (0.4, 0.0, 0.0), Y, (-2.3213, 0.0), 0.1, (0.0, 0.0, 0.0), 0.2, 5000.0, 20.0),
+           (3, (0.0, 0.0, 0.0), X, (-1.5, 1.5), 0.1, (0.14, 0.0, 0.0), 0.2, 5000.0, 20.0),
+           (4, (0.321, 0.0, 0.0), Y, (-1.094, 0.0), 0.1, (0.0, 0.0, 0.0), 0.05, 1000.0, 2.0),
+           (5, (0.0, 0.0, 0.0), X, (-1.5, 1.5), 0.1, (0.03, 0.0, 0.0), 0.05, 1000.0, 5.0)]
+    for i, (parent, pos, axis, rng, damp, com, inertia, kp, kv) in enumerate(arm):
+        s.parent[i], s.n_slide[i], s.n_link_dof[i], s.q_start[i], s.dof_start[i] = parent, 0, 1, i, i
+        _set3(s.link_pos, i, pos)
+        _set3(s.link_rot, i, ident)
+        _set3(s.joint_rot, i, _axis_quat(axis))
+        _set3(s.com, i, com)
+        s.mass[i] = PUSHER_MASSES["mass_" + names[i]]
+        _set3(s.inv_inertia, i, (1.0 / inertia,) * 3)
+        s.dof_lo[i], s.dof_hi[i] = rng
+        s.dof_damping[i] = damp
+        s.k_pos[i], s.k_vel[i], s.k_limit[i], s.k_ang_damp[i] = kp, kv, 100.0, 0.5
+        s.act_dof[i], s.act_gear[i], s.act_lo[i], s.act_hi[i] = i, 1.0, -2.0, 2.0
+    # the puck: two slides against the world, no rotational dof
+    s.parent[7], s.n_slide[7], s.n_link_dof[7], s.q_start[7], s.dof_start[7] = -1, 2, 2, 7, 7
+    _set3(s.link_pos, 7, (0.45, -0.05, -0.275))
+    _set3(s.link_rot, 7, ident)
+    _set3(s.joint_rot, 7, ident)
+    for k, ax in enumerate((X, Y)):
+        for c, v in enumerate(ax):
+            s.slide_axis[7][k][c] = float(v)
+        s.dof_lo[7 + k], s.dof_hi[7 + k] = -10.3213, 10.3213
+        s.dof_damping[7 + k] = 0.5
+    s.mass[7] = PUSHER_MASSES["mass_object"]
+    _set3(s.inv_inertia, 7, (1.0,) * 3)
+    s.k_pos[7], s.k_vel[7], s.k_limit[7], s.k_ang_damp[7] = 500.0, 0.5, 100.0, 1.0
+    for i in range(8):
+        s.dof_sign3[i] = 1.0
+    s.n_coll = 0
+    # the fork of r_wrist_roll_link: cross bar (0, +-0.1, 0) and two prongs reaching x = 0.1
+    fork = [(0.0, -0.1, 0.0), (0.0, 0.0, 0.0), (0.0, 0.1, 0.0), (0.05, -0.1, 0.0), (0.1, -0.1, 0.0),
+            (0.05, 0.1, 0.0), (0.1, 0.1, 0.0)]
+    s.n_pair, s.pair_link = len(fork), 6
+    for k, pos in enumerate(fork):
+        _set3(s.pair_pos, k, pos)
+        s.pair_radius[k] = 0.02
+    s.pair_obj_radius, s.pair_obj_half, s.pair_k, s.pair_c = 0.05, 0.05, 500.0, 0.5
+    _wire_context(s, feature_names, reference_compat, {n: i for i, n in enumerate(names)}, PUSHER_MASSES)
+    return s
+
+
+SYSTEMS = {"pusher": pusher_sys, "reacher": reacher_sys, "inverted_double_pendulum": inverted_double_pendulum_sys, "humanoidstandup": humanoidstandup_sys, "ant": ant_sys, "halfcheetah": halfcheetah_sys, "humanoid": humanoid_sys, "hopper": hopper_sys,
            "walker2d": walker2d_sys, "inverted_pendulum": inverted_pendulum_sys}

@@ -213,10 +213,11 @@ int32_t carl_done_compact_scratch_elems(int32_t n);
 #define CARL_BRAX_MAX_ACT 24
 #define CARL_BRAX_MAX_COLL 32
 #define CARL_BRAX_MAX_CTX_MASS 16
+#define CARL_BRAX_MAX_PAIR 8
 
 enum { CARL_BRAX_ANT = 0, CARL_BRAX_HALFCHEETAH = 1, CARL_BRAX_HUMANOID = 2, CARL_BRAX_HOPPER = 3, CARL_BRAX_WALKER2D = 4,
        CARL_BRAX_INVERTED_PENDULUM = 5, CARL_BRAX_HUMANOIDSTANDUP = 6, CARL_BRAX_INVERTED_DOUBLE_PENDULUM = 7,
-       CARL_BRAX_REACHER = 8 };
+       CARL_BRAX_REACHER = 8, CARL_BRAX_PUSHER = 9 };
 
 /* context-table rows the physics reads (row index in the family's feature table, -1 =
  * feature absent -> the model default is used) */
@@ -227,6 +228,7 @@ typedef struct carl_brax_ctx_map {
   int32_t mass_row[CARL_BRAX_MAX_CTX_MASS];     /* table row */
   int32_t mass_link[CARL_BRAX_MAX_CTX_MASS];    /* link it scales */
   float mass_nominal[CARL_BRAX_MAX_CTX_MASS];   /* CARL default: value / nominal scales the link's effective mass */
+  int32_t goal_position[3];                     /* push task: goal_position_x / _y / _z rows (carl_pusher.py:80-103) */
 } carl_brax_ctx_map_t;
 
 typedef struct carl_brax_sys {
@@ -304,6 +306,31 @@ typedef struct carl_brax_sys {
    * ctrl_cost_weight * |a|^2; never terminates.  0: not used */
   int32_t target_link;
   float target_max_dist;
+  /* push task (brax.envs.pusher; reference class carl/envs/brax/carl_pusher.py:9-103): push_link > 0 names
+   * the LAST link (the object), on two slides against the world; every link before it is the arm (hinges
+   * only), tip_link its end effector.  With goal = the context's goal_position_* (ctx.goal_position; rows
+   * absent: push_goal):
+   *   reset: arm q = init_q + reset_noise_scale U(-1, 1), arm rates U(-reset_vel_scale, reset_vel_scale);
+   *          object offset c = push_lo + (push_hi - push_lo) U (draws n_q + n_dof and + 1 of the reset
+   *          stream); d = link_pos[push_link].xy + c - goal.xy is stretched to length push_min_dist when
+   *          shorter; object slides = goal.xy + d - link_pos.xy, at rest;
+   *   observation = q[:na] ++ qd[:na] ++ COM(tip_link) ++ COM(push_link) ++ goal (na = arm dofs);
+   *   reward = -|COM(object) - goal| - ctrl_cost_weight |a|^2 - push_near_weight |COM(object) - COM(tip)|;
+   *   never terminates.  0: not used */
+  int32_t push_link;
+  float push_goal[3];
+  float push_near_weight, push_min_dist;
+  float push_lo[2], push_hi[2];
+  /* link-pair contact of the push task: n_pair spheres fixed to pair_link (centre pair_pos[k] in its
+   * frame, radius pair_radius[k]) against the object, an upright cylinder (radius pair_obj_radius, half
+   * height pair_obj_half) centred at the frame origin of push_link.  A sphere whose centre is within
+   * pair_obj_half + r_k of the object's mid-height and closer than r_k + R in the horizontal plane pushes
+   * the object along the horizontal normal n with max(0, pair_k depth + pair_c closing speed); the
+   * opposite force acts on pair_link at the sphere's centre (frictionless; the object's own rotation is
+   * locked by its joint) */
+  int32_t n_pair, pair_link;
+  float pair_pos[CARL_BRAX_MAX_PAIR][3], pair_radius[CARL_BRAX_MAX_PAIR];
+  float pair_obj_radius, pair_obj_half, pair_k, pair_c;
   float slide_axis[CARL_BRAX_MAX_LINKS][2][3]; /* unit axes in the PARENT frame, mutually orthogonal */
   carl_brax_ctx_map_t ctx;
 } carl_brax_sys_t;

@@ -99,6 +99,7 @@ static qt f4(const float* p) { qt r = {p[0], p[1], p[2], p[3]}; return r; }
 typedef struct {
   double gravity_z, friction, elasticity, ang_damping, stiffness_scale;
   double mass[L_MAX];
+  double goal[3]; /* push task */
 } lane_ctx;
 
 static lane_ctx make_ctx(const carl_brax_sys_t* s, const double* row) {
@@ -112,6 +113,8 @@ static lane_ctx make_ctx(const carl_brax_sys_t* s, const double* row) {
   for (int i = 0; i < s->n_links; ++i) c.mass[i] = s->mass[i];
   for (int k = 0; k < m->n_mass; ++k)
     c.mass[m->mass_link[k]] = s->mass[m->mass_link[k]] * ((double)(float)row[m->mass_row[k]] / m->mass_nominal[k]);
+  for (int k = 0; k < 3; ++k)
+    c.goal[k] = (s->push_link > 0 && m->goal_position[k] >= 0) ? (double)(float)row[m->goal_position[k]] : s->push_goal[k];
   return c;
 }
 
@@ -350,6 +353,29 @@ static void substep(const carl_brax_sys_t* s, const lane_ctx* c, const double* t
       F[P] = vsub(F[P], f);
       T[P] = vsub(T[P], vadd(vcross(vsub(g.A_p, b[P].p), f), t));
     }
+    if (s->n_pair > 0 && i == s->push_link) { /* the gripper's spheres against the object (carl_brax_sys_t::n_pair) */
+      const int a = s->pair_link;
+      const v3 o = vsub(b[i].p, qrot(b[i].r, f3(s->com[i])));
+      for (int k = 0; k < s->n_pair; ++k) {
+        const v3 rel = qrot(b[a].r, vsub(f3(s->pair_pos[k]), f3(s->com[a])));
+        const v3 cs = vadd(b[a].p, rel);
+        const double rk = s->pair_radius[k];
+        if (!(fabs(cs.z - o.z) < s->pair_obj_half + rk)) continue;
+        const double dx = o.x - cs.x, dy = o.y - cs.y;
+        const double dist = sqrt(dx * dx + dy * dy);
+        const double depth = rk + s->pair_obj_radius - dist;
+        if (!(depth > 0.0) || !(dist > 1e-9)) continue;
+        const v3 n = V(dx / dist, dy / dist, 0.0);
+        const v3 vs = vadd(b[a].v, vcross(b[a].w, rel));
+        const double closing = vdot(vsub(vs, b[i].v), n);
+        const double fm = s->pair_k * depth + s->pair_c * closing;
+        if (!(fm > 0.0)) continue;
+        const v3 fc = vscale(n, fm);
+        F[i] = vadd(F[i], fc);
+        F[a] = vsub(F[a], fc);
+        T[a] = vsub(T[a], vcross(rel, fc));
+      }
+    }
   }
   /* --- semi-implicit Euler: velocity update before the collision pass -------------- */
   for (int i = 0; i < L; ++i) {
@@ -436,6 +462,16 @@ static void observe(const carl_brax_sys_t* s, const lane_ctx* c, const body* b, 
     obs[k++] = (float)d.x; obs[k++] = (float)d.y; obs[k++] = (float)d.z;
     return;
   }
+  if (s->push_link > 0) { /* brax.envs.pusher._get_obs: arm q ++ arm qd ++ COM of the end effector, the object, the goal */
+    const int na = s->q_start[s->push_link];
+    for (int i = 0; i < na; ++i) obs[k++] = (float)q[i];
+    for (int i = 0; i < na; ++i) obs[k++] = (float)qd[i];
+    const v3 tp = b[s->tip_link].p, op = b[s->push_link].p;
+    obs[k++] = (float)tp.x; obs[k++] = (float)tp.y; obs[k++] = (float)tp.z;
+    obs[k++] = (float)op.x; obs[k++] = (float)op.y; obs[k++] = (float)op.z;
+    for (int j = 0; j < 3; ++j) obs[k++] = (float)c->goal[j];
+    return;
+  }
   if (s->obs_trig_from > 0) { /* q[:from] ++ sin(q[from:]) ++ cos(q[from:]) */
     for (int i = s->exclude_current_positions; i < s->obs_trig_from; ++i) obs[k++] = (float)q[i];
     for (int i = s->obs_trig_from; i < s->n_q; ++i) obs[k++] = (float)sin((double)(float)q[i]);
@@ -483,7 +519,7 @@ static double draw_u(uint64_t seed, uint64_t g, uint32_t ep, int k) {
   return (double)oracle_u01(w[k & 3]);
 }
 
-static void reset_lane(const carl_brax_sys_t* s, uint64_t seed, uint64_t g, uint32_t ep, body* b) {
+static void reset_lane(const carl_brax_sys_t* s, const lane_ctx* c, uint64_t seed, uint64_t g, uint32_t ep, body* b) {
   double q[CARL_BRAX_MAX_Q], qd[CARL_BRAX_MAX_DOF];
   int k = 0;
   for (int i = 0; i < s->n_q; ++i, ++k)
@@ -503,6 +539,18 @@ static void reset_lane(const carl_brax_sys_t* s, uint64_t seed, uint64_t g, uint
     const double ang = 2.0 * M_PI * draw_u(seed, g, ep, s->n_q + s->n_dof + 1);
     q[tq] = dist * cos(ang);
     q[tq + 1] = dist * sin(ang);
+    for (int i = td; i < s->n_dof; ++i) qd[i] = 0.0;
+  }
+  if (s->push_link > 0) { /* brax.envs.pusher.reset: object placed in a box in front of the arm, pushed out
+                             of the goal's push_min_dist disc; at rest */
+    const int pl = s->push_link, tq = s->q_start[pl], td = s->dof_start[pl];
+    const double cx = s->push_lo[0] + ((double)s->push_hi[0] - s->push_lo[0]) * draw_u(seed, g, ep, s->n_q + s->n_dof);
+    const double cy = s->push_lo[1] + ((double)s->push_hi[1] - s->push_lo[1]) * draw_u(seed, g, ep, s->n_q + s->n_dof + 1);
+    double dx = s->link_pos[pl][0] + cx - c->goal[0], dy = s->link_pos[pl][1] + cy - c->goal[1];
+    const double nrm = sqrt(dx * dx + dy * dy);
+    if (nrm < s->push_min_dist) { const double sc = s->push_min_dist / (nrm > 1e-12 ? nrm : 1e-12); dx *= sc; dy *= sc; }
+    q[tq] = c->goal[0] + dx - s->link_pos[pl][0];
+    q[tq + 1] = c->goal[1] + dy - s->link_pos[pl][1];
     for (int i = td; i < s->n_dof; ++i) qd[i] = 0.0;
   }
   forward_kinematics(s, q, qd, b);
@@ -589,13 +637,13 @@ void obx_engine_reset(const carl_brax_sys_t* s, const oracle_cfg_t* cfg, const d
     ctx_idx[i] = select_ctx(cfg, ctx_idx[i], g, episode[i]);
     n_calls[i] += 1;
     body b[L_MAX];
-    reset_lane(s, cfg->seed, g, episode[i], b);
+    const lane_ctx c = make_ctx(s, ctx_table + (size_t)ctx_idx[i] * n_feat);
+    reset_lane(s, &c, cfg->seed, g, episode[i], b);
     store_bodies(s, b, state + (size_t)i * S);
     episode[i] += 1;
     elapsed[i] = 0;
     ep_return[i] = 0.0;
     if (goal_pos) { goal_pos[2 * i] = 0.0; goal_pos[2 * i + 1] = 0.0; } /* wrapper reset: position = (0, 0) */
-    const lane_ctx c = make_ctx(s, ctx_table + (size_t)ctx_idx[i] * n_feat);
     observe(s, &c, b, NULL, obs + (size_t)i * s->obs_dim); /* reset obs: qfrc_actuator of a zero action */
   }
 }
@@ -643,7 +691,12 @@ void obx_engine_step(const carl_brax_sys_t* s, const oracle_cfg_t* cfg, const do
                (s->terminate_when_unhealthy ? s->healthy_reward : s->healthy_reward * healthy) -
                s->ctrl_cost_weight * ctrl;
     int term = s->terminate_when_unhealthy ? !healthy : 0;
-    if (s->target_link > 0) { /* brax.envs.reacher: -|tip - goal| - |a|^2 */
+    if (s->push_link > 0) { /* brax.envs.pusher: -|object - goal| - w_ctrl |a|^2 - w_near |object - end effector| */
+      const v3 op = b[s->push_link].p;
+      const v3 d1 = vsub(op, b[s->tip_link].p), d2 = vsub(op, V(c.goal[0], c.goal[1], c.goal[2]));
+      r = -sqrt(vdot(d2, d2)) - s->ctrl_cost_weight * ctrl - s->push_near_weight * sqrt(vdot(d1, d1));
+      term = 0;
+    } else if (s->target_link > 0) { /* brax.envs.reacher: -|tip - goal| - |a|^2 */
       const int tl = s->tip_link, gl = s->target_link;
       const v3 tip = vadd(vsub(b[tl].p, qrot(b[tl].r, f3(s->com[tl]))), qrot(b[tl].r, f3(s->tip_offset)));
       const v3 d = vsub(tip, vsub(b[gl].p, qrot(b[gl].r, f3(s->com[gl]))));
@@ -682,12 +735,12 @@ void obx_engine_step(const carl_brax_sys_t* s, const oracle_cfg_t* cfg, const do
         if (final_obs) memcpy(final_obs + (size_t)i * D, obs + (size_t)i * D, sizeof(float) * D);
         ctx_idx[i] = select_ctx(cfg, ctx_idx[i], g, episode[i]);
         n_calls[i] += 1;
-        reset_lane(s, cfg->seed, g, episode[i], b);
+        const lane_ctx c2 = make_ctx(s, ctx_table + (size_t)ctx_idx[i] * n_feat);
+        reset_lane(s, &c2, cfg->seed, g, episode[i], b);
         episode[i] += 1;
         elapsed[i] = 0;
         ep_return[i] = 0.0;
         if (goal_pos) { goal_pos[2 * i] = 0.0; goal_pos[2 * i + 1] = 0.0; }
-        const lane_ctx c2 = make_ctx(s, ctx_table + (size_t)ctx_idx[i] * n_feat);
         observe(s, &c2, b, NULL, obs + (size_t)i * D);
       }
     }

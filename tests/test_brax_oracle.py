@@ -517,3 +517,80 @@ def test_reacher_goal_draw_observation_and_reward():
         assert np.abs(o[:, 10]).max() < 5e-3                              # gravity sag of the springs
     assert np.abs(th[:, 1]).max() <= 3.05                                  # elbow range +-3 rad
     assert np.abs(o[:, 6:8]).max() < 40.0                                  # gear 25 against damping 1
+
+
+def pusher_contact_state(s, n_lanes, pan_rate=1.0):
+    """[n_lanes, 13 * 8] states with the arm lowered to table height (shoulder lift 0.3909 rad, elbow
+    straight: wrist at x = 0.767, z = -0.275) and swinging about the shoulder pan; even lanes hold the
+    puck inside the fork (0.09 ahead of the cross bar, touching nothing yet), odd lanes 0.3 away."""
+    q = np.zeros(9)
+    q[1] = 0.3909
+    qd = np.zeros(9)
+    qd[0] = pan_rate
+    out = np.zeros((n_lanes, 13 * 8))
+    wrist_x = 0.1 + 0.721 * np.cos(0.3909)
+    for i in range(n_lanes):
+        qq = q.copy()
+        px = wrist_x + (0.09 if i % 2 == 0 else 0.09 - 0.3)
+        qq[7], qq[8] = px - 0.45, -0.6 - (-0.05)  # slides are offsets from the puck's MJCF position
+        out[i] = B.forward_kinematics(s, qq, qd).reshape(-1)
+    return out
+
+
+def test_pusher_reset_observation_reward_and_gripper_contact():
+    """push task (carl_brax_sys_t::push_link / n_pair): puck drawn in its box and kept 0.17 from the
+    goal, observation arm q ++ arm qd ++ gripper / puck / goal positions, reward = -|puck - goal| -
+    0.1 |a|^2 - 0.5 |puck - gripper|, and the fork pushes the puck it sweeps into (and only that one)."""
+    from carl_amd.envs.brax.models import PUSHER_MASSES, pusher_sys
+
+    names, default = _features("CARLBraxPusher")
+    assert names[5:13] == list(PUSHER_MASSES) and names[13:] == ["goal_position_x", "goal_position_y", "goal_position_z"]
+    s = pusher_sys(names)
+    assert (s.n_links, s.n_q, s.n_dof, s.n_act, s.obs_dim) == (8, 9, 9, 7, 23) and s.ctx.n_mass == 8
+    n = 128
+    rows = np.tile(default, (n, 1))
+    rows[:, names.index("gravity")] = -1e-6          # the MJCF has no gravity; the feature's upper bound
+    rng = np.random.default_rng(5)
+    rows[:, 13] = rng.uniform(0.2, 0.6, n)           # goals across the puck's box: some draws fall inside
+    rows[:, 14] = rng.uniform(-0.2, 0.1, n)          # the 0.17 disc and are pushed out
+    rows = rows.astype(np.float32).astype(np.float64)
+    e = B.Engine(s, rows, n, selector=O.SEL_STATIC, seed=1, ctx_idx0=np.arange(n))
+    obs = e.reset().astype(np.float64)
+    np.testing.assert_array_equal(obs[:, 0:7], 0.0)
+    assert np.abs(obs[:, 7:14]).max() <= 0.00501
+    np.testing.assert_allclose(obs[:, 20:23], rows[:, 13:16], rtol=1e-6)
+    puck, goal = obs[:, 17:20], obs[:, 20:23]
+    np.testing.assert_allclose(puck[:, 2], -0.275, atol=1e-6)
+    d = np.hypot(puck[:, 0] - goal[:, 0], puck[:, 1] - goal[:, 1])
+    assert d.min() >= 0.17 - 1e-6 and np.isclose(d, 0.17, atol=1e-6).sum() >= 5
+    free = d > 0.17 + 1e-6                            # untouched draws lie in the MJCF box
+    assert np.all((puck[free, 0] >= 0.15 - 1e-6) & (puck[free, 0] <= 0.45 + 1e-6))
+    assert np.all((puck[free, 1] >= -0.25 - 1e-6) & (puck[free, 1] <= 0.15 + 1e-6))
+    # gripper link COM at init_q: wrist origin (0.821, -0.6, 0) + R com (0.03, 0, 0)
+    np.testing.assert_allclose(obs[:, 14:17] - np.array([0.851, -0.6, 0.0]), 0.0, atol=1e-6)
+    for t in range(20):
+        a = rng.uniform(-2, 2, (n, 7)).astype(np.float32)
+        out = e.step(a)
+        o = out.obs.astype(np.float64)
+        assert np.isfinite(o).all() and not out.terminated.any() and not out.truncated.any()
+        want = (-np.linalg.norm(o[:, 17:20] - o[:, 20:23], axis=1) - 0.1 * (a.astype(np.float64) ** 2).sum(1)
+                - 0.5 * np.linalg.norm(o[:, 17:20] - o[:, 14:17], axis=1))
+        np.testing.assert_allclose(out.reward, want, rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(o[:, 17:20], puck, atol=1e-4)  # nobody reaches the puck in one second
+    # ---- the fork sweeps into the puck
+    m = 8
+    e2 = B.Engine(s, rows[:m], m, selector=O.SEL_STATIC, seed=1, ctx_idx0=np.arange(m))
+    e2.reset()
+    e2.state[:] = pusher_contact_state(s, m)
+    p0 = e2.state.reshape(m, 8, 13)[:, 7, 0:3].copy()
+    a = np.zeros((m, 7), np.float32)
+    a[:, 0] = 2.0                                     # keep swinging
+    for t in range(8):
+        out = e2.step(a)
+    p1 = e2.state.reshape(m, 8, 13)[:, 7, 0:3]
+    grip = e2.state.reshape(m, 8, 13)[:, 6, 0:3]
+    assert np.all(p1[0::2, 1] - p0[0::2, 1] > 0.08)                  # pushed along the sweep (+y)
+    np.testing.assert_allclose(p1[1::2], p0[1::2], atol=1e-5)          # the far puck is not
+    assert np.all(np.linalg.norm(p1[0::2, :2] - grip[0::2, :2], axis=1) < 0.2)  # and it stays in the fork
+    np.testing.assert_allclose(p1[:, 2], -0.275, atol=1e-4)
+    assert np.isfinite(out.obs).all()

@@ -488,7 +488,7 @@ def _planar(cls_name, fn_name):
 
 @pytest.mark.parametrize("lanes_per_env", [2, 4, 7, 9, 11, 16])
 @pytest.mark.parametrize("model", ["ant", "halfcheetah", "humanoid", "hopper", "walker2d", "inverted_pendulum",
-                                   "humanoidstandup", "inverted_double_pendulum", "reacher"])
+                                   "humanoidstandup", "inverted_double_pendulum", "reacher", "pusher"])
 def test_every_lane_group_width_matches_oracle(device, model, lanes_per_env, monkeypatch):
     """The host picks the lanes per env (one per link, rounded up to an instantiated width: 2, 4, 7,
     9, 11, 16) from the model and the batch size
@@ -513,6 +513,8 @@ def test_every_lane_group_width_matches_oracle(device, model, lanes_per_env, mon
         s, names, default = _planar("CARLBraxInvertedDoublePendulum", "inverted_double_pendulum_sys")
     elif model == "reacher":
         s, names, default = _planar("CARLBraxReacher", "reacher_sys")
+    elif model == "pusher":
+        s, names, default = _planar("CARLBraxPusher", "pusher_sys")
     else:
         s, names, default = _planar("CARLBraxInvertedPendulum", "inverted_pendulum_sys")
     rng = np.random.default_rng(100 + lanes_per_env)
@@ -525,6 +527,10 @@ def test_every_lane_group_width_matches_oracle(device, model, lanes_per_env, mon
     ora = B.Engine(s, rows, n, max_steps=4, **kw)
     obs = eng.reset().cpu().numpy()
     assert rel_err(obs, ora.reset()).max() < 5e-6
+    if model == "pusher":  # even lanes: the fork sweeps into the puck within the first step (pair contacts)
+        from test_brax_oracle import pusher_contact_state
+
+        eng.state.copy_(torch.as_tensor(pusher_contact_state(s, n).T.astype(np.float32)))
     lo = float(s.act_lo[0])
     errs = []
     for t in range(9):
@@ -688,3 +694,56 @@ def test_reacher_env_api_and_goal_stays_put(device):
     single = CARLBraxReacher()
     o, _ = single.reset()
     assert o["obs"].shape == (11,)
+
+
+def test_pusher_env_api_goal_context_and_contact(device):
+    """CARLBraxPusher through the CARL-shaped API (reference class carl/envs/brax/carl_pusher.py:9-103):
+    spaces, the goal_position_* context shows up as the observation's goal block and moves the reward,
+    the puck keeps 0.17 from the goal at reset, and the fork pushes the puck on the device as it does in
+    the oracle (bit-for-bit the same contact set: compared through the puck's displacement)."""
+    from carl_amd.brax_engine import BraxVecEngine
+    from carl_amd.envs import CARLBraxPusher
+    from test_brax_oracle import pusher_contact_state
+
+    feats = CARLBraxPusher.get_context_features()
+    names = list(feats)
+    default = {k: float(f.default_value) for k, f in feats.items()}
+    n = 64
+    contexts = {i: dict(default, gravity=-1e-6, goal_position_x=0.2 + 0.005 * i, goal_position_y=0.05 - 0.003 * i)
+                for i in range(n)}
+    env = CARLBraxPusher(contexts=contexts, batch_size=n, device=device)
+    obs, info = env.reset(seed=0)
+    o = obs["obs"].cpu().numpy().astype(np.float64)
+    assert o.shape == (n, 23) and env.action_space.shape == (n, 7)
+    cid = info["context_id"].cpu().numpy()
+    np.testing.assert_allclose(o[:, 20], 0.2 + 0.005 * cid, rtol=1e-6)
+    np.testing.assert_allclose(o[:, 21], 0.05 - 0.003 * cid, rtol=1e-5, atol=1e-7)
+    assert np.hypot(o[:, 17] - o[:, 20], o[:, 18] - o[:, 21]).min() >= 0.17 - 1e-6
+    a = torch.zeros((n, 7), device=device)
+    o2, r, te, tr, _ = env.step(a)
+    on = o2["obs"].cpu().numpy().astype(np.float64)
+    want = -np.linalg.norm(on[:, 17:20] - on[:, 20:23], axis=1) - 0.5 * np.linalg.norm(on[:, 17:20] - on[:, 14:17], axis=1)
+    np.testing.assert_allclose(r.cpu().numpy(), want, rtol=1e-5, atol=1e-5)
+    assert not te.any() and not tr.any()
+    # contact on the device vs the oracle, free-running for 8 steps
+    s, names, dflt = _planar("CARLBraxPusher", "pusher_sys")
+    rows = dflt[None].copy()
+    rows[:, 0] = -1e-6
+    m = 32
+    kw = dict(selector=O.SEL_STATIC, seed=1)
+    eng = BraxVecEngine(s, len(names), rows, m, device, **kw)
+    ora = B.Engine(s, rows, m, **kw)
+    eng.reset()
+    ora.reset()
+    st = pusher_contact_state(s, m)
+    eng.state.copy_(torch.as_tensor(st.T.astype(np.float32)))
+    ora.state[:] = eng.state.t().cpu().numpy()
+    act = np.zeros((m, 7), np.float32)
+    act[:, 0] = 2.0
+    for t in range(8):
+        eng.step(torch.as_tensor(act))
+        ora.step(act)
+    got = eng.state.t().cpu().numpy().reshape(m, 8, 13)[:, 7, :3]
+    wnt = ora.state.reshape(m, 8, 13)[:, 7, :3]
+    assert np.all(got[0::2, 1] - st.reshape(m, 8, 13)[0::2, 7, 1] > 0.08)
+    np.testing.assert_allclose(got, wnt, atol=2e-4)

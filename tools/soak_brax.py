@@ -13,7 +13,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 chunk = 50
 for cls in (E.CARLBraxAnt, E.CARLBraxHalfcheetah, E.CARLBraxHumanoid, E.CARLBraxHopper, E.CARLBraxWalker2d,
-            E.CARLBraxInvertedPendulum, E.CARLBraxHumanoidStandup, E.CARLBraxInvertedDoublePendulum, E.CARLBraxReacher):
+            E.CARLBraxInvertedPendulum, E.CARLBraxHumanoidStandup, E.CARLBraxInvertedDoublePendulum, E.CARLBraxReacher, E.CARLBraxPusher):
     env = cls(batch_size=n, device="cuda:0")
     eng = env.env
     env.reset(seed=0)
