@@ -40,6 +40,7 @@ struct CartPole {
   using Aux = NoAux;
   enum { GRAVITY, MASSCART, MASSPOLE, LENGTH, FORCE_MAG, TAU, INIT_LO, INIT_HI };
   static constexpr bool kNeedsStepNoise = false;
+  static constexpr bool kPredraw = true;  // short episodes: init-state words drawn once per chunk (engine_kernels.cuh)
 
   struct Params {
     float gravity, masspole, length, force_mag, tau, inv_total_mass, polemass_length;

@@ -33,10 +33,13 @@ __device__ __forceinline__ ctx_t<LDS> make_ctx(const carl_batch_t& b, float* lds
 // context observation rewritten) only when the selector moves the lane to another context
 // (`force`: first reset).  With a static selector a reset therefore reads no memory at all.
 // Returns true when memory was read.
+// `pre`: the episode's init-state words drawn ahead of time (staged rollout, families with kPredraw);
+// nullptr: drawn here.
 template <class Fam, class Ctx>
 __device__ __forceinline__ bool reset_lane(const carl_batch_t& b, const Ctx& ctx, int lane, uint64_t glane,
                                            int& cidx, uint32_t& episode, typename Fam::Params& p,
-                                           float (&s)[Fam::S], bool force, bool valid = true) {
+                                           float (&s)[Fam::S], bool force, bool valid = true,
+                                           const u32x4* pre = nullptr) {
   const int old = cidx;
   cidx = select_context(b, cidx, glane, episode);
   const bool changed = force || (cidx != old);
@@ -53,7 +56,7 @@ __device__ __forceinline__ bool reset_lane(const carl_batch_t& b, const Ctx& ctx
         b.ctx_obs[(size_t)k * b.n_lanes + lane] = ctx.get(b.ctx_obs_feat[k], cidx);
     }
   }
-  const u32x4 w = lane_words(b.seed, glane, episode, kSubInit);
+  const u32x4 w = (pre != nullptr) ? *pre : lane_words(b.seed, glane, episode, kSubInit);
   Fam::reset(p, w, s);
   episode += 1u;
   return changed;
@@ -110,6 +113,8 @@ struct LaneRegs {
   int n_new_episodes;   // episodes finished in this launch
   bool valid;           // false: a padding lane of a ragged last workgroup (a register-only clone of
                         // the batch's last lane: it computes, but nothing it does reaches global memory)
+  u32x4 next_w;         // kPredraw families in the staged rollout: the init-state words of the lane's NEXT
+  bool next_ok;         // episode, drawn once per chunk for the whole wave (see predraw)
   typename Fam::Params p;
   typename Fam::Aux aux;  // derived from s: shared by this step's obs and the next step
 };
@@ -175,11 +180,32 @@ struct LdsSink {
   }
 };
 
+// Families whose episodes are short under any policy (CartPole: ~22 steps under a random one) finish an
+// episode in some lane of nearly every wave on nearly every step, so the wave-uniform done path runs
+// almost every step and its largest piece -- the Philox4x32-10 block of the init-state draw, ~110
+// instructions -- is issued for 64 lanes to serve one or two.  The words only depend on (seed, lane,
+// episode number), not on the trajectory: the staged rollout draws them for every lane of the wave ONCE
+// PER CHUNK, ahead of time, and a finishing lane just consumes its pending words.  A lane that finishes
+// twice inside one chunk draws inline (rare).  Same words, same order: results are bit-identical.
+template <class Fam, class = void>
+struct predraw_of : std::false_type {};
+template <class Fam>
+struct predraw_of<Fam, std::void_t<decltype(Fam::kPredraw)>> : std::bool_constant<Fam::kPredraw> {};
+
+template <class Fam>
+__device__ __forceinline__ void predraw(const carl_batch_t& b, uint64_t glane, LaneRegs<Fam>& r) {
+  if (__ballot(!r.next_ok) != 0ull) {
+    const u32x4 w = lane_words(b.seed, glane, r.episode, kSubInit);
+    if (!r.next_ok) r.next_w = w;
+    r.next_ok = true;
+  }
+}
+
 // The rarely-taken part of a step, entered only by wavefronts in which some lane just
 // finished an episode (wave-uniform branch on a ballot): episode statistics, the compact
 // finished-episode log (ballot + one atomic per wave), and the in-kernel auto-reset
 // (Philox draws, selector advance, context re-gather).
-template <class Fam, class Ctx>
+template <class Fam, class Ctx, bool PRE = false>
 __device__ __forceinline__ void finish_episodes(const carl_batch_t& b, const Ctx& ctx, bool done, int lane,
                                                 uint64_t glane, float* final_obs, float (&o)[Fam::D],
                                                 LaneRegs<Fam>& r) {
@@ -198,7 +224,14 @@ __device__ __forceinline__ void finish_episodes(const carl_batch_t& b, const Ctx
       r.episode_valid = true;
       settle(r.episode);  // wait here, inside the branch (see reset_lane)
     }
-    reset_lane<Fam>(b, ctx, lane, glane, r.cidx, r.episode, r.p, r.s, false, r.valid);
+    if constexpr (PRE) {
+      u32x4 w = r.next_w;
+      if (!r.next_ok) w = lane_words(b.seed, glane, r.episode, kSubInit);  // second finish inside one chunk
+      r.next_ok = false;
+      reset_lane<Fam>(b, ctx, lane, glane, r.cidx, r.episode, r.p, r.s, false, r.valid, &w);
+    } else {
+      reset_lane<Fam>(b, ctx, lane, glane, r.cidx, r.episode, r.p, r.s, false, r.valid);
+    }
     r.elapsed = 0;
     r.ep_return = 0.0f;
     r.n_new_calls += 1;
@@ -251,7 +284,7 @@ __device__ __forceinline__ void step_lane(const carl_batch_t& b, const Ctx& ctx,
       if (active) cur.put_flags(te, tr);
     }
 #endif
-    finish_episodes<Fam>(b, ctx, done, lane, glane, cur.final_obs_ptr(), o, r);
+    finish_episodes<Fam, Ctx, Sink::kLazyFlags && predraw_of<Fam>::value>(b, ctx, done, lane, glane, cur.final_obs_ptr(), o, r);
   }
 #ifndef CARL_EXP_NO_OBS_STORE
   if (active) cur.put_obs(o);
@@ -707,6 +740,7 @@ __global__ void __launch_bounds__(kStagedThreads) rollout_staged_kernel(const ca
     if (compute) {
       const Action* my = act_buf + buf * kBufActs + threadIdx.x;
       char* rec = out_buf + (size_t)buf * kStageChunk * SK::kStepBytes;
+      if constexpr (predraw_of<Fam>::value) predraw<Fam>(b, glane, r);
       Action a_next = my[0];
       settle(a_next);  // arrive before the loop: its head then only waits for the read issued one
                        // step earlier (lgkmcnt(#record writes)), not for the record writes
