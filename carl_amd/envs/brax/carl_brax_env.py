@@ -124,7 +124,9 @@ class CARLBraxEnv(CARLEnv):
         return spaces.Box(lo, hi, dtype=np.float32)  # wrappers.py:50-51 (sys.actuator.ctrl_range)
 
     def _update_context(self) -> None:
-        check_context(self.context, REGISTERED_CFS)
+        # task features are taken out before the system check, as CARLBraxPusher._update_context does
+        # with its goal position (carl_pusher.py:91-103)
+        check_context(self.context, REGISTERED_CFS + list(self.task_context_features))
         super()._update_context()
 
     @property

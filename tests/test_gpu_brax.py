@@ -747,3 +747,27 @@ def test_pusher_env_api_goal_context_and_contact(device):
     wnt = ora.state.reshape(m, 8, 13)[:, 7, :3]
     assert np.all(got[0::2, 1] - st.reshape(m, 8, 13)[0::2, 7, 1] > 0.08)
     np.testing.assert_allclose(got, wnt, atol=2e-4)
+
+
+def test_reference_brax_env_test_over_every_class(device):
+    """The reference's own Brax test (test/test_brax_env.py:8-23), statement for statement, on this
+    package: every CARL class exported by ``envs.brax`` builds with its defaults, progresses its
+    instance, updates its context and resets.  (Plus: all ten reference classes are there, and the
+    default reset observation has the class's dimension and is finite.)"""
+    import inspect
+
+    import carl_amd.envs.brax as brax_envs
+
+    seen = []
+    for env_name, env_obj in inspect.getmembers(brax_envs):
+        if inspect.isclass(env_obj) and "CARL" in env_name and env_name != "CARLBraxEnv":
+            env_obj.get_context_features()
+            env = env_obj()
+            env._progress_instance()
+            env._update_context()
+            obs, info = env.reset()
+            assert np.isfinite(obs["obs"]).all() and obs["obs"].shape == env.observation_space["obs"].shape
+            seen.append(env_name)
+    assert sorted(seen) == sorted(
+        "CARLBrax" + n for n in ("Ant", "Halfcheetah", "Hopper", "Humanoid", "HumanoidStandup", "InvertedDoublePendulum",
+                                 "InvertedPendulum", "Pusher", "Reacher", "Walker2d"))
