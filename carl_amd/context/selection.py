@@ -9,7 +9,6 @@ round trip.  Custom selectors run on the host (no in-kernel auto-reset).
 """
 from __future__ import annotations
 
-from abc import abstractmethod
 from typing import Any, Callable, List, Optional, Tuple
 
 import numpy as np
@@ -20,50 +19,59 @@ from carl_amd.utils.types import Context, Contexts
 SEL_STATIC, SEL_ROUND_ROBIN, SEL_RANDOM, SEL_HOST = 0, 1, 2, 3
 
 
-class AbstractSelector(object):
-    """Base class; the context is chosen in ``select``, not in ``__init__``."""
+class AbstractSelector:
+    """A selector walks over a context set.  Public state, as the reference exposes it: ``contexts`` (the
+    set), ``contexts_keys`` (its keys in order), ``context_ids`` (positions 0..n-1), ``context_id``
+    (position of the current context, ``None`` before the first ``select``), ``n_calls``.  Subclasses say
+    which position comes next (``_next_id``); ``device_rule`` names the same rule for the in-kernel
+    auto-reset."""
 
     device_rule: int = SEL_HOST
 
     def __init__(self, contexts: Contexts):
-        self.contexts: Contexts = contexts
-        self.context_ids: List[int] = list(np.arange(len(contexts)))
-        self.contexts_keys: List[Any] = list(contexts.keys())
-        self.n_calls: int = 0
+        self.contexts = contexts
+        self.contexts_keys: List[Any] = [*contexts.keys()]
+        self.context_ids: List[int] = list(np.arange(len(self.contexts_keys)))
         self.context_id: Optional[int] = None
+        self.n_calls = 0
 
-    @abstractmethod
+    # -- what subclasses provide ---------------------------------------------------------
+    def _next_id(self) -> int:
+        raise NotImplementedError
+
     def _select(self) -> Tuple[Context, int]:
-        ...
+        """(context, position) of the next context; also moves ``context_id`` there"""
+        self.context_id = self._next_id()
+        return self._at(self.context_id), self.context_id
+
+    # -- API -----------------------------------------------------------------------------
+    def _at(self, position: int) -> Context:
+        return self.contexts[self.contexts_keys[position]]
 
     def select(self) -> Context:
-        context, context_id = self._select()
-        self.context_id = context_id
+        context, self.context_id = self._select()
         self.n_calls += 1
         return context
 
     @property
     def context_key(self) -> Any | None:
-        # Quirk S2 of the reference (selection.py:91): id 0 is falsy -> None
-        if self.context_id:
-            return self.contexts_keys[self.context_id]
-        return None
+        """Key of the current context.  Position 0 reports ``None`` as well as "nothing selected yet":
+        the reference tests the id for truth (selection.py:91, Quirk S2), and callers may rely on it."""
+        return self.contexts_keys[self.context_id] if self.context_id else None
 
 
 class RandomSelector(AbstractSelector):
-    """Uniformly random context each reset.  The reference draws from the global,
-    unseeded ``np.random`` (selection.py:105); so does the host object.  On device
-    the draw is the lane's Philox stream (reproducible from the env seed)."""
+    """A uniformly random position at every reset.  On the host this is the global, unseeded
+    ``np.random`` stream the reference uses (selection.py:105); on the device, the lane's Philox stream."""
 
     device_rule = SEL_RANDOM
 
-    def _select(self) -> Tuple[Context, int]:
-        context_id = np.random.choice(self.context_ids)
-        return self.contexts[self.contexts_keys[context_id]], context_id
+    def _next_id(self) -> int:
+        return np.random.choice(self.context_ids)
 
 
 class RoundRobinSelector(AbstractSelector):
-    """Next context in order, wrapping (selection.py:116-122)."""
+    """Positions 0, stride, 2 stride, ... modulo the set size (selection.py:116-122 is stride 1)."""
 
     device_rule = SEL_ROUND_ROBIN
 
@@ -71,35 +79,30 @@ class RoundRobinSelector(AbstractSelector):
         super().__init__(contexts)
         self.stride = stride
 
-    def _select(self) -> Tuple[Context, int]:
-        if self.context_id is None:
-            self.context_id = -self.stride
-        self.context_id = (self.context_id + self.stride) % len(self.contexts)
-        return self.contexts[self.contexts_keys[self.context_id]], self.context_id
+    def _next_id(self) -> int:
+        previous = -self.stride if self.context_id is None else self.context_id
+        return (previous + self.stride) % len(self.contexts)
 
 
 class StaticSelector(AbstractSelector):
-    """Never changes the context (selection.py:131-136)."""
+    """Stays where it is; starts at the first context (selection.py:131-136)."""
 
     device_rule = SEL_STATIC
 
-    def _select(self) -> Tuple[Context, int]:
-        if self.context_id is None:
-            self.context_id = self.context_ids[0]
-        return self.contexts[self.contexts_keys[self.context_id]], self.context_id
+    def _next_id(self) -> int:
+        return self.context_ids[0] if self.context_id is None else self.context_id
 
 
 class CustomSelector(AbstractSelector):
-    """User function ``f(selector) -> (context, context_id)`` (selection.py:139-180)."""
+    """``selector_function(selector) -> (context, position)`` decides (selection.py:139-180).  Runs on the
+    host only: a batched env with this selector cannot auto-reset inside the kernel."""
 
     device_rule = SEL_HOST
 
-    def __init__(self, contexts: Contexts,
-                 selector_function: Callable[[AbstractSelector], Tuple[Context, int]]):
-        super().__init__(contexts=contexts)
+    def __init__(self, contexts: Contexts, selector_function: Callable[[AbstractSelector], Tuple[Context, int]]):
+        super().__init__(contexts)
         self.selector_function = selector_function
 
     def _select(self) -> Tuple[Context, int]:
-        context, context_id = self.selector_function(self)
-        self.context_id = context_id
-        return context, context_id
+        context, self.context_id = self.selector_function(self)
+        return context, self.context_id

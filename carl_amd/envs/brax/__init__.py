@@ -1,16 +1,16 @@
-# flake8: noqa: F401
-from carl_amd.envs.brax.carl_ant import CARLBraxAnt
-from carl_amd.envs.brax.carl_brax_env import CARLBraxEnv
-from carl_amd.envs.brax.carl_halfcheetah import CARLBraxHalfcheetah
-from carl_amd.envs.brax.carl_hopper import CARLBraxHopper
-from carl_amd.envs.brax.carl_humanoid import CARLBraxHumanoid
-from carl_amd.envs.brax.carl_humanoidstandup import CARLBraxHumanoidStandup
-from carl_amd.envs.brax.carl_inverted_double_pendulum import CARLBraxInvertedDoublePendulum
-from carl_amd.envs.brax.carl_pusher import CARLBraxPusher
-from carl_amd.envs.brax.carl_reacher import CARLBraxReacher
-from carl_amd.envs.brax.carl_inverted_pendulum import CARLBraxInvertedPendulum
-from carl_amd.envs.brax.carl_walker2d import CARLBraxWalker2d
+"""The ten Brax families (module and class names as in the reference package) and their base class."""
+import importlib
 
-__all__ = ["CARLBraxEnv", "CARLBraxAnt", "CARLBraxHalfcheetah", "CARLBraxHumanoid", "CARLBraxHopper", "CARLBraxWalker2d",
-           "CARLBraxInvertedPendulum", "CARLBraxHumanoidStandup", "CARLBraxInvertedDoublePendulum",
-           "CARLBraxReacher", "CARLBraxPusher"]
+from carl_amd.envs.brax.carl_brax_env import CARLBraxEnv  # noqa: F401
+
+_FAMILIES = {
+    "ant": "Ant", "halfcheetah": "Halfcheetah", "humanoid": "Humanoid", "hopper": "Hopper", "walker2d": "Walker2d",
+    "inverted_pendulum": "InvertedPendulum", "humanoidstandup": "HumanoidStandup",
+    "inverted_double_pendulum": "InvertedDoublePendulum", "reacher": "Reacher", "pusher": "Pusher",
+}
+__all__ = ["CARLBraxEnv"]
+for _mod, _suffix in _FAMILIES.items():
+    _cls = "CARLBrax" + _suffix
+    globals()[_cls] = getattr(importlib.import_module(f"{__name__}.carl_{_mod}"), _cls)
+    __all__.append(_cls)
+del _mod, _suffix, _cls

@@ -19,6 +19,7 @@ import math
 import numpy as np
 
 from carl_amd import _lib
+from carl_amd.envs.brax.feature_tables import masses
 
 
 def _axis_quat(axis) -> tuple[float, float, float, float]:
@@ -282,12 +283,7 @@ def _vol(kind, a, b, r):
     return math.pi * r * r * float(np.linalg.norm(np.subtract(b, a))) + 4.0 / 3.0 * math.pi * r**3
 
 
-HUMANOID_MASSES = {
-    "mass_torso": 10.0, "mass_lwaist": 2.2619467, "mass_pelvis": 6.6161942, "mass_right_thigh": 4.751751,
-    "mass_right_shin": 4.522842, "mass_left_thigh": 4.751751, "mass_left_shin": 4.522842,
-    "mass_right_upper_arm": 1.6610805, "mass_right_lower_arm": 1.2295402, "mass_left_upper_arm": 1.6610805,
-    "mass_left_lower_arm": 1.2295402,
-}
+HUMANOID_MASSES = masses("humanoid")  # mass_<link> -> CARL default (feature_tables.py)
 
 
 def humanoid_sys(feature_names: list[str] | None = None, reference_compat: bool = False) -> _lib.BraxSys:
@@ -745,11 +741,7 @@ def reacher_sys(feature_names: list[str] | None = None, reference_compat: bool =
     return s
 
 
-PUSHER_MASSES = {
-    "mass_r_shoulder_pan_link": 7.2935214, "mass_r_shoulder_lift_link": math.pi, "mass_r_upper_arm_roll_link": 1.7140529,
-    "mass_r_elbow_flex_link": 4.0715042e-01, "mass_r_forearm_roll_link": 9.2818356e-01,
-    "mass_r_wrist_flex_link": 5.0265482e-03, "mass_r_wrist_roll_link": 1.8346901e-01, "mass_object": 1.8325957e-03,
-}
+PUSHER_MASSES = masses("pusher")
 
 
 def pusher_sys(feature_names: list[str] | None = None, reference_compat: bool = False) -> _lib.BraxSys:

@@ -1,9 +1,12 @@
-"""Type aliases of the reference API (carl/utils/types.py:5-8)."""
-from typing import Any, Dict, List, TypeVar, Union
+"""Names the reference API annotates with (carl/utils/types.py:5-8): a context is a mapping from feature
+name to value, a context set maps ids to contexts, a vector is a list or an array."""
+from __future__ import annotations
+
+import typing as t
 
 import numpy as np
 
-Context = Dict[str, Any]
-Contexts = Dict[Any, Context]
-Vector = Union[List[Any], np.ndarray]
-ObsType = TypeVar("ObsType")
+ObsType = t.TypeVar("ObsType")
+Context = t.Dict[str, t.Any]          # feature name -> value
+Contexts = t.Dict[t.Any, Context]     # context id -> context
+Vector = t.Union[t.List[t.Any], np.ndarray]
