@@ -34,13 +34,18 @@ def _num(v):
     return v
 
 
-def _directions() -> list:
-    """the compass codes (a module-level list literal of brax_walker_goal_wrapper.py) the walker classes import"""
+def _goal_wrapper_literal(name: str):
+    """a module-level literal of brax_walker_goal_wrapper.py (``directions``: the compass codes the walker
+    classes import; ``DIRECTION_NAMES``: their spoken names)"""
     tree = ast.parse(open(os.path.join(REF, "brax", "brax_walker_goal_wrapper.py")).read())
     for node in tree.body:
-        if isinstance(node, ast.Assign) and getattr(node.targets[0], "id", "") == "directions":
+        if isinstance(node, ast.Assign) and getattr(node.targets[0], "id", "") == name:
             return ast.literal_eval(node.value)
-    raise RuntimeError("directions not found")
+    raise RuntimeError(f"{name} not found")
+
+
+def _directions() -> list:
+    return _goal_wrapper_literal("directions")
 
 
 def tables_of(path: str) -> dict:
@@ -73,6 +78,8 @@ def main() -> None:
             if f.startswith("carl_") and f.endswith(".py"):
                 for cls, feats in tables_of(os.path.join(d, f)).items():
                     golden[cls] = feats
+    golden["_goal_wrapper"] = {"directions": _goal_wrapper_literal("directions"),
+                               "DIRECTION_NAMES": {str(k): v for k, v in _goal_wrapper_literal("DIRECTION_NAMES").items()}}
     dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "context_feature_tables.json")
     with open(dst, "w") as fh:
         json.dump(golden, fh, indent=1, sort_keys=True)

@@ -13,6 +13,7 @@ import pytest
 import carl_amd.envs as E
 
 GOLDEN = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "context_feature_tables.json")))
+GOAL_WRAPPER = GOLDEN.pop("_goal_wrapper")
 
 
 # joint_stiffness: BASELINE.json config 5 varies it; the reference's classes do not declare it
@@ -49,3 +50,11 @@ def test_feature_table_matches_reference(cls_name):
 
 def test_every_reference_env_class_of_the_path_is_built():
     assert len(GOLDEN) == 15  # 5 classic-control + 10 Brax classes
+
+
+def test_goal_wrapper_names_user_code_imports():
+    """``directions`` / ``DIRECTION_NAMES`` of carl/envs/brax/brax_walker_goal_wrapper.py:16-50"""
+    from carl_amd.envs.brax.brax_walker_goal_wrapper import DIRECTION_NAMES, directions
+
+    assert directions == GOAL_WRAPPER["directions"]
+    assert {str(k): v for k, v in DIRECTION_NAMES.items()} == GOAL_WRAPPER["DIRECTION_NAMES"]
