@@ -72,8 +72,6 @@ class CARLBraxEnv(CARLEnv):
     ) -> None:
         """Reference parameters (carl_brax_env.py:119-131) plus the lane-engine ones.
         ``batch_size`` is the reference's name for the number of parallel envs (:164)."""
-        if use_language_goals:
-            raise NotImplementedError("language goals are strings on the host: out of scope (SURVEY.md section 2 row 7)")
         goal_mode = False
         if contexts is not None and len(contexts):
             first = contexts[list(contexts.keys())[0]]
@@ -99,6 +97,10 @@ class CARLBraxEnv(CARLEnv):
                 seed=seed, lane_offset=lane_offset, fin_capacity=fin_capacity,
             )
         self.use_language_goals = use_language_goals
+        # the reference stacks BraxLanguageWrapper on the goal wrapper, i.e. only when goals vary (:216-218)
+        self._language = bool(use_language_goals and goal_mode)
+        self._goal_text: dict[Any, str] = {}
+        self._was_reset = False
         super().__init__(
             env=env,
             contexts=contexts,
@@ -139,6 +141,44 @@ class CARLBraxEnv(CARLEnv):
             check_context(c, REGISTERED_CFS + list(self.task_context_features))
         CARLEnv.contexts.fset(self, contexts)
 
+    # ---- language goals (carl/envs/brax/brax_walker_goal_wrapper.py:143-181) -------------------------
+    @staticmethod
+    def describe_goal(context: Context) -> str:
+        """the sentence ``BraxLanguageWrapper.get_goal_desc`` builds from a context's goal features"""
+        from carl_amd.envs.brax.brax_walker_goal_wrapper import DIRECTION_NAMES
+
+        where = f"{context['target_distance']}m {DIRECTION_NAMES[context['target_direction']]}"
+        if "target_radius" in context:
+            return f"The distance to the goal is {where}. Move within {context['target_radius']} steps of the goal."
+        return f"Move {where}."
+
+    def _with_goal_text(self, obs: dict, context_ids) -> dict:
+        """``obs["obs"]`` becomes ``{"obs": ..., "goal": text}`` -- one string for the scalar API, a list with
+        one string per env for a batch (built from the envs' context ids on the host: strings do not live
+        in HBM; texts are cached per context)"""
+        if not self._language:
+            return obs
+        if self._scalar_api:
+            text: Any = self.describe_goal(self.context)
+        else:
+            keys = self.context_selector.contexts_keys
+            text = []
+            for cid in (context_ids.tolist() if torch.is_tensor(context_ids) else context_ids):
+                if cid not in self._goal_text:
+                    self._goal_text[cid] = self.describe_goal(self.contexts[keys[cid]])
+                text.append(self._goal_text[cid])
+        obs["obs"] = {"obs": obs["obs"], "goal": text}
+        return obs
+
+    @property
+    def position(self):
+        """the goal wrapper's integrated planar position: ``None`` until the first reset (and without goal
+        mode), then (x, y) -- a length-2 array for one env, an ``[N, 2]`` tensor for a batch"""
+        if not self.env.sys.goal_mode or not self._was_reset:
+            return None
+        pos = self.env.goal_pos  # [2][N]
+        return pos[:, 0].cpu().numpy() if self._scalar_api else pos.t()
+
     def step(self, action: Any):
         if self._scalar_api:  # one env: action is a length-A vector
             a = np.asarray(action, dtype=np.float32).reshape(1, -1)
@@ -150,17 +190,19 @@ class CARLBraxEnv(CARLEnv):
             done = bool(term[0]) or bool(trunc[0])
             if self.env.sys.goal_mode:
                 info["success"] = int(self.env.success[0])
-            return self._add_context_to_state(state), float(reward[0]), done, False, info
+            return self._with_goal_text(self._add_context_to_state(state), None), float(reward[0]), done, False, info
         out = super().step(action)
         if self.env.sys.goal_mode:
             out[4]["success"] = self.env.success
+        self._with_goal_text(out[0], out[4].get("context_id"))
         return out
 
     def reset(self, *, seed: int | None = None, options: dict[str, Any] | None = None):
         obs, info = super().reset(seed=seed, options=options)
+        self._was_reset = True
         if self.env.sys.goal_mode:  # brax_walker_goal_wrapper.py:121
             info["success"] = 0 if self._scalar_api else torch.zeros_like(self.env.success)
-        return obs, info
+        return self._with_goal_text(obs, info.get("context_id")), info
 
     @classmethod
     def get_default_context(cls) -> Context:

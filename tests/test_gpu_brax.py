@@ -771,3 +771,52 @@ def test_reference_brax_env_test_over_every_class(device):
     assert sorted(seen) == sorted(
         "CARLBrax" + n for n in ("Ant", "Halfcheetah", "Hopper", "Humanoid", "HumanoidStandup", "InvertedDoublePendulum",
                                  "InvertedPendulum", "Pusher", "Reacher", "Walker2d"))
+
+
+def test_language_goals_as_the_reference_tests_them(device):
+    """test/test_language_goals.py:86-121 (wrapper selection: ``position`` is None before reset, set after)
+    and :170-260 (TestLanguageWrapper: ``state["obs"]["goal"]`` is a string naming the context's distance
+    and direction on reset and on every step; without ``use_language_goals`` there is no goal entry),
+    with the reference's own context sampling."""
+    from carl_amd.context.context_space import CategoricalContextFeature, NormalFloatContextFeature
+    from carl_amd.context.sampler import ContextSampler
+    from carl_amd.envs import CARLBraxAnt, CARLBraxHalfcheetah
+    from carl_amd.envs.brax.brax_walker_goal_wrapper import DIRECTION_NAMES, directions
+
+    def sampled(cls):
+        dists = [NormalFloatContextFeature("target_distance", mu=9.8, sigma=1, upper=50, lower=-40),
+                 CategoricalContextFeature("target_direction", choices=directions)]
+        return ContextSampler(context_distributions=dists, context_space=cls.get_context_space(),
+                              seed=0).sample_contexts(n_contexts=10)
+
+    for cls in (CARLBraxAnt, CARLBraxHalfcheetah):
+        env = cls(contexts=sampled(cls), use_language_goals=True)
+        assert env.env.sys.goal_mode == 1 and env.position is None
+        state, info = env.reset()
+        assert env.position is not None and info is not None
+        for _ in range(10):
+            assert type(state) is dict and type(state["obs"]) is dict and type(state["obs"]["goal"]) is str
+            goal = state["obs"]["goal"]
+            assert str(env.context["target_distance"]) in goal and DIRECTION_NAMES[env.context["target_direction"]] in goal
+            assert goal.startswith("The distance to the goal is ") and "Move within" in goal
+            assert state["obs"]["obs"].shape == env.observation_space["obs"].shape
+            state, _, _, _, _ = env.step(env.action_space.sample())
+        plain = cls(contexts=sampled(cls))
+        state, _ = plain.reset()
+        for _ in range(3):
+            assert "goal" not in state and not isinstance(state["obs"], dict)
+            state, _, _, _, _ = plain.step(plain.action_space.sample())
+    # a batch: one sentence per env, following the envs' context ids
+    contexts = sampled(CARLBraxAnt)
+    benv = CARLBraxAnt(batch_size=32, contexts=contexts, use_language_goals=True)
+    obs, info = benv.reset(seed=0)
+    texts, ids = obs["obs"]["goal"], info["context_id"].tolist()
+    assert len(texts) == 32 and obs["obs"]["obs"].shape == (32, 27) and benv.position.shape == (32, 2)
+    keys = list(contexts)
+    for t, cid in zip(texts, ids):
+        assert t == CARLBraxAnt.describe_goal(benv.contexts[keys[cid]])
+    # goals that do not vary: no goal wrapper, hence no language wrapper either (carl_brax_env.py:216-218)
+    same = {0: {"target_distance": 5.0, "target_direction": 1}, 1: {"target_distance": 5.0, "target_direction": 1}}
+    env = CARLBraxAnt(contexts=same, use_language_goals=True)
+    state, _ = env.reset()
+    assert not isinstance(state["obs"], dict) and env.position is None
