@@ -145,15 +145,23 @@ int launch_step(const carl_batch_t* b, const carl_step_io_t* io, int n_steps, hi
   // resets, so the global table costs nothing there; the LDS copy pays off in the per-call kernel)
   if (!no_staged && b->n_lanes % 16 == 0) {  // 16-byte pieces of every output row stay inside the batch
     const size_t sh_staged = carl::rollout_staged_lds_bytes<Fam>();
-    const void* fn = a64 ? reinterpret_cast<const void*>(carl::rollout_staged_kernel<Fam, true>)
-                         : reinterpret_cast<const void*>(carl::rollout_staged_kernel<Fam, false>);
-    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_staged);
+    using kern_t = void (*)(carl_batch_t, carl_step_io_t, int);
+    kern_t kern = a64 ? static_cast<kern_t>(carl::rollout_staged_kernel<Fam, true>)
+                      : static_cast<kern_t>(carl::rollout_staged_kernel<Fam, false>);
+    if constexpr (carl::predraw_of<Fam>::value) {
+      // short-episode families: the done path without the optional features when none of them is on
+      // (lanes keep their contexts, no finished-episode log, no terminal observations)
+      const bool plain = (b->selector == CARL_SEL_STATIC || b->selector == CARL_SEL_HOST) && b->fin_count == nullptr &&
+                         io->final_obs == nullptr;
+      if (plain)
+        kern = a64 ? static_cast<kern_t>(carl::rollout_staged_kernel<Fam, true, true>)
+                   : static_cast<kern_t>(carl::rollout_staged_kernel<Fam, false, true>);
+    }
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_staged);
     if (e != hipSuccess) return fail((int)e, "carl_rollout: hipFuncSetAttribute: %s", hipGetErrorString(e));
     const dim3 ts(carl::kStagedThreads);  // 4 compute waves + loader wave + storer wave
-    if (a64)
-      hipLaunchKernelGGL((carl::rollout_staged_kernel<Fam, true>), g, ts, sh_staged, s, *b, *io, n_steps);
-    else
-      hipLaunchKernelGGL((carl::rollout_staged_kernel<Fam, false>), g, ts, sh_staged, s, *b, *io, n_steps);
+    hipLaunchKernelGGL(kern, g, ts, sh_staged, s, *b, *io, n_steps);
     return check_launch("carl_rollout");
   }
   CARL_LAUNCH(rollout_kernel, *b, *io, n_steps);

@@ -35,14 +35,16 @@ __device__ __forceinline__ ctx_t<LDS> make_ctx(const carl_batch_t& b, float* lds
 // Returns true when memory was read.
 // `pre`: the episode's init-state words drawn ahead of time (staged rollout, families with kPredraw);
 // nullptr: drawn here.
-template <class Fam, class Ctx>
+// PLAIN: the caller knows that the lane keeps its context (static / host selector, not a first reset):
+// no selector code, no re-gather branch.
+template <class Fam, class Ctx, bool PLAIN = false>
 __device__ __forceinline__ bool reset_lane(const carl_batch_t& b, const Ctx& ctx, int lane, uint64_t glane,
                                            int& cidx, uint32_t& episode, typename Fam::Params& p,
                                            float (&s)[Fam::S], bool force, bool valid = true,
                                            const u32x4* pre = nullptr) {
   const int old = cidx;
-  cidx = select_context(b, cidx, glane, episode);
-  const bool changed = force || (cidx != old);
+  if constexpr (!PLAIN) cidx = select_context(b, cidx, glane, episode);
+  const bool changed = !PLAIN && (force || (cidx != old));
   if (changed) {
     p = Fam::load(ctx, cidx, b.flags);
     // the gathered parameters must have ARRIVED before this branch rejoins: otherwise the
@@ -111,6 +113,8 @@ struct LaneRegs {
   bool episode_valid;
   int n_new_calls;      // resets performed in this launch
   int n_new_episodes;   // episodes finished in this launch
+  float fin_return;     // return / length of the last of them (-> last_return / last_length at the end of
+  int fin_length;       // the launch: two global stores less on the done path of every finished episode)
   bool valid;           // false: a padding lane of a ragged last workgroup (a register-only clone of
                         // the batch's last lane: it computes, but nothing it does reaches global memory)
   u32x4 next_w;         // kPredraw families in the staged rollout: the init-state words of the lane's NEXT
@@ -205,20 +209,27 @@ __device__ __forceinline__ void predraw(const carl_batch_t& b, uint64_t glane, L
 // finished an episode (wave-uniform branch on a ballot): episode statistics, the compact
 // finished-episode log (ballot + one atomic per wave), and the in-kernel auto-reset
 // (Philox draws, selector advance, context re-gather).
-template <class Fam, class Ctx, bool PRE = false>
+// PLAIN (staged rollout of a kPredraw family, chosen by the host): static / host selector, no
+// finished-episode log, no terminal-observation output -- the done path of the common fused-rollout
+// configuration without the code of the optional features (measured on CartPole, 65 536 lanes: 768 ->
+// 553 ns/step; the optional features cost even when a wave-uniform branch skips them: scalar registers
+// spilled to VGPR lanes and restored, exec-mask bookkeeping, waits at the joins).
+template <class Fam, class Ctx, bool PRE = false, bool PLAIN = false>
 __device__ __forceinline__ void finish_episodes(const carl_batch_t& b, const Ctx& ctx, bool done, int lane,
                                                 uint64_t glane, float* final_obs, float (&o)[Fam::D],
                                                 LaneRegs<Fam>& r) {
   const float fin_ret = r.ep_return;
   const int fin_len = r.elapsed;
-  if (done && r.valid) {
-    if (b.last_return) b.last_return[lane] = fin_ret;
-    if (b.last_length) b.last_length[lane] = fin_len;
+  if (done && r.valid) {  // the lane's last finished episode: kept in registers, written once by store_lane
+    r.fin_return = fin_ret;
+    r.fin_length = fin_len;
     r.n_new_episodes += 1;
   }
-  log_finished(b, done && r.valid, glane, fin_ret, fin_len);
+  if constexpr (!PLAIN) log_finished(b, done && r.valid, glane, fin_ret, fin_len);
   if ((b.flags & CARL_FLAG_AUTORESET) && done) {
-    if (final_obs != nullptr) store_obs<Fam::D>(final_obs, 0, o);
+    if constexpr (!PLAIN) {
+      if (final_obs != nullptr) store_obs<Fam::D>(final_obs, 0, o);
+    }
     if (!r.episode_valid) {  // (never on a padding lane: the rollout kernels preload the counter)
       r.episode = b.episode[lane];
       r.episode_valid = true;
@@ -228,9 +239,9 @@ __device__ __forceinline__ void finish_episodes(const carl_batch_t& b, const Ctx
       u32x4 w = r.next_w;
       if (!r.next_ok) w = lane_words(b.seed, glane, r.episode, kSubInit);  // second finish inside one chunk
       r.next_ok = false;
-      reset_lane<Fam>(b, ctx, lane, glane, r.cidx, r.episode, r.p, r.s, false, r.valid, &w);
+      reset_lane<Fam, Ctx, PLAIN>(b, ctx, lane, glane, r.cidx, r.episode, r.p, r.s, false, r.valid, &w);
     } else {
-      reset_lane<Fam>(b, ctx, lane, glane, r.cidx, r.episode, r.p, r.s, false, r.valid);
+      reset_lane<Fam, Ctx, PLAIN>(b, ctx, lane, glane, r.cidx, r.episode, r.p, r.s, false, r.valid);
     }
     r.elapsed = 0;
     r.ep_return = 0.0f;
@@ -248,7 +259,7 @@ __device__ __forceinline__ void finish_episodes(const carl_batch_t& b, const Ctx
 // One step of one lane.  `cur` points at this step's output records for this lane.
 // ALL_ACTIVE: the whole wave is inside the batch (every full workgroup), so the per-step
 // `if (active)` exec-mask dance disappears from the loop.
-template <class Fam, class Ctx, bool ALL_ACTIVE = false, class Sink = Cursors<Fam>>
+template <class Fam, class Ctx, bool ALL_ACTIVE = false, class Sink = Cursors<Fam>, bool PLAIN = false>
 __device__ __forceinline__ void step_lane(const carl_batch_t& b, const Ctx& ctx, const Sink& cur,
                                           int max_steps, bool active_in, int lane, uint64_t glane,
                                           typename Fam::Action action, LaneRegs<Fam>& r) {
@@ -277,6 +288,9 @@ __device__ __forceinline__ void step_lane(const carl_batch_t& b, const Ctx& ctx,
     te = terminated;
     tr = truncated;
     done = terminated | truncated;
+#ifdef CARL_EXP_NO_DONE  // profiling only: the floor of a family's step without the done path
+    done = false;
+#endif
   }
   if (__builtin_expect(__ballot(done) != 0ull, 0)) {
 #ifndef CARL_EXP_NO_FLAG_STORES
@@ -284,7 +298,8 @@ __device__ __forceinline__ void step_lane(const carl_batch_t& b, const Ctx& ctx,
       if (active) cur.put_flags(te, tr);
     }
 #endif
-    finish_episodes<Fam, Ctx, Sink::kLazyFlags && predraw_of<Fam>::value>(b, ctx, done, lane, glane, cur.final_obs_ptr(), o, r);
+    finish_episodes<Fam, Ctx, Sink::kLazyFlags && predraw_of<Fam>::value, PLAIN>(b, ctx, done, lane, glane,
+                                                                                 cur.final_obs_ptr(), o, r);
   }
 #ifndef CARL_EXP_NO_OBS_STORE
   if (active) cur.put_obs(o);
@@ -325,7 +340,11 @@ __device__ __forceinline__ void store_lane(const carl_batch_t& b, int lane, cons
   for (int j = 0; j < Fam::S; ++j) b.state[(size_t)j * b.n_lanes + lane] = r.s[j];
   b.elapsed[lane] = r.elapsed;
   b.ep_return[lane] = r.ep_return;
-  if (r.n_new_episodes != 0 && b.episodes_done != nullptr) b.episodes_done[lane] += r.n_new_episodes;
+  if (r.n_new_episodes != 0) {
+    if (b.episodes_done != nullptr) b.episodes_done[lane] += r.n_new_episodes;
+    if (b.last_return != nullptr) b.last_return[lane] = r.fin_return;
+    if (b.last_length != nullptr) b.last_length[lane] = r.fin_length;
+  }
   if (r.n_new_calls != 0) {  // only lanes that were reset in this launch
     b.ctx_idx[lane] = r.cidx;
     b.episode[lane] = r.episode;
@@ -687,7 +706,7 @@ __device__ __forceinline__ void zero_flag_rows(char* out_buf, int l, int which) 
 
 // Preconditions (checked by the host): n_lanes % 16 == 0 (the last workgroup may be ragged), global
 // context table.
-template <class Fam, bool A64>
+template <class Fam, bool A64, bool PLAIN = false>
 __global__ void __launch_bounds__(kStagedThreads) rollout_staged_kernel(const carl_batch_t b, const carl_step_io_t io,
                                                                         const int n_steps) {
   extern __shared__ float lds_dyn[];
@@ -748,7 +767,7 @@ __global__ void __launch_bounds__(kStagedThreads) rollout_staged_kernel(const ca
         const Action a = a_next;
         a_next = my[min(u + 1, kStageChunk - 1) * kRolloutLanes];
         const SK sink{rec + (size_t)u * SK::kStepBytes, final_base, n * Fam::D, t0 + u, (int)threadIdx.x};
-        step_lane<Fam, GlobalCtx, true, SK>(b, ctx, sink, max_steps, true, lane, glane, a, r);
+        step_lane<Fam, GlobalCtx, true, SK, PLAIN>(b, ctx, sink, max_steps, true, lane, glane, a, r);
       }
     } else if (loader) {
 #ifndef CARL_EXP_NO_LOADER

@@ -528,3 +528,37 @@ def test_absurd_actions_do_not_spin_the_acrobot(device):
     e.reset()                               # ... and the engine is usable afterwards
     out = e.rollout(torch.ones((10, n), dtype=torch.int32, device=device))
     assert torch.isfinite(out["obs"]).all()
+
+
+@pytest.mark.parametrize("fam", range(5), ids=O.FAMILY_NAMES)
+@pytest.mark.parametrize("T,n,max_steps", [(9, 1024, 5), (37, 1008, 5), (200, 1024, 0), (64, 272, 3)])
+def test_staged_rollout_without_optional_outputs_equals_repeated_step(fam, T, n, max_steps, device):
+    """The fused rollout in its leanest configuration -- static selector, no terminal observations, no
+    finished-episode log -- which for short-episode families (CartPole) runs a done path compiled
+    WITHOUT those features (rollout_staged_kernel<Fam, A64, PLAIN = true>) and with the init-state words
+    drawn ahead per chunk: bit-identical to T per-call steps of an engine that has them all switched
+    on, in every output and every counter, through resets of every lane (max_steps 3 / 5: several
+    finishes inside one 8-step chunk) and natural terminations (max_steps 0 = the family's limit)."""
+    rng = np.random.default_rng(fam * 7 + T)
+    table = random_table(fam, rng, n)
+    acts = torch.as_tensor(random_actions(fam, rng, (T, n)), device=device)
+    kw = dict(selector=O.SEL_STATIC, seed=11, ctx_idx0=np.arange(n))
+    if max_steps:
+        kw["max_episode_steps"] = max_steps
+    e1 = _engine(fam, table, n, device, **kw)                       # lean: PLAIN where the family has it
+    e2 = _engine(fam, table, n, device, fin_capacity=1 << 15, **kw)  # everything on, per-call kernel
+    e1.reset()
+    e2.reset()
+    out = e1.rollout(acts, e1.alloc_rollout(T, final_obs=False))
+    n_done = 0
+    for t in range(T):
+        obs, rew, term, trunc = e2.step(acts[t])
+        assert torch.equal(out["obs"][t], obs) and torch.equal(out["reward"][t], rew), t
+        assert torch.equal(out["terminated"][t], term) and torch.equal(out["truncated"][t], trunc), t
+        n_done += int((term | trunc).sum())
+    for name in ("state", "elapsed", "ctx_idx", "episode", "n_calls", "ep_return", "last_return", "last_length",
+                 "episodes_done"):
+        assert torch.equal(getattr(e1, name), getattr(e2, name)), name
+    assert int(e1.episodes_done.sum()) == n_done
+    if max_steps:
+        assert n_done >= n * (T // max_steps)
