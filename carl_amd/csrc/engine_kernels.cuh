@@ -35,16 +35,14 @@ __device__ __forceinline__ ctx_t<LDS> make_ctx(const carl_batch_t& b, float* lds
 // Returns true when memory was read.
 // `pre`: the episode's init-state words drawn ahead of time (staged rollout, families with kPredraw);
 // nullptr: drawn here.
-// PLAIN: the caller knows that the lane keeps its context (static / host selector, not a first reset):
-// no selector code, no re-gather branch.
-template <class Fam, class Ctx, bool PLAIN = false>
+template <class Fam, class Ctx>
 __device__ __forceinline__ bool reset_lane(const carl_batch_t& b, const Ctx& ctx, int lane, uint64_t glane,
                                            int& cidx, uint32_t& episode, typename Fam::Params& p,
                                            float (&s)[Fam::S], bool force, bool valid = true,
                                            const u32x4* pre = nullptr) {
   const int old = cidx;
-  if constexpr (!PLAIN) cidx = select_context(b, cidx, glane, episode);
-  const bool changed = !PLAIN && (force || (cidx != old));
+  cidx = select_context(b, cidx, glane, episode);
+  const bool changed = force || (cidx != old);
   if (changed) {
     p = Fam::load(ctx, cidx, b.flags);
     // the gathered parameters must have ARRIVED before this branch rejoins: otherwise the
@@ -209,12 +207,7 @@ __device__ __forceinline__ void predraw(const carl_batch_t& b, uint64_t glane, L
 // finished an episode (wave-uniform branch on a ballot): episode statistics, the compact
 // finished-episode log (ballot + one atomic per wave), and the in-kernel auto-reset
 // (Philox draws, selector advance, context re-gather).
-// PLAIN (staged rollout of a kPredraw family, chosen by the host): static / host selector, no
-// finished-episode log, no terminal-observation output -- the done path of the common fused-rollout
-// configuration without the code of the optional features (measured on CartPole, 65 536 lanes: 768 ->
-// 553 ns/step; the optional features cost even when a wave-uniform branch skips them: scalar registers
-// spilled to VGPR lanes and restored, exec-mask bookkeeping, waits at the joins).
-template <class Fam, class Ctx, bool PRE = false, bool PLAIN = false>
+template <class Fam, class Ctx, bool PRE = false>
 __device__ __forceinline__ void finish_episodes(const carl_batch_t& b, const Ctx& ctx, bool done, int lane,
                                                 uint64_t glane, float* final_obs, float (&o)[Fam::D],
                                                 LaneRegs<Fam>& r) {
@@ -225,11 +218,9 @@ __device__ __forceinline__ void finish_episodes(const carl_batch_t& b, const Ctx
     r.fin_length = fin_len;
     r.n_new_episodes += 1;
   }
-  if constexpr (!PLAIN) log_finished(b, done && r.valid, glane, fin_ret, fin_len);
+  log_finished(b, done && r.valid, glane, fin_ret, fin_len);
   if ((b.flags & CARL_FLAG_AUTORESET) && done) {
-    if constexpr (!PLAIN) {
-      if (final_obs != nullptr) store_obs<Fam::D>(final_obs, 0, o);
-    }
+    if (final_obs != nullptr) store_obs<Fam::D>(final_obs, 0, o);
     if (!r.episode_valid) {  // (never on a padding lane: the rollout kernels preload the counter)
       r.episode = b.episode[lane];
       r.episode_valid = true;
@@ -239,9 +230,9 @@ __device__ __forceinline__ void finish_episodes(const carl_batch_t& b, const Ctx
       u32x4 w = r.next_w;
       if (!r.next_ok) w = lane_words(b.seed, glane, r.episode, kSubInit);  // second finish inside one chunk
       r.next_ok = false;
-      reset_lane<Fam, Ctx, PLAIN>(b, ctx, lane, glane, r.cidx, r.episode, r.p, r.s, false, r.valid, &w);
+      reset_lane<Fam>(b, ctx, lane, glane, r.cidx, r.episode, r.p, r.s, false, r.valid, &w);
     } else {
-      reset_lane<Fam, Ctx, PLAIN>(b, ctx, lane, glane, r.cidx, r.episode, r.p, r.s, false, r.valid);
+      reset_lane<Fam>(b, ctx, lane, glane, r.cidx, r.episode, r.p, r.s, false, r.valid);
     }
     r.elapsed = 0;
     r.ep_return = 0.0f;
@@ -254,6 +245,64 @@ __device__ __forceinline__ void finish_episodes(const carl_batch_t& b, const Ctx
   // step loop into lgkmcnt(0) (= also wait for the record writes just issued).  The compiler
   // models an explicit s_waitcnt: vmcnt/expcnt untouched, lgkmcnt(0).
   __builtin_amdgcn_s_waitcnt(0xC07F);
+}
+
+// word-wise `c ? a : b` of any trivially copyable register-resident value (v_cndmask per 32-bit word)
+template <class T>
+__device__ __forceinline__ T select_words(bool c, const T& a, const T& b) {
+  if constexpr (sizeof(T) < 4) {
+    return c ? a : b;
+  } else {
+    static_assert(sizeof(T) % 4 == 0, "select_words() works on 32-bit words");
+    uint32_t wa[sizeof(T) / 4], wb[sizeof(T) / 4];
+    __builtin_memcpy(wa, &a, sizeof(T));
+    __builtin_memcpy(wb, &b, sizeof(T));
+#pragma unroll
+    for (size_t k = 0; k < sizeof(T) / 4; ++k) wa[k] = c ? wa[k] : wb[k];
+    T out;
+    __builtin_memcpy(&out, wa, sizeof(T));
+    return out;
+  }
+}
+
+// PLAIN (staged rollout of a kPredraw family, chosen by the host when lanes keep their contexts -- static /
+// host selector -- and neither the finished-episode log nor terminal observations are asked for): the done
+// path of the common fused-rollout configuration without the code of the optional features.  Those cost
+// even when a wave-uniform branch skips them -- scalar registers spilled to VGPR lanes and restored,
+// exec-mask bookkeeping, waits at the joins: CartPole, 65 536 lanes, 768 -> 553 ns/step.
+// It is written as straight-line selects: entered under the wave-uniform
+// ballot branch, it has no divergent control flow of its own (the one inner branch -- a lane finishing
+// twice inside a chunk -- is wave-uniform as well), so the compiler has one join to reconcile instead of
+// five and the exec mask is never rewritten.  With `if (done) { ... }` blocks the same work cost ~30
+// register copies at the joins on top of its ~35 instructions.
+template <class Fam>
+__device__ __forceinline__ void finish_plain(const carl_batch_t& b, uint64_t glane, bool done, float (&o)[Fam::D],
+                                             LaneRegs<Fam>& r) {
+  u32x4 w = r.next_w;
+  if (__ballot(done && !r.next_ok) != 0ull) {
+    const u32x4 wi = lane_words(b.seed, glane, r.episode, kSubInit);
+    w = select_words(r.next_ok, w, wi);
+  }
+  float ns[Fam::S], no[Fam::D];
+  typename Fam::Aux na;
+  Fam::reset(r.p, w, ns);
+  Fam::prepare(ns, na);
+  Fam::observe(ns, na, no);
+  const bool rs = done && (b.flags & CARL_FLAG_AUTORESET) != 0;
+  r.fin_return = done ? r.ep_return : r.fin_return;
+  r.fin_length = done ? r.elapsed : r.fin_length;
+  r.n_new_episodes += done ? 1 : 0;
+#pragma unroll
+  for (int j = 0; j < Fam::S; ++j) r.s[j] = rs ? ns[j] : r.s[j];
+#pragma unroll
+  for (int d = 0; d < Fam::D; ++d) o[d] = rs ? no[d] : o[d];
+  r.aux = select_words(rs, na, r.aux);
+  r.elapsed = rs ? 0 : r.elapsed;
+  r.ep_return = rs ? 0.0f : r.ep_return;
+  r.episode += rs ? 1u : 0u;
+  r.n_new_calls += rs ? 1 : 0;
+  r.next_ok = r.next_ok && !rs;
+  __builtin_amdgcn_s_waitcnt(0xC07F);  // as at the end of finish_episodes
 }
 
 // One step of one lane.  `cur` points at this step's output records for this lane.
@@ -298,8 +347,11 @@ __device__ __forceinline__ void step_lane(const carl_batch_t& b, const Ctx& ctx,
       if (active) cur.put_flags(te, tr);
     }
 #endif
-    finish_episodes<Fam, Ctx, Sink::kLazyFlags && predraw_of<Fam>::value, PLAIN>(b, ctx, done, lane, glane,
-                                                                                 cur.final_obs_ptr(), o, r);
+    if constexpr (PLAIN)
+      finish_plain<Fam>(b, glane, done, o, r);
+    else
+      finish_episodes<Fam, Ctx, Sink::kLazyFlags && predraw_of<Fam>::value>(b, ctx, done, lane, glane,
+                                                                            cur.final_obs_ptr(), o, r);
   }
 #ifndef CARL_EXP_NO_OBS_STORE
   if (active) cur.put_obs(o);
