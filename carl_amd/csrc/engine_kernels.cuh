@@ -35,7 +35,9 @@ __device__ __forceinline__ ctx_t<LDS> make_ctx(const carl_batch_t& b, float* lds
 // Returns true when memory was read.
 // `pre`: the episode's init-state words drawn ahead of time (staged rollout, families with kPredraw);
 // nullptr: drawn here.
-template <class Fam, class Ctx>
+// CTX_OBS = false: the caller rewrites the lane's context observation itself (the step / rollout kernels
+// do it once per launch, in store_lane, instead of on every reset).
+template <class Fam, class Ctx, bool CTX_OBS = true>
 __device__ __forceinline__ bool reset_lane(const carl_batch_t& b, const Ctx& ctx, int lane, uint64_t glane,
                                            int& cidx, uint32_t& episode, typename Fam::Params& p,
                                            float (&s)[Fam::S], bool force, bool valid = true,
@@ -51,9 +53,11 @@ __device__ __forceinline__ bool reset_lane(const carl_batch_t& b, const Ctx& ctx
     // statistics just stored (a full store round trip per reset; CartPole under a random policy
     // resets some lane of nearly every wave on nearly every step: 983 -> 852 ns/step, A/B on one box)
     settle(p);
-    if (b.ctx_obs != nullptr && valid) {
-      for (int k = 0; k < b.n_ctx_obs; ++k)
-        b.ctx_obs[(size_t)k * b.n_lanes + lane] = ctx.get(b.ctx_obs_feat[k], cidx);
+    if constexpr (CTX_OBS) {
+      if (b.ctx_obs != nullptr && valid) {
+        for (int k = 0; k < b.n_ctx_obs; ++k)
+          b.ctx_obs[(size_t)k * b.n_lanes + lane] = ctx.get(b.ctx_obs_feat[k], cidx);
+      }
     }
   }
   const u32x4 w = (pre != nullptr) ? *pre : lane_words(b.seed, glane, episode, kSubInit);
@@ -230,9 +234,9 @@ __device__ __forceinline__ void finish_episodes(const carl_batch_t& b, const Ctx
       u32x4 w = r.next_w;
       if (!r.next_ok) w = lane_words(b.seed, glane, r.episode, kSubInit);  // second finish inside one chunk
       r.next_ok = false;
-      reset_lane<Fam>(b, ctx, lane, glane, r.cidx, r.episode, r.p, r.s, false, r.valid, &w);
+      reset_lane<Fam, Ctx, false>(b, ctx, lane, glane, r.cidx, r.episode, r.p, r.s, false, r.valid, &w);
     } else {
-      reset_lane<Fam>(b, ctx, lane, glane, r.cidx, r.episode, r.p, r.s, false, r.valid);
+      reset_lane<Fam, Ctx, false>(b, ctx, lane, glane, r.cidx, r.episode, r.p, r.s, false, r.valid);
     }
     r.elapsed = 0;
     r.ep_return = 0.0f;
@@ -386,8 +390,8 @@ __device__ __forceinline__ void load_lane(const carl_batch_t& b, const Ctx& ctx,
   if constexpr (Fam::kNeedsStepNoise) settle(r.episode);
 }
 
-template <class Fam>
-__device__ __forceinline__ void store_lane(const carl_batch_t& b, int lane, const LaneRegs<Fam>& r) {
+template <class Fam, class Ctx>
+__device__ __forceinline__ void store_lane(const carl_batch_t& b, const Ctx& ctx, int lane, const LaneRegs<Fam>& r) {
 #pragma unroll
   for (int j = 0; j < Fam::S; ++j) b.state[(size_t)j * b.n_lanes + lane] = r.s[j];
   b.elapsed[lane] = r.elapsed;
@@ -401,6 +405,14 @@ __device__ __forceinline__ void store_lane(const carl_batch_t& b, int lane, cons
     b.ctx_idx[lane] = r.cidx;
     b.episode[lane] = r.episode;
     b.n_calls[lane] += r.n_new_calls;
+    // the lane's context observation: only its value at the end of the launch is visible, so it is
+    // written here instead of on every context change.  (On the done path this loop -- per feature an
+    // s_load of the feature id, a wait, the table read, a wait, the store -- cost 750 ns of a 1670 ns
+    // CartPole step under a round-robin / random selector with the default eight observed features.)
+    if (b.ctx_obs != nullptr) {
+      for (int k = 0; k < b.n_ctx_obs; ++k)
+        b.ctx_obs[(size_t)k * b.n_lanes + lane] = ctx.get(b.ctx_obs_feat[k], r.cidx);
+    }
   }
 }
 
@@ -436,7 +448,7 @@ __global__ void __launch_bounds__(256) step_kernel(const carl_batch_t b, const c
   }
   const Cursors<Fam> cur = make_cursors<Fam>(io, active ? lane : 0);
   step_lane<Fam>(b, ctx, cur, b.max_episode_steps, active, lane, glane, action, r);
-  if (active) store_lane<Fam>(b, lane, r);
+  if (active) store_lane<Fam>(b, ctx, lane, r);
 }
 
 // -------------------------------- rollout (T steps fused) ---------------------------
@@ -572,7 +584,7 @@ __global__ void __launch_bounds__(kRolloutThreads) rollout_kernel(const carl_bat
     __syncthreads();
 #endif
   }
-  if (active) store_lane<Fam>(b, lane, r);
+  if (active) store_lane<Fam>(b, ctx, lane, r);
 }
 
 // -------------------------------- rollout, LDS-staged outputs -----------------------
@@ -836,7 +848,7 @@ __global__ void __launch_bounds__(kStagedThreads) rollout_staged_kernel(const ca
     __syncthreads();
   }
   if (compute) {
-    if (active) store_lane<Fam>(b, lane, r);
+    if (active) store_lane<Fam>(b, ctx, lane, r);
   } else if (!loader) {  // records of the last chunk
     const int last_t0 = ((n_steps - 1) / kStageChunk) * kStageChunk;
     drain_records<Fam>(out_buf + (size_t)(buf ^ 1) * kStageChunk * SK::kStepBytes, io, n, lane_base, hl, storer,
