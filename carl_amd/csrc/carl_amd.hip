@@ -144,18 +144,24 @@ int launch_step(const carl_batch_t* b, const carl_step_io_t* io, int n_steps, hi
   // (also for tables small enough for LDS: a fused rollout gathers parameters once per launch and on
   // resets, so the global table costs nothing there; the LDS copy pays off in the per-call kernel)
   if (!no_staged && b->n_lanes % 16 == 0) {  // 16-byte pieces of every output row stay inside the batch
-    const size_t sh_staged = carl::rollout_staged_lds_bytes<Fam>();
+    size_t sh_staged = carl::rollout_staged_lds_bytes<Fam>();
     using kern_t = void (*)(carl_batch_t, carl_step_io_t, int);
     kern_t kern = a64 ? static_cast<kern_t>(carl::rollout_staged_kernel<Fam, true>)
                       : static_cast<kern_t>(carl::rollout_staged_kernel<Fam, false>);
     if constexpr (carl::predraw_of<Fam>::value) {
-      // short-episode families: the done path without the optional features when none of them is on
-      // (lanes keep their contexts, no finished-episode log, no terminal observations)
-      const bool plain = (b->selector == CARL_SEL_STATIC || b->selector == CARL_SEL_HOST) && b->fin_count == nullptr &&
-                         io->final_obs == nullptr;
-      if (plain)
+      // short-episode families: the done path runs on nearly every step, so it gets two specialisations
+      const bool keeps_context = b->selector == CARL_SEL_STATIC || b->selector == CARL_SEL_HOST;
+      const size_t table_bytes = (size_t)Fam::F * b->n_contexts * sizeof(float);
+      if (keeps_context && b->fin_count == nullptr && io->final_obs == nullptr) {
+        // none of the optional features is on: the done path compiled without them
         kern = a64 ? static_cast<kern_t>(carl::rollout_staged_kernel<Fam, true, true>)
                    : static_cast<kern_t>(carl::rollout_staged_kernel<Fam, false, true>);
+      } else if (!keeps_context && lds && sh_staged + table_bytes <= 160 * 1024) {
+        // lanes change contexts on reset and the table is small: re-gather from LDS, not from HBM
+        kern = a64 ? static_cast<kern_t>(carl::rollout_staged_kernel<Fam, true, false, true>)
+                   : static_cast<kern_t>(carl::rollout_staged_kernel<Fam, false, false, true>);
+        sh_staged += table_bytes;
+      }
     }
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_staged);

@@ -770,7 +770,11 @@ __device__ __forceinline__ void zero_flag_rows(char* out_buf, int l, int which) 
 
 // Preconditions (checked by the host): n_lanes % 16 == 0 (the last workgroup may be ragged), global
 // context table.
-template <class Fam, bool A64, bool PLAIN = false>
+// LDSCTX (short-episode families under a round-robin / random selector, small tables; chosen by the host):
+// the [F][C] context table is staged in LDS behind the record buffers, so the parameter re-gather of a
+// lane that moves to another context -- on the done path of nearly every step for CartPole -- is an LDS
+// read instead of an HBM / L2 round trip the whole wave waits for.
+template <class Fam, bool A64, bool PLAIN = false, bool LDSCTX = false>
 __global__ void __launch_bounds__(kStagedThreads) rollout_staged_kernel(const carl_batch_t b, const carl_step_io_t io,
                                                                         const int n_steps) {
   extern __shared__ float lds_dyn[];
@@ -779,7 +783,8 @@ __global__ void __launch_bounds__(kStagedThreads) rollout_staged_kernel(const ca
   using SK = LdsSink<Fam>;
   Action* act_buf = reinterpret_cast<Action*>(lds_dyn);  // [2][kStageChunk][256]
   char* out_buf = reinterpret_cast<char*>(lds_dyn) + (size_t)2 * kStageChunk * kRolloutLanes * sizeof(float);
-  const GlobalCtx ctx{b.ctx_table, b.ctx_stride};
+  float* ctx_lds = reinterpret_cast<float*>(out_buf + (size_t)2 * kStageChunk * SK::kStepBytes);
+  const ctx_t<LDSCTX> ctx = make_ctx<LDSCTX, Fam::F>(b, ctx_lds);  // LDSCTX: stages the table, then a barrier
   // 0..3 compute, 4 loader, 5.. storers (wave-uniform).  Eight waves = two per SIMD: every
   // compute wave shares its SIMD with exactly one light helper wave, so no compute wave is
   // slowed more than the others before the chunk barrier.
@@ -831,7 +836,7 @@ __global__ void __launch_bounds__(kStagedThreads) rollout_staged_kernel(const ca
         const Action a = a_next;
         a_next = my[min(u + 1, kStageChunk - 1) * kRolloutLanes];
         const SK sink{rec + (size_t)u * SK::kStepBytes, final_base, n * Fam::D, t0 + u, (int)threadIdx.x};
-        step_lane<Fam, GlobalCtx, true, SK, PLAIN>(b, ctx, sink, max_steps, true, lane, glane, a, r);
+        step_lane<Fam, ctx_t<LDSCTX>, true, SK, PLAIN>(b, ctx, sink, max_steps, true, lane, glane, a, r);
       }
     } else if (loader) {
 #ifndef CARL_EXP_NO_LOADER
