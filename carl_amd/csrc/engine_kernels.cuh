@@ -119,7 +119,6 @@ struct LaneRegs {
   int fin_length;       // the launch: two global stores less on the done path of every finished episode)
   bool valid;           // false: a padding lane of a ragged last workgroup (a register-only clone of
                         // the batch's last lane: it computes, but nothing it does reaches global memory)
-  bool ctx_changed;     // some reset of this launch moved the lane to another context
   u32x4 next_w;         // kPredraw families in the staged rollout: the init-state words of the lane's NEXT
   bool next_ok;         // episode, drawn once per chunk for the whole wave (see predraw)
   typename Fam::Params p;
@@ -235,9 +234,9 @@ __device__ __forceinline__ void finish_episodes(const carl_batch_t& b, const Ctx
       u32x4 w = r.next_w;
       if (!r.next_ok) w = lane_words(b.seed, glane, r.episode, kSubInit);  // second finish inside one chunk
       r.next_ok = false;
-      r.ctx_changed |= reset_lane<Fam, Ctx, false>(b, ctx, lane, glane, r.cidx, r.episode, r.p, r.s, false, r.valid, &w);
+      reset_lane<Fam, Ctx, false>(b, ctx, lane, glane, r.cidx, r.episode, r.p, r.s, false, r.valid, &w);
     } else {
-      r.ctx_changed |= reset_lane<Fam, Ctx, false>(b, ctx, lane, glane, r.cidx, r.episode, r.p, r.s, false, r.valid);
+      reset_lane<Fam, Ctx, false>(b, ctx, lane, glane, r.cidx, r.episode, r.p, r.s, false, r.valid);
     }
     r.elapsed = 0;
     r.ep_return = 0.0f;
@@ -376,7 +375,6 @@ __device__ __forceinline__ void load_lane(const carl_batch_t& b, const Ctx& ctx,
   r.episode_valid = Fam::kNeedsStepNoise;
   if constexpr (Fam::kNeedsStepNoise) r.episode = b.episode[lane];
   r.n_new_calls = 0;
-  r.ctx_changed = false;
   r.n_new_episodes = 0;
   r.valid = true;
   r.p = Fam::load(ctx, r.cidx, b.flags);
@@ -404,6 +402,7 @@ __device__ __forceinline__ void store_lane(const carl_batch_t& b, const Ctx& ctx
     if (b.last_length != nullptr) b.last_length[lane] = r.fin_length;
   }
   if (r.n_new_calls != 0) {  // only lanes that were reset in this launch
+    const bool moved = b.ctx_idx[lane] != r.cidx;  // (re-read here: no register is held for it across the steps)
     b.ctx_idx[lane] = r.cidx;
     b.episode[lane] = r.episode;
     b.n_calls[lane] += r.n_new_calls;
@@ -411,7 +410,7 @@ __device__ __forceinline__ void store_lane(const carl_batch_t& b, const Ctx& ctx
     // written here instead of on every context change.  (On the done path this loop -- per feature an
     // s_load of the feature id, a wait, the table read, a wait, the store -- cost 750 ns of a 1670 ns
     // CartPole step under a round-robin / random selector with the default eight observed features.)
-    if (r.ctx_changed && b.ctx_obs != nullptr) {
+    if (moved && b.ctx_obs != nullptr) {
       for (int k = 0; k < b.n_ctx_obs; ++k)
         b.ctx_obs[(size_t)k * b.n_lanes + lane] = ctx.get(b.ctx_obs_feat[k], r.cidx);
     }
