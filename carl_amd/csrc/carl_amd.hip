@@ -149,7 +149,8 @@ int launch_step(const carl_batch_t* b, const carl_step_io_t* io, int n_steps, hi
     kern_t kern = a64 ? static_cast<kern_t>(carl::rollout_staged_kernel<Fam, true>)
                       : static_cast<kern_t>(carl::rollout_staged_kernel<Fam, false>);
     if constexpr (carl::predraw_of<Fam>::value) {
-      // short-episode families: the done path runs on nearly every step, so it gets two specialisations
+      // two specialisations of the done path (made for CartPole, whose done path runs on nearly every step;
+      // every family opts in: the leaner code also helps the step loop's register allocation)
       const bool keeps_context = b->selector == CARL_SEL_STATIC || b->selector == CARL_SEL_HOST;
       const size_t table_bytes = (size_t)Fam::F * b->n_contexts * sizeof(float);
       if (keeps_context && b->fin_count == nullptr && io->final_obs == nullptr) {

@@ -40,7 +40,11 @@ struct CartPole {
   using Aux = NoAux;
   enum { GRAVITY, MASSCART, MASSPOLE, LENGTH, FORCE_MAG, TAU, INIT_LO, INIT_HI };
   static constexpr bool kNeedsStepNoise = false;
-  static constexpr bool kPredraw = true;  // short episodes: init-state words drawn once per chunk (engine_kernels.cuh)
+  // the staged rollout's specialisations (engine_kernels.cuh: init-state words drawn once per chunk, the PLAIN
+  // done path, the LDS-resident context table).  Made for CartPole's short episodes; switched on for every
+  // family because the smaller done path also frees the step loop's registers: Pendulum 279 -> 266,
+  // MountainCar 292 -> 273, MountainCarContinuous 313 -> 276, Acrobot 2330 -> 2205 ns/step (A/B, one box)
+  static constexpr bool kPredraw = true;
 
   struct Params {
     float gravity, masspole, length, force_mag, tau, inv_total_mass, polemass_length;
@@ -131,6 +135,7 @@ struct Pendulum {
   using Action = float;
   enum { GRAVITY_DEAD, DT, G, M, L, INIT_ANGLE_MAX, INIT_VEL_MAX };
   static constexpr bool kNeedsStepNoise = false;
+  static constexpr bool kPredraw = true;
 
   // `3*g/(2*l)*sin(th)` and `3.0/(m*l**2)*u` evaluate left to right, so the two
   // quotients are per-context constants with the reference's own rounding order
@@ -209,6 +214,7 @@ struct AcrobotT {
   using Action = int;
   enum { L1, L2, M1, M2, C1, C2, MOI, MAXV1, MAXV2, NOISE, IA_LO, IA_HI, IV_LO, IV_HI };
   static constexpr bool kNeedsStepNoise = true;
+  static constexpr bool kPredraw = true;
 
   struct Params {
     Real m1lc1sq;  // m1 * lc1^2, the context-only leading term of d1
@@ -375,6 +381,7 @@ struct MountainCar {
   using Aux = NoAux;
   enum { MIN_POS, MAX_POS, MAX_SPEED, GOAL_POS, GOAL_VEL, FORCE, GRAVITY, MINP_START, MAXP_START, MINV_START, MAXV_START };
   static constexpr bool kNeedsStepNoise = false;
+  static constexpr bool kPredraw = true;
 
   struct Params {
     float min_position, max_position, max_speed, goal_position, goal_velocity, force, gravity;
@@ -425,6 +432,7 @@ struct MountainCarCont {
   using Aux = NoAux;
   enum { MIN_POS, MAX_POS, MAX_SPEED, GOAL_POS, GOAL_VEL, POWER, MINP_START, MAXP_START, MINV_START, MAXV_START };
   static constexpr bool kNeedsStepNoise = false;
+  static constexpr bool kPredraw = true;
 
   struct Params {
     float min_position, max_position, max_speed, goal_position, goal_velocity, power;
