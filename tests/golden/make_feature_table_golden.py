@@ -48,6 +48,22 @@ def _directions() -> list:
     return _goal_wrapper_literal("directions")
 
 
+def _goal_sentences() -> list:
+    """outputs of the reference's ``BraxLanguageWrapper.get_goal_desc`` (the method alone is compiled from the
+    module's syntax tree -- the module itself imports gym and brax -- and run on a few contexts)"""
+    path = os.path.join(REF, "brax", "brax_walker_goal_wrapper.py")
+    tree = ast.parse(open(path).read())
+    fn = next(n for c in tree.body if isinstance(c, ast.ClassDef) and c.name == "BraxLanguageWrapper"
+              for n in c.body if isinstance(n, ast.FunctionDef) and n.name == "get_goal_desc")
+    ns = {"DIRECTION_NAMES": _goal_wrapper_literal("DIRECTION_NAMES")}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), path, "exec"), ns)
+    contexts = [{"target_distance": 9.8, "target_direction": 112, "target_radius": 5},
+                {"target_distance": 11.764052345967665, "target_direction": 34, "target_radius": 0.5},
+                {"target_distance": 100, "target_direction": 1},
+                {"target_distance": 2.5, "target_direction": 434}]
+    return [{"context": c, "sentence": ns["get_goal_desc"](None, c)} for c in contexts]
+
+
 def tables_of(path: str) -> dict:
     tree = ast.parse(open(path).read())
     out = {}
@@ -78,7 +94,7 @@ def main() -> None:
             if f.startswith("carl_") and f.endswith(".py"):
                 for cls, feats in tables_of(os.path.join(d, f)).items():
                     golden[cls] = feats
-    golden["_goal_wrapper"] = {"directions": _goal_wrapper_literal("directions"),
+    golden["_goal_wrapper"] = {"sentences": _goal_sentences(), "directions": _goal_wrapper_literal("directions"),
                                "DIRECTION_NAMES": {str(k): v for k, v in _goal_wrapper_literal("DIRECTION_NAMES").items()}}
     dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "context_feature_tables.json")
     with open(dst, "w") as fh:

@@ -58,3 +58,13 @@ def test_goal_wrapper_names_user_code_imports():
 
     assert directions == GOAL_WRAPPER["directions"]
     assert {str(k): v for k, v in DIRECTION_NAMES.items()} == GOAL_WRAPPER["DIRECTION_NAMES"]
+
+
+def test_language_goal_sentences_equal_the_reference_output():
+    """``CARLBraxEnv.describe_goal`` against sentences produced by running the reference's
+    ``BraxLanguageWrapper.get_goal_desc`` (brax_walker_goal_wrapper.py:169-181) on the same contexts"""
+    from carl_amd.envs.brax.carl_brax_env import CARLBraxEnv
+
+    assert len(GOAL_WRAPPER["sentences"]) >= 4
+    for case in GOAL_WRAPPER["sentences"]:
+        assert CARLBraxEnv.describe_goal(case["context"]) == case["sentence"]
