@@ -47,6 +47,18 @@ def inverse_kinematics(sys_struct, state):
     return q, qd
 
 
+def goal_step(sys_struct, ctx_row, obs, pos):
+    """one step of the goal-wrapper epilogue: (reward, success); ``pos`` (float64[2]) is advanced in place"""
+    s = _Sys(sys_struct)
+    row = np.ascontiguousarray(ctx_row, dtype=np.float64)
+    o = np.ascontiguousarray(obs, dtype=np.float32)
+    ok = C.c_int32(0)
+    fn = O.lib().obx_goal_step
+    fn.restype = C.c_double
+    r = fn(s.ptr, _p(row), _p(o), _p(pos), C.byref(ok))
+    return float(r), int(ok.value)
+
+
 def substeps(sys_struct, ctx_row, tau, n_sub, state) -> np.ndarray:
     s = _Sys(sys_struct)
     st = np.ascontiguousarray(state, dtype=np.float64).reshape(-1).copy()

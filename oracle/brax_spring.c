@@ -608,6 +608,13 @@ static double goal_epilogue(const carl_brax_sys_t* s, const double* ctx_row, con
 }
 
 /* exported: pure helpers for tests */
+/* one step of the goal wrapper on one observation: returns the reward, updates pos[2], sets *success */
+double obx_goal_step(const carl_brax_sys_t* s, const double* ctx_row, const float* obs, double* pos, int32_t* success) {
+  int ok = 0;
+  const double r = goal_epilogue(s, ctx_row, obs, pos, &ok);
+  *success = ok;
+  return r;
+}
 void obx_forward_kinematics(const carl_brax_sys_t* s, const double* q, const double* qd, double* state) {
   body b[L_MAX];
   forward_kinematics(s, q, qd, b);

@@ -3,6 +3,7 @@ invariants on CPU.  brax itself is not importable here and the reference's tests
 step value (test/test_brax_env.py:8-23 is construct/reset only), so this is NOT parity with
 brax -- it pins the specification the HIP kernel is then compared against."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -594,3 +595,40 @@ def test_pusher_reset_observation_reward_and_gripper_contact():
     assert np.all(np.linalg.norm(p1[0::2, :2] - grip[0::2, :2], axis=1) < 0.2)  # and it stays in the fork
     np.testing.assert_allclose(p1[:, 2], -0.275, atol=1e-4)
     assert np.isfinite(out.obs).all()
+
+
+def test_goal_epilogue_against_the_reference_wrapper_run(golden_dir):
+    """The goal-reward epilogue (a14) against sequences produced by RUNNING the reference's
+    BraxWalkerGoalWrapper.reset / .step (tests/golden/make_goal_wrapper_golden.py): observation indices
+    of every walker family, the 16 compass directions, position integration, progress reward,
+    success / termination inside the radius."""
+    import json
+
+    from carl_amd.envs.brax import models
+
+    g = json.load(open(os.path.join(golden_dir, "goal_wrapper_sequences.json")))
+    assert set(g["STATE_INDICES"]) == {"ant", "humanoid", "halfcheetah", "hopper", "walker2d"}
+    saw_success = 0
+    for case in g["cases"]:
+        names, default = _features({"ant": "CARLBraxAnt", "humanoid": "CARLBraxHumanoid", "halfcheetah": "CARLBraxHalfcheetah",
+                                    "hopper": "CARLBraxHopper", "walker2d": "CARLBraxWalker2d"}[case["env_name"]])
+        s = models.SYSTEMS[case["env_name"]](names)
+        assert [s.goal_obs_idx[0], s.goal_obs_idx[1]] == g["STATE_INDICES"][case["env_name"]] == case["obs_indices"]
+        s.goal_mode, s.goal_dt = 1, case["dt"]
+        row = default.copy()
+        row[names.index("target_direction")] = case["target_direction"]
+        row[names.index("target_distance")] = case["target_distance"]
+        row[names.index("target_radius")] = case["target_radius"]
+        row = row.astype(np.float32).astype(np.float64)  # the context table is float32 on the device
+        pos = np.zeros(2)
+        for t, (vx, vy) in enumerate(case["velocities"]):
+            obs = np.zeros(s.obs_dim, np.float32)
+            obs[s.goal_obs_idx[0]], obs[s.goal_obs_idx[1]] = vx, vy
+            r, ok = B.goal_step(s, row, obs, pos)
+            assert ok == case["success"][t] == int(case["terminated"][t])
+            np.testing.assert_allclose(r, case["reward"][t], rtol=1e-5, atol=2e-7)
+            np.testing.assert_allclose(pos, case["position"][t], rtol=1e-6, atol=1e-9)
+            saw_success += ok
+        d = np.asarray(g["direction_values"][str(case["target_direction"])]) * np.float32(case["target_distance"])
+        np.testing.assert_allclose(d, case["goal_position"], rtol=1e-6)
+    assert saw_success > 20
