@@ -1,29 +1,40 @@
 #!/usr/bin/env python
 """Headline benchmark: env-steps/sec at 65 536 parallel contexts per MI355X.
 
-    python bench.py --gpus 1 --steps 2000 --warmup 200
+    python bench.py --gpus 1 --steps 20 --warmup 5           (what the driver runs)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
 Workload (BASELINE.json configs[1]): CARLPendulum, 65 536 contexts per GPU sampled over
 the features `g ~ U(1,20)` and `l ~ U(0.5,2)` (CARL's feature literally
 called "gravity" is inert, Quirk P1), lane i <-> context i (StaticSelector), auto-reset
-on, synthetic actions U(-2,2) resident in HBM.  One "step" = one env step of every lane
-(65 536 env-steps per GPU).  The timed region runs the K steps through the engine's
-fused entry point `carl_rollout` in launches of `--chunk` steps; every step writes its
-complete transition (obs, reward, terminated, truncated) to HBM -- nothing is skipped.
-The per-call path (`carl_step`, one launch per step, eager and hipGraph-replayed) is
-measured right after and reported under "per_call" in the same JSON line.
+on, synthetic actions U(-2,2) resident in HBM.
 
-Multi-GPU: weak scaling, lanes sharded by contiguous global-id ranges, no data-path
-collective; one RCCL all-gather of the per-lane episodic returns after the timed region
-(the reporting collective of SURVEY.md 8e), timed separately.
+One "step" of this benchmark = ONE PASS of the hot path over one batch of synthetic input:
+one fused `carl_rollout` launch that advances every lane by `--chunk` (250) env steps and
+writes every step's complete transition (obs, reward, terminated, truncated) to HBM --
+nothing is skipped.  `--steps K` times exactly K such launches after `--warmup W` untimed
+ones; `value` = lanes x chunk x K / elapsed (env-steps/s), `ms_per_step` = per launch,
+`config.env_steps_per_step` = lanes x chunk.  Launches rotate through `--buffer-sets` (2)
+action / output buffer sets (Pendulum: 2 x 361 MB > the 256 MB Infinity Cache), so the
+stream is an HBM stream from the first timed launch on.
+
+Also in the same JSON line:
+  roofline      the fused kernel against the HBM peak, from HIP events on the launch stream
+  cpu_baseline  the reference-style scalar Python loop on the host cores (kind "port":
+                gymnasium / brax are not installable here, the reference cannot be timed)
+  per_call      the one-launch-per-env-step path (`carl_step`, eager and hipGraph-replayed)
+  also          the same launch train for north_star's target env (CARLCartPole x 65 536) and
+                BASELINE configs 3-5 (Acrobot+MountainCar mixed batch, Ant, Halfcheetah+Humanoid)
+
+Multi-GPU: lanes sharded by contiguous global-id ranges, no data-path collective (weak
+scaling: 65 536 lanes per GPU); one RCCL all-gather of the per-lane episodic returns after
+the timed region (the reporting collective of SURVEY.md 8e), timed separately.
 """
 from __future__ import annotations
 
 import argparse
 import json
-import math
 import os
 import sys
 import time
@@ -51,40 +62,49 @@ PER_LAUNCH = {"pendulum": 8 + 4 + 16 + 4 + 4 + 8 + 4 + 4, "cartpole": 16 + 4 + 2
               "halfcheetah": 2 * 13 * 7 * 4 + 4 + 12 * 4 + 4 + 4 + 4 + 4,
               "humanoid": 2 * 13 * 11 * 4 + 4 + 15 * 4 + 4 + 4 + 4 + 4}
 
-
 BRAX_ENVS = ("ant", "halfcheetah", "humanoid")
+DEFAULT_CHUNK = {e: (20 if e in BRAX_ENVS else 250) for e in BYTES_8D}
+# the other BASELINE workloads, run after the headline one (same launch train, fewer words):
+#   name -> (families, total lanes per family, "weak" = per GPU / "strong" = split over the GPUs)
+ALSO = {
+    "cartpole": (("cartpole",), 65536, "weak"),                      # north_star's target env
+    "config3": (("acrobot", "mountaincar"), 65536, "weak"),          # 131 072-context mixed batch per GPU
+    "config4": (("ant",), 32768, "strong"),                          # 32 768 contexts over the node
+    "config5": (("halfcheetah", "humanoid"), 32768, "strong"),       # 65 536 contexts over the node
+}
 
 
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=50000)
-    p.add_argument("--warmup", type=int, default=5000)
-    p.add_argument("--env", default="pendulum", choices=list(BYTES_8D))
-    p.add_argument("--lanes", type=int, default=65536, help="lanes (= contexts) per GPU")
-    p.add_argument("--chunk", type=int, default=250, help="env steps per fused launch")
+    p.add_argument("--steps", type=int, default=200, help="timed fused launches (each = --chunk env steps of every lane)")
+    p.add_argument("--warmup", type=int, default=20, help="untimed launches before them")
+    p.add_argument("--env", default="pendulum",
+                   help="family, or a+b for a mixed batch (e.g. acrobot+mountaincar); one of " + ", ".join(BYTES_8D))
+    p.add_argument("--lanes", type=int, default=65536, help="lanes (= contexts) per family per GPU")
+    p.add_argument("--chunk", type=int, default=0, help="env steps per fused launch (default 250; Brax 20)")
+    p.add_argument("--buffer-sets", type=int, default=2, help="action/output buffer sets the launches rotate through")
     p.add_argument("--strong", action="store_true",
-                   help="strong scaling: --lanes is the TOTAL number of contexts, split over the GPUs "
+                   help="strong scaling: --lanes is the TOTAL number of contexts per family, split over the GPUs "
                         "(default: weak scaling, --lanes per GPU)")
+    p.add_argument("--also", default="cartpole,config3,config4,config5",
+                   help="comma list of extra workloads reported under 'also' (" + ", ".join(ALSO) + "), or 'none'")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-per-call", action="store_true")
     p.add_argument("--cpu-envs-per-core", type=int, default=256)
     p.add_argument("--cpu-steps-per-env", type=int, default=1000)
-    return p.parse_args()
+    a = p.parse_args()
+    a.families = tuple(a.env.split("+"))
+    for f in a.families:
+        if f not in BYTES_8D:
+            p.error(f"unknown env {f}")
+    return a
 
 
-def make_env(args, rank, world, device):
-    import numpy as np
-
+def context_dists(env):
     from carl_amd.context.context_space import UniformFloatContextFeature as U
-    from carl_amd.context.sampler import ContextSampler
-    from carl_amd.context.selection import StaticSelector
-    from carl_amd import envs as E
 
-    cls = {"pendulum": E.CARLPendulum, "cartpole": E.CARLCartPole, "acrobot": E.CARLAcrobot,
-           "mountaincar": E.CARLMountainCar, "mountaincar_cont": E.CARLMountainCarContinuous,
-           "ant": E.CARLBraxAnt, "halfcheetah": E.CARLBraxHalfcheetah, "humanoid": E.CARLBraxHumanoid}[args.env]
-    dists = {
+    return {
         "pendulum": [U("g", 1, 20), U("l", 0.5, 2.0)],
         "cartpole": [U("gravity", 5, 15), U("length", 0.3, 1.0), U("masspole", 0.05, 0.3)],
         "acrobot": [U("LINK_LENGTH_1", 0.5, 2), U("LINK_MASS_1", 0.5, 2), U("LINK_MASS_2", 0.5, 2),
@@ -96,30 +116,142 @@ def make_env(args, rank, world, device):
         # BASELINE config 5
         "halfcheetah": [U("joint_stiffness", 0.5, 2.0), U("gravity", -15, -5), U("mass_torso", 5, 15)],
         "humanoid": [U("mass_torso", 5, 15), U("gravity", -15, -5), U("friction", 0.3, 1.5)],
-    }[args.env]
-    n = args.lanes // world if args.strong else args.lanes
-    # one global context set (seed 0), each rank uploads only its lanes' rows
-    table = ContextSampler(dists, cls.get_context_space(), seed=0).sample_context_table(n * world)
+    }[env]
+
+
+def make_env(env, n, rank, world, device, lane_base=0):
+    """One family: `n` lanes on this rank = global lanes [lane_base + rank n, lane_base + (rank+1) n) of one
+    global context set (seed 0); each rank uploads only its lanes' rows."""
+    from carl_amd import envs as E
+    from carl_amd.context.sampler import ContextSampler
+    from carl_amd.context.selection import StaticSelector
     from carl_amd.context.table import ContextTable
 
+    cls = {"pendulum": E.CARLPendulum, "cartpole": E.CARLCartPole, "acrobot": E.CARLAcrobot,
+           "mountaincar": E.CARLMountainCar, "mountaincar_cont": E.CARLMountainCarContinuous,
+           "ant": E.CARLBraxAnt, "halfcheetah": E.CARLBraxHalfcheetah, "humanoid": E.CARLBraxHumanoid}[env]
+    table = ContextSampler(context_dists(env), cls.get_context_space(), seed=0).sample_context_table(n * world)
     local = ContextTable(table.names, table.values_2d[rank * n:(rank + 1) * n])
-    size_kw = {"batch_size": n} if args.env in BRAX_ENVS else {"num_envs": n}
-    env = cls(contexts=local, device=device, context_selector=StaticSelector, seed=0,
-              lane_offset=rank * n, fin_capacity=0, **size_kw)
-    return env, table
+    size_kw = {"batch_size": n, "autotune": False} if env in BRAX_ENVS else {"num_envs": n}
+    carl_env = cls(contexts=local, device=device, context_selector=StaticSelector, seed=0,
+                   lane_offset=lane_base + rank * n, fin_capacity=0, **size_kw)
+    return carl_env, table
 
 
-def make_actions(args, env, T, device, rank):
+def make_actions(eng, T, device, seed):
     import torch
 
     g = torch.Generator(device=device)
-    g.manual_seed(1 + rank)
-    info = env.env.info
+    g.manual_seed(seed)
+    info = eng.info
     if info.action_is_discrete:
-        return torch.randint(0, info.n_actions, (T, env.num_envs), generator=g, device=device, dtype=torch.int32)
+        return torch.randint(0, info.n_actions, (T, eng.n), generator=g, device=device, dtype=torch.int32)
     lo, hi = float(info.action_low), float(info.action_high)
-    shape = (T, env.num_envs) if info.action_dim == 1 else (T, env.num_envs, int(info.action_dim))
+    shape = (T, eng.n) if info.action_dim == 1 else (T, eng.n, int(info.action_dim))
     return torch.rand(shape, generator=g, device=device, dtype=torch.float32) * (hi - lo) + lo
+
+
+class Workload:
+    """One or several families on this rank, their rotating action/output buffer sets, and the launch train."""
+
+    def __init__(self, families, lanes_per_gpu, T, sets, rank, world, device):
+        import torch
+
+        from carl_amd.mixed import MixedVecEngine
+
+        self.families, self.T, self.device = tuple(families), T, device
+        self.envs, self.tables = [], []
+        for k, f in enumerate(self.families):
+            e, t = make_env(f, lanes_per_gpu, rank, world, device, lane_base=k * lanes_per_gpu * world)
+            self.envs.append(e)
+            self.tables.append(t)
+        self.mixed = len(self.families) > 1
+        self.eng = MixedVecEngine([e.env for e in self.envs], self.families) if self.mixed else self.envs[0].env
+        parts = self.eng.parts if self.mixed else [self.eng]
+        self.n = sum(p.n for p in parts)
+        self.acts = [[make_actions(p, T, device, 1 + rank + 1000 * s + 100 * k) for k, p in enumerate(parts)]
+                     for s in range(sets)]
+        self.outs = [[p.alloc_rollout(T) for p in parts] for _ in range(sets)]
+        for e in self.envs:
+            e.reset(seed=0)
+        if any(f in BRAX_ENVS for f in self.families):  # launch shape chosen by timing on this batch
+            self.eng.autotune()                          # (results do not depend on it)
+        torch.cuda.synchronize()
+        self._i = 0
+        self.units_per_launch = self.n * T
+        self.bytes_per_launch = sum((IO_PER_STEP[f] * T + PER_LAUNCH[f]) * p.n for f, p in zip(self.families, parts))
+        self.bytes_per_launch_8d = sum(BYTES_8D[f] * T * p.n for f, p in zip(self.families, parts))
+
+    def launch(self):
+        s = self._i % len(self.acts)
+        self._i += 1
+        if self.mixed:
+            self.eng.rollout(self.acts[s], self.outs[s])
+        else:
+            self.eng.rollout(self.acts[s][0], self.outs[s][0])
+
+    def train(self, K, W, barrier):
+        """W untimed launches, then exactly K timed ones -> (wall seconds incl. the syncs, average launch
+        seconds from one HIP-event pair on the launch stream)."""
+        import torch
+
+        for _ in range(W):
+            self.launch()
+        torch.cuda.synchronize()
+        # one HIP-event pair around the whole launch train, on the stream the kernels run on (torch's
+        # current stream): launches are back-to-back, so elapsed / K is the kernel's average duration
+        # plus the ~1-2 us kernel boundary
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        e0.record()
+        for _ in range(K):
+            self.launch()
+        e1.record()
+        torch.cuda.synchronize()
+        barrier()
+        wall = time.perf_counter() - t0
+        return wall, e0.elapsed_time(e1) * 1e-3 / K
+
+    def kernel_name(self):
+        names = []
+        for f in self.families:
+            names.append("brax_kernel<1>" if f in BRAX_ENVS else "rollout_staged_kernel<%s>" % f)
+        return " + ".join(names)
+
+    def mean_last_return(self):
+        return float(self.eng.last_return.mean())
+
+
+def traffic_record(key):
+    """HBM traffic per launch from the PMC passes of tools/profile_gpu.sh (FETCH_SIZE x 2 per the gfx950
+    correction + WRITE_SIZE), recorded under profiles/: a bench run cannot collect counters itself, so this is
+    the committed measurement for this exact workload (key = env:lanes:chunk)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            return json.load(f).get(key)
+    except OSError:
+        return None
+
+
+def roofline_of(wl, avg_launch_s):
+    achieved = wl.bytes_per_launch / avg_launch_s / 1e9
+    r = {
+        "bound": "hbm", "kernel": wl.kernel_name(), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+        "bytes_per_unit": wl.bytes_per_launch / wl.units_per_launch,
+        "bytes_per_unit_survey_8d": wl.bytes_per_launch_8d / wl.units_per_launch,
+        "achieved_with_survey_8d_bytes": wl.bytes_per_launch_8d / avg_launch_s / 1e9,
+        "avg_launch_ms": avg_launch_s * 1e3, "units_per_launch": wl.units_per_launch,
+        "algorithmic_bytes_per_launch": wl.bytes_per_launch,
+    }
+    part_n = wl.n // len(wl.families)
+    rec = traffic_record(f"{'+'.join(wl.families)}:{part_n}:{wl.T}")
+    if rec:
+        r["traffic"] = rec["hbm_bytes_per_launch"]
+        r["traffic_source"] = rec["source"]
+    return r
 
 
 def _cpu_worker(job):
@@ -151,7 +283,7 @@ def _cpu_worker_brax(job):
     return n * steps, time.perf_counter() - t0
 
 
-def cpu_baseline_brax(args, table):
+def cpu_baseline_brax(env, table):
     """Brax families: the fp64 C restatement of the spring pipeline (oracle/brax_spring.c), one
     process per host core, on a bounded sample of the same context set.  kind = "port" (brax /
     jax are not installable here)."""
@@ -161,36 +293,36 @@ def cpu_baseline_brax(args, table):
     per, steps = 16, 200
     rows = table.values_2d
     names = list(table.names)
-    jobs = [(args.env, names, rows[(c * per) % len(rows):(c * per) % len(rows) + per].tolist(), steps)
+    jobs = [(env, names, rows[(c * per) % len(rows):(c * per) % len(rows) + per].tolist(), steps)
             for c in range(cores)]
     ctx = mp.get_context("spawn")
     with ctx.Pool(cores) as pool:
-        pool.map(_cpu_worker_brax, [(args.env, names, j[2][:2], 2) for j in jobs])  # warm the workers
+        pool.map(_cpu_worker_brax, [(env, names, j[2][:2], 2) for j in jobs])  # warm the workers
         t0 = time.perf_counter()
         res = pool.map(_cpu_worker_brax, jobs)
         wall = time.perf_counter() - t0
     return {
         "value": sum(r[0] for r in res) / wall, "unit": "env-steps/s", "cores": cores, "kind": "port",
-        "sample": f"fp64 C oracle of the spring pipeline (oracle/brax_spring.c), {cores} processes x {per} contexts "
-                  f"x {steps} env steps of the same {args.env} context set, auto-reset on",
+        "sample": f"fp64 C restatement of the spring pipeline (oracle/brax_spring.c), {cores} processes x {per} contexts "
+                  f"x {steps} env steps of the same {env} context set, auto-reset on",
         "single_core_value": res[0][0] / res[0][1],
     }
 
 
-def cpu_baseline(args, table):
+def cpu_baseline(args, env, table, lanes):
     """The reference-style scalar Python loop (oracle/ref_style.py: CARL wrapper ->
     TimeLimit -> env object, dict obs rebuilt per step) on all host cores, on a bounded
-    sample of the same contexts.  kind = "port": the reference itself cannot run here
-    (gymnasium is not installed)."""
-    if args.env in BRAX_ENVS:
-        return cpu_baseline_brax(args, table)
+    sample of the same contexts.  kind = "port": a RESTATEMENT of the reference path -- the
+    reference itself cannot run here (gymnasium is not installed)."""
+    if env in BRAX_ENVS:
+        return cpu_baseline_brax(env, table)
     import multiprocessing as mp
 
     import numpy as np
 
     from oracle import oracle as O
 
-    fam = O.FAMILY_NAMES.index(args.env)
+    fam = O.FAMILY_NAMES.index(env)
     cores = os.cpu_count() or 1
     per = args.cpu_envs_per_core
     F = len(O.FEATURES[fam])
@@ -199,7 +331,6 @@ def cpu_baseline(args, table):
     jobs = [(fam, rows[(c * per) % len(rows):(c * per) % len(rows) + per].tolist(), names, args.cpu_steps_per_env)
             for c in range(cores)]
     ctx = mp.get_context("spawn")
-    t0 = time.perf_counter()
     with ctx.Pool(cores) as pool:
         pool.map(_cpu_worker, [(fam, j[1][:2], names, 10) for j in jobs])  # warm the workers (imports)
         t0 = time.perf_counter()
@@ -208,7 +339,7 @@ def cpu_baseline(args, table):
     total = sum(r[0] for r in res)
     single = res[0][0] / res[0][1]
     # stronger CPU line: the vectorised C oracle (float64), one thread
-    eng = O.Engine(fam, rows[: args.lanes].astype(np.float32).astype(np.float64), min(args.lanes, len(rows)),
+    eng = O.Engine(fam, rows[:lanes].astype(np.float32).astype(np.float64), min(lanes, len(rows)),
                    selector=O.SEL_STATIC, precision="f64")
     eng.reset()
     a = np.zeros(eng.n, dtype=np.float32 if fam in O.CONTINUOUS else np.int32)
@@ -220,11 +351,67 @@ def cpu_baseline(args, table):
     c_rate = k * eng.n / (time.perf_counter() - t1)
     return {
         "value": total / wall, "unit": "env-steps/s", "cores": cores, "kind": "port",
-        "sample": f"reference-style scalar Python loop (oracle/ref_style.py), {cores} processes x {per} contexts "
-                  f"x {args.cpu_steps_per_env} steps of the same {args.env} context set, auto-reset on",
+        "sample": f"restatement of the reference's scalar Python step() loop (oracle/ref_style.py), {cores} processes x "
+                  f"{per} contexts x {args.cpu_steps_per_env} steps of the same {env} context set, auto-reset on",
         "single_core_value": single,
         "c_oracle_f64_1thread_value": c_rate,
     }
+
+
+def per_call_record(eng, action, n_total, Kc, device, world, barrier):
+    """The one-launch-per-env-step path a policy-in-the-loop caller uses: eager `step`, and the engine's own
+    captured hipGraph (`capture_step`) replayed."""
+    import torch
+
+    for _ in range(50):
+        eng.step(action)
+    torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(Kc):
+        eng.step(action)
+    torch.cuda.synchronize()
+    eager = time.perf_counter() - t0
+    rec = {"eager_value": n_total * Kc / eager, "eager_ms_per_step": eager / Kc * 1e3,
+           "graph_value": None, "graph_ms_per_step": None, "roofline": None}
+    return rec
+
+
+def graph_per_call(rec, eng, action, env, n, Kc, device):
+    """hipGraph replay of 100 step launches (single process only: under multi-process RCCL the NCCL watchdog
+    thread's event queries can invalidate a capture)."""
+    import torch
+
+    graph = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream(device=device)
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        eng.step(action)
+        with torch.cuda.graph(graph, stream=s, capture_error_mode="thread_local"):
+            for _ in range(100):
+                eng.step(action)
+    torch.cuda.current_stream().wait_stream(s)
+    graph.replay()
+    torch.cuda.synchronize()
+    g0e, g1e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = max(1, Kc // 100)
+    t0 = time.perf_counter()
+    g0e.record()
+    for _ in range(reps):
+        graph.replay()
+    g1e.record()
+    torch.cuda.synchronize()
+    gwall = time.perf_counter() - t0
+    per_step_s = g0e.elapsed_time(g1e) * 1e-3 / (reps * 100)
+    b8d = BYTES_8D[env] + 8  # + running-return read/write the engine adds
+    rec.update({
+        "graph_value": n * reps * 100 / gwall, "graph_ms_per_step": per_step_s * 1e3,
+        "roofline": {"bound": "hbm", "kernel": "step_kernel", "bytes_per_unit": b8d,
+                     "achieved": b8d * n / per_step_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": b8d * n / per_step_s / 1e9 / HBM_PEAK_GBS,
+                     "note": "duration = graph-replayed launch-to-launch period (includes the "
+                             "~1.5 us kernel boundary)"},
+    })
 
 
 def main():
@@ -251,156 +438,122 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    env, table = make_env(args, rank, world, device)
-    eng = env.env
-    n = env.num_envs
+    def max_over_ranks(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def gather_over_ranks(x):
+        if dist is None:
+            return [x]
+        t = torch.tensor([x], device=device, dtype=torch.float64)
+        out = torch.empty(world, device=device, dtype=torch.float64)
+        dist.all_gather_into_tensor(out, t)
+        return [float(v) for v in out.tolist()]
+
     K, W = args.steps, args.warmup
-    T = max(1, min(args.chunk, K))
-    chunks = [T] * (K // T) + ([K % T] if K % T else [])
-    actions = make_actions(args, env, T, device, rank)
-    out = eng.alloc_rollout(T)
+    T = args.chunk or DEFAULT_CHUNK[args.families[0]]
+    n_fam = args.lanes // world if args.strong else args.lanes
+    wl = Workload(args.families, n_fam, T, args.buffer_sets, rank, world, device)
+    n = wl.n
 
-    env.reset(seed=0)
-    if args.env in BRAX_ENVS:  # launch shape chosen by timing on this batch (results do not depend on it)
-        eng.autotune()
-    done_w = 0
-    while done_w < W:
-        t = min(T, W - done_w)
-        eng.rollout(actions[:t], out)
-        done_w += t
-    torch.cuda.synchronize()
-
-    # ---- timed region: exactly K env steps of every lane -------------------------
-    # one HIP-event pair around the whole launch train, on the stream the kernels run on
-    # (torch's current stream): launches are back-to-back, so (elapsed / launches) is the
-    # kernel's average duration plus the ~1-2 us kernel boundary
-    e_first, e_last = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    e_first.record()
-    for t in chunks:
-        eng.rollout(actions[:t], out)
-    e_last.record()
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-    # average duration of a full-length launch (a shorter tail launch is pro-rated)
-    avg_launch_s = e_first.elapsed_time(e_last) * 1e-3 * T / K
-    bytes_per_step = IO_PER_STEP[args.env] + PER_LAUNCH[args.env] / T
-    achieved = bytes_per_step * n * T / avg_launch_s / 1e9
-    kernel_name = ("brax_kernel<1>" if args.env in BRAX_ENVS else
-                   "rollout_staged_kernel" if n % 16 == 0 else "rollout_kernel")
-    roofline = {
-        "bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-        "bytes_per_unit": bytes_per_step, "bytes_per_unit_survey_8d": BYTES_8D[args.env],
-        "achieved_with_survey_8d_bytes": BYTES_8D[args.env] * n * T / avg_launch_s / 1e9,
-        "avg_launch_ms": avg_launch_s * 1e3, "units_per_launch": n * T,
-    }
-    # HBM traffic per launch from the PMC passes of tools/profile_gpu.sh (FETCH_SIZE x 2
-    # per the gfx950 correction + WRITE_SIZE), recorded under profiles/; a bench run cannot
-    # collect counters itself, so this is the committed measurement for this exact workload
-    try:
-        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            rec = json.load(f).get(f"{args.env}:{n}:{T}")
-        if rec:
-            roofline["traffic"] = rec["hbm_bytes_per_launch"]
-            roofline["traffic_source"] = rec["source"]
-    except OSError:
-        pass
+    # ---- timed region: exactly K fused launches (K x T env steps of every lane) --------
+    wall, avg_launch_s = wl.train(K, W, barrier)
+    elapsed = max_over_ranks(wall)
+    roofline = roofline_of(wl, avg_launch_s)
+    per_rank_launch_ms = gather_over_ranks(avg_launch_s * 1e3)
 
     # ---- reporting collective: episodic returns all-gathered over RCCL ------------
-    gather_ms = None
+    gather_ms, rccl_ranks = None, None
     if dist is not None:
         from carl_amd.distributed import all_gather_episode_stats
 
+        all_gather_episode_stats(wl.eng)  # first call: communicator set-up, untimed
         torch.cuda.synchronize()
+        barrier()
         g0 = time.perf_counter()
-        try:
-            stats = all_gather_episode_stats(eng)
-            torch.cuda.synchronize()
-            gather_ms = (time.perf_counter() - g0) * 1e3
-            mean_return = float(stats["last_return"].mean())
-        except Exception as e:  # reporting collective only: never lose the measurement over it
-            print(f"[bench] episodic-return all-gather failed: {e!r}", file=sys.stderr)
-            mean_return = float(eng.last_return.mean())
+        stats = all_gather_episode_stats(wl.eng)  # an RCCL failure here is fatal: it is the path under test
+        torch.cuda.synchronize()
+        gather_ms = (time.perf_counter() - g0) * 1e3
+        rccl_ranks = int(stats["last_return"].numel() // max(n, 1))
+        mean_return = float(stats["last_return"].mean())
     else:
-        mean_return = float(eng.last_return.mean())
+        mean_return = wl.mean_last_return()
 
     # ---- per-call path (one launch per env step) -----------------------------------
     per_call = None
-    if not args.no_per_call:
-        Kc = min(K, 1000)
-        a1 = actions[0].contiguous()
-        for _ in range(50):
-            eng.step(a1)
-        torch.cuda.synchronize()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(Kc):
-            eng.step(a1)
-        torch.cuda.synchronize()
-        eager = time.perf_counter() - t0
-        per_call = {"eager_value": n * world * Kc / eager, "eager_ms_per_step": eager / Kc * 1e3,
-                    "graph_value": None, "graph_ms_per_step": None, "roofline": None}
-        # hipGraph replay of 100 step launches.  Skipped under multi-process RCCL (the NCCL
-        # watchdog thread's event queries can invalidate a capture) and never fatal.
+    if not args.no_per_call and not wl.mixed:
+        Kc = 1000
+        eng = wl.eng
+        a1 = wl.acts[0][0][0].contiguous()
+        per_call = per_call_record(eng, a1, n * world, Kc, device, world, barrier)
         if world == 1:
             try:
-                graph = torch.cuda.CUDAGraph()
-                s = torch.cuda.Stream(device=device)
-                s.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(s):
-                    eng.step(a1)
-                    with torch.cuda.graph(graph, stream=s, capture_error_mode="thread_local"):
-                        for _ in range(100):
-                            eng.step(a1)
-                torch.cuda.current_stream().wait_stream(s)
-                graph.replay()
-                torch.cuda.synchronize()
-                g0e, g1e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                reps = max(1, Kc // 100)
-                t0 = time.perf_counter()
-                g0e.record()
-                for _ in range(reps):
-                    graph.replay()
-                g1e.record()
-                torch.cuda.synchronize()
-                gwall = time.perf_counter() - t0
-                per_step_s = g0e.elapsed_time(g1e) * 1e-3 / (reps * 100)
-                b8d = BYTES_8D[args.env] + 8  # + running-return read/write the engine adds
-                per_call.update({
-                    "graph_value": n * world * reps * 100 / gwall, "graph_ms_per_step": per_step_s * 1e3,
-                    "roofline": {"bound": "hbm", "kernel": "step_kernel", "bytes_per_unit": b8d,
-                                 "achieved": b8d * n / per_step_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                 "frac": b8d * n / per_step_s / 1e9 / HBM_PEAK_GBS,
-                                 "note": "duration = graph-replayed launch-to-launch period (includes the "
-                                         "~1.5 us kernel boundary)"},
-                })
+                graph_per_call(per_call, eng, a1, args.families[0], n, Kc, device)
             except Exception as e:  # graph capture is an optimisation of the measurement, not the product
                 per_call["graph_error"] = repr(e)[:200]
+            if hasattr(eng, "capture_step"):  # the engine's own replayable step (what CARLEnv.step uses for a
+                g = eng.capture_step(a1)      # fixed-address action buffer)
+                for _ in range(50):
+                    g.replay()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(Kc):
+                    g.replay()
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                per_call["captured_value"] = n * Kc / dt
+                per_call["captured_ms_per_step"] = dt / Kc * 1e3
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args, table)
+        cpu = cpu_baseline(args, args.families[0], wl.tables[0], n_fam)
+
+    # ---- the other BASELINE workloads, same launch train ---------------------------
+    also = {}
+    names = [] if args.also in ("", "none") else args.also.split(",")
+    del wl
+    torch.cuda.empty_cache()
+    for name in names:
+        fams, total, mode = ALSO[name]
+        if fams == args.families:
+            continue
+        lanes = total // world if mode == "strong" else total
+        Ta = DEFAULT_CHUNK[fams[0]]
+        w2 = Workload(fams, lanes, Ta, args.buffer_sets, rank, world, device)
+        wall2, avg2 = w2.train(K, W, barrier)
+        el2 = max_over_ranks(wall2)
+        r2 = roofline_of(w2, avg2)
+        also[name] = {
+            "workload": " + ".join(f"CARL{f} x {lanes}" for f in fams) + f" contexts/GPU, {Ta} env steps per launch",
+            "value": w2.n * world * Ta * K / el2, "unit": "env-steps/s", "scaling": mode,
+            "lanes_per_gpu": w2.n, "chunk": Ta, "ms_per_step": el2 / K * 1e3,
+            "avg_launch_ms": avg2 * 1e3, "frac": r2["frac"], "achieved_GBs": r2["achieved"],
+            "bytes_per_unit": r2["bytes_per_unit"], "traffic": r2["traffic"],
+            "mean_last_episode_return": w2.mean_last_return(),
+        }
+        del w2
+        torch.cuda.empty_cache()
 
     if rank == 0:
+        fam_txt = " + ".join(f"CARL{f} x {n_fam}" for f in args.families)
         line = {
             "metric": "env-steps/sec (whole node) at 65k parallel contexts per GPU",
-            "value": n * world * K / elapsed, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
+            "value": n * world * T * K / elapsed, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
+            "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"CARL{args.env} x {n} contexts/GPU, StaticSelector "
-                                   f"lane<->context, auto-reset, fused carl_rollout in launches of {T} steps, "
-                                   "full transition written per step",
-                       "lanes_per_gpu": n, "total_lanes": n * world, "chunk": T, "parallelism": f"lane-shard x{world}"},
-            "roofline": roofline, "cpu_baseline": cpu, "per_call": per_call,
-            "mean_last_episode_return": mean_return, "return_allgather_ms": gather_ms,
+            "config": {"workload": f"{fam_txt} contexts/GPU, StaticSelector lane<->context, auto-reset; one step = one "
+                                   f"fused carl_rollout launch of {T} env steps of every lane, full transition written "
+                                   f"per env step; {args.buffer_sets} rotating action/output buffer sets",
+                       "lanes_per_gpu": n, "total_lanes": n * world, "chunk": T,
+                       "env_steps_per_step": n * world * T, "buffer_sets": args.buffer_sets,
+                       "parallelism": f"lane-shard x{world}"},
+            "roofline": roofline, "cpu_baseline": cpu, "per_call": per_call, "also": also,
+            "mean_last_episode_return": mean_return, "return_allgather_ms": gather_ms, "rccl_ranks": rccl_ranks,
+            "per_rank_avg_launch_ms": per_rank_launch_ms,
         }
         print(json.dumps(line), flush=True)
     if dist is not None:

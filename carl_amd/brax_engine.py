@@ -46,6 +46,7 @@ class BraxVecEngine(VecEngine):
         # device copy of the model table (the kernels stage it into LDS once per workgroup)
         raw = bytes(self.sys)
         self.sys_dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
+        self._sys_ref = C.byref(self.sys)
 
     def _family_info(self):
         s = self.sys
@@ -59,6 +60,9 @@ class BraxVecEngine(VecEngine):
     def _c_step(self, io) -> int:
         return self.lib.carl_brax_step(C.byref(self.b), _ptr(self.sys_dev), C.byref(self.sys), C.byref(io),
                                        self._stream())
+
+    def _c_step_fast(self, stream: int) -> int:
+        return self.lib.carl_brax_step(self._b_ref, self.sys_dev.data_ptr(), self._sys_ref, self._io_ref, stream)
 
     def _c_rollout(self, io, n_steps: int) -> int:
         return self.lib.carl_brax_rollout(C.byref(self.b), _ptr(self.sys_dev), C.byref(self.sys), C.byref(io),

@@ -62,7 +62,17 @@ def needs_build(extra_flags: list[str] | None = None) -> bool:
         return f.read().strip() != _source_hash(extra_flags)
 
 
+def _refuse_ablation(extra_flags: list[str] | None) -> None:
+    """The product library is never built with profiling-only switches (CARL_EXP_*: kernels that skip
+    stores / the done path).  Ablation libraries are made by tools/build_ablations.sh under gpurun_in/."""
+    bad = [f for f in (extra_flags or []) if "CARL_EXP_" in f or "CARL_ABLATION" in f or "CARL_STORERS" in f]
+    if bad:
+        raise ValueError(f"refusing to build carl_amd/lib/libcarl_amd.so with ablation switches {bad}; "
+                         "use tools/build_ablations.sh (writes gpurun_in/libcarl_<variant>.so)")
+
+
 def build(force: bool = False, verbose: bool = False, extra_flags: list[str] | None = None) -> str:
+    _refuse_ablation(extra_flags)
     if not force and not needs_build(extra_flags):
         return LIB_PATH
     import fcntl

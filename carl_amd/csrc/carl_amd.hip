@@ -7,6 +7,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
+#include <utility>
 
 #include "../../include/carl_amd.h"
 #include "classic_control.cuh"
@@ -29,6 +32,21 @@ int fail(int code, const char* fmt, ...) {
 int check_launch(const char* what) {
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail((int)e, "%s: %s", what, hipGetErrorString(e));
+  return 0;
+}
+
+int ensure_dynamic_lds(const void* kernel, size_t bytes, const char* who) {
+  static std::mutex mu;
+  static std::map<std::pair<int, const void*>, size_t> granted;
+  int dev = 0;
+  if (const hipError_t e = hipGetDevice(&dev); e != hipSuccess)
+    return fail((int)e, "%s: hipGetDevice: %s", who, hipGetErrorString(e));
+  std::lock_guard<std::mutex> lock(mu);
+  size_t& have = granted[{dev, kernel}];
+  if (have >= bytes) return 0;
+  const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) return fail((int)e, "%s: hipFuncSetAttribute(%zu B of LDS): %s", who, bytes, hipGetErrorString(e));
+  have = bytes;
   return 0;
 }
 
@@ -164,9 +182,7 @@ int launch_step(const carl_batch_t* b, const carl_step_io_t* io, int n_steps, hi
         sh_staged += table_bytes;
       }
     }
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_staged);
-    if (e != hipSuccess) return fail((int)e, "carl_rollout: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    if (int e = carl_host::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), sh_staged, "carl_rollout")) return e;
     const dim3 ts(carl::kStagedThreads);  // 4 compute waves + loader wave + storer wave
     hipLaunchKernelGGL(kern, g, ts, sh_staged, s, *b, *io, n_steps);
     return check_launch("carl_rollout");

@@ -187,9 +187,7 @@ int launch_brax(const carl_batch_t* b, const carl_brax_sys_t* sd, const carl_bra
 #undef CARL_PICK_TASK
   if (kern == nullptr) return fail(CARL_ERR_UNSUPPORTED, "%s: no kernel for %d lanes per env", who, K);
   if (sh_bytes > 48 * 1024) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_bytes);
-    if (e != hipSuccess) return fail((int)e, "%s: hipFuncSetAttribute: %s", who, hipGetErrorString(e));
+    if (int e = carl_host::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), sh_bytes, who)) return e;
   }
   const int grid = (b->n_lanes + envs - 1) / envs;
   carl_step_io_t io_v{};

@@ -12,6 +12,17 @@
 
 #include "carl_device.cuh"
 
+// CARL_EXP_* switches compile PROFILING-ONLY kernels that skip stores, loads or the done path
+// (tools/build_ablations.sh).  A product build must never carry one by accident: they are refused
+// unless the build also says -DCARL_ABLATION (carl_amd/build.py adds it only for `--ablation`, and
+// writes such libraries under gpurun_in/, never to carl_amd/lib/).
+#if (defined(CARL_EXP_NO_REWARD_STORE) || defined(CARL_EXP_NO_FLAG_STORES) || defined(CARL_EXP_NO_DONE) ||      \
+     defined(CARL_EXP_NO_OBS_STORE) || defined(CARL_EXP_NO_ACTIONS) || defined(CARL_EXP_NO_LOADER) ||            \
+     defined(CARL_EXP_NO_DRAIN) || defined(CARL_EXP_TEMPORAL) || defined(CARL_STORERS)) &&                       \
+    !defined(CARL_ABLATION)
+#error "CARL_EXP_* / CARL_STORERS build profiling-only kernels; pass -DCARL_ABLATION to confirm (never for the product library)"
+#endif
+
 namespace carl {
 
 template <bool LDS>

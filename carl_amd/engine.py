@@ -26,6 +26,43 @@ def _ptr(t: torch.Tensor | None) -> int | None:
     return None if t is None else t.data_ptr()
 
 
+# raw handles straight from torch's C binding (the public wrappers build Stream / device objects: ~1.5 us per call,
+# a fifth of an eager step at 65 536 lanes)
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None) or (
+    lambda idx: torch.cuda.current_stream(idx).cuda_stream)
+_current_device = getattr(torch._C, "_cuda_getDevice", None) or torch.cuda.current_device
+
+
+class CapturedStep:
+    """``VecEngine.capture_step``: a hipGraph of ``n_steps`` ``carl_step`` launches on a fixed action buffer."""
+
+    def __init__(self, eng: "VecEngine", action_buffer: torch.Tensor, n_steps: int = 1):
+        a, dt = eng._action_tensor(action_buffer, ())
+        if a.data_ptr() != action_buffer.data_ptr():
+            raise ValueError("capture_step needs the action buffer in its final form (device, dtype, contiguous): "
+                             "the graph reads this exact address on every replay")
+        self.eng, self.action, self.n_steps = eng, action_buffer, int(n_steps)
+        dev = eng.device
+        # the first launch of a kernel loads its code object, which is not capturable: run one real step on
+        # the capture stream first, on a snapshot that is put back afterwards
+        snap = eng.snapshot()
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            eng.step(action_buffer)
+            eng.restore(snap)
+            with torch.cuda.graph(self.graph, stream=side, capture_error_mode="thread_local"):
+                for _ in range(self.n_steps):
+                    eng.step(action_buffer)
+        torch.cuda.current_stream(dev).wait_stream(side)
+
+    def replay(self):
+        self.graph.replay()
+        e = self.eng
+        return e.obs, e.reward, e.terminated, e.truncated
+
+
 class VecEngine:
     """N lanes of one env family on one device.
 
@@ -120,6 +157,11 @@ class VecEngine:
         self.set_contexts(ctx_table, ctx_idx0)
         self._io = _lib.StepIO()
         self._sync_pointers()
+        # per-call fast path (see step()): everything the ctypes call needs, prepared once
+        self._dev_index = int(self.device.index)
+        self._b_ref, self._io_ref = C.byref(self.b), C.byref(self._io)
+        self._step_fn = self.lib.carl_step
+        self._last_action = None
 
     # ------------------------------------------------------------------ contexts
     def default_ctx_idx(self, n_contexts: int) -> torch.Tensor:
@@ -196,6 +238,9 @@ class VecEngine:
 
     def _c_step(self, io) -> int:
         return self.lib.carl_step(C.byref(self.b), C.byref(io), self._stream())
+
+    def _c_step_fast(self, stream: int) -> int:  # self._io, prepared references
+        return self._step_fn(self._b_ref, self._io_ref, stream)
 
     def _c_rollout(self, io, n_steps: int) -> int:
         return self.lib.carl_rollout(C.byref(self.b), C.byref(io), n_steps, self._stream())
@@ -296,21 +341,47 @@ class VecEngine:
     def step(self, action):
         """One step of every lane -> (obs[N,D], reward[N], terminated[N] u8, truncated[N] u8).
 
-        This is the per-call path (one launch per env step), so the host side is kept to the action
-        pointer, one ctypes call and the stream handle: the output pointers of ``self._io`` are set
-        once (``_sync_pointers``), and the device guard is only entered when another device is
-        current (it costs ~3 us, a third of an eager step at 65 536 lanes)."""
-        a, dt = self._action_tensor(action, ())
+        This is the per-call path (one launch per env step) a policy-in-the-loop caller sits on, so the host
+        side is pared down to what a launch needs: the output pointers of ``self._io`` are set once
+        (``_sync_pointers``); an action tensor that is the SAME object at the same address as in the previous
+        call (the usual case: the policy writes into one buffer) skips dtype / shape / device validation; the
+        raw stream handle comes from torch's C binding; the ctypes function and its two by-reference arguments
+        are prepared once; the device guard is only entered when another device is current."""
         io = self._io
-        io.action, io.action_dtype = a.data_ptr(), dt
-        if torch.cuda.current_device() == self.device.index:
-            code = self._c_step(io)
+        if action is self._last_action and action.data_ptr() == io.action:
+            pass
+        else:
+            a, dt = self._action_tensor(action, ())
+            io.action, io.action_dtype = a.data_ptr(), dt
+            # only a tensor used as-is can take the fast path next time (a converted copy is a temporary)
+            self._last_action = action if a is action else None
+        if _current_device() == self._dev_index:
+            code = self._c_step_fast(_raw_stream(self._dev_index))
         else:
             with torch.cuda.device(self.device):
                 code = self._c_step(io)
         if code != 0:
             _lib.check(code)
         return self.obs, self.reward, self.terminated, self.truncated
+
+    # ------------------------------------------------------------------ replayable step (hipGraph)
+    def snapshot(self) -> dict:
+        """Copies of every buffer a launch can change (state, counters, bookkeeping, step outputs)."""
+        names = ["state", "elapsed", "ctx_idx", "episode", "n_calls", "ep_return", "last_return", "last_length",
+                 "episodes_done", "obs", "reward", "terminated", "truncated", "final_obs", "ctx_obs"]
+        names += [k for k in ("goal_pos", "success", "fin_count") if getattr(self, k, None) is not None]
+        return {k: getattr(self, k).clone() for k in names}
+
+    def restore(self, snap: dict) -> None:
+        for k, v in snap.items():
+            getattr(self, k).copy_(v)
+
+    def capture_step(self, action_buffer: torch.Tensor, n_steps: int = 1) -> "CapturedStep":
+        """Capture ``n_steps`` per-call step launches that read ``action_buffer`` (a device tensor whose
+        ADDRESS stays fixed: the policy writes the next action into it) into a hipGraph.  ``replay()`` then
+        costs one graph launch instead of the Python + ctypes + launch path of ``step`` -- the form a
+        policy-in-the-loop caller should hold on to.  Engine state is untouched by the capture."""
+        return CapturedStep(self, action_buffer, n_steps)
 
     def alloc_rollout(self, n_steps: int, final_obs: bool = False) -> dict:
         dev, n, D = self.device, self.n, self.D

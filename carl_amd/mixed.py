@@ -1,0 +1,116 @@
+"""Mixed-family batches: several families' lanes on ONE device stepped as one object.
+
+BASELINE config 3 ("CARLAcrobot + CARLMountainCar mixed batch, 131 072 contexts") and
+config 5 ("CARLBraxHalfcheetah + CARLBraxHumanoid, 65 536 contexts") name batches whose
+lanes belong to different env classes.  The reference has no such object -- every env is
+its own Python object (carl/envs/carl_env.py:245-342 holds no cross-env state), so the lanes
+stay independent and a mixed batch is a *partition* of the global lane range into one
+contiguous piece per family.  SURVEY.md 8e: "split each family evenly across GPUs so every
+GPU runs the same kernel sequence".
+
+``MixedVecEngine`` owns one ``VecEngine`` / ``BraxVecEngine`` per family and
+
+* enqueues every family's launch of a step (or fused rollout) on its own HIP stream,
+  forked from and joined back into the caller's stream with events, so small per-call
+  launches of different families overlap and the whole step is ONE stream-ordered
+  operation for the caller (it also captures into a hipGraph as one fork/join);
+* re-homes the parts' episodic-return bookkeeping (``ep_return``, ``last_return``,
+  ``last_length``, ``episodes_done``) and per-step ``reward`` / ``terminated`` /
+  ``truncated`` into contiguous ``[N_total]`` buffers, so the reporting all-gather
+  (``carl_amd.distributed.all_gather_episode_stats``) moves one vector per rank and the
+  caller sees one ``[N]`` view; observations keep their per-family width.
+
+Part k owns global lanes ``[lane_offset_k, lane_offset_k + n_k)``; results are bit-identical
+to running the parts as separate engines (tests/test_gpu_parity.py).
+"""
+from __future__ import annotations
+
+from typing import Sequence
+
+import torch
+
+from carl_amd.engine import VecEngine
+
+_SHARED_1D = ("ep_return", "last_return", "last_length", "episodes_done", "reward", "terminated", "truncated")
+
+
+class MixedVecEngine:
+    def __init__(self, parts: Sequence[VecEngine], names: Sequence[str] | None = None):
+        if not parts:
+            raise ValueError("a mixed batch needs at least one part")
+        dev = parts[0].device
+        if any(p.device != dev for p in parts):
+            raise ValueError("all parts of a mixed batch live on one device")
+        self.parts = list(parts)
+        self.names = list(names) if names is not None else [f"part{k}" for k in range(len(parts))]
+        self.device = dev
+        self.sizes = [p.n for p in self.parts]
+        self.n = sum(self.sizes)
+        self.offsets = [sum(self.sizes[:k]) for k in range(len(self.parts))]
+        # one contiguous [N_total] home for everything that is a per-lane scalar
+        for name in _SHARED_1D:
+            whole = torch.zeros(self.n, dtype=getattr(self.parts[0], name).dtype, device=dev)
+            for p, off in zip(self.parts, self.offsets):
+                piece = whole[off:off + p.n]
+                piece.copy_(getattr(p, name))
+                setattr(p, name, piece)
+            setattr(self, name, whole)
+        for p in self.parts:
+            p._sync_pointers()
+        self._streams = [torch.cuda.Stream(device=dev) for _ in self.parts]
+        self._fork = torch.cuda.Event()
+        self._joins = [torch.cuda.Event() for _ in self.parts]
+
+    # ------------------------------------------------------------------ fork / join
+    def _each(self, fn):
+        """Run ``fn(k, part)`` for every part on the part's stream, ordered after what the caller's
+        stream holds now and before what it enqueues next."""
+        cur = torch.cuda.current_stream(self.device)
+        self._fork.record(cur)
+        out = []
+        for k, (p, s) in enumerate(zip(self.parts, self._streams)):
+            s.wait_event(self._fork)
+            with torch.cuda.stream(s):
+                out.append(fn(k, p))
+            self._joins[k].record(s)
+        for j in self._joins:
+            cur.wait_event(j)
+        return out
+
+    def part_slice(self, k: int) -> slice:
+        return slice(self.offsets[k], self.offsets[k] + self.sizes[k])
+
+    # ------------------------------------------------------------------ API (VecEngine-shaped)
+    def seed(self, seed: int) -> None:
+        for p in self.parts:
+            p.seed(seed)
+
+    def reset(self, mask: torch.Tensor | None = None) -> list[torch.Tensor]:
+        if mask is not None and mask.numel() != self.n:
+            raise ValueError("mask must have one entry per lane of the mixed batch")
+        return self._each(lambda k, p: p.reset(None if mask is None else mask[self.part_slice(k)]))
+
+    def step(self, actions: Sequence):
+        """One step of every lane of every family -> (obs per part, reward[N], terminated[N], truncated[N])."""
+        if len(actions) != len(self.parts):
+            raise ValueError(f"expected {len(self.parts)} action arrays (one per family)")
+        res = self._each(lambda k, p: p.step(actions[k]))
+        return [r[0] for r in res], self.reward, self.terminated, self.truncated
+
+    def alloc_rollout(self, n_steps: int, final_obs: bool = False) -> list[dict]:
+        return [p.alloc_rollout(n_steps, final_obs) for p in self.parts]
+
+    def rollout(self, actions: Sequence, outs: Sequence[dict] | None = None) -> list[dict]:
+        """T fused steps of every family; ``actions[k]`` is part k's ``[T, n_k(, A_k)]``."""
+        if len(actions) != len(self.parts):
+            raise ValueError(f"expected {len(self.parts)} action arrays (one per family)")
+        return self._each(lambda k, p: p.rollout(actions[k], None if outs is None else outs[k]))
+
+    def autotune(self) -> None:
+        for p in self.parts:
+            if hasattr(p, "autotune"):
+                p.autotune()
+
+    @property
+    def ctx_idx(self) -> list[torch.Tensor]:
+        return [p.ctx_idx for p in self.parts]

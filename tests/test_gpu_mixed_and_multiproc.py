@@ -1,0 +1,239 @@
+"""Mixed-family batches (BASELINE configs 3 and 5 as ONE object), the replayable per-call step, and the
+HIP engine under a process group on real hardware -- needs an MI355X.
+
+Everything here is a bit-exactness statement: a mixed batch, a captured hipGraph step, or a lane shard run
+by another process must produce exactly the bytes the plain engine produces.
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+from tests.test_gpu_parity import _engine, random_actions, random_table
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_BOOKKEEPING = ("state", "elapsed", "ctx_idx", "episode", "n_calls", "ep_return", "last_return", "last_length",
+                "episodes_done")
+
+
+def _pair(device, n, seed=3, **kw):
+    rng = np.random.default_rng(seed)
+    fams = (O.ACROBOT, O.MOUNTAINCAR)
+    tables = [random_table(f, rng, n) for f in fams]
+    mk = lambda: [_engine(f, t, n, device, selector=O.SEL_STATIC, seed=5, ctx_idx0=np.arange(n),  # noqa: E731
+                          lane_offset=k * n, **kw) for k, (f, t) in enumerate(zip(fams, tables))]
+    return fams, rng, mk
+
+
+@pytest.mark.parametrize("n,T", [(4096, 260), (65536, 250)])
+def test_mixed_batch_equals_separate_engines(n, T, device):
+    """BASELINE config 3 (Acrobot + MountainCar, 65 536 contexts each) as one MixedVecEngine: both families'
+    launches of a fused rollout run on their own streams, joined into the caller's; every output and every
+    counter equals the two engines run one after the other; the episodic returns are ONE [2n] vector."""
+    from carl_amd.mixed import MixedVecEngine
+
+    fams, rng, mk = _pair(device, n)
+    sep, parts = mk(), mk()
+    mixed = MixedVecEngine(parts, ["acrobot", "mountaincar"])
+    acts = [torch.as_tensor(random_actions(f, rng, (T, n)), device=device) for f in fams]
+    for e in sep:
+        e.reset()
+    mixed.reset()
+    outs = mixed.rollout(acts)
+    ref = [e.rollout(a) for e, a in zip(sep, acts)]
+    torch.cuda.synchronize()
+    for k in range(2):
+        for name in ("obs", "reward", "terminated", "truncated"):
+            assert torch.equal(outs[k][name], ref[k][name]), (k, name)
+        for name in _BOOKKEEPING:
+            assert torch.equal(getattr(parts[k], name), getattr(sep[k], name)), (k, name)
+    assert mixed.last_return.shape == (2 * n,) and mixed.last_return.is_contiguous()
+    assert torch.equal(mixed.last_return, torch.cat([e.last_return for e in sep]))
+    assert torch.equal(mixed.episodes_done, torch.cat([e.episodes_done for e in sep]))
+    assert int(mixed.episodes_done.min()) >= 1  # MountainCar truncates at 200: every lane finished an episode
+
+
+def test_mixed_batch_per_call_step(device):
+    """the per-call path of a mixed batch: reward / flags arrive as one [2n] vector"""
+    from carl_amd.mixed import MixedVecEngine
+
+    n, T = 2048, 40
+    fams, rng, mk = _pair(device, n, max_episode_steps=7)
+    sep, parts = mk(), mk()
+    mixed = MixedVecEngine(parts)
+    acts = [torch.as_tensor(random_actions(f, rng, (T, n)), device=device) for f in fams]
+    for e in sep:
+        e.reset()
+    mixed.reset()
+    for t in range(T):
+        obs, rew, term, trunc = mixed.step([a[t] for a in acts])
+        for k, e in enumerate(sep):
+            o, r, te, tr = e.step(acts[k][t])
+            sl = mixed.part_slice(k)
+            assert torch.equal(obs[k], o) and torch.equal(rew[sl], r), (t, k)
+            assert torch.equal(term[sl], te) and torch.equal(trunc[sl], tr), (t, k)
+    assert int(mixed.episodes_done.sum()) >= 2 * n * (T // 7)
+
+
+def test_mixed_brax_batch_equals_separate_engines(device):
+    """BASELINE config 5 (Halfcheetah + Humanoid) as one object, at a size the test finishes in seconds"""
+    from carl_amd.envs import CARLBraxHalfcheetah, CARLBraxHumanoid
+    from carl_amd.context.selection import StaticSelector
+    from carl_amd.mixed import MixedVecEngine
+
+    n, T = 1024, 12
+    def mk():
+        return [cls(batch_size=n, device=device, context_selector=StaticSelector, seed=2, lane_offset=k * n,
+                    autotune=False) for k, cls in enumerate((CARLBraxHalfcheetah, CARLBraxHumanoid))]
+    sep, parts = mk(), mk()
+    mixed = MixedVecEngine([p.env for p in parts], ["halfcheetah", "humanoid"])
+    g = torch.Generator(device=device).manual_seed(0)
+    acts = [torch.rand((T, n, e.env.info.action_dim), generator=g, device=device) * 0.8 - 0.4 for e in sep]
+    for e in sep:
+        e.reset(seed=2)
+    for p in parts:
+        p.env.seed(2)
+    mixed.reset()
+    outs = mixed.rollout(acts)
+    ref = [e.env.rollout(a) for e, a in zip(sep, acts)]
+    for k in range(2):
+        for name in ("obs", "reward", "terminated", "truncated"):
+            assert torch.equal(outs[k][name], ref[k][name]), (k, name)
+    assert torch.equal(mixed.ep_return, torch.cat([e.env.ep_return for e in sep]))
+
+
+@pytest.mark.parametrize("fam", [O.CARTPOLE, O.PENDULUM], ids=["cartpole", "pendulum"])
+def test_captured_step_equals_eager_step(fam, device):
+    """VecEngine.capture_step: a hipGraph of the per-call launch reading a fixed action buffer; the capture
+    leaves the engine untouched and every replay equals an eager step, through auto-resets"""
+    n, T = 4096, 60
+    rng = np.random.default_rng(fam)
+    table = random_table(fam, rng, n)
+    acts = torch.as_tensor(random_actions(fam, rng, (T, n)), device=device)
+    kw = dict(selector=O.SEL_STATIC, seed=9, ctx_idx0=np.arange(n), max_episode_steps=11)
+    e1, e2 = _engine(fam, table, n, device, **kw), _engine(fam, table, n, device, **kw)
+    e1.reset()
+    e2.reset()
+    buf = acts[0].clone()
+    before = e1.snapshot()
+    g = e1.capture_step(buf)
+    for k, v in before.items():
+        assert torch.equal(getattr(e1, k), v), k
+    for t in range(T):
+        buf.copy_(acts[t])
+        o1, r1, te1, tr1 = g.replay()
+        o2, r2, te2, tr2 = e2.step(acts[t])
+        assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(te1, te2) and torch.equal(tr1, tr2), t
+    for name in _BOOKKEEPING:
+        assert torch.equal(getattr(e1, name), getattr(e2, name)), name
+
+
+def test_step_fast_path_tracks_a_changed_action_tensor(device):
+    """the per-call fast path skips validation only for the SAME tensor at the same address: a new tensor, a
+    NumPy array or another dtype goes through validation again"""
+    fam, n = O.MOUNTAINCAR, 512
+    e1 = _engine(fam, random_table(fam, np.random.default_rng(0), n), n, device, selector=O.SEL_STATIC, seed=1)
+    e2 = _engine(fam, random_table(fam, np.random.default_rng(0), n), n, device, selector=O.SEL_STATIC, seed=1)
+    e1.reset(); e2.reset()
+    a32 = torch.randint(0, 3, (n,), dtype=torch.int32, device=device)
+    a64 = torch.randint(0, 3, (n,), dtype=torch.int64, device=device)
+    seq = [a32, a32, a64, a64.cpu().numpy(), a32, a32.clone(), a64]
+    for a in seq:
+        r1 = e1.step(a)
+        r2 = e2.step(torch.as_tensor(a).to(device).clone())
+        assert all(torch.equal(x, y) for x, y in zip(r1, r2))
+    with pytest.raises(ValueError):
+        e1.step(a32[:-1])
+
+
+_WORKER = r"""
+import os, sys
+sys.path.insert(0, os.environ["CARL_ROOT"])
+import numpy as np, torch, torch.distributed as dist
+from carl_amd.engine import VecEngine
+from carl_amd.distributed import lane_shard, shard_context_rows, all_gather_episode_stats, reduce_episode_summary
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+backend = os.environ["CARL_BACKEND"]
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+if backend == "nccl":
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+else:
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+d = np.load(os.environ["CARL_CASE"])
+N, T = int(d["acts"].shape[1]), int(d["acts"].shape[0])
+sh = lane_shard(N, rank, world)
+eng = VecEngine(int(d["fam"]), shard_context_rows(d["table"], sh, True), sh.count, dev, selector=0, seed=13,
+                lane_offset=sh.offset, ctx_idx0=np.arange(sh.count), max_episode_steps=int(d["max_steps"]))
+eng.reset()
+out = eng.rollout(torch.as_tensor(np.ascontiguousarray(d["acts"][:, sh.slice]), device=dev))
+torch.cuda.synchronize()
+if backend == "nccl":
+    stats = all_gather_episode_stats(eng)
+    summary = reduce_episode_summary(eng)
+else:  # gloo moves host tensors: the HIP engine still ran under the process group, the collective is staged
+    stats = all_gather_episode_stats({k: getattr(eng, k).cpu() for k in ("last_return", "last_length", "episodes_done")})
+    summary = reduce_episode_summary({k: getattr(eng, k).cpu() for k in ("last_return", "last_length", "episodes_done")})
+if rank == 0:
+    np.savez(os.environ["CARL_OUT"], backend=backend, summary_mean=summary["mean_return"],
+             **{k: v.cpu().numpy() for k, v in stats.items()})
+np.save(os.environ["CARL_OUT"] + f".obs{rank}.npy", out["obs"][-1].cpu().numpy())
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.parametrize("backend", ["nccl", "gloo"])
+def test_hip_engine_under_a_process_group_on_one_gpu(backend, device, tmp_path):
+    """Two ranks (two processes) share the ONE visible GPU: each runs the HIP engine on its lane shard and the
+    episodic returns are all-gathered -- with RCCL (backend nccl) when it accepts two ranks on one device, and
+    with gloo (host-staged) always.  The gathered vectors must equal the single-process engine's bit for bit:
+    the HIP engine, not the oracle, under `lane_shard` + `all_gather_episode_stats` on hardware."""
+    fam, N, T, max_steps = O.CARTPOLE, 8192 + 48, 96, 17  # uneven split: 4120 / 4120
+    rng = np.random.default_rng(21)
+    table = random_table(fam, rng, N)
+    acts = random_actions(fam, rng, (T, N))
+    case = tmp_path / "case.npz"
+    np.savez(case, fam=fam, table=table, acts=acts, max_steps=max_steps)
+    out = tmp_path / f"out_{backend}.npz"
+    port = 29500 + (os.getpid() % 2000) + (7 if backend == "gloo" else 0)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), CARL_ROOT=ROOT, CARL_CASE=str(case), CARL_OUT=str(out),
+                   CARL_BACKEND=backend, CARL_AMD_NO_BUILD="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, "-c", _WORKER], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    logs = []
+    failed = False
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            o, _ = p.communicate()
+            failed = True
+        logs.append(o)
+        failed |= p.returncode != 0
+    if failed and backend == "nccl":
+        # RCCL refuses (or hangs on) two ranks that map to one device on this build: recorded, not hidden --
+        # the gloo variant of this test is the one that must pass
+        pytest.skip("RCCL does not run two ranks on one device here: " + " | ".join(l[-300:] for l in logs))
+    assert not failed, "\n".join(logs)
+    got = np.load(out)
+    ref = _engine(fam, table, N, device, selector=0, seed=13, ctx_idx0=np.arange(N), max_episode_steps=max_steps)
+    ref.reset()
+    ref_out = ref.rollout(torch.as_tensor(acts, device=device))
+    for k in ("last_return", "last_length", "episodes_done"):
+        np.testing.assert_array_equal(got[k], getattr(ref, k).cpu().numpy(), err_msg=k)
+    half = N // 2
+    np.testing.assert_array_equal(np.load(str(out) + ".obs0.npy"), ref_out["obs"][-1][:half].cpu().numpy())
+    np.testing.assert_array_equal(np.load(str(out) + ".obs1.npy"), ref_out["obs"][-1][half:].cpu().numpy())
+    fin = got["episodes_done"] > 0
+    assert abs(float(got["summary_mean"]) - float(got["last_return"][fin].mean())) < 1e-4

@@ -4,7 +4,7 @@ export CARL_AMD_NO_BUILD=1
 mkdir -p gpurun_out
 run() {  # name, extra bench args...
   local name=$1; shift
-  python bench.py --steps 1000 --warmup 100 --no-cpu-baseline --no-per-call "$@" > gpurun_out/abl_$name.log 2>&1
+  python bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-per-call --also none "$@" > gpurun_out/abl_$name.log 2>&1
   python - "$name" <<'PY'
 import json, sys
 n = sys.argv[1]
@@ -18,7 +18,7 @@ PY
 }
 for e in ${ENVS:-pendulum mountaincar}; do
   run base_$e --env $e
-  run base_T1000_$e --env $e --chunk 1000 --steps 2000 --warmup 1000
+  run base_T1000_$e --env $e --chunk 1000 --steps 50 --warmup 5
   for v in NO_DRAIN NO_LOADER NO_BOTH NO_SINK NO_ALL; do
     CARL_AMD_LIB_PATH=$PWD/gpurun_in/libcarl_$v.so run ${v}_$e --env $e
   done

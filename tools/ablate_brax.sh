@@ -4,7 +4,7 @@ export CARL_AMD_NO_BUILD=1
 mkdir -p gpurun_out
 for e in ${ENVS:-ant humanoid halfcheetah}; do
 for v in ${VARIANTS}; do
-  CARL_AMD_LIB_PATH=$PWD/gpurun_in/libcarl_$v.so timeout 200 python bench.py --env $e --lanes ${LANES:-32768} --chunk 20 --steps 100 --warmup 20 --no-cpu-baseline --no-per-call > gpurun_out/bb_${e}_$v.log 2>&1
+  CARL_AMD_LIB_PATH=$PWD/gpurun_in/libcarl_$v.so timeout 200 python bench.py --env $e --lanes ${LANES:-32768} --chunk 20 --steps 100 --warmup 20 --no-cpu-baseline --no-per-call --also none > gpurun_out/bb_${e}_$v.log 2>&1
   python - $e $v <<'PY'
 import json,sys
 e,v=sys.argv[1:3]

@@ -3,7 +3,7 @@
 export CARL_AMD_NO_BUILD=1
 mkdir -p gpurun_out
 for e in ${ENVS:-pendulum cartpole acrobot mountaincar}; do
-  python bench.py --env $e --steps ${STEPS:-1000} --warmup 100 --no-cpu-baseline "$@" > gpurun_out/bench_$e.log 2>&1
+  python bench.py --env $e --steps ${STEPS:-200} --warmup 20 --no-cpu-baseline --also none "$@" > gpurun_out/bench_$e.log 2>&1
   python - "$e" <<'PY'
 import json, sys
 e = sys.argv[1]

@@ -2,7 +2,7 @@
 # SQ counters for the rollout kernel: tools/pmc_sq.sh <tag> [bench args]
 set -u
 TAG=${1:-sq}; shift || true
-ARGS=${*:-"--steps 1000 --warmup 100 --no-cpu-baseline --no-per-call"}
+ARGS=${*:-"--steps 200 --warmup 20 --no-cpu-baseline --no-per-call --also none"}
 export TMPDIR=/tmp CARL_AMD_NO_BUILD=1
 OUT=$PWD/gpurun_out/pmc_$TAG
 mkdir -p "$OUT"

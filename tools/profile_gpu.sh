@@ -7,7 +7,7 @@
 #    never combined with tracing domains) -> HBM traffic per launch.
 set -u
 TAG=${1:-r01}; shift || true
-ARGS=${*:-"--steps 1000 --warmup 100 --no-cpu-baseline --no-per-call"}
+ARGS=${*:-"--steps 200 --warmup 20 --no-cpu-baseline --no-per-call --also none"}
 export TMPDIR=/tmp CARL_AMD_NO_BUILD=1
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
