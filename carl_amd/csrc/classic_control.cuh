@@ -45,6 +45,9 @@ struct CartPole {
   // family because the smaller done path also frees the step loop's registers: Pendulum 279 -> 266,
   // MountainCar 292 -> 273, MountainCarContinuous 313 -> 276, Acrobot 2330 -> 2205 ns/step (A/B, one box)
   static constexpr bool kPredraw = true;
+  // short episodes under any policy: the done handling of the PLAIN staged rollout is straight-line selects on
+  // every step instead of a wave-uniform branch that is taken ~95 % of the time (engine_kernels.cuh: step_dense)
+  static constexpr bool kDenseDone = true;
 
   struct Params {
     float gravity, masspole, length, force_mag, tau, inv_total_mass, polemass_length;

@@ -320,6 +320,80 @@ __device__ __forceinline__ void finish_plain(const carl_batch_t& b, uint64_t gla
   __builtin_amdgcn_s_waitcnt(0xC07F);  // as at the end of finish_episodes
 }
 
+// DENSE done handling (families with kDenseDone, in the PLAIN staged rollout): CartPole under a random
+// policy ends an episode every ~22 steps, so SOME lane of nearly every wave finishes on nearly every step
+// (P(no lane of 64 finishes) ~ 5 %): the "rarely taken" wave-uniform done branch of step_lane is the common
+// path there, and what it costs is not its ~45 instructions but what surrounds them with one compute wave
+// per SIMD and nothing to overlap: five taken branches per step, the VALU -> SALU -> branch hand-overs, an
+// lgkmcnt(0) at its end (r01j: 104 VALU + 23 SALU in ~1000 cycles per wave-step, against a 298 ns memory
+// floor).  Here the done handling is STRAIGHT-LINE for every step:
+//   * once per 8-step chunk the wave draws the init-state words of every lane whose pending draw was consumed
+//     (same Philox block as predraw) and turns them into the lane's next reset STATE (and its Aux) -- the
+//     uniform conversion and the fma leave the per-step path;
+//   * a step then ends with S + |Aux| + 6 selects on `done` (v_cndmask on the compare's own lane mask): no
+//     ballot branch, no exec-mask change, no wait;
+//   * "pending draw valid" is a wave-uniform 64-bit mask in SGPRs, maintained with scalar ops from the done
+//     ballot; the only branch left is the never-taken one for a lane that finishes a second time before the
+//     next chunk's draw (drawn inline: same words, same order -> bit-identical to the per-call kernel).
+template <class Fam, class = void>
+struct dense_done_of : std::false_type {};
+template <class Fam>
+struct dense_done_of<Fam, std::void_t<decltype(Fam::kDenseDone)>> : std::bool_constant<Fam::kDenseDone> {};
+
+template <class Fam>
+struct DenseNext {
+  unsigned long long ok_mask;  // bit l: lane l's `s` / `aux` below hold its NEXT episode's init state
+  float s[Fam::S];
+  typename Fam::Aux aux;
+};
+
+template <class Fam>
+__device__ __forceinline__ void dense_draw(const carl_batch_t& b, uint64_t glane, const LaneRegs<Fam>& r,
+                                           unsigned long long lanes, DenseNext<Fam>& nx) {
+  const u32x4 w = lane_words(b.seed, glane, r.episode, kSubInit);
+  float fresh[Fam::S];
+  typename Fam::Aux fa;
+  Fam::reset(r.p, w, fresh);
+  Fam::prepare(fresh, fa);
+  const bool mine = ((lanes >> lane_id()) & 1ull) != 0ull;
+#pragma unroll
+  for (int j = 0; j < Fam::S; ++j) nx.s[j] = mine ? fresh[j] : nx.s[j];
+  nx.aux = select_words(mine, fa, nx.aux);
+}
+
+template <class Fam, class Sink>
+__device__ __forceinline__ void step_dense(const carl_batch_t& b, const Sink& cur, int max_steps, bool autoreset,
+                                           uint64_t glane, typename Fam::Action action, LaneRegs<Fam>& r,
+                                           DenseNext<Fam>& nx) {
+  static_assert(!Fam::kNeedsStepNoise, "dense done handling: families without per-step noise");
+  float reward;
+  const bool terminated = Fam::step(r.p, r.s, r.aux, action, 0.0f, r.elapsed, reward);
+  r.elapsed += 1;
+  const bool truncated = (max_steps > 0) && (r.elapsed >= max_steps);  // gymnasium TimeLimit.step
+  r.ep_return += reward;
+  cur.put_reward(reward);
+  cur.put_flags(terminated, truncated);  // every step (the lazy flag rows only save work when done is rare)
+  const bool done = terminated | truncated;
+  const unsigned long long dm = __ballot(done);
+  const unsigned long long again = dm & ~nx.ok_mask;
+  if (__builtin_expect(again != 0ull, 0)) dense_draw<Fam>(b, glane, r, again, nx);
+  const bool rs = done && autoreset;
+  r.fin_return = done ? r.ep_return : r.fin_return;
+  r.fin_length = done ? r.elapsed : r.fin_length;
+  r.n_new_episodes += done ? 1 : 0;
+#pragma unroll
+  for (int j = 0; j < Fam::S; ++j) r.s[j] = rs ? nx.s[j] : r.s[j];
+  r.aux = select_words(rs, nx.aux, r.aux);
+  r.elapsed = rs ? 0 : r.elapsed;
+  r.ep_return = rs ? 0.0f : r.ep_return;
+  r.episode += rs ? 1u : 0u;
+  r.n_new_calls += rs ? 1 : 0;
+  nx.ok_mask &= autoreset ? ~dm : ~0ull;
+  float o[Fam::D];
+  Fam::observe(r.s, r.aux, o);
+  cur.put_obs(o);
+}
+
 // One step of one lane.  `cur` points at this step's output records for this lane.
 // ALL_ACTIVE: the whole wave is inside the batch (every full workgroup), so the per-step
 // `if (active)` exec-mask dance disappears from the loop.
@@ -835,11 +909,41 @@ __global__ void __launch_bounds__(kStagedThreads) rollout_staged_kernel(const ca
   }
   __syncthreads();
   int buf = 0;
+  [[maybe_unused]] DenseNext<Fam> nx{};  // dense done handling (PLAIN, kDenseDone families): nothing drawn yet
+  [[maybe_unused]] const bool autoreset = (b.flags & CARL_FLAG_AUTORESET) != 0;
   for (int t0 = 0; t0 < n_steps; t0 += kStageChunk, buf ^= 1) {
     const int steps = min(kStageChunk, n_steps - t0);
     if (compute) {
       const Action* my = act_buf + buf * kBufActs + threadIdx.x;
       char* rec = out_buf + (size_t)buf * kStageChunk * SK::kStepBytes;
+      if constexpr (PLAIN && dense_done_of<Fam>::value) {
+        // every lane's next init state in registers before the chunk's first step
+        if (nx.ok_mask != ~0ull) {
+          dense_draw<Fam>(b, glane, r, ~nx.ok_mask, nx);
+          nx.ok_mask = ~0ull;
+        }
+        // the chunk's actions in registers: one LDS wait per chunk instead of one per step
+        Action acts[kStageChunk];
+#pragma unroll
+        for (int u = 0; u < kStageChunk; ++u) acts[u] = my[u * kRolloutLanes];
+        if (steps == kStageChunk) {  // fully unrolled: record addresses are immediates, no loop control
+#pragma unroll
+          for (int u = 0; u < kStageChunk; ++u) {
+            const SK sink{rec + (size_t)u * SK::kStepBytes, nullptr, n * Fam::D, t0 + u, (int)threadIdx.x};
+            step_dense<Fam, SK>(b, sink, max_steps, autoreset, glane, acts[u], r, nx);
+          }
+        } else {  // the rollout's last, ragged chunk
+#pragma unroll 1
+          for (int u = 0; u < steps; ++u) {
+            const SK sink{rec + (size_t)u * SK::kStepBytes, nullptr, n * Fam::D, t0 + u, (int)threadIdx.x};
+            Action a = acts[0];
+#pragma unroll
+            for (int k = 1; k < kStageChunk; ++k) a = (u == k) ? acts[k] : a;
+            step_dense<Fam, SK>(b, sink, max_steps, autoreset, glane, a, r, nx);
+          }
+        }
+      }
+      if constexpr (!(PLAIN && dense_done_of<Fam>::value)) {
       if constexpr (predraw_of<Fam>::value) predraw<Fam>(b, glane, r);
       Action a_next = my[0];
       settle(a_next);  // arrive before the loop: its head then only waits for the read issued one
@@ -849,6 +953,7 @@ __global__ void __launch_bounds__(kStagedThreads) rollout_staged_kernel(const ca
         a_next = my[min(u + 1, kStageChunk - 1) * kRolloutLanes];
         const SK sink{rec + (size_t)u * SK::kStepBytes, final_base, n * Fam::D, t0 + u, (int)threadIdx.x};
         step_lane<Fam, ctx_t<LDSCTX>, true, SK, PLAIN>(b, ctx, sink, max_steps, true, lane, glane, a, r);
+      }
       }
     } else if (loader) {
 #ifndef CARL_EXP_NO_LOADER
