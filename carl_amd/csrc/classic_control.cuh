@@ -23,6 +23,8 @@
 // Acrobot's RK4, which is fp64 by default (see AcrobotT).
 #pragma once
 
+#include <type_traits>
+
 #include "carl_device.cuh"
 #include "fast_math.cuh"
 
@@ -202,6 +204,53 @@ struct Pendulum {
   }
 };
 
+// ---- fp64 sin/cos from an LDS table (Acrobot) -------------------------------------
+// Acrobot's RK4 needs eight fp64 sin/cos pairs per step (the reference's float64 arithmetic is needed there,
+// see AcrobotT), and with the polynomial sincos_fast they were two thirds of the step's 562 vector
+// instructions (46 each: 3-term reduction, two degree-6 polynomials in z, and the quadrant swap / sign logic on
+// 64-bit values).  Here x = i * (pi / 256) + r with |r| <= pi / 512: (sin, cos) of the grid point come from a
+// 512-entry table of correctly rounded doubles (8 KiB of LDS, staged once per workgroup from a constant array;
+// generated by tools/gen_sincos_table.py), sin r and cos r need three and two terms, and
+//   sin x = S cos r + C sin r,   cos x = C cos r - S sin r
+// -- ~19 instructions and no quadrant logic; max error ~1.5e-16 (tests/test_gpu_parity.py: vs libm).
+#include "sincos_table.inc"
+__device__ const double kSinCosTab[2 * CARL_SINCOS_TAB_N] = {CARL_SINCOS_TAB_VALUES};
+
+struct SinCosTab {
+  typedef double vd2 __attribute__((ext_vector_type(2)));
+  __device__ static __forceinline__ vd2* lds() {
+    __shared__ vd2 tab[CARL_SINCOS_TAB_N];
+    return tab;
+  }
+  // every thread of the workgroup; the caller synchronises before the first lookup
+  __device__ static __forceinline__ void stage() {
+    vd2* t = lds();
+    const vd2* g = reinterpret_cast<const vd2*>(kSinCosTab);
+    for (int i = threadIdx.x; i < CARL_SINCOS_TAB_N; i += blockDim.x) t[i] = g[i];
+  }
+  // two angles at once (an RK4 stage): both table reads are issued before the polynomials
+  __device__ static __forceinline__ void sincos2(double xa, double xb, double& sna, double& csa, double& snb,
+                                                 double& csb) {
+    const vd2* t = lds();
+    const double inv = CARL_SINCOS_TAB_INV_STEP, hi = CARL_SINCOS_TAB_STEP_HI, lo = CARL_SINCOS_TAB_STEP_LO;
+    const double ka = rint(xa * inv), kb = rint(xb * inv);
+    const vd2 ea = t[(int)ka & (CARL_SINCOS_TAB_N - 1)], eb = t[(int)kb & (CARL_SINCOS_TAB_N - 1)];
+    double ra = fma(ka, -hi, xa), rb = fma(kb, -hi, xb);
+    ra = fma(ka, -lo, ra);
+    rb = fma(kb, -lo, rb);
+    const double za = ra * ra, zb = rb * rb;
+    // sin r = r + r z (-1/6 + z / 120), cos r = 1 + z (-1/2 + z / 24):  |r| <= pi / 512 -> truncation < 1e-16
+    const double sra = fma(ra * za, fma(za, 1.0 / 120.0, -1.0 / 6.0), ra);
+    const double srb = fma(rb * zb, fma(zb, 1.0 / 120.0, -1.0 / 6.0), rb);
+    const double cra = fma(za, fma(za, 1.0 / 24.0, -0.5), 1.0);
+    const double crb = fma(zb, fma(zb, 1.0 / 24.0, -0.5), 1.0);
+    sna = fma(ea.x, cra, ea.y * sra);
+    csa = fma(ea.y, cra, -(ea.x * sra));
+    snb = fma(eb.x, crb, eb.y * srb);
+    csb = fma(eb.y, crb, -(eb.x * srb));
+  }
+};
+
 // ================================ Acrobot =========================================
 // features: carl_acrobot.py:15-69
 //
@@ -219,9 +268,13 @@ struct AcrobotT {
   static constexpr bool kNeedsStepNoise = true;
   static constexpr bool kPredraw = true;
 
+  // Context-only combinations of _dsdt, formed once per launch / reset instead of in each of the four RK4
+  // stages (they regroup the reference's left-to-right products; in float64 that moves results by ~1e-16
+  // relative, nine orders below the parity bar):
+  //   A = m2 l1 lc2            B = (m1 lc1 + m2 l1) g        C = m2 lc2 g
+  //   D = m2 lc2^2 + I2        E = m1 lc1^2 + m2 (l1^2 + lc2^2) + I1 + I2
   struct Params {
-    Real m1lc1sq;  // m1 * lc1^2, the context-only leading term of d1
-    Real m1, m2, l1, lc1, lc2, moi;
+    Real A, B, C, D, E;
     Real max_vel_1, max_vel_2;
     float noise_max;
     float ia_lo, ia_hi, iv_lo, iv_hi;
@@ -234,13 +287,14 @@ struct AcrobotT {
   template <class Ctx>
   __device__ static __forceinline__ Params load(const Ctx& ctx, int c, int) {
     Params p;
-    p.m1 = ctx.get(M1, c);
-    p.m2 = ctx.get(M2, c);
-    p.l1 = ctx.get(L1, c);
-    p.lc1 = ctx.get(C1, c);
-    p.lc2 = ctx.get(C2, c);
-    p.moi = ctx.get(MOI, c);
-    p.m1lc1sq = p.m1 * (p.lc1 * p.lc1);
+    const Real m1 = ctx.get(M1, c), m2 = ctx.get(M2, c), l1 = ctx.get(L1, c);
+    const Real lc1 = ctx.get(C1, c), lc2 = ctx.get(C2, c), moi = ctx.get(MOI, c);
+    const Real g = (Real)9.8;  // AcrobotEnv._dsdt: literal
+    p.A = m2 * l1 * lc2;
+    p.B = (m1 * lc1 + m2 * l1) * g;
+    p.C = m2 * lc2 * g;
+    p.D = m2 * (lc2 * lc2) + moi;
+    p.E = m1 * (lc1 * lc1) + m2 * (l1 * l1 + lc2 * lc2) + moi + moi;
     p.max_vel_1 = ctx.get(MAXV1, c);
     p.max_vel_2 = ctx.get(MAXV2, c);
     p.noise_max = ctx.get(NOISE, c);
@@ -251,9 +305,15 @@ struct AcrobotT {
     return p;
   }
 
+  // the fp64 variant reads sin / cos of the table's grid points from LDS: every kernel instantiated with this
+  // family stages the table first (engine_kernels.cuh: stage_family_tables)
+  static constexpr bool kUsesSinCosTab = std::is_same_v<Real, double>;
+  __device__ static __forceinline__ void stage_tables() {
+    if constexpr (kUsesSinCosTab) SinCosTab::stage();
+  }
+
   __device__ static __forceinline__ void prepare(const float (&s)[S], Aux& a) {
-    sincos_fast((Real)s[0], a.ks0, a.kc0);
-    sincos_fast((Real)s[1], a.ks1, a.kc1);
+    sincos_pair((Real)s[0], (Real)s[1], a.ks0, a.kc0, a.ks1, a.kc1);
     a.s0 = (float)a.ks0; a.c0 = (float)a.kc0;
     a.s1 = (float)a.ks1; a.c1 = (float)a.kc1;
   }
@@ -261,6 +321,29 @@ struct AcrobotT {
   struct Deriv {
     Real d0, d1, d2, d3;
   };
+
+  // sin/cos of an RK4 stage angle or of the new angle: |x| <= pi + a few turns (velocities are clipped), so
+  // the fp64 version runs without the library fallback for huge arguments (fast_math.cuh)
+  __device__ static __forceinline__ void sincos_stage(Real x, Real& sn, Real& cs) {
+    if constexpr (std::is_same_v<Real, double>)
+      sincos_fast<false>(x, sn, cs);
+    else
+      sincos_fast(x, sn, cs);
+  }
+  __device__ static __forceinline__ void sincos_pair(Real xa, Real xb, Real& sa, Real& ca, Real& sb, Real& cb) {
+    if constexpr (std::is_same_v<Real, double>) {
+      SinCosTab::sincos2(xa, xb, sa, ca, sb, cb);
+    } else {
+      sincos_fast(xa, sa, ca);
+      sincos_fast(xb, sb, cb);
+    }
+  }
+  __device__ static __forceinline__ Real recip(Real d) {
+    if constexpr (std::is_same_v<Real, double>)
+      return rcp_fast(d);
+    else
+      return (Real)1.0 / d;
+  }
 
   // AcrobotEnv._dsdt, book_or_nips == "book", g = 9.8 literal.
   // cos(theta1 + theta2 - pi/2) and cos(theta1 - pi/2) are sin(theta1 + theta2) and
@@ -270,24 +353,24 @@ struct AcrobotT {
   __device__ static __forceinline__ Deriv dsdt(const Params& p, Real theta1, Real theta2, Real dtheta1,
                                                Real dtheta2, Real a) {
     Real s1, c1, s2, c2;
-    sincos_fast(theta1, s1, c1);
-    sincos_fast(theta2, s2, c2);
+    sincos_pair(theta1, theta2, s1, c1, s2, c2);
     return dsdt_trig(p, s1, c1, s2, c2, dtheta1, dtheta2, a);
   }
 
   __device__ static __forceinline__ Deriv dsdt_trig(const Params& p, Real s1, Real c1, Real s2, Real c2, Real dtheta1,
                                                     Real dtheta2, Real a) {
-    const Real m1 = p.m1, m2 = p.m2, l1 = p.l1, lc1 = p.lc1, lc2 = p.lc2, I1 = p.moi, I2 = p.moi;
-    const Real g = (Real)9.8;
+    // d1 = m1 lc1^2 + m2 (l1^2 + lc2^2 + 2 l1 lc2 cos t2) + I1 + I2;  d2 = m2 (lc2^2 + l1 lc2 cos t2) + I2
+    // phi2 = m2 lc2 g sin(t1 + t2);  phi1 = -m2 l1 lc2 w2^2 sin t2 - 2 m2 l1 lc2 w2 w1 sin t2 + (m1 lc1 + m2 l1) g sin t1 + phi2
+    // ddtheta2 = (a + d2 / d1 phi1 - m2 l1 lc2 w1^2 sin t2 - phi2) / (m2 lc2^2 + I2 - d2^2 / d1);  ddtheta1 = -(d2 ddtheta2 + phi1) / d1
     const Real s12 = s1 * c2 + c1 * s2;
-    const Real d1 = p.m1lc1sq + m2 * (l1 * l1 + lc2 * lc2 + (Real)2.0 * l1 * lc2 * c2) + I1 + I2;
-    const Real d2 = m2 * (lc2 * lc2 + l1 * lc2 * c2) + I2;
-    const Real phi2 = m2 * lc2 * g * s12;
-    const Real phi1 = -m2 * l1 * lc2 * (dtheta2 * dtheta2) * s2 -
-                      (Real)2.0 * m2 * l1 * lc2 * dtheta2 * dtheta1 * s2 + (m1 * lc1 + m2 * l1) * g * s1 + phi2;
-    const Real inv_d1 = (Real)1.0 / d1;
-    const Real ddtheta2 = (a + d2 * inv_d1 * phi1 - m2 * l1 * lc2 * (dtheta1 * dtheta1) * s2 - phi2) /
-                          (m2 * (lc2 * lc2) + I2 - (d2 * d2) * inv_d1);
+    const Real d1 = p.E + (Real)2.0 * p.A * c2;
+    const Real d2 = p.D + p.A * c2;
+    const Real phi2 = p.C * s12;
+    const Real as2 = p.A * s2;
+    const Real phi1 = p.B * s1 + phi2 - (as2 * dtheta2) * (dtheta2 + (Real)2.0 * dtheta1);
+    const Real inv_d1 = recip(d1);
+    const Real w = d2 * inv_d1;
+    const Real ddtheta2 = (a + w * phi1 - (as2 * dtheta1) * dtheta1 - phi2) * recip(p.D - d2 * w);
     const Real ddtheta1 = -(d2 * ddtheta2 + phi1) * inv_d1;
     return Deriv{dtheta1, dtheta2, ddtheta1, ddtheta2};
   }
@@ -306,6 +389,26 @@ struct AcrobotT {
     return x;
   }
 
+  // Both angles of a step.  One turn in either direction is the common case (velocities are clipped at a few
+  // rad per step), so it is done with selects -- exactly the first iteration of each of the reference's loops --
+  // and the loops themselves run only when some lane of the wave is still out of range afterwards (four
+  // exec-masked loop nests and ~90 scalar instructions per step otherwise).
+  __device__ static __forceinline__ void wrap_pair(Real& x0, Real& x1) {
+    const Real pi = (Real)3.14159265358979323846;
+    const Real diff = pi - (-pi);
+    Real y0 = x0 > pi ? x0 - diff : x0;
+    Real y1 = x1 > pi ? x1 - diff : x1;
+    y0 = y0 < -pi ? y0 + diff : y0;
+    y1 = y1 < -pi ? y1 + diff : y1;
+    const bool more = !(y0 <= pi && y0 >= -pi && y1 <= pi && y1 >= -pi);  // several turns, or non-finite
+    if (__builtin_expect(__ballot(more) != 0ull, 0)) {
+      y0 = wrap_pi(x0);
+      y1 = wrap_pi(x1);
+    }
+    x0 = y0;
+    x1 = y1;
+  }
+
   // AcrobotEnv.step: rk4 over [0, dt = 0.2] on (state, torque), wrap, bound, _terminal
   __device__ static __forceinline__ bool step(const Params& p, float (&s)[S], Aux& aux, int action, float noise,
                                               int /*elapsed*/, float& reward) {
@@ -322,10 +425,10 @@ struct AcrobotT {
     Real n1 = y1 + dt / six * (k1.d1 + two * k2.d1 + two * k3.d1 + k4.d1);
     Real n2 = y2 + dt / six * (k1.d2 + two * k2.d2 + two * k3.d2 + k4.d2);
     Real n3 = y3 + dt / six * (k1.d3 + two * k2.d3 + two * k3.d3 + k4.d3);
-    n0 = wrap_pi(n0);
-    n1 = wrap_pi(n1);
-    n2 = n2 < -p.max_vel_1 ? -p.max_vel_1 : (n2 > p.max_vel_1 ? p.max_vel_1 : n2);
-    n3 = n3 < -p.max_vel_2 ? -p.max_vel_2 : (n3 > p.max_vel_2 ? p.max_vel_2 : n3);
+    wrap_pair(n0, n1);
+    // bound(x, m, M) = min(max(x, m), M)
+    n2 = fmin(fmax(n2, -p.max_vel_1), p.max_vel_1);
+    n3 = fmin(fmax(n3, -p.max_vel_2), p.max_vel_2);
     s[0] = (float)n0;
     s[1] = (float)n1;
     s[2] = (float)n2;
@@ -333,8 +436,7 @@ struct AcrobotT {
     // _terminal and the observation's trig on the unrounded angles, like the reference's
     // float64 state: -cos t1 - cos(t1 + t2) > 1, cos(t1 + t2) = c0 c1 - s0 s1
     Real s0r, c0r, s1r, c1r;
-    sincos_fast(n0, s0r, c0r);
-    sincos_fast(n1, s1r, c1r);
+    sincos_pair(n0, n1, s0r, c0r, s1r, c1r);
     const bool terminated = (-c0r - (c0r * c1r - s0r * s1r)) > (Real)1.0;
     // trig of the ROUNDED angles for the next step's first stage: sin(x + d) = sin x + d cos x to
     // O(d^2) with |d| <= 2e-7 (the float32 rounding of an angle in [-pi, pi]) -> error < 2e-14

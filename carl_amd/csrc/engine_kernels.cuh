@@ -28,6 +28,21 @@ namespace carl {
 template <bool LDS>
 using ctx_t = std::conditional_t<LDS, LdsCtx, GlobalCtx>;
 
+// Families whose physics reads a constant table from LDS (Acrobot's fp64 sin/cos grid, classic_control.cuh)
+// stage it at the top of every kernel, before the first `prepare` / `step`.
+template <class Fam, class = void>
+struct has_tables : std::false_type {};
+template <class Fam>
+struct has_tables<Fam, std::void_t<decltype(Fam::kUsesSinCosTab)>> : std::bool_constant<Fam::kUsesSinCosTab> {};
+
+template <class Fam>
+__device__ __forceinline__ void stage_family_tables() {
+  if constexpr (has_tables<Fam>::value) {
+    Fam::stage_tables();
+    __syncthreads();
+  }
+}
+
 template <bool LDS, int F>
 __device__ __forceinline__ ctx_t<LDS> make_ctx(const carl_batch_t& b, float* lds) {
   if constexpr (LDS) {
@@ -86,6 +101,7 @@ __global__ void __launch_bounds__(256) reset_kernel(const carl_batch_t b, const 
                                                     const int32_t* __restrict__ idx,
                                                     const int32_t* __restrict__ count, float* __restrict__ obs) {
   extern __shared__ float lds_ctx[];
+  stage_family_tables<Fam>();
   const ctx_t<LDS> ctx = make_ctx<LDS, Fam::F>(b, lds_ctx);
   const int n_work = (idx != nullptr) ? *count : b.n_lanes;
   for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n_work; k += gridDim.x * blockDim.x) {
@@ -522,6 +538,7 @@ using action_store_t = std::conditional_t<std::is_same_v<typename Fam::Action, f
 template <class Fam, bool LDS, bool A64>
 __global__ void __launch_bounds__(256) step_kernel(const carl_batch_t b, const carl_step_io_t io) {
   extern __shared__ float lds_ctx[];
+  stage_family_tables<Fam>();
   const ctx_t<LDS> ctx = make_ctx<LDS, Fam::F>(b, lds_ctx);
   const int lane = blockIdx.x * blockDim.x + threadIdx.x;
   const bool active = lane < b.n_lanes;
@@ -605,6 +622,7 @@ template <class Fam, bool LDS, bool A64>
 __global__ void __launch_bounds__(kRolloutThreads) rollout_kernel(const carl_batch_t b, const carl_step_io_t io,
                                                                   const int n_steps) {
   extern __shared__ float lds_dyn[];
+  stage_family_tables<Fam>();
   using AStore = action_store_t<Fam, A64>;
   using Action = typename Fam::Action;
   Action* act_buf = reinterpret_cast<Action*>(lds_dyn);                    // [2][kActChunk][256]
@@ -864,6 +882,7 @@ template <class Fam, bool A64, bool PLAIN = false, bool LDSCTX = false>
 __global__ void __launch_bounds__(kStagedThreads) rollout_staged_kernel(const carl_batch_t b, const carl_step_io_t io,
                                                                         const int n_steps) {
   extern __shared__ float lds_dyn[];
+  stage_family_tables<Fam>();
   using AStore = action_store_t<Fam, A64>;
   using Action = typename Fam::Action;
   using SK = LdsSink<Fam>;

@@ -45,10 +45,37 @@ __device__ __forceinline__ void sincos_fast(float x, float& sn, float& cs) {
   }
 }
 
+// A double constant pinned in a scalar register pair.  The fp64 Horner steps below are `p = fma(z, p, c)` with a
+// CONSTANT addend; left alone, the compiler shrinks each to the two-address v_fmac_f64 and first copies the
+// constant into the destination pair (v_mov_b64, plus v_mov_b32s to assemble pairs): 12 copies per sincos, a
+// sixth of the Acrobot step's instruction stream (114 v_mov_b64 in its loop).  An SGPR addend cannot be a
+// v_fmac destination, so the three-address v_fma_f64 with the constant on the scalar operand bus is what is left.
+__device__ __forceinline__ double sconst(double c) {
+  asm("" : "+s"(c));
+  return c;
+}
+
+// 1 / d from v_rcp_f64 and two Newton steps (relative error ~1e-16, not correctly rounded): 5 instructions
+// against the ~12 of the IEEE division sequence (div_scale x2, rcp, 5 fma, div_fmas, div_fixup)
+__device__ __forceinline__ double rcp_fast(double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  double e = fma(-d, r, 1.0);
+  r = fma(r, e, r);
+  e = fma(-d, r, 1.0);
+  return fma(r, e, r);
+}
+
+// FALLBACK = false: the caller's arguments are bounded (Acrobot's RK4 stages: a wrapped angle plus at most a few
+// turns), so the library path for |x| > 1e6 -- an exec-masked region with the Payne-Hanek reduction inlined,
+// ~150 instructions and ~8 scalar instructions of mask bookkeeping per call site even when skipped -- is left
+// out; beyond 1e6 the Cody-Waite reduction loses accuracy gradually, non-finite inputs give NaN.
+template <bool FALLBACK = true>
 __device__ __forceinline__ void sincos_fast(double x, double& sn, double& cs) {
-  if (__builtin_expect(!(fabs(x) <= 1.0e6), 0)) {
-    sincos(x, &sn, &cs);
-    return;
+  if constexpr (FALLBACK) {
+    if (__builtin_expect(!(fabs(x) <= 1.0e6), 0)) {
+      sincos(x, &sn, &cs);
+      return;
+    }
   }
   const double two_over_pi = 0x1.45f306dc9c883p-1;
   const double hi = 0x1.921fb54442d18p+0, mid = 0x1.1a62633145c07p-54, lo = -0x1.f1976b7ed8fbcp-110;
@@ -57,22 +84,61 @@ __device__ __forceinline__ void sincos_fast(double x, double& sn, double& cs) {
   r = fma(k, -mid, r);
   r = fma(k, -lo, r);
   const double z = r * r;
-  double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
-  ps = fma(z, ps, 2.75573137070700676789e-06);
-  ps = fma(z, ps, -1.98412698298579493134e-04);
-  ps = fma(z, ps, 8.33333333332248946124e-03);
-  ps = fma(z, ps, -1.66666666666666324348e-01);
+  double ps = fma(z, 1.58969099521155010221e-10, sconst(-2.50507602534068634195e-08));
+  ps = fma(z, ps, sconst(2.75573137070700676789e-06));
+  ps = fma(z, ps, sconst(-1.98412698298579493134e-04));
+  ps = fma(z, ps, sconst(8.33333333332248946124e-03));
+  ps = fma(z, ps, sconst(-1.66666666666666324348e-01));
   const double S = fma(r * z, ps, r);
-  double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
-  pc = fma(z, pc, -2.75573143513906633035e-07);
-  pc = fma(z, pc, 2.48015872894767294178e-05);
-  pc = fma(z, pc, -1.38888888888741095749e-03);
-  pc = fma(z, pc, 4.16666666666666019037e-02);
+  double pc = fma(z, -1.13596475577881948265e-11, sconst(2.08757232129817482790e-09));
+  pc = fma(z, pc, sconst(-2.75573143513906633035e-07));
+  pc = fma(z, pc, sconst(2.48015872894767294178e-05));
+  pc = fma(z, pc, sconst(-1.38888888888741095749e-03));
+  pc = fma(z, pc, sconst(4.16666666666666019037e-02));
   const double C = fma(z * z, pc, fma(z, -0.5, 1.0));
   const int q = (int)k;
   const double s2 = (q & 1) ? C : S, c2 = (q & 1) ? S : C;
   sn = (q & 2) ? -s2 : s2;
   cs = ((q + 1) & 2) ? -c2 : c2;
+}
+
+// Two angles at once, statement-interleaved: the four Horner chains (sin / cos of each angle) advance in lock
+// step, so consecutive instructions are independent.  The compiler keeps source order here (it serialises the
+// chains of sincos_fast one after the other), and with ONE wave per SIMD a dependent fp64 fma waits out its
+// latency with nothing else to issue -- Acrobot's RK4 stages are two such angles each.  Same operations and
+// constants as sincos_fast<false>: bit-identical results.
+__device__ __forceinline__ void sincos2_fast(double xa, double xb, double& sna, double& csa, double& snb, double& csb) {
+  const double two_over_pi = 0x1.45f306dc9c883p-1;
+  const double hi = 0x1.921fb54442d18p+0, mid = 0x1.1a62633145c07p-54, lo = -0x1.f1976b7ed8fbcp-110;
+  const double ka = rint(xa * two_over_pi), kb = rint(xb * two_over_pi);
+  double ra = fma(ka, -hi, xa), rb = fma(kb, -hi, xb);
+  ra = fma(ka, -mid, ra);
+  rb = fma(kb, -mid, rb);
+  ra = fma(ka, -lo, ra);
+  rb = fma(kb, -lo, rb);
+  const double za = ra * ra, zb = rb * rb;
+  const double s5 = 1.58969099521155010221e-10, s4 = sconst(-2.50507602534068634195e-08),
+               s3 = sconst(2.75573137070700676789e-06), s2 = sconst(-1.98412698298579493134e-04),
+               s1 = sconst(8.33333333332248946124e-03), s0 = sconst(-1.66666666666666324348e-01);
+  const double c5 = -1.13596475577881948265e-11, c4 = sconst(2.08757232129817482790e-09),
+               c3 = sconst(-2.75573143513906633035e-07), c2 = sconst(2.48015872894767294178e-05),
+               c1 = sconst(-1.38888888888741095749e-03), c0 = sconst(4.16666666666666019037e-02);
+  double psa = fma(za, s5, s4), pca = fma(za, c5, c4), psb = fma(zb, s5, s4), pcb = fma(zb, c5, c4);
+  const double rza = ra * za, rzb = rb * zb;
+  psa = fma(za, psa, s3); pca = fma(za, pca, c3); psb = fma(zb, psb, s3); pcb = fma(zb, pcb, c3);
+  const double zza = za * za, zzb = zb * zb;
+  psa = fma(za, psa, s2); pca = fma(za, pca, c2); psb = fma(zb, psb, s2); pcb = fma(zb, pcb, c2);
+  const double ha = fma(za, -0.5, 1.0), hb = fma(zb, -0.5, 1.0);
+  psa = fma(za, psa, s1); pca = fma(za, pca, c1); psb = fma(zb, psb, s1); pcb = fma(zb, pcb, c1);
+  const int qa = (int)ka, qb = (int)kb;
+  psa = fma(za, psa, s0); pca = fma(za, pca, c0); psb = fma(zb, psb, s0); pcb = fma(zb, pcb, c0);
+  const double Sa = fma(rza, psa, ra), Ca = fma(zza, pca, ha), Sb = fma(rzb, psb, rb), Cb = fma(zzb, pcb, hb);
+  const double s2a = (qa & 1) ? Ca : Sa, c2a = (qa & 1) ? Sa : Ca;
+  const double s2b = (qb & 1) ? Cb : Sb, c2b = (qb & 1) ? Sb : Cb;
+  sna = (qa & 2) ? -s2a : s2a;
+  csa = ((qa + 1) & 2) ? -c2a : c2a;
+  snb = (qb & 2) ? -s2b : s2b;
+  csb = ((qb + 1) & 2) ? -c2b : c2b;
 }
 
 __device__ __forceinline__ float cos_fast(float x) {
