@@ -102,7 +102,7 @@ struct CartPole {
     const bool was_terminated = (elapsed > 0) && out_of_bounds(x, theta);
     const float force = (action == 1) ? p.force_mag : -p.force_mag;
     float sintheta, costheta;
-    sincos_fast(theta, sintheta, costheta);
+    sincos_fast_smallarg(theta, sintheta, costheta);
     const float temp = (force + p.polemass_length * (theta_dot * theta_dot) * sintheta) * p.inv_total_mass;
     const float thetaacc =
         div_fast(p.gravity * sintheta - costheta * temp,

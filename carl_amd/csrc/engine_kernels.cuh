@@ -18,7 +18,8 @@
 // writes such libraries under gpurun_in/, never to carl_amd/lib/).
 #if (defined(CARL_EXP_NO_REWARD_STORE) || defined(CARL_EXP_NO_FLAG_STORES) || defined(CARL_EXP_NO_DONE) ||      \
      defined(CARL_EXP_NO_OBS_STORE) || defined(CARL_EXP_NO_ACTIONS) || defined(CARL_EXP_NO_LOADER) ||            \
-     defined(CARL_EXP_NO_DRAIN) || defined(CARL_EXP_TEMPORAL) || defined(CARL_STORERS)) &&                       \
+     defined(CARL_EXP_NO_DRAIN) || defined(CARL_EXP_TEMPORAL) || defined(CARL_STORERS) ||                        \
+     defined(CARL_EXP_DENSE_ROLLED)) &&                                                                          \
     !defined(CARL_ABLATION)
 #error "CARL_EXP_* / CARL_STORERS build profiling-only kernels; pass -DCARL_ABLATION to confirm (never for the product library)"
 #endif
@@ -390,7 +391,7 @@ __device__ __forceinline__ void step_dense(const carl_batch_t& b, const Sink& cu
   cur.put_reward(reward);
   cur.put_flags(terminated, truncated);  // every step (the lazy flag rows only save work when done is rare)
   const bool done = terminated | truncated;
-  const unsigned long long dm = __ballot(done);
+  const unsigned long long dm = __builtin_amdgcn_ballot_w64(done);
   const unsigned long long again = dm & ~nx.ok_mask;
   if (__builtin_expect(again != 0ull, 0)) dense_draw<Fam>(b, glane, r, again, nx);
   const bool rs = done && autoreset;
@@ -945,7 +946,11 @@ __global__ void __launch_bounds__(kStagedThreads) rollout_staged_kernel(const ca
         Action acts[kStageChunk];
 #pragma unroll
         for (int u = 0; u < kStageChunk; ++u) acts[u] = my[u * kRolloutLanes];
+#ifdef CARL_EXP_DENSE_ROLLED
+        if (false) {
+#else
         if (steps == kStageChunk) {  // fully unrolled: record addresses are immediates, no loop control
+#endif
 #pragma unroll
           for (int u = 0; u < kStageChunk; ++u) {
             const SK sink{rec + (size_t)u * SK::kStepBytes, nullptr, n * Fam::D, t0 + u, (int)threadIdx.x};
