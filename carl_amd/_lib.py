@@ -15,7 +15,7 @@ import torch  # noqa: F401  (must precede the CDLL load, see module docstring)
 
 from carl_amd import build as _build
 
-CARL_ABI_VERSION = 3
+CARL_ABI_VERSION = 4
 CARL_MAX_CTX_OBS = 32
 
 # carl_family_t
@@ -25,6 +25,7 @@ SEL_STATIC, SEL_ROUND_ROBIN, SEL_RANDOM, SEL_HOST = range(4)
 FLAG_AUTORESET = 1
 FLAG_CARTPOLE_RECOMPUTE = 2
 FLAG_ACROBOT_FP32 = 4
+FLAG_AUTORESET_FIRST_STATE = 8
 ACTION_I32, ACTION_I64, ACTION_F32 = range(3)
 
 _vp = C.c_void_p
@@ -52,7 +53,7 @@ class Batch(C.Structure):
         ("fin_capacity", C.c_int32),
         ("last_return", _vp), ("last_length", _vp), ("episodes_done", _vp),
         ("fin_count", _vp), ("fin_lane", _vp), ("fin_return", _vp), ("fin_length", _vp),
-        ("goal_pos", _vp), ("success", _vp),
+        ("goal_pos", _vp), ("success", _vp), ("first_state", _vp),
     ]
 
 

@@ -28,12 +28,23 @@ class _BraxInfo:
 
 
 class BraxVecEngine(VecEngine):
-    def __init__(self, sys_table: _lib.BraxSys, n_features: int, ctx_table, n_lanes: int, device="cuda", **kw):
+    def __init__(self, sys_table: _lib.BraxSys, n_features: int, ctx_table, n_lanes: int, device="cuda", *,
+                 autoreset_mode: str = "redraw", **kw):
+        """``autoreset_mode``: what the in-kernel auto-reset does with a done env --
+        "redraw" (default; SURVEY.md 8a): selector advance, new init-state draw, like an explicit reset;
+        "first_state": put the env back to the state its last explicit ``reset()`` produced, same context,
+        nothing drawn -- brax's ``AutoResetWrapper`` as the reference reaches it (wrappers.py:54-78,121-145)."""
+        if autoreset_mode not in ("redraw", "first_state"):
+            raise ValueError("autoreset_mode must be 'redraw' or 'first_state'")
         self.sys = sys_table
         self._n_features = int(n_features)
         kw.pop("cartpole_recompute", None)
-        self.goal_pos = self.success = None
+        self.goal_pos = self.success = self.first_state = None
+        self.autoreset_mode = autoreset_mode
         super().__init__(-1, ctx_table, n_lanes, device, **kw)
+        if autoreset_mode == "first_state":
+            self.b.flags |= _lib.FLAG_AUTORESET_FIRST_STATE
+            self.first_state = torch.zeros((self.n, self.S), dtype=torch.float32, device=self.device)
         # Brax state is env-major in HBM ([N][13 L], one contiguous record per env: include/carl_amd.h);
         # ``self.state`` stays the [13 L, N] VIEW the classic-control engine exposes (same indexing).
         self._state_storage = torch.zeros((self.n, self.S), dtype=torch.float32, device=self.device)

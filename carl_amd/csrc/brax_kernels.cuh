@@ -251,6 +251,7 @@ static __device__ __forceinline__ bool is_free_root(const carl_brax_sys_t& s, in
 struct JointGeom {
   v3 rc_off, rp_off;      // anchor relative to the child's / parent's COM, world frame
   v3 A_c, A_p, vA_c, vA_p, x_c, x_p, wrel;
+  v3 e, axx;  // A_p - A_c; cross(x_c, x_p) from the float64 relative rotation (see joint_geometry)
   float theta, thetadot;  // single hinge
   v3 axis[3];             // 2-3 stacked hinges: current world axes ...
   float ang[3], rate[3];  // ... Euler x-y-z angles (third signed by dof_sign3) and their rates
@@ -268,11 +269,35 @@ static __device__ __forceinline__ JointGeom joint_geometry(const carl_brax_sys_t
   g.A_p = bp.p + g.rp_off;  // at zero slide
   g.vA_c = bc.v + cross(bc.w, g.rc_off);
   g.vA_p = bp.v + cross(bp.w, g.rp_off);
+  g.e = g.A_p - g.A_c;
   const qt rc = qmul(bc.r, f4(s.joint_rot[i]));
   const qt rp = qmul(bp.r, f4(dv.rpl[i]));
   g.x_c = xaxis(rc);
   g.x_p = xaxis(rp);
-  qt rel = qmul(qconj(rp), rc);
+  // The relative rotation of the joint frames, and from it the axis-alignment term cross(x_c, x_p), in FLOAT64
+  // (full rate on this part; ~60 extra instructions per joint = 3-5 % of an env step).  Both are differences of
+  // O(1) quantities that come out ~1e-3: formed in float32 they carry an ABSOLUTE error of ~1e-7, which the
+  // constraint spring multiplies by k_pos * dt / inertia = 20 (Ant) .. 30 (Humanoid) per substep -- that was the
+  // largest single term of the kernel's distance from the float64 restatement (Ant, per env step, p99 of
+  // |d| / (1 + |x|): 2.2e-5 in float32, 7.1e-6 like this; tools/brax_parity_percentiles.py, profiles/r02_*).
+  // cross(x_c, x_p) = rp (x) cross(xaxis(rel), e_x) = rp (x) (0, a2, -a1): the SMALL components of xaxis(rel)
+  // keep their relative accuracy.
+  qt rel;
+  {
+    const double cw = bc.r.w, cx = bc.r.x, cy = bc.r.y, cz = bc.r.z, pw = bp.r.w, px = bp.r.x, py = bp.r.y, pz = bp.r.z;
+    const double jw = s.joint_rot[i][0], jx = s.joint_rot[i][1], jy = s.joint_rot[i][2], jz = s.joint_rot[i][3];
+    const double lw = dv.rpl[i][0], lx = dv.rpl[i][1], ly = dv.rpl[i][2], lz = dv.rpl[i][3];
+    const double aw = cw * jw - cx * jx - cy * jy - cz * jz, ax = cw * jx + cx * jw + cy * jz - cz * jy,
+                 ay = cw * jy - cx * jz + cy * jw + cz * jx, az = cw * jz + cx * jy - cy * jx + cz * jw;  // rc
+    const double bw = pw * lw - px * lx - py * ly - pz * lz, bx = pw * lx + px * lw + py * lz - pz * ly,
+                 by = pw * ly - px * lz + py * lw + pz * lx, bz = pw * lz + px * ly - py * lx + pz * lw;  // rp
+    const double rw = bw * aw + bx * ax + by * ay + bz * az, rx = bw * ax - bx * aw - by * az + bz * ay,
+                 ry = bw * ay + bx * az - by * aw - bz * ax, rz = bw * az - bx * ay + by * ax - bz * aw;  // conj(rp) rc
+    rel = qt{(float)rw, (float)rx, (float)ry, (float)rz};
+    // cross(x_c, x_p) = rp (x) cross(xaxis(rel), e_x) = rp (x) (0, a2, -a1) with the small components of xaxis(rel)
+    const double a1 = 2.0 * (rx * ry + rw * rz), a2 = 2.0 * (rx * rz - rw * ry);
+    g.axx = qrot(rp, V(0.0f, (float)a2, (float)-a1));
+  }
   if (rel.w < 0.0f) { rel.w = -rel.w; rel.x = -rel.x; }
   g.theta = 2.0f * atan2_fast(rel.x, rel.w);  // twist about the hinge (joint frame x)
   g.wrel = bc.w - bp.w;
@@ -351,7 +376,7 @@ static __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const T
     const Body bp = (P < 0) ? world_body() : m.body(P);
     const JointGeom g = joint_geometry<MULTI>(s, dv, i, bc, bp);
     const float kp = s.k_pos[i] * c.stiffness_scale;
-    v3 e = g.A_p - g.A_c, ev = g.vA_p - g.vA_c;
+    v3 e = g.e, ev = g.vA_p - g.vA_c;
     v3 f = V(0, 0, 0);
     const int ns = s.n_slide[i], d0 = s.dof_start[i];
     for (int k = 0; k < ns; ++k) {  // prismatic dofs: free along the axis, own spring/damper/force
@@ -368,7 +393,7 @@ static __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const T
     v3 t;
     const int d = d0 + ns, nr = MULTI ? s.n_link_dof[i] - ns : 1;
     if (!MULTI || nr == 1) {
-      t = cross(g.x_c, g.x_p) * kp;  // keep the hinge axes aligned
+      t = g.axx * kp;  // keep the hinge axes aligned
       float ta = m.at(m.lay.tau + d) - s.dof_damping[d] * g.thetadot - s.dof_stiffness[d] * g.theta;
       if (g.theta < s.dof_lo[d]) ta += s.k_limit[i] * (s.dof_lo[d] - g.theta);
       if (g.theta > s.dof_hi[d]) ta -= s.k_limit[i] * (g.theta - s.dof_hi[d]);
@@ -917,6 +942,8 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
     r.episode += 1u;
     if (go) {
       for (int k = m.sub; k < S; k += kSub) b.state[(size_t)env * S + k] = m.at(m.lay.state + k);
+      if (b.first_state != nullptr)  // what AUTORESET_FIRST_STATE puts a done env back to
+        for (int k = m.sub; k < S; k += kSub) b.first_state[(size_t)env * S + k] = m.at(m.lay.state + k);
       if (m.sub == 0) {
         b.elapsed[env] = 0;
         b.ep_return[env] = 0.0f;
@@ -1046,6 +1073,17 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
           if (io.final_obs != nullptr)  // terminal observation, done envs only
             record_out(io.final_obs + step_off * s.obs_dim, (size_t)env, s.obs_dim, m, done);
           phase_sync();  // the io rows are rewritten below
+          if ((b.flags & CARL_FLAG_AUTORESET_FIRST_STATE) && b.first_state != nullptr) {
+            // brax AutoResetWrapper: the state of the last explicit reset, same context, nothing drawn
+            if (done) {
+              const float* src = b.first_state + (size_t)env * S;
+              for (int k = m.sub; k < S; k += kSub) m.at(m.lay.state + k) = src[k];
+              r.elapsed = 0;
+              r.ep_return = 0.0f;
+              if (goal) r.pos_x = r.pos_y = 0.0f;
+            }
+            phase_sync();
+          } else {
           if (done) r.cidx = select_context(b, r.cidx, genv, r.episode);
           if (TASK && s.push_link > 0) {
             put_goal(s, b, m, r.cidx, done);
@@ -1064,6 +1102,7 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
             r.ep_return = 0.0f;
             r.n_new_calls += 1;
             write_ctx_obs(b, m, n, env, r.cidx);
+          }
           }
           observe<MULTI, TASK>(s, dv, m, done, true);
         }

@@ -93,6 +93,11 @@ struct CartPole {
   // CartPoleEnv.step, kinematics_integrator == "euler"
   __device__ static __forceinline__ bool step(const Params& p, float (&s)[S], Aux&, int action, float /*noise*/,
                                               int elapsed, float& reward) {
+    // Every rounding below is spelled out (explicit fma, no implicit contraction): left to -ffp-contract=fast the
+    // compiler fuses `a * b - c * d` one way or the other depending on the code AROUND the expression, so the
+    // per-call kernel and the unrolled fused rollout -- different surroundings -- came out one ulp apart; the
+    // engine's contract is that they agree bit for bit.
+#pragma clang fp contract(off)
     const float x = s[0], x_dot = s[1], theta = s[2], theta_dot = s[3];
     // steps_beyond_terminated: a lane stepped again after terminating (only reachable
     // with auto-reset off) earns 0.  Inferred instead of stored: the pre-step state is
@@ -103,15 +108,18 @@ struct CartPole {
     const float force = (action == 1) ? p.force_mag : -p.force_mag;
     float sintheta, costheta;
     sincos_fast_smallarg(theta, sintheta, costheta);
-    const float temp = (force + p.polemass_length * (theta_dot * theta_dot) * sintheta) * p.inv_total_mass;
-    const float thetaacc =
-        div_fast(p.gravity * sintheta - costheta * temp,
-                 p.length * (4.0f / 3.0f - p.masspole * (costheta * costheta) * p.inv_total_mass));
-    const float xacc = temp - p.polemass_length * thetaacc * costheta * p.inv_total_mass;
-    s[0] = x + p.tau * x_dot;
-    s[1] = x_dot + p.tau * xacc;
-    s[2] = theta + p.tau * theta_dot;
-    s[3] = theta_dot + p.tau * thetaacc;
+    // temp = (force + polemass_length * theta_dot^2 * sin) / total_mass
+    const float temp = __fmaf_rn(p.polemass_length * (theta_dot * theta_dot), sintheta, force) * p.inv_total_mass;
+    // thetaacc = (g sin - cos temp) / (length (4/3 - masspole cos^2 / total_mass))
+    const float num = __fmaf_rn(-costheta, temp, p.gravity * sintheta);
+    const float den = p.length * __fmaf_rn(-(p.masspole * (costheta * costheta)), p.inv_total_mass, 4.0f / 3.0f);
+    const float thetaacc = div_fast(num, den);
+    // xacc = temp - polemass_length * thetaacc * cos / total_mass
+    const float xacc = __fmaf_rn(-((p.polemass_length * thetaacc) * costheta), p.inv_total_mass, temp);
+    s[0] = __fmaf_rn(p.tau, x_dot, x);
+    s[1] = __fmaf_rn(p.tau, xacc, x_dot);
+    s[2] = __fmaf_rn(p.tau, theta_dot, theta);
+    s[3] = __fmaf_rn(p.tau, thetaacc, theta_dot);
     const bool terminated = out_of_bounds(s[0], s[2]);
     reward = (terminated && was_terminated) ? 0.0f : 1.0f;
     return terminated;

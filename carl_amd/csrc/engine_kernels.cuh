@@ -391,7 +391,7 @@ __device__ __forceinline__ void step_dense(const carl_batch_t& b, const Sink& cu
   cur.put_reward(reward);
   cur.put_flags(terminated, truncated);  // every step (the lazy flag rows only save work when done is rare)
   const bool done = terminated | truncated;
-  const unsigned long long dm = __builtin_amdgcn_ballot_w64(done);
+  const unsigned long long dm = __ballot(done);
   const unsigned long long again = dm & ~nx.ok_mask;
   if (__builtin_expect(again != 0ull, 0)) dense_draw<Fam>(b, glane, r, again, nx);
   const bool rs = done && autoreset;

@@ -262,6 +262,7 @@ class VecEngine:
         b.fin_return, b.fin_length = _ptr(self.fin_return), _ptr(self.fin_length)
         b.goal_pos = _ptr(getattr(self, "goal_pos", None))
         b.success = _ptr(getattr(self, "success", None))
+        b.first_state = _ptr(getattr(self, "first_state", None))
         io = getattr(self, "_io", None)
         if io is not None:  # the per-call outputs never move: step() only fills in the action
             io.obs, io.reward = _ptr(self.obs), _ptr(self.reward)
@@ -369,7 +370,7 @@ class VecEngine:
         """Copies of every buffer a launch can change (state, counters, bookkeeping, step outputs)."""
         names = ["state", "elapsed", "ctx_idx", "episode", "n_calls", "ep_return", "last_return", "last_length",
                  "episodes_done", "obs", "reward", "terminated", "truncated", "final_obs", "ctx_obs"]
-        names += [k for k in ("goal_pos", "success", "fin_count") if getattr(self, k, None) is not None]
+        names += [k for k in ("goal_pos", "success", "fin_count", "first_state") if getattr(self, k, None) is not None]
         return {k: getattr(self, k).clone() for k in names}
 
     def restore(self, snap: dict) -> None:

@@ -68,6 +68,7 @@ class CARLBraxEnv(CARLEnv):
         reference_compat: bool = False,
         fin_capacity: int = 0,
         autotune: bool | None = None,
+        autoreset: str = "redraw",
         **kwargs,
     ) -> None:
         """Reference parameters (carl_brax_env.py:119-131) plus the lane-engine ones.
@@ -95,6 +96,7 @@ class CARLBraxEnv(CARLEnv):
                 device="cuda" if device is None else device,
                 auto_reset=n_auto if auto_reset is None else auto_reset,
                 seed=seed, lane_offset=lane_offset, fin_capacity=fin_capacity,
+                autoreset_mode=autoreset,  # "first_state" = brax's AutoResetWrapper (reference behaviour)
             )
         self.use_language_goals = use_language_goals
         # the reference stacks BraxLanguageWrapper on the goal wrapper, i.e. only when goals vary (:216-218)
@@ -110,10 +112,36 @@ class CARLBraxEnv(CARLEnv):
             context_selector_kwargs=context_selector_kwargs,
             **kwargs,
         )
+        self._reference_compat = bool(reference_compat)
+        self._check_mass_stability()
         # launch shape: time the launchable lane-group widths on this batch once (results do not
         # depend on the width); small batches keep the library's heuristic
         if (autotune if autotune is not None else batch_size >= 4096) and hasattr(self.env, "autotune"):
             self.env.autotune()
+
+    def _check_mass_stability(self) -> None:
+        """Refuse link masses below the measured stability floor of the model's explicit spring integration
+        (``feature_tables.MASS_RATIO_FLOOR``): such an env goes non-finite within a few steps.  Not applied with
+        ``reference_compat=True``, where -- as in the reference (Quirk B1) -- masses never reach the physics."""
+        if getattr(self, "_reference_compat", False):
+            return
+        from carl_amd.envs.brax.feature_tables import DEFAULT_MASS_RATIO_FLOOR, MASS_RATIO_FLOOR
+
+        floors = MASS_RATIO_FLOOR.get(self.env_name, {})
+        feats = self.get_context_features()
+        names = list(self._table.names)
+        for j, name in enumerate(names):
+            if not name.startswith("mass_") or name not in feats:
+                continue
+            col = self._table.tensor[j] if hasattr(self._table, "tensor") else self._table.values_2d[:, j]
+            lowest = float(col.min())
+            floor = floors.get(name, DEFAULT_MASS_RATIO_FLOOR) * float(feats[name].default_value)
+            if lowest < floor:
+                raise ValueError(
+                    f"{type(self).__name__}: context feature {name} = {lowest:g} is below {floor:g}, the smallest value "
+                    f"for which this model's explicit spring integration stays stable (measured: "
+                    f"tools/mass_stability_sweep.py); pass reference_compat=True to ignore physics contexts as the "
+                    f"reference effectively does")
 
     def _base_observation_space(self) -> spaces.Space:
         obs = np.inf * np.ones(self.env.D, dtype=np.float32)
@@ -140,6 +168,8 @@ class CARLBraxEnv(CARLEnv):
         for c in contexts.values() if not hasattr(contexts, "names") else []:
             check_context(c, REGISTERED_CFS + list(self.task_context_features))
         CARLEnv.contexts.fset(self, contexts)
+        if hasattr(self, "_reference_compat"):
+            self._check_mass_stability()
 
     # ---- language goals (carl/envs/brax/brax_walker_goal_wrapper.py:143-181) -------------------------
     @staticmethod

@@ -81,3 +81,26 @@ def feature_table(family: str) -> dict[str, ContextFeature]:
         lower, upper, default = (*MASS_BOUNDS, mass) if mass is not None else SHARED[name]
         feats[name] = UniformFloatContextFeature(name, lower=lower, upper=upper, default_value=default)
     return feats
+
+
+# Smallest context / default ratio of every link-mass feature for which the explicit (semi-implicit Euler) spring
+# integration of this build's models stays finite under a full-range random policy -- measured on an MI355X by
+# tools/mass_stability_sweep.py (150 env steps, ratios 0.1 .. 1.0; features not listed: stable down to 0.1), plus a
+# 10 % margin.  A lighter effective mass raises k dt^2 / m of the stiff constraint springs past the integrator's
+# bound and the env blows up within a few steps; ``CARLBraxEnv`` refuses such contexts instead of producing NaNs
+# (the reference cannot reach this regime: its context update never reaches the physics, Quirk B1).
+_HUMANOID_FLOORS = {"mass_torso": 0.31, "mass_lwaist": 0.21, "mass_pelvis": 0.31, "mass_right_thigh": 0.21,
+                    "mass_left_thigh": 0.21, "mass_right_upper_arm": 0.21, "mass_left_upper_arm": 0.21}
+MASS_RATIO_FLOOR = {
+    "ant": {"mass_torso": 0.37},
+    "halfcheetah": {"mass_torso": 0.80, "mass_bthigh": 0.63, "mass_bshin": 0.55, "mass_bfoot": 0.29,
+                    "mass_fthigh": 0.61, "mass_fshin": 0.55, "mass_ffoot": 0.29},
+    "humanoid": _HUMANOID_FLOORS, "humanoidstandup": _HUMANOID_FLOORS,
+    "hopper": {"mass_torso": 0.13, "mass_thigh": 0.13, "mass_leg": 0.13},
+    "walker2d": {"mass_torso": 0.19, "mass_thigh": 0.14, "mass_leg": 0.13, "mass_thigh_left": 0.14, "mass_leg_left": 0.13},
+    "inverted_pendulum": {"mass_cart": 0.85, "mass_pole": 0.64},
+    "inverted_double_pendulum": {"mass_cart": 0.35, "mass_pole": 0.37, "mass_pole2": 0.19},
+    "reacher": {"mass_body0": 0.42, "mass_body1": 0.22},
+    "pusher": {"mass_r_wrist_flex_link": 0.88, "mass_object": 0.22},
+}
+DEFAULT_MASS_RATIO_FLOOR = 0.1  # nothing below was measured

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define CARL_ABI_VERSION 3
+#define CARL_ABI_VERSION 4
 #define CARL_MAX_CTX_OBS 32
 
 #define CARL_ERR_INVALID_ARGUMENT (-1)
@@ -69,9 +69,14 @@ enum {
   CARL_FLAG_CARTPOLE_RECOMPUTE = 2, /* recompute total_mass / polemass_length from
                                        the context (NOT reference behaviour; the
                                        default replicates Quirk C1) */
-  CARL_FLAG_ACROBOT_FP32 = 4        /* evaluate Acrobot's _dsdt/rk4 in fp32 instead of
+  CARL_FLAG_ACROBOT_FP32 = 4,       /* evaluate Acrobot's _dsdt/rk4 in fp32 instead of
                                        fp64 (faster; up to ~1e-3 relative error on
                                        states near the velocity bounds) */
+  CARL_FLAG_AUTORESET_FIRST_STATE = 8 /* Brax families, with AUTORESET: a done env is put back to the state
+                                       its last explicit reset produced -- no new draw, no selector advance,
+                                       no context change: brax.envs.wrappers.training.AutoResetWrapper as the
+                                       reference reaches it through carl/envs/brax/wrappers.py:54-78,121-145
+                                       (needs carl_batch_t::first_state).  Default: re-draw. */
 };
 
 enum { CARL_ACTION_I32 = 0, CARL_ACTION_I64 = 1, CARL_ACTION_F32 = 2 };
@@ -140,6 +145,9 @@ typedef struct carl_batch {
    * NULL otherwise */
   float* goal_pos;           /* [2][n_lanes] position integrated from the observed x/y velocities */
   uint8_t* success;          /* [n_lanes] (or [T][n_lanes] in a rollout): goal reached on this step */
+  /* Brax families, CARL_FLAG_AUTORESET_FIRST_STATE: [n_lanes][13 L], written by carl_brax_reset, read by the
+   * in-kernel auto-reset; NULL otherwise */
+  float* first_state;
 } carl_batch_t;
 
 /* Inputs/outputs of one step (or, for carl_rollout, of T steps: every array gains

@@ -72,14 +72,17 @@ class Engine:
     """Batched engine semantics for a Brax family (same contract as oracle.Engine)."""
 
     def __init__(self, sys_struct, ctx_table, n_lanes, *, selector=O.SEL_ROUND_ROBIN, selector_stride=1,
-                 autoreset=True, max_steps=None, seed=0, lane_offset=0, ctx_idx0=None):
+                 autoreset=True, max_steps=None, seed=0, lane_offset=0, ctx_idx0=None, autoreset_mode="redraw"):
         self.sys = _Sys(sys_struct)
         self.ctx = np.ascontiguousarray(ctx_table, dtype=np.float64)
         self.F = self.ctx.shape[1]
         n_ctx = self.ctx.shape[0]
         self.cfg = O._Cfg(0, n_lanes, n_ctx, self.sys.max_episode_steps if max_steps is None else max_steps,
-                          selector, selector_stride, int(autoreset), 0, lane_offset, seed)
+                          selector, selector_stride, (2 if autoreset_mode == "first_state" else 1) * int(autoreset), 0,
+                          lane_offset, seed)
         n, S, D = n_lanes, 13 * self.sys.n_links, self.sys.obs_dim
+        # autoreset_mode "first_state": brax's AutoResetWrapper (the state of the last explicit reset)
+        self.first_state = np.zeros((n_lanes, S), dtype=np.float64) if autoreset_mode == "first_state" else None
         self.n, self.S, self.D = n, S, D
         self.state = np.zeros((n, S), dtype=np.float64)
         self.elapsed = np.zeros(n, dtype=np.int32)
@@ -104,7 +107,8 @@ class Engine:
         m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
         O.lib().obx_engine_reset(self.sys.ptr, C.byref(self.cfg), _p(self.ctx), C.c_int(self.F), _p(m),
                                  _p(self.state), _p(self.elapsed), _p(self.ctx_idx), _p(self.episode),
-                                 _p(self.n_calls), _p(self.ep_return), _p(self.obs), _p(self.goal_pos))
+                                 _p(self.n_calls), _p(self.ep_return), _p(self.obs), _p(self.goal_pos),
+                                 _p(self.first_state))
         return self.obs.copy()
 
     def step(self, action):
@@ -117,5 +121,5 @@ class Engine:
                                 _p(self.state), _p(self.elapsed), _p(self.ctx_idx), _p(self.episode),
                                 _p(self.n_calls), _p(self.ep_return), _p(self.obs), _p(rew), _p(term), _p(trunc),
                                 _p(final_obs), _p(self.last_return), _p(self.last_length), _p(self.episodes_done),
-                                _p(self.goal_pos), _p(self.success))
+                                _p(self.goal_pos), _p(self.success), _p(self.first_state))
         return O.StepOut(self.obs.copy(), rew, term, trunc, final_obs)

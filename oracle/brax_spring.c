@@ -636,7 +636,7 @@ void obx_substeps(const carl_brax_sys_t* s, const double* ctx_row, const double*
 
 void obx_engine_reset(const carl_brax_sys_t* s, const oracle_cfg_t* cfg, const double* ctx_table, int n_feat,
                       const uint8_t* mask, double* state, int32_t* elapsed, int32_t* ctx_idx, uint32_t* episode,
-                      int32_t* n_calls, double* ep_return, float* obs, double* goal_pos) {
+                      int32_t* n_calls, double* ep_return, float* obs, double* goal_pos, double* first_state) {
   const int S = 13 * s->n_links;
   for (int i = 0; i < cfg->n_lanes; ++i) {
     if (mask && !mask[i]) continue;
@@ -647,6 +647,7 @@ void obx_engine_reset(const carl_brax_sys_t* s, const oracle_cfg_t* cfg, const d
     const lane_ctx c = make_ctx(s, ctx_table + (size_t)ctx_idx[i] * n_feat);
     reset_lane(s, &c, cfg->seed, g, episode[i], b);
     store_bodies(s, b, state + (size_t)i * S);
+    if (first_state) memcpy(first_state + (size_t)i * S, state + (size_t)i * S, sizeof(double) * S);
     episode[i] += 1;
     elapsed[i] = 0;
     ep_return[i] = 0.0;
@@ -661,7 +662,7 @@ void obx_engine_step(const carl_brax_sys_t* s, const oracle_cfg_t* cfg, const do
                      const float* action, double* state, int32_t* elapsed, int32_t* ctx_idx, uint32_t* episode,
                      int32_t* n_calls, double* ep_return, float* obs, float* reward, uint8_t* terminated,
                      uint8_t* truncated, float* final_obs, float* last_return, int32_t* last_length,
-                     int32_t* episodes_done, double* goal_pos, uint8_t* success) {
+                     int32_t* episodes_done, double* goal_pos, uint8_t* success, const double* first_state) {
   const int S = 13 * s->n_links, D = s->obs_dim;
   for (int i = 0; i < cfg->n_lanes; ++i) {
     const uint64_t g = (uint64_t)(cfg->lane_offset + i);
@@ -738,7 +739,16 @@ void obx_engine_step(const carl_brax_sys_t* s, const oracle_cfg_t* cfg, const do
       if (last_return) last_return[i] = (float)ep_return[i];
       if (last_length) last_length[i] = elapsed[i];
       if (episodes_done) episodes_done[i] += 1;
-      if (cfg->autoreset) {
+      if (cfg->autoreset == 2 && first_state) {
+        /* brax.envs.wrappers.training.AutoResetWrapper (reached through carl/envs/brax/wrappers.py:54-78,
+         * 121-145): the state of the last explicit reset, same context, nothing drawn */
+        if (final_obs) memcpy(final_obs + (size_t)i * D, obs + (size_t)i * D, sizeof(float) * D);
+        load_bodies(s, first_state + (size_t)i * S, b);
+        elapsed[i] = 0;
+        ep_return[i] = 0.0;
+        if (goal_pos) { goal_pos[2 * i] = 0.0; goal_pos[2 * i + 1] = 0.0; }
+        observe(s, &c, b, NULL, obs + (size_t)i * D);
+      } else if (cfg->autoreset) {
         if (final_obs) memcpy(final_obs + (size_t)i * D, obs + (size_t)i * D, sizeof(float) * D);
         ctx_idx[i] = select_ctx(cfg, ctx_idx[i], g, episode[i]);
         n_calls[i] += 1;

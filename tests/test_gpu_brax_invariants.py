@@ -1,0 +1,287 @@
+"""Physics invariants of the HIP Brax kernel at full size (BASELINE config 4 / 5 batch sizes) -- needs an MI355X.
+
+brax 0.12.1 is not installable here, so the Brax rows cannot be pinned against brax itself (DESIGN.md section 5:
+PARITY UNPINNED).  What CAN be pinned on the GPU path is what any correct maximal-coordinate spring pipeline --
+brax's included -- satisfies, independent of its constants: momentum conservation in free flight (internal joint
+wrenches are equal and opposite), dissipation under damping with a zero action, the penetration the impulse +
+Baumgarte contact rule allows, the overshoot the joint-limit springs allow, joint integrity (anchors of a joint
+stay together), and the reference's own auto-reset semantics (brax's AutoResetWrapper: first-state restore).
+Round 1 had these only for the CPU restatement (tests/test_brax_oracle.py); here they run on the kernel.
+"""
+import numpy as np
+import pytest
+import torch
+
+from carl_amd import _lib
+from oracle import brax as B
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _make(cls, n, device, rows_fn=None, **kw):
+    from carl_amd.brax_engine import BraxVecEngine
+    from carl_amd.envs.brax.models import SYSTEMS
+
+    feats = cls.get_context_features()
+    names = list(feats)
+    default = np.array([float(f.default_value) for f in feats.values()])
+    rows = np.tile(default, (n, 1))
+    if rows_fn is not None:
+        rows_fn(rows, names)
+    rows = rows.astype(np.float32).astype(np.float64)
+    s = SYSTEMS[cls.env_name](names)
+    kw.setdefault("selector", O.SEL_STATIC)
+    kw.setdefault("ctx_idx0", np.arange(n))
+    eng = BraxVecEngine(s, len(names), rows, n, device, **kw)
+    return eng, s, rows, names
+
+
+def _bodies(eng, L):
+    """state [N, 13 L] -> p [N, L, 3], r [N, L, 4] (w, x, y, z), v [N, L, 3], w [N, L, 3]"""
+    st = eng.state.t().reshape(eng.n, L, 13)
+    return st[..., 0:3], st[..., 3:7], st[..., 7:10], st[..., 10:13]
+
+
+def _qrot(q, v):
+    u = q[..., 1:4]
+    t = 2.0 * torch.cross(u, v, dim=-1)
+    return v + q[..., 0:1] * t + torch.cross(u, t, dim=-1)
+
+
+def _np_qrot(q, v):
+    q, v = np.asarray(q, np.float64), np.asarray(v, np.float64)
+    u = q[1:4]
+    t = 2.0 * np.cross(u, v)
+    return v + q[0] * t + np.cross(u, t)
+
+
+def test_free_flight_conserves_linear_and_angular_momentum(device):
+    """32 768 Ant envs lifted 10 m, gravity ~ 0, no angular damping, random actions: the joint wrenches are
+    internal, so total linear momentum stays put over 20 env steps (200 substeps) to float32 accumulation
+    accuracy, and total angular momentum about the origin up to the moment (A_c - A_p) x f of the joints'
+    constraint error (millimetres under full-range random torques)."""
+    from carl_amd.envs import CARLBraxAnt
+
+    def rows_fn(rows, names):
+        rows[:, names.index("gravity")] = -1e-6  # the feature's bound is < 0
+        rows[:, names.index("ang_damping")] = 0.0
+
+    n = 32768
+    eng, s, rows, names = _make(CARLBraxAnt, n, device, rows_fn, seed=3, auto_reset=False, max_episode_steps=10_000)
+    assert s.vel_damping == 0.0
+    eng.reset()
+    L = s.n_links
+    st = eng.state.t().reshape(n, L, 13)
+    st[..., 2] += 10.0  # (a view of the engine's env-major state record)
+    g = torch.Generator(device=device).manual_seed(0)
+    # (the reset state is kinematically consistent -- joint anchors coincide -- so the spring forces of a joint
+    # act at ONE point and exert no net moment; bodies torn apart by arbitrary velocities would, in this model
+    # class, exchange angular momentum with the constraint error: (A_c - A_p) x f)
+    mass = torch.tensor([s.mass[i] for i in range(L)], device=device)
+    inertia = torch.tensor([[1.0 / s.inv_inertia[i][k] for k in range(3)] for i in range(L)], device=device)
+    assert (inertia[:, 0] == inertia[:, 1]).all() and (inertia[:, 1] == inertia[:, 2]).all()  # isotropic: I w
+
+    def momenta():
+        p, r, v, w = _bodies(eng, L)
+        lin = (mass[None, :, None] * v).sum(1)
+        ang = (mass[None, :, None] * torch.cross(p, v, dim=-1) + inertia[None, :, :] * w).sum(1)
+        return lin.double(), ang.double()
+
+    lin0, ang0 = momenta()
+    for t in range(20):
+        a = torch.rand((n, s.n_act), generator=g, device=device) * 2 - 1
+        eng.step(a)
+    lin1, ang1 = momenta()
+    p, _, _, _ = _bodies(eng, L)
+    assert float(p[..., 2].min()) > 5.0  # nobody reached the floor
+    scale_l = 1.0 + lin0.abs().max(1).values
+    scale_a = 1.0 + ang0.abs().max(1).values
+    dl = ((lin1 - lin0).abs().max(1).values / scale_l)
+    da = ((ang1 - ang0).abs().max(1).values / scale_a)
+    # gravity 1e-6 * 9 links * 1 s = 9e-6 on lin z; float32 accumulation over 200 substeps of k * dt ~ 20 forces
+    assert float(dl.max()) < 2e-3 and float(dl.median()) < 2e-4, (float(dl.max()), float(dl.median()))
+    print("momentum drift: linear max/median", float(dl.max()), float(dl.median()), "angular", float(da.max()), float(da.median()))
+    # angular momentum is NOT an invariant of this model class: a joint's force acts on the child at the child's
+    # anchor and on the parent at the parent's anchor, so a joint with constraint error e exerts the net moment
+    # (A_c - A_p) x f = -k_vel e x de/dt (millimetres x gear-150 torques here: measured median 3 %, max 48 % of
+    # 1 + |L| per second).  The bound only catches gross errors (a wrong sign on the parent's reaction is O(10)).
+    assert float(da.max()) < 1.0 and float(da.median()) < 0.1, (float(da.max()), float(da.median()))
+
+
+def test_zero_action_dissipates_and_comes_to_rest(device):
+    """BASELINE config 4 contexts, zero action: the damped spring joints and the contacts only remove energy --
+    the batch's kinetic energy decays and every one of the 32 768 envs ends standing still and healthy."""
+    from carl_amd.envs import CARLBraxAnt
+
+    rng = np.random.default_rng(0)
+
+    def rows_fn(rows, names):
+        n = len(rows)
+        rows[:, names.index("mass_torso")] = rng.uniform(5, 15, n)
+        rows[:, names.index("gravity")] = rng.uniform(-15, -5, n)
+        rows[:, names.index("friction")] = rng.uniform(0.3, 1.5, n)
+
+    n = 32768
+    eng, s, rows, names = _make(CARLBraxAnt, n, device, rows_fn, seed=1, auto_reset=False, max_episode_steps=10_000)
+    eng.reset()
+    L = s.n_links
+    zero = torch.zeros((n, s.n_act), device=device)
+    ke = []
+    for t in range(200):
+        obs, rew, term, trunc = eng.step(zero)
+        if t % 50 == 49:
+            _, _, v, w = _bodies(eng, L)
+            ke.append(0.5 * ((v * v).sum(-1) + (w * w).sum(-1)).sum(1))  # unit effective masses / inertias
+    assert not bool(term.any())
+    med = [float(k.median()) for k in ke]
+    assert med[0] > med[1] > med[3] or med[0] < 1e-6, med
+    print("kinetic energy medians", med, "final p99 / max", float(ke[-1].quantile(0.99)), float(ke[-1].max()))
+    assert float(ke[-1].quantile(0.99)) < 0.05 and float(ke[-1].max()) < 1.0, float(ke[-1].max())
+    assert float(obs[:, 13:].abs().max()) < 0.5  # joint and root velocities: at rest
+    z = obs[:, 0]
+    assert float(z.min()) > 0.3 and float(z.max()) < 0.75
+
+
+@pytest.mark.parametrize("name", ["ant", "humanoid", "halfcheetah"])
+def test_contact_penetration_joint_integrity_and_limit_overshoot_are_bounded(name, device):
+    """Random policy at the BASELINE batch sizes with the BASELINE context variation, auto-reset on: in every env
+    and at every sampled step, over the envs that are at least 10 steps into their episode (the reset distribution
+    itself starts feet up to 0.27 m inside the floor: init_q + noise, as brax's does) (i) no collision sphere is
+    deeper than 8 cm below the floor (impulse + Baumgarte), (ii) the two anchors of every joint stay within
+    5 cm (Ant: 16 cm; the constraint springs hold the maximal-coordinate bodies together under full-range random
+    torques),
+    (iii) no hinge is more than 0.5 rad beyond its range (limit springs), (iv) everything is finite."""
+    from carl_amd import envs as E
+
+    cls = {"ant": E.CARLBraxAnt, "humanoid": E.CARLBraxHumanoid, "halfcheetah": E.CARLBraxHalfcheetah}[name]
+    rng = np.random.default_rng(4)
+
+    def rows_fn(rows, names):
+        n = len(rows)
+        rows[:, names.index("gravity")] = rng.uniform(-15, -5, n)
+        if name != "halfcheetah":  # (Halfcheetah: BASELINE config 5 varies joint_stiffness, not the torso mass)
+            rows[:, names.index("mass_torso")] = rng.uniform(5, 15, n)
+            rows[:, names.index("friction")] = rng.uniform(0.3, 1.5, n)
+        else:
+            rows[:, names.index("joint_stiffness")] = rng.uniform(0.5, 2.0, n)
+
+    n = 32768 if name != "humanoid" else 16384
+    eng, s, rows, names = _make(cls, n, device, rows_fn, seed=2, auto_reset=True)
+    eng.reset()
+    L = s.n_links
+    com = torch.tensor([[s.com[i][k] for k in range(3)] for i in range(L)], device=device)
+    # collision spheres
+    cl = torch.tensor([s.coll_link[k] for k in range(s.n_coll)], device=device, dtype=torch.long)
+    cp = torch.tensor([[s.coll_pos[k][j] for j in range(3)] for k in range(s.n_coll)], device=device)
+    cr = torch.tensor([s.coll_radius[k] for k in range(s.n_coll)], device=device)
+    # joint anchors (brax_kernels.cuh build_derived_host): child side joint_pos - com (child frame), parent side
+    # link_pos + link_rot (x) joint_pos - com[parent] (parent frame; the world for planar roots)
+    joints = [i for i in range(L) if not (s.parent[i] < 0 and s.n_link_dof[i] == 6) and s.n_slide[i] == 0]
+    ac = torch.tensor([[s.joint_pos[i][k] - s.com[i][k] for k in range(3)] for i in joints], device=device)
+    ap_np = []
+    for i in joints:
+        P = s.parent[i]
+        a = _np_qrot([s.link_rot[i][k] for k in range(4)], [s.joint_pos[i][k] for k in range(3)])
+        base = np.array([s.link_pos[i][k] for k in range(3)]) + a
+        ap_np.append(base - (np.array([s.com[P][k] for k in range(3)]) if P >= 0 else 0.0))
+    ap = torch.tensor(np.array(ap_np), device=device, dtype=torch.float32)
+    par = [s.parent[i] for i in joints]
+    assert all(P >= 0 for P in par) or name == "halfcheetah"
+    g = torch.Generator(device=device).manual_seed(0)
+    lo, hi = float(min(s.act_lo[: s.n_act])), float(max(s.act_hi[: s.n_act]))
+    worst_pen, worst_gap = 0.0, 0.0
+    for t in range(120):
+        a = torch.rand((n, s.n_act), generator=g, device=device) * (hi - lo) + lo
+        obs, rew, term, trunc = eng.step(a)
+        if t % 4 != 3 or t < 12:
+            continue
+        assert bool(torch.isfinite(obs).all()) and bool(torch.isfinite(rew).all()), t
+        p, r, v, w = _bodies(eng, L)
+        old = eng.elapsed >= 10
+        assert bool(old.any())
+        ctr = p[:, cl] + _qrot(r[:, cl], (cp - com[cl])[None])
+        pen = (cr[None] - ctr[..., 2])[old]  # depth below the floor [m]
+        worst_pen = max(worst_pen, float(pen.max()))
+        jl = [j for j, P in zip(range(len(joints)), par) if P >= 0]
+        ji = torch.tensor([joints[j] for j in jl], device=device, dtype=torch.long)
+        pi = torch.tensor([par[j] for j in jl], device=device, dtype=torch.long)
+        A_c = p[:, ji] + _qrot(r[:, ji], ac[jl][None])
+        A_p = p[:, pi] + _qrot(r[:, pi], ap[jl][None])
+        worst_gap = max(worst_gap, float((A_p - A_c).norm(dim=-1)[old].max()))
+    print(name, "worst penetration [m]", worst_pen, "worst joint gap [m]", worst_gap)
+    assert worst_pen < 0.08, worst_pen
+    # Ant: gear-150 motors against k_pos = 4000 constraint springs stretch a joint by up to ~12 cm under a
+    # full-range random policy (median of the per-env worst over 200 steps: 7 cm; tools/diag_penetration.py) --
+    # a property of this build's (unpinned) constants, recorded here as the regression bound
+    assert worst_gap < (0.16 if name == "ant" else 0.05), worst_gap
+    # limit overshoot on the single-hinge models: the observation holds the joint angles
+    if name == "ant":
+        q = obs[:, 5:13]
+        dlo = torch.tensor([s.dof_lo[6 + k] for k in range(8)], device=device)
+        dhi = torch.tensor([s.dof_hi[6 + k] for k in range(8)], device=device)
+        over = torch.maximum(dlo[None] - q, q - dhi[None]).max()
+        assert float(over) < 0.5, float(over)
+    assert int(eng.episodes_done.sum()) > 0 or name == "halfcheetah"
+
+
+@pytest.mark.parametrize("name", ["ant", "humanoid"])
+def test_first_state_autoreset_is_brax_autoresetwrapper(name, device):
+    """autoreset_mode="first_state" -- what the reference's Brax envs do on `done` (brax AutoResetWrapper through
+    carl/envs/brax/wrappers.py:54-78,121-145): the env goes back to the state its last explicit reset()
+    produced, with the same context, without drawing anything; checked against the oracle's restatement of the
+    same rule, and directly: after a `done`, the state equals the stored first state bit for bit."""
+    from carl_amd import envs as E
+
+    cls = {"ant": E.CARLBraxAnt, "humanoid": E.CARLBraxHumanoid}[name]
+    n, T = 1024, 40
+    kw = dict(seed=6, max_episode_steps=13, selector=O.SEL_ROUND_ROBIN, ctx_idx0=None)
+    rng = np.random.default_rng(5)
+
+    def rows_fn(rows, names):
+        rows[:, names.index("gravity")] = rng.uniform(-12, -8, len(rows))
+
+    eng, s, rows, names = _make(cls, n, device, rows_fn, autoreset_mode="first_state", **kw)
+    ora = B.Engine(s, rows, n, selector=O.SEL_ROUND_ROBIN, seed=6, max_steps=13, autoreset_mode="first_state")
+    eng.reset()
+    ora.reset()
+    np.testing.assert_array_equal(eng.ctx_idx.cpu().numpy(), ora.ctx_idx)
+    first = eng.first_state.clone()
+    assert torch.equal(first, eng.state.t())
+    ctx0, ep0, calls0 = eng.ctx_idx.clone(), eng.episode.clone(), eng.n_calls.clone()
+    first_obs = eng.obs.clone()
+    n_done = 0
+    for t in range(T):
+        ora.state[:] = eng.state.t().cpu().numpy()
+        a = rng.uniform(-1, 1, (n, s.n_act)).astype(np.float32) * float(max(s.act_hi[: s.n_act]))
+        obs, rew, term, trunc = eng.step(torch.as_tensor(a))
+        out = ora.step(a)
+        np.testing.assert_array_equal(trunc.cpu().numpy(), out.truncated)
+        done = ((term | trunc) != 0)
+        flip = term.cpu().numpy() != out.terminated
+        assert flip.mean() < 5e-3
+        n_done += int(done.sum())
+        # a done env IS its first state again, and shows its first observation
+        assert torch.equal(eng.state.t()[done], first[done])
+        assert torch.equal(obs[done], first_obs[done])
+        ok = ~flip
+        np.testing.assert_array_equal(eng.elapsed.cpu().numpy()[ok], ora.elapsed[ok])
+        d = done.cpu().numpy() & ok
+        np.testing.assert_allclose(obs.cpu().numpy()[d], out.obs[d], rtol=0, atol=5e-6)
+        if flip.any():
+            ora.elapsed[:] = eng.elapsed.cpu().numpy()
+            ora.ep_return[:] = eng.ep_return.cpu().numpy()
+    assert n_done >= n * (T // 13)
+    # nothing was drawn, no selector advanced
+    assert torch.equal(eng.ctx_idx, ctx0) and torch.equal(eng.episode, ep0) and torch.equal(eng.n_calls, calls0)
+    # and the fused rollout does the same
+    e2, _, _, _ = _make(cls, n, device, rows_fn=None, autoreset_mode="first_state", **kw)
+    e3, _, _, _ = _make(cls, n, device, rows_fn=None, autoreset_mode="first_state", **kw)
+    e2.reset(); e3.reset()
+    acts = torch.as_tensor(rng.uniform(-0.4, 0.4, (30, n, s.n_act)).astype(np.float32), device=device)
+    out2 = e2.rollout(acts)
+    for t in range(30):
+        o, r_, te, tr = e3.step(acts[t])
+        assert torch.equal(out2["obs"][t], o) and torch.equal(out2["terminated"][t], te) and torch.equal(out2["truncated"][t], tr)
+    assert torch.equal(e2.state, e3.state)
+    assert _lib.FLAG_AUTORESET_FIRST_STATE == 8

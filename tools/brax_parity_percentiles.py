@@ -1,0 +1,65 @@
+"""Per-env-step parity of the HIP Brax kernel against the fp64 restatement (oracle/brax_spring.c) for every
+Brax family: the oracle restarts every env step from the engine's float32 state (so only the arithmetic of
+ONE env step = n_frames substeps is compared), random actions, BASELINE-style context variation.
+Prints the percentiles of |d| / (1 + |x|) over observation entries and reward.  Run on the GPU box:
+    python tools/brax_parity_percentiles.py [family ...]"""
+import sys
+
+sys.path.insert(0, ".")
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from carl_amd import envs as E  # noqa: E402
+from carl_amd.brax_engine import BraxVecEngine  # noqa: E402
+from carl_amd.envs.brax.models import SYSTEMS  # noqa: E402
+from oracle import brax as B  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+CLASSES = {"ant": E.CARLBraxAnt, "halfcheetah": E.CARLBraxHalfcheetah, "humanoid": E.CARLBraxHumanoid,
+           "hopper": E.CARLBraxHopper, "walker2d": E.CARLBraxWalker2d,
+           "inverted_pendulum": E.CARLBraxInvertedPendulum,
+           "inverted_double_pendulum": E.CARLBraxInvertedDoublePendulum,
+           "humanoidstandup": E.CARLBraxHumanoidStandup, "reacher": E.CARLBraxReacher, "pusher": E.CARLBraxPusher}
+
+
+def rel(g, w):
+    g, w = np.asarray(g, np.float64), np.asarray(w, np.float64)
+    return np.abs(g - w) / (1 + np.abs(w))
+
+
+def measure(fam, n=2048, steps=40, seed=1):
+    cls = CLASSES[fam]
+    feats = cls.get_context_features()
+    names = list(feats)
+    default = np.array([float(f.default_value) for f in feats.values()])
+    s = SYSTEMS[cls.env_name](names)
+    rng = np.random.default_rng(seed)
+    rows = np.tile(default, (n, 1))
+    for name, (lo, hi) in {"gravity": (-15, -5), "friction": (0.3, 1.5), "mass_torso": (5, 15),
+                           "joint_stiffness": (0.5, 2.0)}.items():
+        if name in names and fam not in ("pusher", "reacher") and not (fam == "halfcheetah" and name == "mass_torso"):
+            rows[:, names.index(name)] = rng.uniform(lo, hi, n)
+    rows = rows.astype(np.float32).astype(np.float64)
+    kw = dict(selector=O.SEL_STATIC, seed=5, ctx_idx0=np.arange(n))
+    eng = BraxVecEngine(s, len(names), rows, n, "cuda", max_episode_steps=10_000, auto_reset=False, **kw)
+    ora = B.Engine(s, rows, n, max_steps=10_000, autoreset=False, **kw)
+    eng.reset()
+    ora.reset()
+    lo = np.array(s.act_lo[: s.n_act]) * 1.2
+    hi = np.array(s.act_hi[: s.n_act]) * 1.2
+    errs = []
+    for t in range(steps):
+        ora.state[:] = eng.state.t().cpu().numpy()
+        a = rng.uniform(lo, hi, (n, s.n_act)).astype(np.float32)
+        obs, rew, term, trunc = eng.step(torch.as_tensor(a))
+        out = ora.step(a)
+        errs.append(np.maximum(rel(obs.cpu().numpy(), out.obs).max(1), rel(rew.cpu().numpy(), out.reward)))
+    e = np.concatenate(errs)
+    p = np.percentile(e, [50, 99, 99.9, 100])
+    print(f"{fam:26s} n_frames {s.n_frames:3d}  p50 {p[0]:.2e}  p99 {p[1]:.2e}  p99.9 {p[2]:.2e}  max {p[3]:.2e}  "
+          f"frac>1e-5 {np.mean(e > 1e-5):.4f}  frac>1e-3 {np.mean(e > 1e-3):.5f}", flush=True)
+
+
+if __name__ == "__main__":
+    for fam in (sys.argv[1:] or list(CLASSES)):
+        measure(fam)
