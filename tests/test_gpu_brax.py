@@ -3,16 +3,33 @@ specification (oracle/brax_spring.c).  PARITY WITH BRAX ITSELF IS UNPINNED (brax
 neither in the reference tree nor installable) -- these tests pin the
 fp32 LDS-resident kernel against an independent fp64 implementation, per transition.
 
-Tolerance.  The reference's own arithmetic here is float32 (JAX default), and the spring
-pipeline is stiff: a joint spring turns position rounding into velocity error
-k * dt * eps * |p| = 4000 * 0.005 * 6e-8 * O(1) ~ 1e-6 per substep per joint, so two correct
-fp32 evaluation orders differ by a few 1e-6 per substep (measured: median 3.3e-6, p99.9 1.7e-5
-for ONE substep against the fp64 oracle; tools/diag_brax_parity.py).  The contact rule is
-also discontinuous (an impulse is applied only while the point approaches, vn < 0), so a lane
-whose vn crosses 0 within rounding differs by O(erp * depth / dt).  Hence, per env step
-(= 10 substeps) from identical fp32 state: p99 <= 4e-5, p99.9 <= 2e-4 of
-|d| / (1 + |x|) over observation entries and reward, and fewer than 0.3 % of lane-steps
-above 1e-3.  Discrete outputs (truncation, counters, context ids) are exact."""
+Tolerance -- north_star's bar is "within 1e-5 fp32", and for the Brax rows it is NOT MET on every entry; what is
+measured instead is stated here and asserted below.  Per env step (= n_frames substeps) from identical float32
+state, |d| / (1 + |x|) over observation entries and reward against the float64 restatement, 2 048 envs x 40 steps
+under BASELINE-style context variation and a full-range random policy (tools/brax_parity_percentiles.py on an
+MI355X, round 2, profiles/r02_brax_parity_percentiles.txt):
+
+    family                       p50      p99      p99.9    share > 1e-5   share > 1e-3
+    ant                          2.2e-6   7.1e-6   1.1e-5   0.2 %          0.006 %
+    halfcheetah                  2.8e-6   1.1e-5   1.5e-5   1.3 %          0.015 %
+    humanoid                     4.5e-6   2.4e-5   1.0e-3   17 %           0.10 %
+    hopper                       2.6e-6   1.2e-5   1.7e-5   2.4 %          0.007 %
+    walker2d                     4.1e-6   1.8e-5   9.6e-5   11 %           0.05 %
+    inverted (double) pendulum   <5e-7    <5e-6    <1e-5    <0.1 %         0
+    humanoidstandup              8.9e-6   2.7e-5   1.9e-3   39 %           0.15 %
+    reacher                      6e-8     2e-7     3e-7     0              0
+    pusher                       1.5e-5   8.3e-5   1.2e-4   65 %           0
+
+So: the 1e-5 bar holds at the 99th percentile for Ant, the inverted pendulums and Reacher, at the median for
+everything but Pusher, and FAILS beyond that.  Two mechanisms, neither removable in float32 state: (1) the pipeline
+is stiff -- a constraint spring turns an absolute error e in a relative position / orientation of two bodies into
+k dt e of velocity per substep (k dt = 20 for Ant, 30 for Humanoid, 47 for Halfcheetah), and float32 body poses
+carry e ~ 1e-7; round 2 moved the largest such term, the relative rotation of the joint frames and the axis-alignment
+torque, to float64 (Ant p99 2.2e-5 -> 7.1e-6, Humanoid p50 1.1e-5 -> 4.5e-6; brax_kernels.cuh: joint_geometry), what
+is left is the rounding of the float32 state itself between substeps; (2) the contact rule is discontinuous (an
+impulse only while the point approaches, vn < 0; termination on a height threshold), so a lane whose vn or height
+crosses within rounding differs by O(erp depth / dt) -- the > 1e-3 tail.  Discrete outputs (truncation, counters,
+context ids) are exact."""
 import numpy as np
 import pytest
 import torch
@@ -105,9 +122,10 @@ def test_stepwise_parity_with_resync(device):
         np.testing.assert_array_equal(eng.elapsed.cpu().numpy(), ora.elapsed)
         np.testing.assert_array_equal(eng.episodes_done.cpu().numpy(), ora.episodes_done)
     e = np.concatenate(errs)
-    assert np.percentile(e, 50) <= 1e-5 and np.percentile(e, 99) <= 4e-5 and np.percentile(e, 99.9) <= 2e-4, (
+    # measured 2.2e-6 / 7.1e-6 / 1.1e-5 (module docstring): the 1e-5 bar holds at p99, not beyond
+    assert np.percentile(e, 50) <= 5e-6 and np.percentile(e, 99) <= 1e-5 and np.percentile(e, 99.9) <= 5e-5, (
         np.percentile(e, [50, 99, 99.9]))
-    assert (e > 1e-3).mean() < 3e-3
+    assert (e > 1e-3).mean() < 1e-3
     assert int(eng.episodes_done.sum()) >= n  # truncation at 40 + falls
 
 
@@ -262,9 +280,9 @@ def test_halfcheetah_stepwise_parity_and_reset(device):
         errs.append(np.maximum(rel_err(got, wnt).max(1), rel_err(rew.cpu().numpy(), out.reward)))
         np.testing.assert_array_equal(eng.elapsed.cpu().numpy(), ora.elapsed)
     e = np.concatenate(errs)
-    # stiffer constraint springs (k = 15000 x up to 2) and 16 substeps per env step: the same
-    # fp32 conditioning argument as for Ant, one notch looser
-    assert np.percentile(e, 50) <= 3e-5 and np.percentile(e, 99) <= 3e-4 and (e > 3e-3).mean() < 3e-3, (
+    # stiffer constraint springs (k = 15000 x up to 2) and 16 substeps per env step; measured 2.8e-6 / 1.1e-5 /
+    # 1.5e-5 (module docstring): the 1e-5 bar is missed at p99 by ~10 %
+    assert np.percentile(e, 50) <= 8e-6 and np.percentile(e, 99) <= 4e-5 and (e > 1e-3).mean() < 1e-3, (
         np.percentile(e, [50, 99, 99.9]))
     # planar: y and the roll / yaw quaternion components stay zero
     st = eng.state.view(7, 13, n)
@@ -437,8 +455,9 @@ def test_humanoid_stepwise_parity_and_reset(device):
         else:
             np.testing.assert_array_equal(eng.elapsed.cpu().numpy(), ora.elapsed)
     e = np.concatenate(errs)
-    # k_pos 20000 at dt 0.0015, 10 substeps: same fp32 conditioning argument as above
-    assert np.percentile(e, 50) <= 3e-5 and np.percentile(e, 99) <= 3e-4 and (e > 3e-3).mean() < 3e-3, (
+    # k_pos 20000 at dt 0.0015, 10 substeps, contacts with terminations; measured 4.5e-6 / 2.4e-5 (module
+    # docstring): the 1e-5 bar holds at the median only
+    assert np.percentile(e, 50) <= 1e-5 and np.percentile(e, 99) <= 8e-5 and (e > 3e-3).mean() < 3e-3, (
         np.percentile(e, [50, 99, 99.9]))
 
 
