@@ -216,6 +216,11 @@ class Workload:
         wall = time.perf_counter() - t0
         return wall, e0.elapsed_time(e1) * 1e-3 / K
 
+    def launch_shape(self):
+        """Brax families: the autotuned lane-group width per part (a pure scheduling choice)"""
+        parts = self.eng.parts if self.mixed else [self.eng]
+        return {f: int(p.sys.lanes_per_env) for f, p in zip(self.families, parts) if hasattr(p, "sys")}
+
     def kernel_name(self):
         names = []
         for f in self.families:
@@ -460,6 +465,7 @@ def main():
     n_fam = args.lanes // world if args.strong else args.lanes
     wl = Workload(args.families, n_fam, T, args.buffer_sets, rank, world, device)
     n = wl.n
+    shape = wl.launch_shape()
 
     # ---- timed region: exactly K fused launches (K x T env steps of every lane) --------
     wall, avg_launch_s = wl.train(K, W, barrier)
@@ -534,7 +540,7 @@ def main():
             "lanes_per_gpu": w2.n, "chunk": Ta, "ms_per_step": el2 / K * 1e3,
             "avg_launch_ms": avg2 * 1e3, "frac": r2["frac"], "achieved_GBs": r2["achieved"],
             "bytes_per_unit": r2["bytes_per_unit"], "traffic": r2["traffic"],
-            "mean_last_episode_return": w2.mean_last_return(),
+            "mean_last_episode_return": w2.mean_last_return(), "lanes_per_env": w2.launch_shape(),
         }
         del w2
         torch.cuda.empty_cache()
@@ -552,7 +558,7 @@ def main():
                                    f"per env step; {args.buffer_sets} rotating action/output buffer sets",
                        "lanes_per_gpu": n, "total_lanes": n * world, "chunk": T,
                        "env_steps_per_step": n * world * T, "buffer_sets": args.buffer_sets,
-                       "parallelism": f"lane-shard x{world}"},
+                       "parallelism": f"lane-shard x{world}", "lanes_per_env": shape},
             "roofline": roofline, "cpu_baseline": cpu, "per_call": per_call, "also": also,
             "mean_last_episode_return": mean_return, "return_allgather_ms": gather_ms, "rccl_ranks": rccl_ranks,
             "per_rank_avg_launch_ms": per_rank_launch_ms,
