@@ -131,7 +131,7 @@ def make_env(env, n, rank, world, device, lane_base=0):
 
     cls = {"pendulum": E.CARLPendulum, "cartpole": E.CARLCartPole, "acrobot": E.CARLAcrobot,
            "mountaincar": E.CARLMountainCar, "mountaincar_cont": E.CARLMountainCarContinuous,
-           "ant": E.CARLBraxAnt, "halfcheetah": E.CARLBraxHalfcheetah, "humanoid": E.CARLBraxHumanoid}[env]
+           "ant": E.CARLBraxAnt, "halfcheetah": E.CARLBraxHalfcheetahStiffness, "humanoid": E.CARLBraxHumanoid}[env]
     table = ContextSampler(context_dists(env), cls.get_context_space(), seed=0).sample_context_table(n * world)
     local = ContextTable(table.names, table.values_2d[rank * n:(rank + 1) * n])
     size_kw = {"batch_size": n, "autotune": False} if env in BRAX_ENVS else {"num_envs": n}

@@ -24,6 +24,8 @@ _LAZY = {
     "CARLBraxInvertedDoublePendulum": "carl_amd.envs.brax",
     "CARLBraxReacher": "carl_amd.envs.brax",
     "CARLBraxPusher": "carl_amd.envs.brax",
+    "CARLBraxHalfcheetahStiffness": "carl_amd.envs.brax",  # opt-in extension classes (joint_stiffness feature)
+    "CARLBraxHumanoidStiffness": "carl_amd.envs.brax",
     "VecEngine": "carl_amd.engine",
 }
 
@@ -41,7 +43,7 @@ def __getattr__(name):
 registry = {
     f"carl/{name}-v0": (module, name)
     for name, module in _LAZY.items()
-    if name.startswith("CARL") and name != "CARLEnv"
+    if name.startswith("CARL") and name != "CARLEnv" and not name.endswith("Stiffness")  # reference ids only
 }
 
 

@@ -69,6 +69,8 @@ def feature_spec(feature: ContextFeature, sampled: bool) -> _lib.FeatureSpec:
     elif isinstance(feature, NormalFloatContextFeature):
         sp.kind, sp.mu, sp.sigma = _lib.FEAT_NORMAL_FLOAT, feature.mu, feature.sigma
     elif isinstance(feature, UniformIntegerContextFeature):
+        if feature.log:  # carl_feature_spec_t has a log scale for uniform floats only
+            raise ValueError(f"{feature.name}: log-scale integer features are sampled on the host only")
         sp.kind = _lib.FEAT_UNIFORM_INT
     elif isinstance(feature, UniformFloatContextFeature):
         sp.kind, sp.log_scale = _lib.FEAT_UNIFORM_FLOAT, int(bool(feature.log))

@@ -59,6 +59,8 @@ class NumericalContextFeature(ContextFeature):
                  log: bool = False, meta: dict | None = None):
         if lower is not None and upper is not None and lower > upper:
             raise ValueError(f"{name}: lower bound {lower} exceeds upper bound {upper}")
+        if log and not (lower is not None and lower > 0):
+            raise ValueError(f"{name}: log=True needs a positive lower bound, got {lower}")
         self.name = name
         self.lower = lower
         self.upper = upper
@@ -71,6 +73,8 @@ class NumericalContextFeature(ContextFeature):
             lo, hi = self.lower, self.upper
             if lo is None or hi is None or math.isinf(lo) or math.isinf(hi):
                 return 0.0
+            if self.log:  # ConfigSpace: the centre of the range ON THE LOG SCALE (geometric mean)
+                return math.exp((math.log(lo) + math.log(hi)) / 2)
             return (lo + hi) / 2
         if not self.is_legal(default_value):
             raise ValueError(
@@ -97,6 +101,9 @@ class UniformFloatContextFeature(NumericalContextFeature):
 
     def _sample_vector(self, size, rs):
         u = rs.uniform(size=size)
+        if self.log:  # log-uniform: uniform on the log scale, as ConfigSpace's log=True (and the device sampler)
+            llo, lhi = math.log(self.lower), math.log(self.upper)
+            return np.clip(np.exp(llo + (lhi - llo) * u), self.lower, self.upper)
         with np.errstate(invalid="ignore", over="ignore"):
             return self.lower + (self.upper - self.lower) * u
 
@@ -109,6 +116,10 @@ class NormalFloatContextFeature(NumericalContextFeature):
         self.sigma = float(sigma)
         lo = -math.inf if lower is None else float(lower)
         hi = math.inf if upper is None else float(upper)
+        if log:
+            # ConfigSpace's log-normal parametrisation is version-dependent (mu / sigma on which scale), the
+            # reference never uses it and the device sampler has no such kind: refuse instead of guessing
+            raise NotImplementedError(f"{name}: NormalFloatContextFeature(log=True) is not supported")
         super().__init__(name, lo, hi, self.mu if default_value is None else default_value, log, meta)
         self.default_value = float(self.default_value)
 
@@ -130,6 +141,10 @@ class UniformIntegerContextFeature(NumericalContextFeature):
         self.default_value = int(round(self.default_value))
 
     def _sample_vector(self, size, rs):
+        if self.log:  # uniform on the log scale over [lower - 1/2, upper + 1/2), rounded (ConfigSpace's rule)
+            llo, lhi = math.log(self.lower - 0.49999), math.log(self.upper + 0.49999)
+            v = np.rint(np.exp(llo + (lhi - llo) * rs.uniform(size=size)))
+            return np.clip(v, self.lower, self.upper).astype(np.int64)
         return rs.randint(self.lower, self.upper + 1, size=size)
 
 

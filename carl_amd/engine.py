@@ -89,7 +89,7 @@ class VecEngine:
                  selector_stride: int = 1, auto_reset: bool = True, max_episode_steps: int | None = None,
                  seed: int = 0, lane_offset: int = 0, cartpole_recompute: bool = False,
                  ctx_obs_rows: Sequence[int] | None = None, ctx_idx0=None, fin_capacity: int = 0,
-                 acrobot_fp32: bool = False):
+                 acrobot_fp32: bool = False, context_offset: int | None = None):
         self.lib = _lib.load()
         if isinstance(family, str):
             family = _FAMILY_BY_NAME[family]
@@ -147,6 +147,8 @@ class VecEngine:
             _lib.FLAG_ACROBOT_FP32 if acrobot_fp32 else 0)
         self.b.lane_offset = int(lane_offset)
         self.b.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        # global id of context-table row 0 (see default_ctx_idx); None: decided per table
+        self.context_offset = None if context_offset is None else int(context_offset)
 
         self.ctx_obs_rows = list(range(F)) if ctx_obs_rows is None else [int(r) for r in ctx_obs_rows]
         if len(self.ctx_obs_rows) > _lib.CARL_MAX_CTX_OBS:
@@ -165,7 +167,18 @@ class VecEngine:
 
     # ------------------------------------------------------------------ contexts
     def default_ctx_idx(self, n_contexts: int) -> torch.Tensor:
-        g = torch.arange(self.n, dtype=torch.int64) + int(self.b.lane_offset)
+        """Context row each lane holds before its first reset: global lane g starts on global context
+        ``g mod C_global`` (round robin: one stride earlier, so that the first reset lands there).  The LOCAL
+        table may be a shard of the global one (multi-GPU: ``distributed.shard_context_rows``); row 0 of it has
+        the global id ``context_offset``.  ``context_offset=None`` (default): a table with exactly one row per
+        lane is this rank's own slice of a lane <-> context identity (row 0 = context ``lane_offset``), any
+        other table is the whole, replicated context set (row 0 = context 0).  With the modulo taken on the
+        global id instead -- as round 1 did -- an uneven split (10 lanes over 3 ranks: offset 4, count 3) read
+        row (4 + i) mod 3 and handed lanes their neighbours' contexts."""
+        off = self.context_offset
+        if off is None:
+            off = int(self.b.lane_offset) if n_contexts == self.n else 0
+        g = torch.arange(self.n, dtype=torch.int64) + int(self.b.lane_offset) - off
         if self.b.selector == _lib.SEL_ROUND_ROBIN:
             g = g - int(self.b.selector_stride)
         return (g % n_contexts).to(torch.int32)

@@ -65,6 +65,7 @@ class CARLBraxEnv(CARLEnv):
         auto_reset: bool | None = None,
         seed: int = 0,
         lane_offset: int = 0,
+        context_offset: int | None = None,
         reference_compat: bool = False,
         fin_capacity: int = 0,
         autotune: bool | None = None,
@@ -95,7 +96,7 @@ class CARLBraxEnv(CARLEnv):
                 batch_size,
                 device="cuda" if device is None else device,
                 auto_reset=n_auto if auto_reset is None else auto_reset,
-                seed=seed, lane_offset=lane_offset, fin_capacity=fin_capacity,
+                seed=seed, lane_offset=lane_offset, fin_capacity=fin_capacity, context_offset=context_offset,
                 autoreset_mode=autoreset,  # "first_state" = brax's AutoResetWrapper (reference behaviour)
             )
         self.use_language_goals = use_language_goals

@@ -5,8 +5,8 @@ One line per family: the columns of its context table, in order (the order is pa
 ``mass_<link>=<default>`` declares a link-mass feature; the other tokens name declarations shared by
 every family (``SHARED``); ``GOAL`` / ``GOAL_POSITION`` expand to the goal features.  The values are
 the reference's (carl/envs/brax/carl_<family>.py ``get_context_features``), pinned against it by
-``tests/test_feature_tables.py``; ``joint_stiffness`` is this build's extension (SURVEY.md Quirk B4),
-always after the reference's columns."""
+``tests/test_feature_tables.py``; ``joint_stiffness`` is this build's extension (SURVEY.md Quirk B4): it is NOT in
+the default tables, only in those of the opt-in ``...Stiffness`` classes, after the reference's columns."""
 from __future__ import annotations
 
 import math
@@ -38,8 +38,8 @@ _PHYSICS = "gravity friction elasticity ang_damping viscosity"
 COLUMNS = {
     "ant": "gravity friction elasticity ang_damping mass_torso=10 viscosity GOAL",
     "halfcheetah": f"{_PHYSICS} mass_torso=10 mass_bthigh=1.5435146 mass_bshin=1.5874476 mass_bfoot=1.0953975 "
-                   "mass_fthigh=1.4380753 mass_fshin=1.2008368 mass_ffoot=0.8845188 GOAL joint_stiffness",
-    "humanoid": f"{_PHYSICS} {_HUMANOID_LINKS} GOAL joint_stiffness",
+                   "mass_fthigh=1.4380753 mass_fshin=1.2008368 mass_ffoot=0.8845188 GOAL",
+    "humanoid": f"{_PHYSICS} {_HUMANOID_LINKS} GOAL",
     "humanoidstandup": f"{_PHYSICS} {_HUMANOID_LINKS}",
     "hopper": f"{_PHYSICS} mass_torso=10 mass_thigh=4.0578904 mass_leg=2.7813568 mass_foot=5.3155746 GOAL",
     "walker2d": f"{_PHYSICS} mass_torso=10 mass_thigh=4.0578904 mass_leg=2.7813568 mass_foot=3.1667254 "
@@ -54,9 +54,16 @@ COLUMNS = {
 }
 
 
-def _columns(family: str) -> list[tuple[str, float | None]]:
+# This build's extension columns (never part of the DEFAULT tables, so that the default context, the "context"
+# observation and the observation space have the reference's shape -- ADVICE r01): appended after the reference's
+# columns by the opt-in classes CARLBraxHalfcheetahStiffness / CARLBraxHumanoidStiffness (BASELINE config 5).
+EXTENSION_COLUMNS = {"halfcheetah": "joint_stiffness", "humanoid": "joint_stiffness"}
+
+
+def _columns(family: str, extensions: bool = False) -> list[tuple[str, float | None]]:
     out: list[tuple[str, float | None]] = []
-    for token in COLUMNS[family].split():
+    spec = COLUMNS[family] + (" " + EXTENSION_COLUMNS.get(family, "") if extensions else "")
+    for token in spec.split():
         if token in MACROS:
             out += [(name, None) for name in MACROS[token]]
         elif "=" in token:
@@ -72,9 +79,9 @@ def masses(family: str) -> dict[str, float]:
     return {name: default for name, default in _columns(family) if default is not None}
 
 
-def feature_table(family: str) -> dict[str, ContextFeature]:
+def feature_table(family: str, extensions: bool = False) -> dict[str, ContextFeature]:
     feats: dict[str, ContextFeature] = {}
-    for name, mass in _columns(family):
+    for name, mass in _columns(family, extensions):
         if name == "target_direction":
             feats[name] = CategoricalContextFeature(name, choices=DIRECTIONS, default_value=1)
             continue

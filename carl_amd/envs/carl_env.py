@@ -10,7 +10,8 @@ Two modes, chosen by ``num_envs``:
   auto-reset (the gymnasium path has none).  The physics still runs on the GPU lane
   engine -- there is no CPU path.
 * ``num_envs == N > 1`` -- N lanes in HBM: observations, rewards and flags are
-  device tensors ``[N, ...]``; ``info["context_id"]`` is an int32 tensor; done lanes are
+  device tensors ``[N, ...]`` that ALIAS the engine's output buffers (no per-step allocation: the next ``step``
+  overwrites them -- ``clone()`` what must outlive it; gymnasium's VectorEnv returns copies); ``info["context_id"]`` is an int32 tensor; done lanes are
   reset inside ``step`` (``auto_reset=True``; returned obs = reset obs, terminal obs in
   ``info["final_observation"]``); each lane advances its own selector state on device
   (static / round robin / random rules of carl/context/selection.py).
@@ -68,6 +69,8 @@ class _Unwrapped:
         names = owner._feature_names
         if name in names:
             eng.ctx_table[names.index(name)].fill_(float(value))
+            if eng.n > 1:  # (scalar mode builds its context observation on the host)
+                eng.refresh_ctx_obs()
             return
         object.__setattr__(self, name, value)
 
@@ -264,6 +267,8 @@ class CARLEnv(abc.ABC):
         if cid is None:
             raise RuntimeError("`_progress_instance` must be called before `_update_context`")
         self.env.ctx_idx.fill_(int(cid))
+        if not self._scalar_api:  # the kernels rewrite a lane's context observation only when a reset moves it
+            self.env.refresh_ctx_obs()
 
     # ------------------------------------------------------------------ reset / step
     def reset(self, *, seed: int | None = None, options: dict[str, Any] | None = None):

@@ -44,6 +44,7 @@ class CARLGymnasiumEnv(CARLEnv):
         auto_reset: bool | None = None,
         seed: int = 0,
         lane_offset: int = 0,
+        context_offset: int | None = None,
         max_episode_steps: int | None = None,
         derived: str = "stale",
         fin_capacity: int = 0,
@@ -54,6 +55,9 @@ class CARLGymnasiumEnv(CARLEnv):
         num_envs : lanes resident on ``device`` (1 = the reference's scalar API)
         auto_reset : reset done lanes inside ``step`` (default: True iff num_envs > 1)
         seed / lane_offset : Philox key and global id of lane 0 (multi-GPU sharding)
+        context_offset : global id of row 0 of ``contexts`` when the table is a shard of a global context set
+            (default: a table with one row per lane is this rank's slice of a lane <-> context identity,
+            any other table is the whole set; VecEngine.default_ctx_idx)
         derived : CartPole only -- "stale" replicates the reference (Quirk C1:
             total_mass / polemass_length stay at gymnasium's init values), "recompute"
             derives them from the context.
@@ -72,6 +76,7 @@ class CARLGymnasiumEnv(CARLEnv):
                 max_episode_steps=max_episode_steps,
                 seed=seed,
                 lane_offset=lane_offset,
+                context_offset=context_offset,
                 cartpole_recompute=(derived == "recompute"),
                 fin_capacity=fin_capacity,
             )

@@ -22,8 +22,24 @@ class FlattenObservation:
         single = env.single_observation_space
         n_ctx = len(self._ctx_names)
         obs_box = single["obs"]
-        lo = np.concatenate([np.full(n_ctx, -np.inf, np.float32), np.asarray(obs_box.low, np.float32).reshape(-1)])
-        hi = np.concatenate([np.full(n_ctx, np.inf, np.float32), np.asarray(obs_box.high, np.float32).reshape(-1)])
+        # context bounds from the env's context space (gymnasium flattens the Dict's "context" Box, which carries
+        # the feature bounds: carl/context/context_space.py:166-188), in the flattened (sorted-key) order
+        feats = env.get_context_features()
+        order = sorted(self._ctx_names) if env.obs_context_as_dict else self._ctx_names
+
+        def bound(name, which, default):
+            v = getattr(feats.get(name), which, None)
+            return default if v is None else float(v)
+
+        c_lo = np.array([bound(k, "lower", -np.inf) for k in order], np.float32)
+        c_hi = np.array([bound(k, "upper", np.inf) for k in order], np.float32)
+        lo = np.concatenate([c_lo, np.asarray(obs_box.low, np.float32).reshape(-1)])
+        hi = np.concatenate([c_hi, np.asarray(obs_box.high, np.float32).reshape(-1)])
+        # lanes move to other contexts on reset unless the selector is static: the TERMINAL observation of a
+        # finished lane belongs to the context of the episode that ended, i.e. the one before the step
+        from carl_amd import _lib
+
+        self._ctx_moves = (not env._scalar_api) and int(env.env.b.selector) not in (_lib.SEL_STATIC, _lib.SEL_HOST)
         self.single_observation_space = spaces.Box(lo, hi, dtype=np.float32)
         self.observation_space = (self.single_observation_space if self.num_envs == 1 or env._scalar_api
                                   else spaces.batch_space(self.single_observation_space, self.num_envs))
@@ -40,12 +56,16 @@ class FlattenObservation:
         obs, info = self.env.reset(**kw)
         return self._flat(obs), info
 
+    def _ctx_matrix(self, ctx):
+        return torch.stack([ctx[k] for k in sorted(ctx)], dim=1) if isinstance(ctx, dict) else ctx
+
     def step(self, action):
+        # (ctx_obs aliases a live engine buffer that the step rewrites for lanes that reset onto another context)
+        before = self._ctx_matrix(self.env._batched_obs()["context"]).clone() if self._ctx_moves else None
         obs, reward, terminated, truncated, info = self.env.step(action)
         if "final_observation" in info and torch.is_tensor(info["final_observation"]):
             info = dict(info)  # terminal observation of done lanes, flattened the same way
-            ctx = obs["context"]
-            c = torch.stack([ctx[k] for k in sorted(ctx)], dim=1) if isinstance(ctx, dict) else ctx
+            c = before if before is not None else self._ctx_matrix(obs["context"])
             info["final_observation"] = torch.cat([c, info["final_observation"]], dim=1)
         return self._flat(obs), reward, terminated, truncated, info
 

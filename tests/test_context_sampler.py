@@ -113,3 +113,56 @@ def test_normal_bounds_are_honoured():
     f = NormalFloatContextFeature("x", mu=0.0, sigma=5.0, lower=-1.0, upper=1.0)
     v = f.rvs(size=2000, random_state=1)
     assert v.min() >= -1.0 and v.max() <= 1.0
+
+
+def test_log_scale_features_sample_on_the_log_scale():
+    """ConfigSpace's log=True (search-space JSON "log": true): uniform on the LOG scale, default = the centre of
+    the range on the log scale.  (the host sampler used to ignore the flag -- median ~501 and default
+    500.0005 for U(1e-3, 1e3, log=True) -- while the device sampler honoured it.)"""
+    import math
+
+    from carl_amd.context.features import (
+        NormalFloatContextFeature,
+        UniformFloatContextFeature,
+        UniformIntegerContextFeature,
+    )
+
+    f = UniformFloatContextFeature("a", 1e-3, 1e3, log=True)
+    assert f.default_value == pytest.approx(1.0)  # geometric mean
+    v = f.rvs(size=20000, random_state=0)
+    assert v.min() >= 1e-3 and v.max() <= 1e3
+    assert 0.8 < np.median(v) < 1.25  # log-uniform: median = geometric mean (linear sampling gives ~500)
+    lg = np.log10(v)
+    assert abs(lg.mean()) < 0.05 and abs(lg.std() - 6 / math.sqrt(12)) < 0.05  # uniform over [-3, 3] decades
+    # same stream as the linear feature: the log flag only changes the map from the uniform draw
+    lin = UniformFloatContextFeature("a", 1e-3, 1e3).rvs(size=5, random_state=3)
+    u = (lin - 1e-3) / (1e3 - 1e-3)
+    np.testing.assert_allclose(f.rvs(size=5, random_state=3), np.exp(math.log(1e-3) + u * math.log(1e6)), rtol=1e-12)
+
+    g = UniformIntegerContextFeature("n", 1, 1000, log=True)
+    assert g.default_value == 32  # round(sqrt(1 * 1000))
+    w = g.rvs(size=20000, random_state=1)
+    assert w.min() >= 1 and w.max() <= 1000 and w.dtype.kind == "i"
+    assert 20 < np.median(w) < 45  # linear sampling gives ~500
+    with pytest.raises(ValueError):
+        UniformFloatContextFeature("b", 0.0, 1.0, log=True)  # log scale needs lower > 0
+    with pytest.raises(NotImplementedError):
+        NormalFloatContextFeature("c", mu=1.0, sigma=1.0, lower=0.1, upper=10, log=True)
+
+
+def test_log_scale_feature_through_the_sampler_and_search_space():
+    from carl_amd.context.context_space import ContextSpace, UniformFloatContextFeature
+    from carl_amd.context.sampler import ContextSampler
+    from carl_amd.context.search_space_encoding import search_space_to_config_space
+
+    space = ContextSpace({"k": UniformFloatContextFeature("k", 1e-2, 1e2, default_value=1.0)})
+    s = ContextSampler([UniformFloatContextFeature("k", 1e-2, 1e2, log=True)], space, seed=0)
+    t = s.sample_context_table(4000)
+    k = t.values_2d[:, t.names.index("k")]
+    assert 0.8 < np.median(k) < 1.25
+    cs = search_space_to_config_space(
+        {"hyperparameters": [{"name": "k", "type": "uniform_float", "log": True, "lower": 0.01, "upper": 100.0,
+                              "default": 1.0}]})
+    assert cs["k"].log is True
+    v = cs["k"].rvs(size=4000, random_state=0)
+    assert 0.8 < np.median(v) < 1.25

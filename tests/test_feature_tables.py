@@ -16,8 +16,9 @@ GOLDEN = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "conte
 GOAL_WRAPPER = GOLDEN.pop("_goal_wrapper")
 
 
-# joint_stiffness: BASELINE.json config 5 varies it; the reference's classes do not declare it
-EXTENSIONS = {"CARLBraxHalfcheetah": {"joint_stiffness"}, "CARLBraxHumanoid": {"joint_stiffness"}}
+# the default tables hold the reference's features and nothing else; joint_stiffness (BASELINE config 5) lives in
+# the opt-in classes CARLBraxHalfcheetahStiffness / CARLBraxHumanoidStiffness only
+EXTENSIONS: dict = {}
 # carl_inverted_double_pendulum.py:32-34: key "mass_pole2" constructed with name "mass_pole"
 KNOWN_NAME_SLIPS = {("CARLBraxInvertedDoublePendulum", "mass_pole2")}
 
@@ -68,3 +69,13 @@ def test_language_goal_sentences_equal_the_reference_output():
     assert len(GOAL_WRAPPER["sentences"]) >= 4
     for case in GOAL_WRAPPER["sentences"]:
         assert CARLBraxEnv.describe_goal(case["context"]) == case["sentence"]
+
+
+def test_extension_classes_append_joint_stiffness_after_the_reference_columns():
+    from carl_amd.envs.brax.feature_tables import feature_table
+
+    for fam in ("halfcheetah", "humanoid"):
+        base, ext = feature_table(fam), feature_table(fam, extensions=True)
+        assert list(ext)[:-1] == list(base) and list(ext)[-1] == "joint_stiffness"
+        assert "joint_stiffness" not in base and ext["joint_stiffness"].default_value == 1.0
+    assert feature_table("ant", extensions=True).keys() == feature_table("ant").keys()

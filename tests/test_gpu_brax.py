@@ -235,7 +235,7 @@ def test_env_api(device):
 
 # ------------------------------------------------------------------ Halfcheetah
 def _cheetah():
-    from carl_amd.envs import CARLBraxHalfcheetah
+    from carl_amd.envs import CARLBraxHalfcheetahStiffness as CARLBraxHalfcheetah  # + joint_stiffness (config 5)
     from carl_amd.envs.brax.models import halfcheetah_sys
 
     feats = CARLBraxHalfcheetah.get_context_features()
@@ -310,11 +310,14 @@ def test_halfcheetah_rollout_equals_step_and_env_api(device):
         o, r, te, tr = e2.step(acts[t])
         assert torch.equal(out["obs"][t], o) and torch.equal(out["reward"][t], r) and torch.equal(out["truncated"][t], tr)
     assert torch.equal(e1.state, e2.state)
-    env = CARLBraxHalfcheetah(batch_size=n, contexts=ContextTable(names, rows), context_selector=StaticSelector)
+    from carl_amd.envs import CARLBraxHalfcheetahStiffness
+
+    env = CARLBraxHalfcheetahStiffness(batch_size=n, contexts=ContextTable(names, rows), context_selector=StaticSelector)
     obs, info = env.reset(seed=0)
     assert obs["obs"].shape == (n, 17) and env.action_space.shape == (n, 6)
     assert "joint_stiffness" in obs["context"] and obs["context"]["mass_bthigh"].shape == (n,)
-    single = CARLBraxHalfcheetah()
+    single = CARLBraxHalfcheetah()  # the reference's class: no extension feature in its context / spaces
+    assert "joint_stiffness" not in single.get_context_features()
     o, _ = single.reset()
     assert o["obs"].shape == (17,)
     o, r, te, tr, _ = single.step(np.zeros(6, np.float32))
@@ -396,7 +399,7 @@ def test_goal_mode_through_the_env_api(device):
 
 # ------------------------------------------------------------------ Humanoid (BASELINE config 5)
 def _humanoid():
-    from carl_amd.envs import CARLBraxHumanoid
+    from carl_amd.envs import CARLBraxHumanoidStiffness as CARLBraxHumanoid  # + joint_stiffness (config 5)
     from carl_amd.envs.brax.models import humanoid_sys
 
     feats = CARLBraxHumanoid.get_context_features()
@@ -483,7 +486,9 @@ def test_humanoid_rollout_equals_step_and_env_api(device):
         assert torch.equal(out["obs"][t], o) and torch.equal(out["reward"][t], r)
         assert torch.equal(out["truncated"][t], tr) and torch.equal(out["terminated"][t], te)
     assert torch.equal(e1.state, e2.state)
-    env = CARLBraxHumanoid(batch_size=n, contexts=ContextTable(names, rows), context_selector=StaticSelector)
+    from carl_amd.envs import CARLBraxHumanoidStiffness
+
+    env = CARLBraxHumanoidStiffness(batch_size=n, contexts=ContextTable(names, rows), context_selector=StaticSelector)
     obs, info = env.reset(seed=0)
     assert obs["obs"].shape == (n, 244) and env.action_space.shape == (n, 17)
     assert obs["context"]["mass_left_lower_arm"].shape == (n,)

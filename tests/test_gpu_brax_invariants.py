@@ -154,7 +154,7 @@ def test_contact_penetration_joint_integrity_and_limit_overshoot_are_bounded(nam
     (iii) no hinge is more than 0.5 rad beyond its range (limit springs), (iv) everything is finite."""
     from carl_amd import envs as E
 
-    cls = {"ant": E.CARLBraxAnt, "humanoid": E.CARLBraxHumanoid, "halfcheetah": E.CARLBraxHalfcheetah}[name]
+    cls = {"ant": E.CARLBraxAnt, "humanoid": E.CARLBraxHumanoid, "halfcheetah": E.CARLBraxHalfcheetahStiffness}[name]
     rng = np.random.default_rng(4)
 
     def rows_fn(rows, names):

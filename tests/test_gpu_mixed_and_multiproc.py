@@ -238,3 +238,41 @@ def test_hip_engine_under_a_process_group_on_one_gpu(backend, device, tmp_path):
     np.testing.assert_array_equal(np.load(str(out) + ".obs1.npy"), ref_out["obs"][-1][half:].cpu().numpy())
     fin = got["episodes_done"] > 0
     assert abs(float(got["summary_mean"]) - float(got["last_return"][fin].mean())) < 1e-4
+
+
+@pytest.mark.parametrize("selector_name", ["static", "round_robin"])
+def test_uneven_lane_shards_through_the_env_api_keep_their_contexts(selector_name, device):
+    """10 lanes over 3 ranks (shards 4 / 3 / 3).  Through the CARLEnv constructors -- no explicit
+    ctx_idx0 -- every shard must read ITS OWN rows of the context set: with the table sharded like the lanes
+    (static selector, lane i <-> context i) and with the whole table replicated (round robin); the shards'
+    transitions must equal the unsharded env's, bit for bit."""
+    from carl_amd.context.selection import RoundRobinSelector, StaticSelector
+    from carl_amd.context.table import ContextTable
+    from carl_amd.distributed import lane_shard, shard_context_rows
+    from carl_amd.envs import CARLPendulum
+
+    N, T = 10, 30
+    rng = np.random.default_rng(2)
+    names = list(CARLPendulum.get_context_features())
+    rows = random_table(O.PENDULUM, rng, N)
+    sel = StaticSelector if selector_name == "static" else RoundRobinSelector
+    identity = selector_name == "static"
+    acts = torch.as_tensor(random_actions(O.PENDULUM, rng, (T, N)), device=device)
+
+    def run(env, a):
+        env.reset(seed=3)
+        out = env.env.rollout(a)
+        return out["obs"].clone(), out["reward"].clone(), env.env.ctx_idx.clone()
+
+    full = CARLPendulum(contexts=ContextTable(names, rows), num_envs=N, device=device, context_selector=sel,
+                        max_episode_steps=7)
+    f_obs, f_rew, f_idx = run(full, acts)
+    for r in range(3):
+        sh = lane_shard(N, r, 3)
+        local = shard_context_rows(rows, sh, identity)
+        env = CARLPendulum(contexts=ContextTable(names, local), num_envs=sh.count, device=device,
+                           context_selector=sel, lane_offset=sh.offset, max_episode_steps=7)
+        obs, rew, idx = run(env, acts[:, sh.slice].contiguous())
+        assert torch.equal(obs, f_obs[:, sh.slice]) and torch.equal(rew, f_rew[:, sh.slice]), (r, sh)
+        want = f_idx[sh.slice] - (sh.offset if identity else 0)  # sharded rows are numbered from the shard's first
+        assert torch.equal(idx, want.to(idx.dtype)), (r, idx, want)

@@ -15,7 +15,7 @@ from carl_amd.envs.brax.models import SYSTEMS  # noqa: E402
 from oracle import brax as B  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 
-CLASSES = {"ant": E.CARLBraxAnt, "halfcheetah": E.CARLBraxHalfcheetah, "humanoid": E.CARLBraxHumanoid,
+CLASSES = {"ant": E.CARLBraxAnt, "halfcheetah": E.CARLBraxHalfcheetahStiffness, "humanoid": E.CARLBraxHumanoid,
            "hopper": E.CARLBraxHopper, "walker2d": E.CARLBraxWalker2d,
            "inverted_pendulum": E.CARLBraxInvertedPendulum,
            "inverted_double_pendulum": E.CARLBraxInvertedDoublePendulum,

@@ -4,7 +4,7 @@ from carl_amd import envs as E
 from carl_amd.brax_engine import BraxVecEngine
 from carl_amd.envs.brax.models import SYSTEMS
 from oracle import brax as B, oracle as O
-cls = E.CARLBraxHalfcheetah
+cls = E.CARLBraxHalfcheetahStiffness
 feats = cls.get_context_features(); names = list(feats)
 default = np.array([float(f.default_value) for f in feats.values()])
 s = SYSTEMS[cls.env_name](names)

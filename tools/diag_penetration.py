@@ -3,7 +3,7 @@ import numpy as np, torch
 from tests.test_gpu_brax_invariants import _make, _bodies, _qrot
 from carl_amd import envs as E
 name = sys.argv[1] if len(sys.argv) > 1 else "ant"
-cls = {"ant": E.CARLBraxAnt, "humanoid": E.CARLBraxHumanoid, "halfcheetah": E.CARLBraxHalfcheetah}[name]
+cls = {"ant": E.CARLBraxAnt, "humanoid": E.CARLBraxHumanoid, "halfcheetah": E.CARLBraxHalfcheetahStiffness}[name]
 rng = np.random.default_rng(4)
 def rows_fn(rows, names):
     n = len(rows)
