@@ -60,7 +60,7 @@ class Batch(C.Structure):
 class StepIO(C.Structure):
     _fields_ = [
         ("action", _vp), ("action_dtype", C.c_int32), ("reserved", C.c_int32),
-        ("obs", _vp), ("reward", _vp), ("terminated", _vp), ("truncated", _vp), ("final_obs", _vp),
+        ("obs", _vp), ("reward", _vp), ("terminated", _vp), ("truncated", _vp), ("final_obs", _vp), ("done", _vp),
     ]
 
 

@@ -31,7 +31,7 @@ def _deps() -> list[str]:
     out = []
     for root in (CSRC, os.path.join(os.path.dirname(_HERE), "include")):
         for f in sorted(os.listdir(root)):
-            if f.endswith((".hip", ".cuh", ".h", ".hpp")):
+            if f.endswith((".hip", ".h", ".hpp", ".inc")):
                 out.append(os.path.join(root, f))
     return out
 

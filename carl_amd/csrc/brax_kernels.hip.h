@@ -1,4 +1,4 @@
-// brax_kernels.cuh -- Brax "spring" locomotion step on MI355X (Ant / Halfcheetah / Humanoid
+// brax_kernels.hip.h -- Brax "spring" locomotion step on MI355X (Ant / Halfcheetah / Humanoid
 // model tables; see include/carl_amd.h carl_brax_sys_t).
 //
 // Replaces, for N envs at once: brax.envs.<env>.step/reset -> n_frames x
@@ -32,8 +32,8 @@
 // rotate^-1 on three floats per lane.
 #pragma once
 
-#include "carl_device.cuh"
-#include "fast_math.cuh"
+#include "carl_device.hip.h"
+#include "fast_math.hip.h"
 
 namespace carl {
 namespace brax {
@@ -1057,6 +1057,7 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
         io.reward[step_off + env] = reward;
         io.terminated[step_off + env] = (uint8_t)terminated;
         io.truncated[step_off + env] = (uint8_t)truncated;
+        if (io.done != nullptr && n_steps == 1) io.done[env] = (uint8_t)(terminated | truncated);  // per-call step
       }
       if (__ballot(done) != 0ull) {
         const float fin_ret = r.ep_return;

@@ -12,9 +12,9 @@
 #include <utility>
 
 #include "../../include/carl_amd.h"
-#include "classic_control.cuh"
-#include "context_kernels.cuh"
-#include "engine_kernels.cuh"
+#include "classic_control.hip.h"
+#include "context_kernels.hip.h"
+#include "engine_kernels.hip.h"
 #include "host_common.hpp"
 
 namespace carl_host {

@@ -9,7 +9,7 @@
 #include <cstdlib>
 
 #include "../../include/carl_amd.h"
-#include "brax_kernels.cuh"
+#include "brax_kernels.hip.h"
 #include "host_common.hpp"
 
 namespace {

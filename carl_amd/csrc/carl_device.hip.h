@@ -1,4 +1,4 @@
-// carl_device.cuh -- device-side building blocks shared by every family kernel
+// carl_device.hip.h -- device-side building blocks shared by every family kernel
 // (gfx950 / CDNA4 only: wave64, no portability shims).
 #pragma once
 

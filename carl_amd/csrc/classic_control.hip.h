@@ -1,6 +1,6 @@
-// classic_control.cuh -- per-lane physics of CARL's classic-control families.
+// classic_control.hip.h -- per-lane physics of CARL's classic-control families.
 //
-// Each family is a traits struct the generic engine kernels (engine_kernels.cuh) are
+// Each family is a traits struct the generic engine kernels (engine_kernels.hip.h) are
 // instantiated with:
 //   S, D, F            state columns, observation length, context-table rows
 //   Action             int (Discrete) or float (Box)
@@ -25,8 +25,8 @@
 
 #include <type_traits>
 
-#include "carl_device.cuh"
-#include "fast_math.cuh"
+#include "carl_device.hip.h"
+#include "fast_math.hip.h"
 
 namespace carl {
 
@@ -42,13 +42,13 @@ struct CartPole {
   using Aux = NoAux;
   enum { GRAVITY, MASSCART, MASSPOLE, LENGTH, FORCE_MAG, TAU, INIT_LO, INIT_HI };
   static constexpr bool kNeedsStepNoise = false;
-  // the staged rollout's specialisations (engine_kernels.cuh: init-state words drawn once per chunk, the PLAIN
+  // the staged rollout's specialisations (engine_kernels.hip.h: init-state words drawn once per chunk, the PLAIN
   // done path, the LDS-resident context table).  Made for CartPole's short episodes; switched on for every
   // family because the smaller done path also frees the step loop's registers: Pendulum 279 -> 266,
   // MountainCar 292 -> 273, MountainCarContinuous 313 -> 276, Acrobot 2330 -> 2205 ns/step (A/B, one box)
   static constexpr bool kPredraw = true;
   // short episodes under any policy: the done handling of the PLAIN staged rollout is straight-line selects on
-  // every step instead of a wave-uniform branch that is taken ~95 % of the time (engine_kernels.cuh: step_dense)
+  // every step instead of a wave-uniform branch that is taken ~95 % of the time (engine_kernels.hip.h: step_dense)
   static constexpr bool kDenseDone = true;
 
   struct Params {
@@ -314,7 +314,7 @@ struct AcrobotT {
   }
 
   // the fp64 variant reads sin / cos of the table's grid points from LDS: every kernel instantiated with this
-  // family stages the table first (engine_kernels.cuh: stage_family_tables)
+  // family stages the table first (engine_kernels.hip.h: stage_family_tables)
   static constexpr bool kUsesSinCosTab = std::is_same_v<Real, double>;
   __device__ static __forceinline__ void stage_tables() {
     if constexpr (kUsesSinCosTab) SinCosTab::stage();
@@ -331,7 +331,7 @@ struct AcrobotT {
   };
 
   // sin/cos of an RK4 stage angle or of the new angle: |x| <= pi + a few turns (velocities are clipped), so
-  // the fp64 version runs without the library fallback for huge arguments (fast_math.cuh)
+  // the fp64 version runs without the library fallback for huge arguments (fast_math.hip.h)
   __device__ static __forceinline__ void sincos_stage(Real x, Real& sn, Real& cs) {
     if constexpr (std::is_same_v<Real, double>)
       sincos_fast<false>(x, sn, cs);

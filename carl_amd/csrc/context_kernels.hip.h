@@ -1,4 +1,4 @@
-// context_kernels.cuh -- dense context sets produced and checked on the device.
+// context_kernels.hip.h -- dense context sets produced and checked on the device.
 //
 // Replaces, for C contexts at once, ContextSampler.sample_contexts (carl/context/sampler.py:45-61)
 // + the default fill of the contexts setter (carl/envs/carl_env.py:135-137) and
@@ -7,8 +7,8 @@
 // (global context id lo, hi, feature index, kSubSampler | attempt): see include/carl_amd.h.
 #pragma once
 
-#include "carl_device.cuh"
-#include "fast_math.cuh"
+#include "carl_device.hip.h"
+#include "fast_math.hip.h"
 
 namespace carl {
 

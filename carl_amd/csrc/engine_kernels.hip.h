@@ -1,4 +1,4 @@
-// engine_kernels.cuh -- the generic batched reset / step / rollout kernels.
+// engine_kernels.hip.h -- the generic batched reset / step / rollout kernels.
 //
 // One lane (thread) = one env instance.  All traffic is coalesced: SoA state
 // columns, feature-major context rows, lane-major observation records written with
@@ -10,7 +10,7 @@
 
 #include <type_traits>
 
-#include "carl_device.cuh"
+#include "carl_device.hip.h"
 
 // CARL_EXP_* switches compile PROFILING-ONLY kernels that skip stores, loads or the done path
 // (tools/build_ablations.sh).  A product build must never carry one by accident: they are refused
@@ -29,7 +29,7 @@ namespace carl {
 template <bool LDS>
 using ctx_t = std::conditional_t<LDS, LdsCtx, GlobalCtx>;
 
-// Families whose physics reads a constant table from LDS (Acrobot's fp64 sin/cos grid, classic_control.cuh)
+// Families whose physics reads a constant table from LDS (Acrobot's fp64 sin/cos grid, classic_control.hip.h)
 // stage it at the top of every kernel, before the first `prepare` / `step`.
 template <class Fam, class = void>
 struct has_tables : std::false_type {};
@@ -163,6 +163,7 @@ struct Cursors {
   uint8_t* term;     // += n
   uint8_t* trunc;    // += n
   float* final_obs;  // += n * D (nullable)
+  uint8_t* done;     // per-call step only (nullable): terminated | truncated
   __device__ __forceinline__ void advance(size_t n) {
     obs += n * Fam::D;
     reward += n;
@@ -176,6 +177,7 @@ struct Cursors {
   __device__ __forceinline__ void put_flags(bool te, bool tr) const {
     *term = (uint8_t)te;
     *trunc = (uint8_t)tr;
+    if (done != nullptr) *done = (uint8_t)(te | tr);
   }
   __device__ __forceinline__ void put_obs(const float (&o)[Fam::D]) const { store_obs<Fam::D>(obs, 0, o); }
   __device__ __forceinline__ float* final_obs_ptr() const { return final_obs; }
@@ -520,8 +522,9 @@ __device__ __forceinline__ void store_lane(const carl_batch_t& b, const Ctx& ctx
 }
 
 template <class Fam>
-__device__ __forceinline__ Cursors<Fam> make_cursors(const carl_step_io_t& io, int lane) {
+__device__ __forceinline__ Cursors<Fam> make_cursors(const carl_step_io_t& io, int lane, bool per_call = false) {
   Cursors<Fam> c;
+  c.done = (per_call && io.done != nullptr) ? io.done + lane : nullptr;
   c.obs = io.obs + (size_t)lane * Fam::D;
   c.reward = io.reward + lane;
   c.term = io.terminated + lane;
@@ -550,7 +553,7 @@ __global__ void __launch_bounds__(256) step_kernel(const carl_batch_t b, const c
     load_lane<Fam>(b, ctx, lane, r);
     action = (typename Fam::Action) static_cast<const action_store_t<Fam, A64>*>(io.action)[lane];
   }
-  const Cursors<Fam> cur = make_cursors<Fam>(io, active ? lane : 0);
+  const Cursors<Fam> cur = make_cursors<Fam>(io, active ? lane : 0, true);
   step_lane<Fam>(b, ctx, cur, b.max_episode_steps, active, lane, glane, action, r);
   if (active) store_lane<Fam>(b, ctx, lane, r);
 }

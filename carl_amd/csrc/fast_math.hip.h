@@ -1,4 +1,4 @@
-// fast_math.cuh -- branch-free sin/cos for the step kernels.
+// fast_math.hip.h -- branch-free sin/cos for the step kernels.
 //
 // The fused rollout kernel runs one wavefront per SIMD at 65 536 lanes, so it is
 // bound by the instruction stream of a single wave; the library sinf/cosf (Payne-Hanek

@@ -121,6 +121,7 @@ class VecEngine:
         self.reward = torch.zeros(self.n, dtype=f32, device=dev)
         self.terminated = torch.zeros(self.n, dtype=torch.uint8, device=dev)
         self.truncated = torch.zeros(self.n, dtype=torch.uint8, device=dev)
+        self.done = torch.zeros(self.n, dtype=torch.uint8, device=dev)  # terminated | truncated of the last step()
         self.final_obs = torch.zeros((self.n, D), dtype=f32, device=dev)
         # done-mask compaction buffers
         self.done_idx = torch.zeros(max(self.n, 1), dtype=i32, device=dev)
@@ -281,6 +282,7 @@ class VecEngine:
             io.obs, io.reward = _ptr(self.obs), _ptr(self.reward)
             io.terminated, io.truncated = _ptr(self.terminated), _ptr(self.truncated)
             io.final_obs = _ptr(self.final_obs)
+            io.done = _ptr(self.done)
 
     def _stream(self) -> int:
         return torch.cuda.current_stream(self.device).cuda_stream
@@ -382,7 +384,7 @@ class VecEngine:
     def snapshot(self) -> dict:
         """Copies of every buffer a launch can change (state, counters, bookkeeping, step outputs)."""
         names = ["state", "elapsed", "ctx_idx", "episode", "n_calls", "ep_return", "last_return", "last_length",
-                 "episodes_done", "obs", "reward", "terminated", "truncated", "final_obs", "ctx_obs"]
+                 "episodes_done", "obs", "reward", "terminated", "truncated", "done", "final_obs", "ctx_obs"]
         names += [k for k in ("goal_pos", "success", "fin_count", "first_state") if getattr(self, k, None) is not None]
         return {k: getattr(self, k).clone() for k in names}
 

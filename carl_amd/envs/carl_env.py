@@ -303,12 +303,27 @@ class CARLEnv(abc.ABC):
             info: dict[str, Any] = {"context_id": self.context_id}
             return (self._add_context_to_state(state), float(out[D]), bool(out[D + 1] != 0),
                     bool(out[D + 2] != 0), info)
-        obs, reward, term, trunc = self.env.step(action)
-        info = {"context_id": self.env.ctx_idx}
-        if self.env.auto_reset:
-            info["final_observation"] = self.env.final_obs
-            info["_final_observation"] = (term | trunc).view(torch.bool)
-        return self._batched_obs(), reward, term.view(torch.bool), trunc.view(torch.bool), info
+        # Batched hot call: everything returned is a view of an engine buffer whose address never changes, so
+        # the views (and the observation dict) are built once; per call this is the engine's launch plus one
+        # small dict.  `_final_observation` is the done mask the step kernel writes (carl_step_io_t::done).
+        c = self._views()
+        _, reward, _, _ = self.env.step(action)
+        info = dict(c["info_auto"] if self.env.auto_reset else c["info_plain"])
+        return c["obs"], reward, c["term"], c["trunc"], info
+
+    def _views(self) -> dict:
+        eng = self.env
+        key = (eng.obs.data_ptr(), eng.ctx_obs.data_ptr(), eng.ctx_idx.data_ptr(), eng.terminated.data_ptr(),
+               eng.done.data_ptr(), tuple(eng.ctx_obs_rows), self.obs_context_as_dict)
+        c = getattr(self, "_view_cache", None)
+        if c is None or c["key"] != key:  # buffers are re-homed by contexts= / MixedVecEngine: rebuild then
+            info_plain = {"context_id": eng.ctx_idx}
+            c = {"key": key, "obs": self._batched_obs(), "term": eng.terminated.view(torch.bool),
+                 "trunc": eng.truncated.view(torch.bool), "info_plain": info_plain,
+                 "info_auto": {**info_plain, "final_observation": eng.final_obs,
+                               "_final_observation": eng.done.view(torch.bool)}}
+            self._view_cache = c
+        return c
 
     def _batched_obs(self) -> dict[str, Any]:
         eng = self.env

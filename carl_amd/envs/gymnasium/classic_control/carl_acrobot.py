@@ -4,7 +4,7 @@ Only the feature table lives here.  The reset distribution the reference impleme
 Python ``reset()`` override -- angles = U(INITIAL_ANGLE_LOWER, INITIAL_ANGLE_UPPER, 2), velocities likewise;
     obs = (cos t1, sin t1, cos t2, sin t2, w1, w2) (:71-115) --
 and the step physics run in the HIP kernels of the ``Acrobot-v1`` family
-(carl_amd/csrc/classic_control.cuh).
+(carl_amd/csrc/classic_control.hip.h).
 """
 from __future__ import annotations
 

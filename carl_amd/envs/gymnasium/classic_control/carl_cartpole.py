@@ -3,7 +3,7 @@
 Only the feature table lives here.  The reset distribution the reference implements as a
 Python ``reset()`` override -- state = U(initial_state_lower, initial_state_upper, size 4); obs = float32(state) (:44-66) --
 and the step physics run in the HIP kernels of the ``CartPole-v1`` family
-(carl_amd/csrc/classic_control.cuh).
+(carl_amd/csrc/classic_control.hip.h).
 """
 from __future__ import annotations
 

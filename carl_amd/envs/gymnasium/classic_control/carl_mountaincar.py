@@ -4,7 +4,7 @@ Only the feature table lives here.  The reset distribution the reference impleme
 Python ``reset()`` override -- position = U(min_position_start, max_position_start), velocity = U(min_velocity_start,
     max_velocity_start) (:53-85) --
 and the step physics run in the HIP kernels of the ``MountainCar-v0`` family
-(carl_amd/csrc/classic_control.cuh).
+(carl_amd/csrc/classic_control.hip.h).
 """
 from __future__ import annotations
 

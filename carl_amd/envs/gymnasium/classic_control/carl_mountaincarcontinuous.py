@@ -3,7 +3,7 @@
 Only the feature table lives here.  The reset distribution the reference implements as a
 Python ``reset()`` override -- same start distribution as CARLMountainCar (:50-82) --
 and the step physics run in the HIP kernels of the ``MountainCarContinuous-v0`` family
-(carl_amd/csrc/classic_control.cuh).
+(carl_amd/csrc/classic_control.hip.h).
 """
 from __future__ import annotations
 

@@ -4,7 +4,7 @@ Only the feature table lives here.  The reset distribution the reference impleme
 Python ``reset()`` override -- theta = U(0, initial_angle_max), thetadot = U(0, initial_velocity_max); obs = (cos, sin, thetadot) (:41-65).
     The feature named ``gravity`` is inert in the reference (Quirk P1); real gravity is ``g``. --
 and the step physics run in the HIP kernels of the ``Pendulum-v1`` family
-(carl_amd/csrc/classic_control.cuh).
+(carl_amd/csrc/classic_control.hip.h).
 """
 from __future__ import annotations
 

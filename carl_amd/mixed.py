@@ -31,7 +31,7 @@ import torch
 
 from carl_amd.engine import VecEngine
 
-_SHARED_1D = ("ep_return", "last_return", "last_length", "episodes_done", "reward", "terminated", "truncated")
+_SHARED_1D = ("ep_return", "last_return", "last_length", "episodes_done", "reward", "terminated", "truncated", "done")
 
 
 class MixedVecEngine:

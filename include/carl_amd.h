@@ -163,6 +163,9 @@ typedef struct carl_step_io {
   uint8_t* terminated;  /* [n_lanes] */
   uint8_t* truncated;   /* [n_lanes] TimeLimit */
   float* final_obs;     /* [n_lanes][D] or NULL; written for done lanes only */
+  uint8_t* done;        /* [n_lanes] or NULL: terminated | truncated, the done mask of this step (what
+                           info["_final_observation"] of a vector env is); per-call carl_step / carl_brax_step
+                           only, ignored by the rollout entry points */
 } carl_step_io_t;
 
 int carl_abi_version(void);

@@ -25,7 +25,7 @@ everything but Pusher, and FAILS beyond that.  Two mechanisms, neither removable
 is stiff -- a constraint spring turns an absolute error e in a relative position / orientation of two bodies into
 k dt e of velocity per substep (k dt = 20 for Ant, 30 for Humanoid, 47 for Halfcheetah), and float32 body poses
 carry e ~ 1e-7; round 2 moved the largest such term, the relative rotation of the joint frames and the axis-alignment
-torque, to float64 (Ant p99 2.2e-5 -> 7.1e-6, Humanoid p50 1.1e-5 -> 4.5e-6; brax_kernels.cuh: joint_geometry), what
+torque, to float64 (Ant p99 2.2e-5 -> 7.1e-6, Humanoid p50 1.1e-5 -> 4.5e-6; brax_kernels.hip.h: joint_geometry), what
 is left is the rounding of the float32 state itself between substeps; (2) the contact rule is discontinuous (an
 impulse only while the point approaches, vn < 0; termination on a height threshold), so a lane whose vn or height
 crosses within rounding differs by O(erp depth / dt) -- the > 1e-3 tail.  Discrete outputs (truncation, counters,

@@ -175,7 +175,7 @@ def test_contact_penetration_joint_integrity_and_limit_overshoot_are_bounded(nam
     cl = torch.tensor([s.coll_link[k] for k in range(s.n_coll)], device=device, dtype=torch.long)
     cp = torch.tensor([[s.coll_pos[k][j] for j in range(3)] for k in range(s.n_coll)], device=device)
     cr = torch.tensor([s.coll_radius[k] for k in range(s.n_coll)], device=device)
-    # joint anchors (brax_kernels.cuh build_derived_host): child side joint_pos - com (child frame), parent side
+    # joint anchors (brax_kernels.hip.h build_derived_host): child side joint_pos - com (child frame), parent side
     # link_pos + link_rot (x) joint_pos - com[parent] (parent frame; the world for planar roots)
     joints = [i for i in range(L) if not (s.parent[i] < 0 and s.n_link_dof[i] == 6) and s.n_slide[i] == 0]
     ac = torch.tensor([[s.joint_pos[i][k] - s.com[i][k] for k in range(3)] for i in joints], device=device)

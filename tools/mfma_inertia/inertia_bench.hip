@@ -1,6 +1,6 @@
 // inertia_bench.hip -- north_star names "MFMA only for the dense 3x3 / 6x6 inertia-matrix contractions in the Brax
 // articulated path".  The contraction is w' = R diag(1/I) R^T tau per link per substep (brax spring: world inverse
-// inertia applied to the net torque; brax_kernels.cuh apply_inv_inertia).  This standalone kernel pair measures it
+// inertia applied to the net torque; brax_kernels.hip.h apply_inv_inertia).  This standalone kernel pair measures it
 // both ways on the batch shape of BASELINE config 5 (32 768 Humanoid envs x 11 links), K chained applications
 // per item held in registers (as inside a substep loop: compute-bound, no HBM in the timed part):
 //
