@@ -432,14 +432,24 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists)")
+    # Plumbing check of the N > 1 path on a ONE-GPU box (tools/bench_2proc_sim.sh): every rank on GPU 0, gloo
+    # for the collectives (RCCL refuses two ranks on one device).  Never what the driver runs.
+    share_gpu = os.environ.get("CARL_BENCH_SHARE_GPU") == "1"
+    backend = os.environ.get("CARL_BENCH_BACKEND", "nccl")
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    coll_dev = device if backend == "nccl" else torch.device("cpu")
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     def barrier():
         if dist is not None:
@@ -448,17 +458,17 @@ def main():
     def max_over_ranks(x):
         if dist is None:
             return x
-        t = torch.tensor([x], device=device, dtype=torch.float64)
+        t = torch.tensor([x], device=coll_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
     def gather_over_ranks(x):
         if dist is None:
             return [x]
-        t = torch.tensor([x], device=device, dtype=torch.float64)
-        out = torch.empty(world, device=device, dtype=torch.float64)
-        dist.all_gather_into_tensor(out, t)
-        return [float(v) for v in out.tolist()]
+        t = torch.tensor([x], device=coll_dev, dtype=torch.float64)
+        parts = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(parts, t)
+        return [float(v.item()) for v in parts]
 
     K, W = args.steps, args.warmup
     T = args.chunk or DEFAULT_CHUNK[args.families[0]]
@@ -478,11 +488,16 @@ def main():
     if dist is not None:
         from carl_amd.distributed import all_gather_episode_stats
 
-        all_gather_episode_stats(wl.eng)  # first call: communicator set-up, untimed
+        def stats_src():  # RCCL gathers the device vectors in place; the gloo plumbing check stages them
+            if backend == "nccl":
+                return wl.eng
+            return {k: getattr(wl.eng, k).cpu() for k in ("last_return", "last_length", "episodes_done")}
+
+        all_gather_episode_stats(stats_src())  # first call: communicator set-up, untimed
         torch.cuda.synchronize()
         barrier()
         g0 = time.perf_counter()
-        stats = all_gather_episode_stats(wl.eng)  # an RCCL failure here is fatal: it is the path under test
+        stats = all_gather_episode_stats(stats_src())  # an RCCL failure here is fatal: it is the path under test
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - g0) * 1e3
         rccl_ranks = int(stats["last_return"].numel() // max(n, 1))
@@ -561,6 +576,7 @@ def main():
                        "parallelism": f"lane-shard x{world}", "lanes_per_env": shape},
             "roofline": roofline, "cpu_baseline": cpu, "per_call": per_call, "also": also,
             "mean_last_episode_return": mean_return, "return_allgather_ms": gather_ms, "rccl_ranks": rccl_ranks,
+            "collective_backend": (backend if world > 1 else None),
             "per_rank_avg_launch_ms": per_rank_launch_ms,
         }
         print(json.dumps(line), flush=True)

@@ -792,9 +792,11 @@ def test_reference_brax_env_test_over_every_class(device):
             obs, info = env.reset()
             assert np.isfinite(obs["obs"]).all() and obs["obs"].shape == env.observation_space["obs"].shape
             seen.append(env_name)
+    # the reference's ten classes, plus this build's two opt-in variants with the joint_stiffness feature
     assert sorted(seen) == sorted(
-        "CARLBrax" + n for n in ("Ant", "Halfcheetah", "Hopper", "Humanoid", "HumanoidStandup", "InvertedDoublePendulum",
-                                 "InvertedPendulum", "Pusher", "Reacher", "Walker2d"))
+        ["CARLBrax" + n for n in ("Ant", "Halfcheetah", "Hopper", "Humanoid", "HumanoidStandup", "InvertedDoublePendulum",
+                                  "InvertedPendulum", "Pusher", "Reacher", "Walker2d")]
+        + ["CARLBraxHalfcheetahStiffness", "CARLBraxHumanoidStiffness"])
 
 
 def test_language_goals_as_the_reference_tests_them(device):
