@@ -19,7 +19,7 @@ for f in find("kt", "*kernel_stats.csv"):
     rows = list(csv.DictReader(open(f)))
     rows.sort(key=lambda r: -float(r.get("TotalDurationNs", 0) or 0))
     print(f"{'calls':>8} {'avg_us':>12} {'total_ms':>12} {'pct':>7}  name")
-    for r in rows[:12]:
+    for r in rows[:18]:
         print(f"{r['Calls']:>8} {float(r['AverageNs']) / 1e3:12.3f} {float(r['TotalDurationNs']) / 1e6:12.3f} "
               f"{float(r['Percentage']):7.2f}  {r['Name'][:110]}")
 
