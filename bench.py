@@ -557,6 +557,10 @@ def main():
             "bytes_per_unit": r2["bytes_per_unit"], "traffic": r2["traffic"],
             "mean_last_episode_return": w2.mean_last_return(), "lanes_per_env": w2.launch_shape(),
         }
+        if name == "cartpole" and rank == 0 and world == 1 and not args.no_cpu_baseline:
+            # north_star: the CartPole number "next to the reference Python step() timed on the host cores (core
+            # count stated) in the same run" -- the restatement of that loop (kind "port"), same context set
+            also[name]["cpu_baseline"] = cpu_baseline(args, "cartpole", w2.tables[0], lanes)
         del w2
         torch.cuda.empty_cache()
 

@@ -176,6 +176,8 @@ struct Pendulum {
   // PendulumEnv.step; reward from the OLD (th, thdot); never terminates
   __device__ static __forceinline__ bool step(const Params& p, float (&s)[S], Aux& aux, float action,
                                               float /*noise*/, int /*elapsed*/, float& reward) {
+    // (every rounding spelled out, no implicit contraction: see CartPole::step)
+#pragma clang fp contract(off)
     const float max_speed = 8.0f, max_torque = 2.0f;
     const float th = s[0], thdot = s[1];
     const float u = fminf(fmaxf(action, -max_torque), max_torque);
@@ -187,10 +189,12 @@ struct Pendulum {
     // differ by 4 pi e), so no fix-up is needed for the cost
     const float r = __fmaf_rn(-floorf(y * inv_two_pi), two_pi, y);
     const float an = r - kPi;
-    const float costs = an * an + 0.1f * (thdot * thdot) + 0.001f * (u * u);
-    float newthdot = thdot + (p.c_sin * aux.sn + p.c_u * u) * p.dt;
+    // costs = an^2 + 0.1 thdot^2 + 0.001 u^2
+    const float costs = __fmaf_rn(an, an, __fmaf_rn(0.1f, thdot * thdot, 0.001f * (u * u)));
+    // newthdot = thdot + (3 g / (2 l) sin th + 3 / (m l^2) u) dt
+    float newthdot = __fmaf_rn(__fmaf_rn(p.c_sin, aux.sn, p.c_u * u), p.dt, thdot);
     newthdot = fminf(fmaxf(newthdot, -max_speed), max_speed);
-    s[0] = th + newthdot * p.dt;
+    s[0] = __fmaf_rn(newthdot, p.dt, th);
     s[1] = newthdot;
     sincos_fast(s[0], aux.sn, aux.cs);
     reward = -costs;
@@ -513,8 +517,10 @@ struct MountainCar {
   // MountainCarEnv.step
   __device__ static __forceinline__ bool step(const Params& p, float (&s)[S], Aux&, int action, float /*noise*/,
                                               int /*elapsed*/, float& reward) {
+#pragma clang fp contract(off)
     float position = s[0], velocity = s[1];
-    velocity += (float)(action - 1) * p.force + cos_fast(3.0f * position) * (-p.gravity);
+    // velocity += (action - 1) force + cos(3 position) (-gravity)     (roundings spelled out: see CartPole::step)
+    velocity = __fmaf_rn(cos_fast(3.0f * position), -p.gravity, __fmaf_rn((float)(action - 1), p.force, velocity));
     velocity = fminf(fmaxf(velocity, -p.max_speed), p.max_speed);
     position += velocity;
     position = fminf(fmaxf(position, p.min_position), p.max_position);
@@ -564,9 +570,11 @@ struct MountainCarCont {
   // Continuous_MountainCarEnv.step (gravity literal 0.0025; penalty on the UNclipped action)
   __device__ static __forceinline__ bool step(const Params& p, float (&s)[S], Aux&, float action, float /*noise*/,
                                               int /*elapsed*/, float& reward) {
+#pragma clang fp contract(off)
     float position = s[0], velocity = s[1];
     const float force = fminf(fmaxf(action, -1.0f), 1.0f);
-    velocity += force * p.power - 0.0025f * cos_fast(3.0f * position);
+    // velocity += force power - 0.0025 cos(3 position)                (roundings spelled out: see CartPole::step)
+    velocity = __fmaf_rn(-0.0025f, cos_fast(3.0f * position), __fmaf_rn(force, p.power, velocity));
     velocity = (velocity > p.max_speed) ? p.max_speed : velocity;
     velocity = (velocity < -p.max_speed) ? -p.max_speed : velocity;
     position += velocity;
@@ -574,7 +582,7 @@ struct MountainCarCont {
     position = (position < p.min_position) ? p.min_position : position;
     if (position == p.min_position && velocity < 0.0f) velocity = 0.0f;
     const bool terminated = (position >= p.goal_position) && (velocity >= p.goal_velocity);
-    reward = (terminated ? 100.0f : 0.0f) - (action * action) * 0.1f;
+    reward = __fmaf_rn(-(action * action), 0.1f, terminated ? 100.0f : 0.0f);
     s[0] = position;
     s[1] = velocity;
     return terminated;
