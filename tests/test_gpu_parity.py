@@ -562,3 +562,45 @@ def test_staged_rollout_without_optional_outputs_equals_repeated_step(fam, T, n,
     assert int(e1.episodes_done.sum()) == n_done
     if max_steps:
         assert n_done >= n * (T // max_steps)
+
+
+def test_full_size_cartpole_65536_dense_done_path_properties(device):
+    """north_star's workload at full size: CARLCartPole x 65 536 sampled contexts, 250 fused steps, random policy
+    (an episode ends every ~22 steps, so the dense done handling of the PLAIN staged rollout runs on every
+    step).  (i) the PLAIN kernel (no terminal observations) equals the generic kernel (terminal observations
+    requested: the branchy `finish_episodes` path) bit for bit in every output and counter; (ii) size-independent
+    identities: reward is 1 on every step, an episode's return equals its length, the done flags add up to the
+    finished-episode counters, elapsed + finished lengths = T per lane, a terminal observation is out of bounds
+    exactly when `terminated` is set, and every reset observation lies inside the CARL init box."""
+    fam, n, T = O.CARTPOLE, 65536, 250
+    rng = np.random.default_rng(3)
+    table = random_table(fam, rng, n)
+    acts = torch.as_tensor(random_actions(fam, rng, (T, n)), device=device)
+    kw = dict(selector=O.SEL_STATIC, seed=21, ctx_idx0=np.arange(n))
+    e1 = _engine(fam, table, n, device, **kw)
+    e2 = _engine(fam, table, n, device, **kw)
+    e1.reset()
+    e2.reset()
+    o1 = e1.rollout(acts)                                      # PLAIN + dense
+    o2 = e2.rollout(acts, e2.alloc_rollout(T, final_obs=True))  # generic done path
+    for k in ("obs", "reward", "terminated", "truncated"):
+        assert torch.equal(o1[k], o2[k]), k
+    for k in ("state", "elapsed", "episode", "n_calls", "ep_return", "last_return", "last_length", "episodes_done"):
+        assert torch.equal(getattr(e1, k), getattr(e2, k)), k
+    done = (o1["terminated"] | o1["truncated"]).bool()
+    assert float(o1["reward"].min()) == 1.0 and float(o1["reward"].max()) == 1.0
+    assert torch.equal(done.sum(0).to(torch.int32), e1.episodes_done)
+    assert 8 < T * n / int(done.sum()) < 80  # tens of steps per episode (tau 0.01 .. 0.03; a few lanes survive all 250)
+    fin = e1.episodes_done > 0
+    assert torch.equal(e1.last_return[fin], e1.last_length[fin].float())
+    # terminal observations: out of bounds <=> terminated (x threshold 2.4, theta threshold 12 degrees)
+    fo = o2["final_obs"][done]
+    term = o1["terminated"][done].bool()
+    oob = (fo[:, 0].abs() > 2.4) | (fo[:, 2].abs() > 12 * 2 * np.pi / 360)
+    assert torch.equal(oob, term)
+    # the observation returned on a done step is the RESET observation: inside the init box of the lane's context
+    lo = torch.as_tensor(table[:, 6], device=device, dtype=torch.float32)
+    hi = torch.as_tensor(table[:, 7], device=device, dtype=torch.float32)
+    t_idx, l_idx = done.nonzero(as_tuple=True)
+    ro = o1["obs"][t_idx, l_idx]
+    assert bool(((ro >= lo[l_idx, None]) & (ro <= hi[l_idx, None])).all())
