@@ -270,19 +270,17 @@ static __device__ __forceinline__ JointGeom joint_geometry(const carl_brax_sys_t
   g.vA_c = bc.v + cross(bc.w, g.rc_off);
   g.vA_p = bp.v + cross(bp.w, g.rp_off);
   g.e = g.A_p - g.A_c;
-  const qt rc = qmul(bc.r, f4(s.joint_rot[i]));
-  const qt rp = qmul(bp.r, f4(dv.rpl[i]));
-  g.x_c = xaxis(rc);
-  g.x_p = xaxis(rp);
-  // The relative rotation of the joint frames, and from it the axis-alignment term cross(x_c, x_p), in FLOAT64
-  // (full rate on this part; ~60 extra instructions per joint = 3-5 % of an env step).  Both are differences of
-  // O(1) quantities that come out ~1e-3: formed in float32 they carry an ABSOLUTE error of ~1e-7, which the
-  // constraint spring multiplies by k_pos * dt / inertia = 20 (Ant) .. 30 (Humanoid) per substep -- that was the
-  // largest single term of the kernel's distance from the float64 restatement (Ant, per env step, p99 of
-  // |d| / (1 + |x|): 2.2e-5 in float32, 7.1e-6 like this; tools/brax_parity_percentiles.py, profiles/r02_*).
+  // The joint frames rc = bc.r (x) joint_rot and rp = bp.r (x) rpl, their relative rotation, and from it the
+  // axis-alignment term cross(x_c, x_p), in FLOAT64 (full rate on this part; ~35 extra instructions per joint = 2-4 %
+  // of an env step; the float32 copies the rest of the phase uses are conversions of these, not a second product).
+  // The relative rotation and the axis cross product are differences of O(1) quantities that come out ~1e-3: formed
+  // in float32 they carry an ABSOLUTE error of ~1e-7, which the constraint spring multiplies by k_pos * dt / inertia
+  // = 20 (Ant) .. 30 (Humanoid) per substep -- that was the largest single term of the kernel's distance from the
+  // float64 restatement (Ant, per env step, p99 of |d| / (1 + |x|): 2.2e-5 in float32, 7.1e-6 like this;
+  // tools/brax_parity_percentiles.py, profiles/r02_*).
   // cross(x_c, x_p) = rp (x) cross(xaxis(rel), e_x) = rp (x) (0, a2, -a1): the SMALL components of xaxis(rel)
   // keep their relative accuracy.
-  qt rel;
+  qt rel, rc, rp;
   {
     const double cw = bc.r.w, cx = bc.r.x, cy = bc.r.y, cz = bc.r.z, pw = bp.r.w, px = bp.r.x, py = bp.r.y, pz = bp.r.z;
     const double jw = s.joint_rot[i][0], jx = s.joint_rot[i][1], jy = s.joint_rot[i][2], jz = s.joint_rot[i][3];
@@ -293,9 +291,12 @@ static __device__ __forceinline__ JointGeom joint_geometry(const carl_brax_sys_t
                  by = pw * ly - px * lz + py * lw + pz * lx, bz = pw * lz + px * ly - py * lx + pz * lw;  // rp
     const double rw = bw * aw + bx * ax + by * ay + bz * az, rx = bw * ax - bx * aw - by * az + bz * ay,
                  ry = bw * ay + bx * az - by * aw - bz * ax, rz = bw * az - bx * ay + by * ax - bz * aw;  // conj(rp) rc
+    rc = qt{(float)aw, (float)ax, (float)ay, (float)az};
+    rp = qt{(float)bw, (float)bx, (float)by, (float)bz};
     rel = qt{(float)rw, (float)rx, (float)ry, (float)rz};
-    // cross(x_c, x_p) = rp (x) cross(xaxis(rel), e_x) = rp (x) (0, a2, -a1) with the small components of xaxis(rel)
     const double a1 = 2.0 * (rx * ry + rw * rz), a2 = 2.0 * (rx * rz - rw * ry);
+    g.x_c = xaxis(rc);
+    g.x_p = xaxis(rp);
     g.axx = qrot(rp, V(0.0f, (float)a2, (float)-a1));
   }
   if (rel.w < 0.0f) { rel.w = -rel.w; rel.x = -rel.x; }
