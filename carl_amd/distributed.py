@@ -47,6 +47,25 @@ def shard_context_rows(values_2d, shard: LaneShard, lane_to_context_identity: bo
     return values_2d[shard.slice] if lane_to_context_identity else values_2d
 
 
+def default_context_index(n_lanes: int, lane_offset: int, n_contexts: int, round_robin: bool = False, stride: int = 1,
+                          context_offset: int | None = None):
+    """Context-table row each of a rank's lanes holds before its first reset (``VecEngine.default_ctx_idx``; pure
+    host arithmetic, int64 NumPy).  Global lane g starts on global context ``g mod C_global`` (round robin: one
+    stride earlier, so that its first reset lands there).  The rank's table may be a SHARD of the global one
+    (``shard_context_rows``): its row 0 has the global id ``context_offset``.  ``context_offset=None``: a table with
+    exactly one row per lane is this rank's own slice of a lane <-> context identity (row 0 = context
+    ``lane_offset``); any other table is the whole, replicated set (row 0 = context 0)."""
+    import numpy as np
+
+    off = context_offset
+    if off is None:
+        off = int(lane_offset) if int(n_contexts) == int(n_lanes) else 0
+    g = np.arange(int(n_lanes), dtype=np.int64) + int(lane_offset) - int(off)
+    if round_robin:
+        g = g - int(stride)
+    return np.mod(g, int(n_contexts))
+
+
 def _all_gather_1d(t: torch.Tensor, counts: list[int] | None = None) -> torch.Tensor:
     import torch.distributed as dist
 

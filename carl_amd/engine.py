@@ -176,13 +176,12 @@ class VecEngine:
         other table is the whole, replicated context set (row 0 = context 0).  With the modulo taken on the
         global id instead -- as round 1 did -- an uneven split (10 lanes over 3 ranks: offset 4, count 3) read
         row (4 + i) mod 3 and handed lanes their neighbours' contexts."""
-        off = self.context_offset
-        if off is None:
-            off = int(self.b.lane_offset) if n_contexts == self.n else 0
-        g = torch.arange(self.n, dtype=torch.int64) + int(self.b.lane_offset) - off
-        if self.b.selector == _lib.SEL_ROUND_ROBIN:
-            g = g - int(self.b.selector_stride)
-        return (g % n_contexts).to(torch.int32)
+        from carl_amd.distributed import default_context_index
+
+        idx = default_context_index(self.n, int(self.b.lane_offset), n_contexts,
+                                    self.b.selector == _lib.SEL_ROUND_ROBIN, int(self.b.selector_stride),
+                                    self.context_offset)
+        return torch.as_tensor(idx).to(torch.int32)
 
     def set_contexts(self, ctx_table, ctx_idx0=None) -> None:
         """Upload a context set ([C, F], reference feature order) and (re)assign lanes.

@@ -106,3 +106,28 @@ def test_world2_gloo_sharded_equals_unsharded():
     fin = full.episodes_done > 0
     assert summ["lanes_finished"] == fin.sum() and summ["episodes"] == full.episodes_done.sum()
     assert summ["mean_return"] == pytest.approx(float(full.last_return[fin].mean()), rel=1e-6)
+
+
+def test_default_lane_context_assignment_is_shard_aware():
+    """10 lanes over 3 ranks (4 / 3 / 3).  With the context table sharded like the lanes (one row per
+    lane) every rank's lanes start on their OWN rows 0..count-1; with the table replicated they start on
+    ``global lane mod C``; an explicit context_offset describes any other slice.  (Round 1 took the modulo of the
+    global id by the LOCAL row count: rank 1 -- offset 4, 3 rows -- read rows (4 + i) mod 3 = 1, 2, 0.)"""
+    import numpy as np
+
+    from carl_amd.distributed import default_context_index, lane_shard
+
+    N = 10
+    seen = []
+    for r in range(3):
+        sh = lane_shard(N, r, 3)
+        idx = default_context_index(sh.count, sh.offset, sh.count)            # sharded table: identity
+        np.testing.assert_array_equal(idx, np.arange(sh.count))
+        rep = default_context_index(sh.count, sh.offset, 7)                   # replicated table of 7 contexts
+        np.testing.assert_array_equal(rep, (np.arange(sh.count) + sh.offset) % 7)
+        seen += list(sh.offset + idx)
+        rr = default_context_index(sh.count, sh.offset, 7, round_robin=True, stride=2)
+        np.testing.assert_array_equal((rr + 2) % 7, rep)                      # first reset lands on g mod C
+    assert seen == list(range(N))                                             # every global context exactly once
+    # an explicit offset: the rank holds rows [8, 16) of the global set and lanes [10, 14)
+    np.testing.assert_array_equal(default_context_index(4, 10, 8, context_offset=8), [2, 3, 4, 5])
