@@ -374,16 +374,20 @@ struct AcrobotT {
     // d1 = m1 lc1^2 + m2 (l1^2 + lc2^2 + 2 l1 lc2 cos t2) + I1 + I2;  d2 = m2 (lc2^2 + l1 lc2 cos t2) + I2
     // phi2 = m2 lc2 g sin(t1 + t2);  phi1 = -m2 l1 lc2 w2^2 sin t2 - 2 m2 l1 lc2 w2 w1 sin t2 + (m1 lc1 + m2 l1) g sin t1 + phi2
     // ddtheta2 = (a + d2 / d1 phi1 - m2 l1 lc2 w1^2 sin t2 - phi2) / (m2 lc2^2 + I2 - d2^2 / d1);  ddtheta1 = -(d2 ddtheta2 + phi1) / d1
+    // The two lines are the 2x2 system  [d1 d2; d2 D] (ddtheta1, ddtheta2) = (-phi1, rhs2)  with
+    // rhs2 = a - A sin t2 w1^2 - phi2, solved by Cramer's rule with ONE reciprocal (of det = d1 D - d2^2) instead of
+    // the reference's two divisions: ddtheta2 = (d1 rhs2 + d2 phi1) / det, ddtheta1 = -(d2 rhs2 + D phi1) / det.
     const Real s12 = s1 * c2 + c1 * s2;
-    const Real d1 = p.E + (Real)2.0 * p.A * c2;
-    const Real d2 = p.D + p.A * c2;
+    const Real ac2 = p.A * c2;
+    const Real d1 = p.E + (Real)2.0 * ac2;
+    const Real d2 = p.D + ac2;
     const Real phi2 = p.C * s12;
     const Real as2 = p.A * s2;
     const Real phi1 = p.B * s1 + phi2 - (as2 * dtheta2) * (dtheta2 + (Real)2.0 * dtheta1);
-    const Real inv_d1 = recip(d1);
-    const Real w = d2 * inv_d1;
-    const Real ddtheta2 = (a + w * phi1 - (as2 * dtheta1) * dtheta1 - phi2) * recip(p.D - d2 * w);
-    const Real ddtheta1 = -(d2 * ddtheta2 + phi1) * inv_d1;
+    const Real rhs2 = a - (as2 * dtheta1) * dtheta1 - phi2;
+    const Real rdet = recip(d1 * p.D - d2 * d2);
+    const Real ddtheta2 = (d1 * rhs2 + d2 * phi1) * rdet;
+    const Real ddtheta1 = -(d2 * rhs2 + p.D * phi1) * rdet;
     return Deriv{dtheta1, dtheta2, ddtheta1, ddtheta2};
   }
 
