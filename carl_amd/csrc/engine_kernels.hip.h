@@ -972,6 +972,19 @@ __global__ void __launch_bounds__(kStagedThreads) rollout_staged_kernel(const ca
       }
       if constexpr (!(PLAIN && dense_done_of<Fam>::value)) {
       if constexpr (predraw_of<Fam>::value) predraw<Fam>(b, glane, r);
+      if (PLAIN && steps == kStageChunk) {
+        // full chunk, lean configuration: the chunk's actions in registers (one LDS wait per chunk) and the eight
+        // steps unrolled (record addresses become immediates, no loop control, no per-step action read): A/B on
+        // one box Pendulum 271 -> 264, MountainCar 254 -> 230, Acrobot 941 -> 910 ns/step, same bits
+        Action acts[kStageChunk];
+#pragma unroll
+        for (int u = 0; u < kStageChunk; ++u) acts[u] = my[u * kRolloutLanes];
+#pragma unroll
+        for (int u = 0; u < kStageChunk; ++u) {
+          const SK sink{rec + (size_t)u * SK::kStepBytes, final_base, n * Fam::D, t0 + u, (int)threadIdx.x};
+          step_lane<Fam, ctx_t<LDSCTX>, true, SK, PLAIN>(b, ctx, sink, max_steps, true, lane, glane, acts[u], r);
+        }
+      } else {
       Action a_next = my[0];
       settle(a_next);  // arrive before the loop: its head then only waits for the read issued one
                        // step earlier (lgkmcnt(#record writes)), not for the record writes
@@ -980,6 +993,7 @@ __global__ void __launch_bounds__(kStagedThreads) rollout_staged_kernel(const ca
         a_next = my[min(u + 1, kStageChunk - 1) * kRolloutLanes];
         const SK sink{rec + (size_t)u * SK::kStepBytes, final_base, n * Fam::D, t0 + u, (int)threadIdx.x};
         step_lane<Fam, ctx_t<LDSCTX>, true, SK, PLAIN>(b, ctx, sink, max_steps, true, lane, glane, a, r);
+      }
       }
       }
     } else if (loader) {
