@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of CartPole variants on one box: tools/ab_cartpole.sh VARIANT...  (libs in gpurun_in/libcarl_<V>.so; "base" = product lib)
+# A/B of library variants for one family (ENV=...) on one box: tools/ab_family.sh VARIANT...  (libs in gpurun_in/libcarl_<V>.so; "base" = product lib)
 export CARL_AMD_NO_BUILD=1
 for rep in 1 2; do
 for v in base "$@"; do
