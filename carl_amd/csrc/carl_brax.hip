@@ -97,6 +97,8 @@ int validate_brax(const carl_batch_t* b, const carl_brax_sys_t* sd, const carl_b
   }
   if (b->fin_count != nullptr && (b->fin_capacity <= 0 || !b->fin_lane || !b->fin_return || !b->fin_length))
     return fail(CARL_ERR_INVALID_ARGUMENT, "%s: finished-episode log is incomplete", who);
+  if ((b->flags & CARL_FLAG_AUTORESET_FIRST_STATE) && b->first_state == nullptr)
+    return fail(CARL_ERR_INVALID_ARGUMENT, "%s: CARL_FLAG_AUTORESET_FIRST_STATE needs carl_batch_t::first_state", who);
   return 0;
 }
 

@@ -144,3 +144,22 @@ def test_brax_and_sampler_entry_points_validate_arguments():
     spec[0].kind, spec[0].lower, spec[0].upper = _lib.FEAT_UNIFORM_FLOAT, 2.0, 1.0
     assert lib.carl_sample_contexts(C.addressof(spec), spec, 1, 4, 4, 0, 0, 1, None) == -1
     assert b"lower" in lib.carl_last_error()
+
+
+def test_first_state_flag_needs_its_buffer():
+    """CARL_FLAG_AUTORESET_FIRST_STATE without carl_batch_t::first_state is refused (no silent fall-back to the
+    re-draw rule); checked on the host before anything is launched, so it runs without a GPU"""
+    import ctypes as C
+
+    from carl_amd import _lib
+    from carl_amd.envs.brax.models import ant_sys
+
+    lib = _lib.load()
+    b = _lib.Batch()
+    b.n_lanes, b.n_contexts, b.ctx_stride = 8, 1, 1
+    for f in ("state", "elapsed", "ctx_idx", "episode", "n_calls", "ep_return", "ctx_table"):
+        setattr(b, f, 0x1000)  # never dereferenced: validation fails first
+    b.flags = _lib.FLAG_AUTORESET | _lib.FLAG_AUTORESET_FIRST_STATE
+    s = ant_sys(["gravity", "friction", "elasticity", "ang_damping", "mass_torso", "viscosity"])
+    rc = lib.carl_brax_reset(C.byref(b), 0x1000, C.byref(s), None, None, None)
+    assert rc == -1 and b"first_state" in lib.carl_last_error()
