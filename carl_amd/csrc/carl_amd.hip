@@ -171,11 +171,31 @@ int launch_step(const carl_batch_t* b, const carl_step_io_t* io, int n_steps, hi
       // every family opts in: the leaner code also helps the step loop's register allocation)
       const bool keeps_context = b->selector == CARL_SEL_STATIC || b->selector == CARL_SEL_HOST;
       const size_t table_bytes = (size_t)Fam::F * b->n_contexts * sizeof(float);
-      if (keeps_context && b->fin_count == nullptr && io->final_obs == nullptr) {
+      const bool lean = b->fin_count == nullptr && io->final_obs == nullptr;
+      const bool table_fits = lds && sh_staged + table_bytes <= 160 * 1024;
+      bool picked = false;
+      if (keeps_context && lean) {
         // none of the optional features is on: the done path compiled without them
         kern = a64 ? static_cast<kern_t>(carl::rollout_staged_kernel<Fam, true, true>)
                    : static_cast<kern_t>(carl::rollout_staged_kernel<Fam, false, true>);
-      } else if (!keeps_context && lds && sh_staged + table_bytes <= 160 * 1024) {
+        picked = true;
+      }
+      if constexpr (carl::dense_done_of<Fam>::value) {
+        if (!picked && !keeps_context && lean) {
+          // short-episode family, lanes change contexts on reset (round robin -- the reference's default selector --
+          // or random): dense done handling with the next context's parameters gathered per chunk
+          if (table_fits) {
+            kern = a64 ? static_cast<kern_t>(carl::rollout_staged_kernel<Fam, true, true, true, true>)
+                       : static_cast<kern_t>(carl::rollout_staged_kernel<Fam, false, true, true, true>);
+            sh_staged += table_bytes;
+          } else {
+            kern = a64 ? static_cast<kern_t>(carl::rollout_staged_kernel<Fam, true, true, false, true>)
+                       : static_cast<kern_t>(carl::rollout_staged_kernel<Fam, false, true, false, true>);
+          }
+          picked = true;
+        }
+      }
+      if (!picked && !keeps_context && table_fits) {
         // lanes change contexts on reset and the table is small: re-gather from LDS, not from HBM
         kern = a64 ? static_cast<kern_t>(carl::rollout_staged_kernel<Fam, true, false, true>)
                    : static_cast<kern_t>(carl::rollout_staged_kernel<Fam, false, false, true>);

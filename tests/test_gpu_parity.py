@@ -604,3 +604,38 @@ def test_full_size_cartpole_65536_dense_done_path_properties(device):
     t_idx, l_idx = done.nonzero(as_tuple=True)
     ro = o1["obs"][t_idx, l_idx]
     assert bool(((ro >= lo[l_idx, None]) & (ro <= hi[l_idx, None])).all())
+
+
+@pytest.mark.parametrize("selector", [O.SEL_ROUND_ROBIN, O.SEL_RANDOM], ids=["round_robin", "random"])
+@pytest.mark.parametrize("n_ctx", [37, 3000], ids=["lds_table", "global_table"])
+@pytest.mark.parametrize("T,n,max_steps", [(41, 1024, 5), (200, 4096, 0)])
+def test_cartpole_dense_rollout_with_moving_contexts_equals_repeated_step(selector, n_ctx, T, n, max_steps, device):
+    """The reference's DEFAULT selector is round robin: every reset moves the lane to another context.  The lean
+    fused rollout of CartPole handles that inside its dense done path (selector rule applied and the next context's
+    parameters gathered once per chunk, `rollout_staged_kernel<..., PLAIN, LDSCTX, MOVES>`; small tables from LDS,
+    large ones from HBM) -- every output, the context ids, the context observation and every counter equal T
+    per-call steps of an engine with all optional features on, through several resets per 8-step chunk."""
+    fam = O.CARTPOLE
+    rng = np.random.default_rng(n_ctx + T)
+    table = random_table(fam, rng, n_ctx)
+    table[:, 6] = rng.uniform(-0.15, -0.05, n_ctx)  # the init box differs per context too
+    table[:, 7] = rng.uniform(0.05, 0.15, n_ctx)
+    table = table.astype(np.float32).astype(np.float64)
+    acts = torch.as_tensor(random_actions(fam, rng, (T, n)), device=device)
+    kw = dict(selector=selector, selector_stride=3, seed=17)
+    if max_steps:
+        kw["max_episode_steps"] = max_steps
+    e1 = _engine(fam, table, n, device, **kw)                       # lean: dense + MOVES
+    e2 = _engine(fam, table, n, device, fin_capacity=1 << 16, **kw)  # everything on, per-call kernel
+    e1.reset()
+    e2.reset()
+    out = e1.rollout(acts)
+    for t in range(T):
+        obs, rew, term, trunc = e2.step(acts[t])
+        assert torch.equal(out["obs"][t], obs) and torch.equal(out["reward"][t], rew), t
+        assert torch.equal(out["terminated"][t], term) and torch.equal(out["truncated"][t], trunc), t
+    for name in ("state", "elapsed", "ctx_idx", "episode", "n_calls", "ep_return", "last_return", "last_length",
+                 "episodes_done", "ctx_obs"):
+        assert torch.equal(getattr(e1, name), getattr(e2, name)), name
+    assert int(e1.episodes_done.sum()) > n  # contexts did move
+    assert len(torch.unique(e1.ctx_idx)) > min(n_ctx, n) // 4
