@@ -181,17 +181,24 @@ int launch_step(const carl_batch_t* b, const carl_step_io_t* io, int n_steps, hi
         picked = true;
       }
       if constexpr (carl::dense_done_of<Fam>::value) {
-        if (!picked && !keeps_context && lean) {
-          // short-episode family, lanes change contexts on reset (round robin -- the reference's default selector --
-          // or random): dense done handling with the next context's parameters gathered per chunk
-          if (table_fits) {
-            kern = a64 ? static_cast<kern_t>(carl::rollout_staged_kernel<Fam, true, true, true, true>)
-                       : static_cast<kern_t>(carl::rollout_staged_kernel<Fam, false, true, true, true>);
-            sh_staged += table_bytes;
+        // short-episode family: the dense done handling also covers lanes that change contexts on reset (round
+        // robin -- the reference's default selector -- or random; the next context's parameters are gathered per
+        // chunk) and terminal observations; only the finished-episode log still takes the generic path
+        if (!picked && b->fin_count == nullptr) {
+          const bool moves = !keeps_context, fin = io->final_obs != nullptr, tl = moves && table_fits;
+          using carl::rollout_staged_kernel;
+#define CARL_DENSE(A, L, M, F) static_cast<kern_t>(rollout_staged_kernel<Fam, A, true, L, M, F>)
+          if (a64) {
+            kern = tl ? (fin ? CARL_DENSE(true, true, true, true) : CARL_DENSE(true, true, true, false))
+                      : moves ? (fin ? CARL_DENSE(true, false, true, true) : CARL_DENSE(true, false, true, false))
+                              : CARL_DENSE(true, false, false, true);
           } else {
-            kern = a64 ? static_cast<kern_t>(carl::rollout_staged_kernel<Fam, true, true, false, true>)
-                       : static_cast<kern_t>(carl::rollout_staged_kernel<Fam, false, true, false, true>);
+            kern = tl ? (fin ? CARL_DENSE(false, true, true, true) : CARL_DENSE(false, true, true, false))
+                      : moves ? (fin ? CARL_DENSE(false, false, true, true) : CARL_DENSE(false, false, true, false))
+                              : CARL_DENSE(false, false, false, true);
           }
+#undef CARL_DENSE
+          if (tl) sh_staged += table_bytes;
           picked = true;
         }
       }

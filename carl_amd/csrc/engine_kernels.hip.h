@@ -403,7 +403,9 @@ __device__ __forceinline__ void dense_draw(const carl_batch_t& b, const Ctx& ctx
   }
 }
 
-template <class Fam, class Ctx, bool MOVES, class Sink>
+// FINAL: terminal observations requested (io.final_obs): a finishing lane stores its pre-reset observation straight
+// to HBM (one exec-masked store; compute waves issue no loads, so nothing queues behind it).
+template <class Fam, class Ctx, bool MOVES, bool FINAL, class Sink>
 __device__ __forceinline__ void step_dense(const carl_batch_t& b, const Ctx& ctx, const Sink& cur, int max_steps,
                                            bool autoreset, uint64_t glane, typename Fam::Action action,
                                            LaneRegs<Fam>& r, DenseNext<Fam>& nx) {
@@ -420,6 +422,13 @@ __device__ __forceinline__ void step_dense(const carl_batch_t& b, const Ctx& ctx
   const unsigned long long again = dm & ~nx.ok_mask;
   if (__builtin_expect(again != 0ull, 0)) dense_draw<Fam, Ctx, MOVES>(b, ctx, glane, r, again, nx);
   const bool rs = done && autoreset;
+  if constexpr (FINAL) {
+    if (rs && r.valid) {  // (as finish_episodes: with auto-reset, the done lanes of the batch)
+      float fo[Fam::D];
+      Fam::observe(r.s, r.aux, fo);
+      store_obs<Fam::D>(cur.final_obs_ptr(), 0, fo);
+    }
+  }
   r.fin_return = done ? r.ep_return : r.fin_return;
   r.fin_length = done ? r.elapsed : r.fin_length;
   r.n_new_episodes += done ? 1 : 0;
@@ -910,7 +919,8 @@ __device__ __forceinline__ void zero_flag_rows(char* out_buf, int l, int which) 
 // lane that moves to another context -- on the done path of nearly every step for CartPole -- is an LDS
 // read instead of an HBM / L2 round trip the whole wave waits for.
 // MOVES (with PLAIN, kDenseDone families): the dense done handling with context changes on reset (see dense_draw).
-template <class Fam, bool A64, bool PLAIN = false, bool LDSCTX = false, bool MOVES = false>
+// FINAL (with PLAIN, kDenseDone families): ... and with terminal observations written (see step_dense).
+template <class Fam, bool A64, bool PLAIN = false, bool LDSCTX = false, bool MOVES = false, bool FINAL = false>
 __global__ void __launch_bounds__(kStagedThreads) rollout_staged_kernel(const carl_batch_t b, const carl_step_io_t io,
                                                                         const int n_steps) {
   extern __shared__ float lds_dyn[];
@@ -984,17 +994,19 @@ __global__ void __launch_bounds__(kStagedThreads) rollout_staged_kernel(const ca
 #endif
 #pragma unroll
           for (int u = 0; u < kStageChunk; ++u) {
-            const SK sink{rec + (size_t)u * SK::kStepBytes, nullptr, n * Fam::D, t0 + u, (int)threadIdx.x};
-            step_dense<Fam, ctx_t<LDSCTX>, MOVES, SK>(b, ctx, sink, max_steps, autoreset, glane, acts[u], r, nx);
+            const SK sink{rec + (size_t)u * SK::kStepBytes, FINAL ? final_base : nullptr, n * Fam::D, t0 + u,
+                          (int)threadIdx.x};
+            step_dense<Fam, ctx_t<LDSCTX>, MOVES, FINAL, SK>(b, ctx, sink, max_steps, autoreset, glane, acts[u], r, nx);
           }
         } else {  // the rollout's last, ragged chunk
 #pragma unroll 1
           for (int u = 0; u < steps; ++u) {
-            const SK sink{rec + (size_t)u * SK::kStepBytes, nullptr, n * Fam::D, t0 + u, (int)threadIdx.x};
+            const SK sink{rec + (size_t)u * SK::kStepBytes, FINAL ? final_base : nullptr, n * Fam::D, t0 + u,
+                          (int)threadIdx.x};
             Action a = acts[0];
 #pragma unroll
             for (int k = 1; k < kStageChunk; ++k) a = (u == k) ? acts[k] : a;
-            step_dense<Fam, ctx_t<LDSCTX>, MOVES, SK>(b, ctx, sink, max_steps, autoreset, glane, a, r, nx);
+            step_dense<Fam, ctx_t<LDSCTX>, MOVES, FINAL, SK>(b, ctx, sink, max_steps, autoreset, glane, a, r, nx);
           }
         }
       }

@@ -566,9 +566,10 @@ def test_staged_rollout_without_optional_outputs_equals_repeated_step(fam, T, n,
 
 def test_full_size_cartpole_65536_dense_done_path_properties(device):
     """north_star's workload at full size: CARLCartPole x 65 536 sampled contexts, 250 fused steps, random policy
-    (an episode ends every ~22 steps, so the dense done handling of the PLAIN staged rollout runs on every
-    step).  (i) the PLAIN kernel (no terminal observations) equals the generic kernel (terminal observations
-    requested: the branchy `finish_episodes` path) bit for bit in every output and counter; (ii) size-independent
+    (an episode ends every ~22 steps, so the dense done handling of the staged rollout runs on every step).
+    (i) the lean kernel (no terminal observations) equals the kernel with terminal observations, and -- a third
+    engine with the finished-episode log on -- the generic kernel (the branchy `finish_episodes` path), bit for
+    bit in every output and counter; (ii) size-independent
     identities: reward is 1 on every step, an episode's return equals its length, the done flags add up to the
     finished-episode counters, elapsed + finished lengths = T per lane, a terminal observation is out of bounds
     exactly when `terminated` is set, and every reset observation lies inside the CARL init box."""
@@ -581,12 +582,18 @@ def test_full_size_cartpole_65536_dense_done_path_properties(device):
     e2 = _engine(fam, table, n, device, **kw)
     e1.reset()
     e2.reset()
-    o1 = e1.rollout(acts)                                      # PLAIN + dense
-    o2 = e2.rollout(acts, e2.alloc_rollout(T, final_obs=True))  # generic done path
+    e3 = _engine(fam, table, n, device, fin_capacity=1 << 22, **kw)
+    e3.reset()
+    o1 = e1.rollout(acts)                                      # dense, lean
+    o2 = e2.rollout(acts, e2.alloc_rollout(T, final_obs=True))  # dense, terminal observations
+    o3 = e3.rollout(acts, e3.alloc_rollout(T, final_obs=True))  # generic done path (finished-episode log on)
     for k in ("obs", "reward", "terminated", "truncated"):
-        assert torch.equal(o1[k], o2[k]), k
+        assert torch.equal(o1[k], o2[k]) and torch.equal(o1[k], o3[k]), k
+    assert torch.equal(o2["final_obs"][(o1["terminated"] | o1["truncated"]).bool()],
+                       o3["final_obs"][(o1["terminated"] | o1["truncated"]).bool()])
     for k in ("state", "elapsed", "episode", "n_calls", "ep_return", "last_return", "last_length", "episodes_done"):
-        assert torch.equal(getattr(e1, k), getattr(e2, k)), k
+        assert torch.equal(getattr(e1, k), getattr(e2, k)) and torch.equal(getattr(e1, k), getattr(e3, k)), k
+    assert int(e3.fin_count) == int(e1.episodes_done.sum())
     done = (o1["terminated"] | o1["truncated"]).bool()
     assert float(o1["reward"].min()) == 1.0 and float(o1["reward"].max()) == 1.0
     assert torch.equal(done.sum(0).to(torch.int32), e1.episodes_done)
@@ -608,8 +615,9 @@ def test_full_size_cartpole_65536_dense_done_path_properties(device):
 
 @pytest.mark.parametrize("selector", [O.SEL_ROUND_ROBIN, O.SEL_RANDOM], ids=["round_robin", "random"])
 @pytest.mark.parametrize("n_ctx", [37, 3000], ids=["lds_table", "global_table"])
+@pytest.mark.parametrize("final", [False, True], ids=["lean", "final_obs"])
 @pytest.mark.parametrize("T,n,max_steps", [(41, 1024, 5), (200, 4096, 0)])
-def test_cartpole_dense_rollout_with_moving_contexts_equals_repeated_step(selector, n_ctx, T, n, max_steps, device):
+def test_cartpole_dense_rollout_with_moving_contexts_equals_repeated_step(selector, n_ctx, T, n, max_steps, final, device):
     """The reference's DEFAULT selector is round robin: every reset moves the lane to another context.  The lean
     fused rollout of CartPole handles that inside its dense done path (selector rule applied and the next context's
     parameters gathered once per chunk, `rollout_staged_kernel<..., PLAIN, LDSCTX, MOVES>`; small tables from LDS,
@@ -629,11 +637,14 @@ def test_cartpole_dense_rollout_with_moving_contexts_equals_repeated_step(select
     e2 = _engine(fam, table, n, device, fin_capacity=1 << 16, **kw)  # everything on, per-call kernel
     e1.reset()
     e2.reset()
-    out = e1.rollout(acts)
+    out = e1.rollout(acts, e1.alloc_rollout(T, final_obs=final))  # final: terminal observations, same dense path
     for t in range(T):
         obs, rew, term, trunc = e2.step(acts[t])
         assert torch.equal(out["obs"][t], obs) and torch.equal(out["reward"][t], rew), t
         assert torch.equal(out["terminated"][t], term) and torch.equal(out["truncated"][t], trunc), t
+        if final:
+            d = (term | trunc).bool()
+            assert torch.equal(out["final_obs"][t][d], e2.final_obs[d]), t
     for name in ("state", "elapsed", "ctx_idx", "episode", "n_calls", "ep_return", "last_return", "last_length",
                  "episodes_done", "ctx_obs"):
         assert torch.equal(getattr(e1, name), getattr(e2, name)), name
