@@ -571,7 +571,9 @@ def main():
             "value": n * world * T * K / elapsed, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
             "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            # arithmetic type of the path (state in HBM is float32 throughout): Acrobot's RK4 runs in float64
+            "dtype": ("f32" if "acrobot" not in args.families else "f64" if set(args.families) == {"acrobot"} else "f32/f64"),
+            "data": "synthetic",
             "config": {"workload": f"{fam_txt} contexts/GPU, StaticSelector lane<->context, auto-reset; one step = one "
                                    f"fused carl_rollout launch of {T} env steps of every lane, full transition written "
                                    f"per env step; {args.buffer_sets} rotating action/output buffer sets",
