@@ -15,7 +15,7 @@ import torch  # noqa: F401  (must precede the CDLL load, see module docstring)
 
 from carl_amd import build as _build
 
-CARL_ABI_VERSION = 4
+CARL_ABI_VERSION = 5
 CARL_MAX_CTX_OBS = 32
 
 # carl_family_t
@@ -61,6 +61,7 @@ class StepIO(C.Structure):
     _fields_ = [
         ("action", _vp), ("action_dtype", C.c_int32), ("reserved", C.c_int32),
         ("obs", _vp), ("reward", _vp), ("terminated", _vp), ("truncated", _vp), ("final_obs", _vp), ("done", _vp),
+        ("branch_sig", _vp),
     ]
 
 
@@ -139,6 +140,7 @@ BRAX_MAX_PAIR = 8
 (BRAX_ANT, BRAX_HALFCHEETAH, BRAX_HUMANOID, BRAX_HOPPER, BRAX_WALKER2D, BRAX_INVERTED_PENDULUM, BRAX_HUMANOIDSTANDUP, BRAX_INVERTED_DOUBLE_PENDULUM,
  BRAX_REACHER, BRAX_PUSHER) = range(10)
 BRAX_LINK_STATE = 13
+BRAX_LINK_RECORD = 20  # floats per link in HBM: pose head 7 | pose tail 7 | velocities 6 (include/carl_amd.h)
 _f, _i = C.c_float, C.c_int32
 
 

@@ -39,16 +39,20 @@ class BraxVecEngine(VecEngine):
         self.sys = sys_table
         self._n_features = int(n_features)
         kw.pop("cartpole_recompute", None)
-        self.goal_pos = self.success = self.first_state = None
+        self.goal_pos = self.success = self.first_state = self.branch_sig = None
         self.autoreset_mode = autoreset_mode
+        branch_record = bool(kw.pop("branch_record", False))
         super().__init__(-1, ctx_table, n_lanes, device, **kw)
         if autoreset_mode == "first_state":
             self.b.flags |= _lib.FLAG_AUTORESET_FIRST_STATE
             self.first_state = torch.zeros((self.n, self.S), dtype=torch.float32, device=self.device)
-        # Brax state is env-major in HBM ([N][13 L], one contiguous record per env: include/carl_amd.h);
-        # ``self.state`` stays the [13 L, N] VIEW the classic-control engine exposes (same indexing).
+        # Brax state is env-major in HBM ([N][20 L], one contiguous record per env: pose heads 7 L | pose tails
+        # 7 L | velocities 6 L, include/carl_amd.h); ``self.state`` is the [20 L, N] VIEW of that storage (the
+        # classic-control engine's indexing); ``state64()`` returns it as float64 [N, L, 13].
         self._state_storage = torch.zeros((self.n, self.S), dtype=torch.float32, device=self.device)
         self.state = self._state_storage.t()
+        if branch_record:  # per-step hash of the physics' discrete decisions (carl_step_io_t::branch_sig)
+            self.branch_sig = torch.zeros((self.n, 2), dtype=torch.int32, device=self.device)
         self._sync_pointers()
         if self.sys.goal_mode:  # BraxWalkerGoalWrapper state: integrated (x, y) + per-step success flag
             self.goal_pos = torch.zeros((2, self.n), dtype=torch.float32, device=self.device)
@@ -61,7 +65,7 @@ class BraxVecEngine(VecEngine):
 
     def _family_info(self):
         s = self.sys
-        return _BraxInfo(_lib.BRAX_LINK_STATE * s.n_links, s.obs_dim, self._n_features, s.n_act, 0, 0,
+        return _BraxInfo(_lib.BRAX_LINK_RECORD * s.n_links, s.obs_dim, self._n_features, s.n_act, 0, 0,
                          s.max_episode_steps, float(min(s.act_lo[: s.n_act])), float(max(s.act_hi[: s.n_act])))
 
     def _c_reset(self, mask_ptr) -> int:
@@ -79,8 +83,34 @@ class BraxVecEngine(VecEngine):
         return self.lib.carl_brax_rollout(C.byref(self.b), _ptr(self.sys_dev), C.byref(self.sys), C.byref(io),
                                           n_steps, self._stream())
 
-    def alloc_rollout(self, n_steps: int, final_obs: bool = False) -> dict:
+    # ------------------------------------------------------------------ state access
+    def state64(self) -> torch.Tensor:
+        """The envs' maximal-coordinate state as float64 ``[N, L, 13]`` (per link COM position 3, rotation 4
+        (w, x, y, z), linear velocity 3, angular velocity 3): pose = head + tail of the HBM record."""
+        L = self.sys.n_links
+        rec = self._state_storage.to(torch.float64)
+        pose = (rec[:, : 7 * L] + rec[:, 7 * L: 14 * L]).reshape(self.n, L, 7)
+        vel = rec[:, 14 * L:].reshape(self.n, L, 6)
+        return torch.cat([pose, vel], dim=2)
+
+    def state_np(self):
+        """``state64()`` on the host as ``[N, 13 L]`` float64 (the oracle's layout)"""
+        return self.state64().reshape(self.n, 13 * self.sys.n_links).cpu().numpy()
+
+    def set_state64(self, state) -> None:
+        """Inverse of ``state64``: ``[N, L, 13]`` (or ``[N, 13 L]``) float64 -> the HBM record (pose split into a
+        float32 head and tail; velocities rounded to float32)."""
+        L = self.sys.n_links
+        st = torch.as_tensor(state, dtype=torch.float64, device=self.device).reshape(self.n, L, 13)
+        pose = st[:, :, :7].reshape(self.n, 7 * L)
+        head = pose.to(torch.float32)
+        tail = (pose - head.to(torch.float64)).to(torch.float32)
+        self._state_storage.copy_(torch.cat([head, tail, st[:, :, 7:].reshape(self.n, 6 * L).to(torch.float32)], dim=1))
+
+    def alloc_rollout(self, n_steps: int, final_obs: bool = False, branch_record: bool = False) -> dict:
         out = super().alloc_rollout(n_steps, final_obs)
+        if branch_record:
+            out["branch_sig"] = torch.zeros((n_steps, self.n, 2), dtype=torch.int32, device=self.device)
         if self.sys.goal_mode:
             out["success"] = torch.zeros((n_steps, self.n), dtype=torch.uint8, device=self.device)
         return out

@@ -79,39 +79,117 @@ __device__ __forceinline__ qt qaxis(int k, float angle) {
 __host__ __device__ __forceinline__ v3 f3(const float* p) { return V(p[0], p[1], p[2]); }
 __host__ __device__ __forceinline__ qt f4(const float* p) { return qt{p[0], p[1], p[2], p[3]}; }
 
+// Pose (COM position, rotation) in FLOAT64, velocities in float32.  The pipeline is stiff: a constraint spring
+// turns an ABSOLUTE error e in the relative position / orientation of two bodies into k dt e of velocity per
+// substep (k dt / m = 20 for Ant, 30 for Humanoid, 47 for Halfcheetah), and a float32 pose carries e ~ 1e-7 from
+// its own rounding between substeps -- round 2's residue against the float64 restatement (Humanoid: 11.7 % of
+// observation entries beyond north_star's 1e-5).  So everything that is a DIFFERENCE OF POSES -- anchor
+// separation, relative rotation and the joint angles read from it, contact depth, the step's forward progress --
+// is formed in float64 from a float64 pose; forces, torques, impulses and velocities (relative errors, never
+// amplified) stay float32.  v_fma_f64 issues at the v_fma_f32 rate on gfx950 (profiles/r03_fp64_rate.txt).
+struct v3d {
+  double x, y, z;
+};
+struct qtd {
+  double w, x, y, z;
+};
+__device__ __forceinline__ v3d D(double x, double y, double z) { return v3d{x, y, z}; }
+__device__ __forceinline__ v3d operator+(v3d a, v3d b) { return D(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ v3d operator-(v3d a, v3d b) { return D(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ v3d operator*(v3d a, double s) { return D(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ double dot(v3d a, v3d b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ v3d cross(v3d a, v3d b) {
+  return D(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ qtd qmul(qtd a, qtd b) {
+  return qtd{a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z, a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
+             a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x, a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w};
+}
+__device__ __forceinline__ qtd qconj(qtd a) { return qtd{a.w, -a.x, -a.y, -a.z}; }
+__device__ __forceinline__ v3d qrot(qtd q, v3d v) {
+  const v3d u = D(q.x, q.y, q.z);
+  const v3d t = cross(u, v) * 2.0;
+  return v + t * q.w + cross(u, t);
+}
+__device__ __forceinline__ v3 tof(v3d a) { return V((float)a.x, (float)a.y, (float)a.z); }
+__device__ __forceinline__ qt tof(qtd a) { return qt{(float)a.w, (float)a.x, (float)a.y, (float)a.z}; }
+__device__ __forceinline__ v3d tod(v3 a) { return D(a.x, a.y, a.z); }
+__device__ __forceinline__ qtd tod(qt a) { return qtd{a.w, a.x, a.y, a.z}; }
+
 struct Body {
-  v3 p;
-  qt r;
+  v3d p;
+  qtd r;
   v3 v, w;
 };
+
+// atan2 in float64 to ~3e-13 (one octant reduction, one division, degree-7 polynomial in t^2 on
+// [0, tan^2(pi/8)], Chebyshev-node fit): a joint angle is multiplied by the limit / joint / locking stiffness
+// (k dt / I up to 30 per substep), so the 2.8e-7 of atan2_fast would reach the velocities at 1e-5 within one env
+// step.  ~40 instructions.
+__device__ __forceinline__ double atan2_f64(double y, double x) {
+  const double ax = fabs(x), ay = fabs(y);
+  const double mx = fmax(ax, ay), mn = fmin(ax, ay);
+  const bool mid = mn > 0.41421356237309503 * mx;  // atan(t) = pi/4 + atan((t - 1) / (t + 1))
+  const double num = mid ? mn - mx : mn, den = mid ? mn + mx : mx;
+  double t = num * rcp_fast(den);
+  t = (mx > 0.0) ? t : 0.0;
+  const double z = t * t;
+  double p = fma(z, -3.76549087472088720e-02, 6.97418621847181036e-02);
+  p = fma(z, p, -8.99255026739464586e-02);
+  p = fma(z, p, 1.11034566044549116e-01);
+  p = fma(z, p, -1.42853865353561232e-01);
+  p = fma(z, p, 1.99999930530023323e-01);
+  p = fma(z, p, -3.33333332769153445e-01);
+  p = fma(z, p, 9.99999999999244826e-01);
+  double r = fma(t, p, mid ? 0.78539816339744831 : 0.0);
+  r = (ay > ax) ? 1.5707963267948966 - r : r;
+  r = (x < 0.0) ? 3.1415926535897932 - r : r;
+  return copysign(r, y);
+}
+// asin(x) = atan2(x, sqrt((1 - x)(1 + x))), |x| <= 1
+__device__ __forceinline__ double asin_f64(double x) { return atan2_f64(x, sqrt((1.0 - x) * (1.0 + x))); }
 
 // per-env context scalars: carl_brax_env.py:255-292 in its intended form
 struct LaneCtx {
   float gravity_z, friction, elasticity, ang_damping, stiffness_scale;
 };
 
-// LDS layout of a workgroup (floats; each row = kEnvs consecutive floats, one per env)
+// LDS layout of a workgroup.  Pose rows are doubles (7 per link: COM position 3, rotation 4) in a region of their
+// own at the start of the dynamic LDS; every other row is a float row.  Each row = kEnvs consecutive elements, one
+// per env.
 struct Layout {
-  int state;   // 13 * L rows
+  int pose_rows;  // 7 * L DOUBLE rows (separate region)
+  int vel;     // 6 * L rows: linear, angular velocity
   int wrench;  // 12 * L rows: per joint (f, t) on the child, (-f, -t') on the parent; reused by FK
   int mass;    // L rows (effective mass per link, context-scaled)
+  int sig;     // 2 * L rows (uint32): per-link hash of the step's contact / limit branch decisions
   int goal;    // 3 rows: push task, the env's goal position (context or model default)
   int tau;     // n_dof rows
   int io;      // staging of the env's action / observation record, and of (q, qd) in reset
-  int total;
+  int total;   // float rows
   __host__ __device__ static Layout make(int L, int n_dof, int io_rows) {
     Layout l;
-    l.state = 0;
-    l.wrench = l.state + 13 * L;
+    l.pose_rows = 7 * L;
+    l.vel = 0;
+    l.wrench = l.vel + 6 * L;
     l.mass = l.wrench + 12 * L;
-    l.goal = l.mass + L;
+    l.sig = l.mass + L;
+    l.goal = l.sig + 2 * L;
     l.tau = l.goal + 3;
     l.io = l.tau + n_dof;
     l.total = l.io + io_rows;
     return l;
   }
+  // bytes of dynamic LDS for `envs` envs per workgroup
+  __host__ __device__ size_t bytes(int envs) const { return ((size_t)pose_rows * 8 + (size_t)total * 4) * envs; }
 };
 
+// Persistent state record of one env in HBM (carl_batch_t::state, ::first_state): CARL_BRAX_LINK_RECORD = 20
+// floats per link, as three blocks
+//   [0, 7 L)    pose, float32 head:  per link COM position 3, rotation 4 (w, x, y, z)
+//   [7 L, 14 L) pose, float32 tail:  pose = (double)head + (double)tail  (48 significant bits)
+//   [14 L, 20 L) per link linear velocity 3, angular velocity 3
+// The head block alone is the pose to float32.
 __host__ __device__ inline int io_rows_of(const carl_brax_sys_t& s) {
   const int qrows = s.n_q + s.n_dof;
   int r = s.obs_dim > qrows ? s.obs_dim : qrows;
@@ -196,26 +274,31 @@ struct Group {
 static constexpr int kEnvs = kLanes / kSub;  // envs per workgroup
 
 struct Lds {
-  float* base;
+  double* pose;  // [7 L][kEnvs]
+  float* base;   // float rows
   Layout lay;
   int env;  // env within the workgroup (0..kEnvs-1)
   int sub;  // lane within the env (0..kSub-1)
   __device__ __forceinline__ float& at(int row) const { return base[row * kEnvs + env]; }
+  __device__ __forceinline__ uint32_t& atu(int row) const { return reinterpret_cast<uint32_t*>(base)[row * kEnvs + env]; }
+  __device__ __forceinline__ double& pd(int row) const { return pose[row * kEnvs + env]; }
+  __device__ __forceinline__ v3d pos(int i) const { return D(pd(7 * i), pd(7 * i + 1), pd(7 * i + 2)); }
+  __device__ __forceinline__ qtd rot(int i) const { return qtd{pd(7 * i + 3), pd(7 * i + 4), pd(7 * i + 5), pd(7 * i + 6)}; }
   __device__ __forceinline__ Body body(int i) const {
-    const int r0 = lay.state + 13 * i;
+    const int r0 = lay.vel + 6 * i;
     Body b;
-    b.p = V(at(r0), at(r0 + 1), at(r0 + 2));
-    b.r = qt{at(r0 + 3), at(r0 + 4), at(r0 + 5), at(r0 + 6)};
-    b.v = V(at(r0 + 7), at(r0 + 8), at(r0 + 9));
-    b.w = V(at(r0 + 10), at(r0 + 11), at(r0 + 12));
+    b.p = pos(i);
+    b.r = rot(i);
+    b.v = V(at(r0), at(r0 + 1), at(r0 + 2));
+    b.w = V(at(r0 + 3), at(r0 + 4), at(r0 + 5));
     return b;
   }
   __device__ __forceinline__ void put(int i, const Body& b) const {
-    const int r0 = lay.state + 13 * i;
-    at(r0) = b.p.x; at(r0 + 1) = b.p.y; at(r0 + 2) = b.p.z;
-    at(r0 + 3) = b.r.w; at(r0 + 4) = b.r.x; at(r0 + 5) = b.r.y; at(r0 + 6) = b.r.z;
-    at(r0 + 7) = b.v.x; at(r0 + 8) = b.v.y; at(r0 + 9) = b.v.z;
-    at(r0 + 10) = b.w.x; at(r0 + 11) = b.w.y; at(r0 + 12) = b.w.z;
+    const int r0 = lay.vel + 6 * i;
+    pd(7 * i) = b.p.x; pd(7 * i + 1) = b.p.y; pd(7 * i + 2) = b.p.z;
+    pd(7 * i + 3) = b.r.w; pd(7 * i + 4) = b.r.x; pd(7 * i + 5) = b.r.y; pd(7 * i + 6) = b.r.z;
+    at(r0) = b.v.x; at(r0 + 1) = b.v.y; at(r0 + 2) = b.v.z;
+    at(r0 + 3) = b.w.x; at(r0 + 4) = b.w.y; at(r0 + 5) = b.w.z;
   }
   __device__ __forceinline__ void put3(int row, v3 a) const {
     at(row) = a.x; at(row + 1) = a.y; at(row + 2) = a.z;
@@ -240,7 +323,7 @@ static __device__ __forceinline__ v3 xaxis(qt q) {
 
 // the static world as a parent body (planar roots are jointed to it)
 static __device__ __forceinline__ Body world_body() {
-  return Body{V(0, 0, 0), qt{1, 0, 0, 0}, V(0, 0, 0), V(0, 0, 0)};
+  return Body{D(0, 0, 0), qtd{1, 0, 0, 0}, V(0, 0, 0), V(0, 0, 0)};
 }
 
 static __device__ __forceinline__ bool is_free_root(const carl_brax_sys_t& s, int i) {
@@ -250,65 +333,54 @@ static __device__ __forceinline__ bool is_free_root(const carl_brax_sys_t& s, in
 // joint geometry shared by joints.resolve and inverse kinematics
 struct JointGeom {
   v3 rc_off, rp_off;      // anchor relative to the child's / parent's COM, world frame
-  v3 A_c, A_p, vA_c, vA_p, x_c, x_p, wrel;
-  v3 e, axx;  // A_p - A_c; cross(x_c, x_p) from the float64 relative rotation (see joint_geometry)
+  v3d ed;                 // A_p - A_c at zero slide, float64
+  v3 vA_c, vA_p, x_c, x_p, wrel;
+  v3 axx;                 // cross(x_c, x_p) from the float64 relative rotation
   float theta, thetadot;  // single hinge
   v3 axis[3];             // 2-3 stacked hinges: current world axes ...
   float ang[3], rate[3];  // ... Euler x-y-z angles (third signed by dof_sign3) and their rates
 };
 
 // MULTI: the model has links with 0, 2 or 3 hinges (Humanoid; a pure slider); false compiles the Euler-angle
-// path out (Ant, Halfcheetah: fewer registers, shorter joint phase)
+// path out (Ant, Halfcheetah: fewer registers, shorter joint phase).
+// Everything that is a difference of the two poses is formed in float64 and rounded ONCE: the anchor
+// separation `ed`, the relative rotation of the joint frames, the axis-alignment term and the joint angles.
 template <bool MULTI>
 static __device__ __forceinline__ JointGeom joint_geometry(const carl_brax_sys_t& s, const Derived& dv, int i, const Body& bc,
                                                     const Body& bp) {
   JointGeom g;
-  g.rc_off = qrot(bc.r, f3(dv.ac[i]));
-  g.rp_off = qrot(bp.r, f3(dv.ap[i]));
-  g.A_c = bc.p + g.rc_off;
-  g.A_p = bp.p + g.rp_off;  // at zero slide
+  {
+    const v3d rc_off = qrot(bc.r, tod(f3(dv.ac[i]))), rp_off = qrot(bp.r, tod(f3(dv.ap[i])));
+    g.ed = (bp.p - bc.p) + (rp_off - rc_off);  // A_p - A_c (at zero slide)
+    g.rc_off = tof(rc_off);
+    g.rp_off = tof(rp_off);
+  }
   g.vA_c = bc.v + cross(bc.w, g.rc_off);
   g.vA_p = bp.v + cross(bp.w, g.rp_off);
-  g.e = g.A_p - g.A_c;
-  // The joint frames rc = bc.r (x) joint_rot and rp = bp.r (x) rpl, their relative rotation, and from it the
-  // axis-alignment term cross(x_c, x_p), in FLOAT64 (full rate on this part; ~35 extra instructions per joint = 2-4 %
-  // of an env step; the float32 copies the rest of the phase uses are conversions of these, not a second product).
-  // The relative rotation and the axis cross product are differences of O(1) quantities that come out ~1e-3: formed
-  // in float32 they carry an ABSOLUTE error of ~1e-7, which the constraint spring multiplies by k_pos * dt / inertia
-  // = 20 (Ant) .. 30 (Humanoid) per substep -- that was the largest single term of the kernel's distance from the
-  // float64 restatement (Ant, per env step, p99 of |d| / (1 + |x|): 2.2e-5 in float32, 7.1e-6 like this;
-  // tools/brax_parity_percentiles.py, profiles/r02_*).
+  // joint frames rc = bc.r (x) joint_rot, rp = bp.r (x) rpl and their relative rotation conj(rp) (x) rc.
   // cross(x_c, x_p) = rp (x) cross(xaxis(rel), e_x) = rp (x) (0, a2, -a1): the SMALL components of xaxis(rel)
   // keep their relative accuracy.
-  qt rel, rc, rp;
+  qtd rel;
+  qt rp;
   {
-    const double cw = bc.r.w, cx = bc.r.x, cy = bc.r.y, cz = bc.r.z, pw = bp.r.w, px = bp.r.x, py = bp.r.y, pz = bp.r.z;
-    const double jw = s.joint_rot[i][0], jx = s.joint_rot[i][1], jy = s.joint_rot[i][2], jz = s.joint_rot[i][3];
-    const double lw = dv.rpl[i][0], lx = dv.rpl[i][1], ly = dv.rpl[i][2], lz = dv.rpl[i][3];
-    const double aw = cw * jw - cx * jx - cy * jy - cz * jz, ax = cw * jx + cx * jw + cy * jz - cz * jy,
-                 ay = cw * jy - cx * jz + cy * jw + cz * jx, az = cw * jz + cx * jy - cy * jx + cz * jw;  // rc
-    const double bw = pw * lw - px * lx - py * ly - pz * lz, bx = pw * lx + px * lw + py * lz - pz * ly,
-                 by = pw * ly - px * lz + py * lw + pz * lx, bz = pw * lz + px * ly - py * lx + pz * lw;  // rp
-    const double rw = bw * aw + bx * ax + by * ay + bz * az, rx = bw * ax - bx * aw - by * az + bz * ay,
-                 ry = bw * ay + bx * az - by * aw - bz * ax, rz = bw * az - bx * ay + by * ax - bz * aw;  // conj(rp) rc
-    rc = qt{(float)aw, (float)ax, (float)ay, (float)az};
-    rp = qt{(float)bw, (float)bx, (float)by, (float)bz};
-    rel = qt{(float)rw, (float)rx, (float)ry, (float)rz};
-    const double a1 = 2.0 * (rx * ry + rw * rz), a2 = 2.0 * (rx * rz - rw * ry);
-    g.x_c = xaxis(rc);
+    const qtd rcd = qmul(bc.r, tod(f4(s.joint_rot[i]))), rpd = qmul(bp.r, tod(f4(dv.rpl[i])));
+    rel = qmul(qconj(rpd), rcd);
+    rp = tof(rpd);
+    const double a1 = 2.0 * (rel.x * rel.y + rel.w * rel.z), a2 = 2.0 * (rel.x * rel.z - rel.w * rel.y);
+    g.x_c = xaxis(tof(rcd));
     g.x_p = xaxis(rp);
     g.axx = qrot(rp, V(0.0f, (float)a2, (float)-a1));
   }
-  if (rel.w < 0.0f) { rel.w = -rel.w; rel.x = -rel.x; }
-  g.theta = 2.0f * atan2_fast(rel.x, rel.w);  // twist about the hinge (joint frame x)
+  if (rel.w < 0.0) { rel.w = -rel.w; rel.x = -rel.x; }
+  g.theta = (float)(2.0 * atan2_f64(rel.x, rel.w));  // twist about the hinge (joint frame x)
   g.wrel = bc.w - bp.w;
   g.thetadot = dot(g.x_c, g.wrel);
   const int nr = MULTI ? s.n_link_dof[i] - s.n_slide[i] : 1;
   if (MULTI && nr != 1) {  // rel = Rx(al) Ry(be) Rz(ga): decompose, ga = sign * theta_3 (nr = 0: all locked)
-    const float R00 = 1.0f - 2.0f * (rel.y * rel.y + rel.z * rel.z), R01 = 2.0f * (rel.x * rel.y - rel.w * rel.z);
-    const float R02 = fminf(fmaxf(2.0f * (rel.x * rel.z + rel.w * rel.y), -1.0f), 1.0f);
-    const float R12 = 2.0f * (rel.y * rel.z - rel.w * rel.x), R22 = 1.0f - 2.0f * (rel.x * rel.x + rel.y * rel.y);
-    const float al = atan2_fast(-R12, R22), be = asinf(R02), ga = atan2_fast(-R01, R00);
+    const double R00 = 1.0 - 2.0 * (rel.y * rel.y + rel.z * rel.z), R01 = 2.0 * (rel.x * rel.y - rel.w * rel.z);
+    const double R02 = fmin(fmax(2.0 * (rel.x * rel.z + rel.w * rel.y), -1.0), 1.0);
+    const double R12 = 2.0 * (rel.y * rel.z - rel.w * rel.x), R22 = 1.0 - 2.0 * (rel.x * rel.x + rel.y * rel.y);
+    const float al = (float)atan2_f64(-R12, R22), be = (float)asin_f64(R02), ga = (float)atan2_f64(-R01, R00);
     const float sg = (nr == 3) ? s.dof_sign3[i] : 1.0f;
     g.ang[0] = al; g.ang[1] = be; g.ang[2] = sg * ga;
     g.axis[0] = g.x_p;
@@ -334,25 +406,28 @@ static __device__ __forceinline__ JointGeom joint_geometry(const carl_brax_sys_t
 // The object hangs on the world, so its parent-side wrench rows are free: the reaction is parked there,
 // and Topo lists the object among the gripper's children, so phase B sums it in.  Everything goes in
 // and out BY VALUE: reference parameters of a non-inlined call pin their variables to scratch memory in
-// the caller for every model, not only for this one.
+// the caller for every model, not only for this one.  The penetration depth (times pair_k) is a pose
+// difference: float64.
 struct PairOut {
   v3 on_obj, on_a, t_a;
 };
 static __device__ __forceinline__ PairOut pair_contact(const carl_brax_sys_t& s, const Lds& m) {
   const int a = s.pair_link;
   const Body ba = m.body(a), bo = m.body(s.push_link);
-  const v3 o = bo.p - qrot(bo.r, f3(s.com[s.push_link]));
+  const v3d o = bo.p - qrot(bo.r, tod(f3(s.com[s.push_link])));
   PairOut r{V(0, 0, 0), V(0, 0, 0), V(0, 0, 0)};
   for (int k = 0; k < s.n_pair; ++k) {
-    const v3 rel = qrot(ba.r, f3(s.pair_pos[k]) - f3(s.com[a]));
-    const v3 cs = ba.p + rel;
+    const v3d reld = qrot(ba.r, tod(f3(s.pair_pos[k]) - f3(s.com[a])));
+    const v3d cs = ba.p + reld;
+    const v3 rel = tof(reld);
     const float rk = s.pair_radius[k];
-    if (!(fabsf(cs.z - o.z) < s.pair_obj_half + rk)) continue;
-    const float dx = o.x - cs.x, dy = o.y - cs.y;
-    const float dist = sqrtf(dx * dx + dy * dy);
-    const float depth = rk + s.pair_obj_radius - dist;
+    if (!((float)fabs(cs.z - o.z) < s.pair_obj_half + rk)) continue;
+    const double dxd = o.x - cs.x, dyd = o.y - cs.y;
+    const double distd = sqrt(dxd * dxd + dyd * dyd);
+    const float depth = (float)((double)rk + (double)s.pair_obj_radius - distd);
+    const float dist = (float)distd;
     if (!(depth > 0.0f) || !(dist > 1e-9f)) continue;
-    const v3 n = V(dx / dist, dy / dist, 0.0f);
+    const v3 n = V((float)dxd / dist, (float)dyd / dist, 0.0f);
     const v3 vs = ba.v + cross(ba.w, rel);
     const float fm = s.pair_k * depth + s.pair_c * dot(vs - bo.v, n);
     if (!(fm > 0.0f)) continue;
@@ -364,7 +439,21 @@ static __device__ __forceinline__ PairOut pair_contact(const carl_brax_sys_t& s,
   return r;
 }
 
+// 1 / sqrt(x), x near 1 (a quaternion's squared norm after one integration step): v_rsq_f64 + two Newton steps
+static __device__ __forceinline__ double rsqrt_f64(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  y = y * fma(-0.5 * x, y * y, 1.5);
+  y = y * fma(-0.5 * x, y * y, 1.5);
+  return y;
+}
+
 // ---- one brax.spring.pipeline.step ---------------------------------------------------------
+// Branch record: every DISCRETE decision of the substep that the float64 restatement also takes is hashed per
+// link (h <- 33 h + bits) into the `sig` rows: row 2 i the contacts that delivered an impulse (bit = the
+// sphere's ordinal on its link), row 2 i + 1 the range limits that were active on link i's joint (slides:
+// bits 0-3, hinges: bits 4-9; below / above per dof).  The step's combination of the rows is an optional output
+// (carl_step_io_t::branch_sig): a parity check can then separate lanes that took the same branches as the
+// reference arithmetic from lanes where a contact switched within rounding -- an impulse is discontinuous there.
 template <bool MULTI, bool TASK>
 static __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const Topo& tp, const Derived& dv, const LaneCtx& c,
                                         const Lds& m) {
@@ -377,27 +466,31 @@ static __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const T
     const Body bp = (P < 0) ? world_body() : m.body(P);
     const JointGeom g = joint_geometry<MULTI>(s, dv, i, bc, bp);
     const float kp = s.k_pos[i] * c.stiffness_scale;
-    v3 e = g.e, ev = g.vA_p - g.vA_c;
+    v3d ed = g.ed;
+    v3 ev = g.vA_p - g.vA_c;
     v3 f = V(0, 0, 0);
+    uint32_t lim = 0u;
     const int ns = s.n_slide[i], d0 = s.dof_start[i];
     for (int k = 0; k < ns; ++k) {  // prismatic dofs: free along the axis, own spring/damper/force
-      const v3 ax = qrot(bp.r, f3(s.slide_axis[i][k]));
-      const float qk = -dot(e, ax), qdk = -dot(ev, ax);
-      e = e + ax * qk;
+      const v3d axd = qrot(bp.r, tod(f3(s.slide_axis[i][k])));
+      const double qkd = -dot(ed, axd);
+      ed = ed + axd * qkd;  // a planar root's slide coordinate is its travelled distance: float64 projection
+      const v3 ax = tof(axd);
+      const float qk = (float)qkd, qdk = -dot(ev, ax);
       ev = ev + ax * qdk;
       float fa = m.at(m.lay.tau + d0 + k) - s.dof_damping[d0 + k] * qdk - s.dof_stiffness[d0 + k] * qk;
-      if (qk < s.dof_lo[d0 + k]) fa += s.k_limit[i] * (s.dof_lo[d0 + k] - qk);  // range of the slide
-      if (qk > s.dof_hi[d0 + k]) fa -= s.k_limit[i] * (qk - s.dof_hi[d0 + k]);
+      if (qk < s.dof_lo[d0 + k]) { fa += s.k_limit[i] * (s.dof_lo[d0 + k] - qk); lim |= 1u << (2 * k); }  // range of the slide
+      if (qk > s.dof_hi[d0 + k]) { fa -= s.k_limit[i] * (qk - s.dof_hi[d0 + k]); lim |= 2u << (2 * k); }
       f = f + ax * fa;
     }
-    f = f + e * kp + ev * s.k_vel[i];
+    f = f + tof(ed) * kp + ev * s.k_vel[i];
     v3 t;
     const int d = d0 + ns, nr = MULTI ? s.n_link_dof[i] - ns : 1;
     if (!MULTI || nr == 1) {
       t = g.axx * kp;  // keep the hinge axes aligned
       float ta = m.at(m.lay.tau + d) - s.dof_damping[d] * g.thetadot - s.dof_stiffness[d] * g.theta;
-      if (g.theta < s.dof_lo[d]) ta += s.k_limit[i] * (s.dof_lo[d] - g.theta);
-      if (g.theta > s.dof_hi[d]) ta -= s.k_limit[i] * (g.theta - s.dof_hi[d]);
+      if (g.theta < s.dof_lo[d]) { ta += s.k_limit[i] * (s.dof_lo[d] - g.theta); lim |= 16u; }
+      if (g.theta > s.dof_hi[d]) { ta -= s.k_limit[i] * (g.theta - s.dof_hi[d]); lim |= 32u; }
       t = t + g.x_c * ta;
     } else {  // 2 or 3 stacked hinges: per-dof torques about the current axes; a missing third
               // dof is locked by the constraint spring on its Euler angle
@@ -408,8 +501,8 @@ static __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const T
         if (k < nr) {
           const int dk = d + k;
           ta = m.at(m.lay.tau + dk) - s.dof_damping[dk] * g.rate[k] - s.dof_stiffness[dk] * g.ang[k];
-          if (g.ang[k] < s.dof_lo[dk]) ta += s.k_limit[i] * (s.dof_lo[dk] - g.ang[k]);
-          if (g.ang[k] > s.dof_hi[dk]) ta -= s.k_limit[i] * (g.ang[k] - s.dof_hi[dk]);
+          if (g.ang[k] < s.dof_lo[dk]) { ta += s.k_limit[i] * (s.dof_lo[dk] - g.ang[k]); lim |= 16u << (2 * k); }
+          if (g.ang[k] > s.dof_hi[dk]) { ta -= s.k_limit[i] * (g.ang[k] - s.dof_hi[dk]); lim |= 32u << (2 * k); }
         } else {
           ta = -kp * g.ang[k];
         }
@@ -417,6 +510,7 @@ static __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const T
       }
     }
     t = t - g.wrel * s.k_ang_damp[i];
+    m.atu(m.lay.sig + 2 * i + 1) = m.atu(m.lay.sig + 2 * i + 1) * 33u + lim;
     const int wr = m.lay.wrench + 12 * i;
     v3 pf = f * -1.0f, pt = (cross(g.rp_off, f) + t) * -1.0f;  // on the parent
     if (TASK && s.n_pair > 0 && i == s.push_link) {
@@ -437,6 +531,7 @@ static __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const T
   const v3 n = V(0, 0, 1);
   for (int i = m.sub; i < L; i += kSub) {
     Body b = m.body(i);
+    const qt rf = tof(b.r);
     v3 F = V(0, 0, 0), T = V(0, 0, 0);
     if (!is_free_root(s, i)) {
       F = m.get3(m.lay.wrench + 12 * i);
@@ -449,37 +544,46 @@ static __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const T
     }
     const float inv_m = __builtin_amdgcn_rcpf(m.at(m.lay.mass + i));  // v_rcp_f32 (1 ulp): the phase is issue-bound
     b.v = b.v + (F * inv_m + V(0, 0, c.gravity_z)) * s.dt;
-    b.w = b.w + apply_inv_inertia(s, i, b.r, T, dv.iso[i] != 0) * s.dt;
+    b.w = b.w + apply_inv_inertia(s, i, rf, T, dv.iso[i] != 0) * s.dt;
     // spring.collisions.resolve: this body's spheres vs the plane z = 0
     v3 cdv = V(0, 0, 0), cdw = V(0, 0, 0);
     float cnt = 0.0f;
+    uint32_t hit = 0u;
     const bool iso = dv.iso[i] != 0;
     // no sphere of this link can reach the plane while its COM is higher than the farthest sphere surface
-    const int k_end = (b.p.z < dv.reach[i]) ? tp.coll_begin[i + 1] : 0;
+    const int k_end = ((float)b.p.z < dv.reach[i]) ? tp.coll_begin[i + 1] : 0;
+    // third row of the rotation matrix in float64: a sphere's height -- hence its depth, which the Baumgarte
+    // term multiplies by erp / dt -- is a pose difference
+    const double R20 = 2.0 * (b.r.x * b.r.z - b.r.w * b.r.y), R21 = 2.0 * (b.r.y * b.r.z + b.r.w * b.r.x),
+                 R22 = 1.0 - 2.0 * (b.r.x * b.r.x + b.r.y * b.r.y);
     for (int kk = tp.coll_begin[i]; kk < k_end; ++kk) {
       const int k = tp.coll_idx[kk];
-      const v3 ctr = b.p + qrot(b.r, f3(s.coll_pos[k]) - f3(s.com[i]));
-      const float depth = s.coll_radius[k] - ctr.z;
+      const v3 off = f3(s.coll_pos[k]) - f3(s.com[i]);
+      const float depth =
+          (float)((double)s.coll_radius[k] - (b.p.z + (R20 * (double)off.x + R21 * (double)off.y + R22 * (double)off.z)));
       if (!(depth > 0.0f)) continue;
-      const v3 r = V(ctr.x, ctr.y, ctr.z - s.coll_radius[k]) - b.p;
+      const v3 ro = qrot(rf, off);
+      const v3 r = V(ro.x, ro.y, ro.z - s.coll_radius[k]);
       const v3 rel = b.v + cross(b.w, r);
       const float vn = dot(n, rel);
-      const float ang = dot(n, cross(apply_inv_inertia(s, i, b.r, cross(r, n), iso), r));
+      const float ang = dot(n, cross(apply_inv_inertia(s, i, rf, cross(r, n), iso), r));
       const float imp = div_fast(-(1.0f + c.elasticity) * vn + s.baumgarte_erp * depth * inv_dt, inv_m + ang);
       if (!(imp > 0.0f) || !(vn < 0.0f)) continue;
+      hit |= 1u << (kk - tp.coll_begin[i]);
       v3 J = n * imp;
       const v3 vt = rel - n * vn;
       const float vt_len = sqrtf(dot(vt, vt));
       if (vt_len > 1e-9f) {
         const v3 dir = vt * __builtin_amdgcn_rcpf(vt_len);
-        const float ang_d = dot(dir, cross(apply_inv_inertia(s, i, b.r, cross(r, dir), iso), r));
+        const float ang_d = dot(dir, cross(apply_inv_inertia(s, i, rf, cross(r, dir), iso), r));
         const float imp_d = fminf(div_fast(vt_len, inv_m + ang_d), c.friction * imp);
         J = J - dir * imp_d;
       }
       cdv = cdv + J * inv_m;
-      cdw = cdw + apply_inv_inertia(s, i, b.r, cross(r, J), iso);
+      cdw = cdw + apply_inv_inertia(s, i, rf, cross(r, J), iso);
       cnt += 1.0f;
     }
+    m.atu(m.lay.sig + 2 * i) = m.atu(m.lay.sig + 2 * i) * 33u + hit;
     // spring.integrator.integrate
     b.v = b.v * dl;
     b.w = b.w * da;
@@ -488,26 +592,30 @@ static __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const T
       b.v = b.v + cdv * ic;
       b.w = b.w + cdw * ic;
     }
-    b.p = b.p + b.v * s.dt;
-    const qt dq = qmul(qt{0.0f, b.w.x, b.w.y, b.w.z}, b.r);
-    const float h = 0.5f * s.dt;
-    b.r = qnormalize(qt{b.r.w + h * dq.w, b.r.x + h * dq.x, b.r.y + h * dq.y, b.r.z + h * dq.z});
+    const double dtd = (double)s.dt;
+    b.p = D(fma((double)b.v.x, dtd, b.p.x), fma((double)b.v.y, dtd, b.p.y), fma((double)b.v.z, dtd, b.p.z));
+    const qtd dq = qmul(qtd{0.0, (double)b.w.x, (double)b.w.y, (double)b.w.z}, b.r);
+    const double h = 0.5 * dtd;
+    qtd r2 = qtd{fma(h, dq.w, b.r.w), fma(h, dq.x, b.r.x), fma(h, dq.y, b.r.y), fma(h, dq.z, b.r.z)};
+    const double inv = rsqrt_f64(r2.w * r2.w + r2.x * r2.x + r2.y * r2.y + r2.z * r2.z);
+    b.r = qtd{r2.w * inv, r2.x * inv, r2.y * inv, r2.z * inv};
     m.put(i, b);
   }
   phase_sync();
 }
 
-// whole-body centre of mass (brax.envs.humanoid.Humanoid._com); *mass_sum = total mass
-static __device__ __forceinline__ v3 system_com(const carl_brax_sys_t& s, const Lds& m, float* mass_sum) {
-  v3 com = V(0, 0, 0);
+// whole-body centre of mass (brax.envs.humanoid.Humanoid._com), float64 (the forward reward is the difference
+// of two of these over one env step); *mass_sum = total mass
+static __device__ __forceinline__ v3d system_com(const carl_brax_sys_t& s, const Lds& m, float* mass_sum) {
+  v3d com = D(0, 0, 0);
   float M = 0.0f;
   for (int i = 0; i < s.n_links; ++i) {
     const float mi = m.at(m.lay.mass + i);
-    com = com + m.get3(m.lay.state + 13 * i) * mi;
+    com = com + m.pos(i) * (double)mi;
     M += mi;
   }
   *mass_sum = M;
-  return com * (1.0f / M);
+  return com * (1.0 / (double)M);
 }
 
 // kinematics.world_to_joint + inverse -> observation rows (q[skip:] ++ qd) in the io staging, one
@@ -530,17 +638,17 @@ static __device__ __forceinline__ void observe(const carl_brax_sys_t& s, const D
     if (keep_raw) m.at(m.lay.wrench + dof) = v;
   };
   float M = 1.0f;
-  v3 com = V(0, 0, 0);
+  v3d com = D(0, 0, 0);
   if (s.obs_extended && go) com = system_com(s, m, &M);
   for (int i = m.sub; i < L; i += kSub) {
     if (!go) continue;
     const int P = s.parent[i];
     const Body b = m.body(i);
     if (is_free_root(s, i)) {
-      const v3 c = qrot(b.r, f3(s.com[i]));
-      const v3 o = b.p - c;
+      const v3d cd = qrot(b.r, tod(f3(s.com[i])));
+      const v3 c = tof(cd), o = tof(b.p - cd);
       const v3 vl = b.v - cross(b.w, c);
-      const float qv[7] = {o.x, o.y, o.z, b.r.w, b.r.x, b.r.y, b.r.z};
+      const float qv[7] = {o.x, o.y, o.z, (float)b.r.w, (float)b.r.x, (float)b.r.y, (float)b.r.z};
 #pragma unroll
       for (int k = 0; k < 7; ++k)
         if (s.q_start[i] + k >= skip) m.at(m.lay.io + s.q_start[i] + k - skip) = qv[k];
@@ -552,9 +660,9 @@ static __device__ __forceinline__ void observe(const carl_brax_sys_t& s, const D
       const JointGeom g = joint_geometry<MULTI>(s, dv, i, b, bp);
       const int ns = s.n_slide[i];
       for (int k = 0; k < ns; ++k) {
-        const v3 ax = qrot(bp.r, f3(s.slide_axis[i][k]));
-        if (s.q_start[i] + k >= skip) m.at(m.lay.io + s.q_start[i] + k - skip) = dot(g.A_c - g.A_p, ax);
-        put_qd(s.dof_start[i] + k, dot(g.vA_c - g.vA_p, ax));
+        const v3d axd = qrot(bp.r, tod(f3(s.slide_axis[i][k])));
+        if (s.q_start[i] + k >= skip) m.at(m.lay.io + s.q_start[i] + k - skip) = (float)-dot(g.ed, axd);
+        put_qd(s.dof_start[i] + k, dot(g.vA_c - g.vA_p, tof(axd)));
       }
       const int nr = MULTI ? s.n_link_dof[i] - ns : 1;
       if (!MULTI || nr == 1) {
@@ -571,10 +679,11 @@ static __device__ __forceinline__ void observe(const carl_brax_sys_t& s, const D
     }
     if (s.obs_extended) {  // inertia about the system com, world axes, row-major, then mass; com velocity
       const int e0 = m.lay.io + qd0 + s.n_dof;
-      const v3 d = b.p - com;
+      const v3 d = tof(b.p - com);
+      const qt rf = tof(b.r);
       const float mi = m.at(m.lay.mass + i), dd = dot(d, d);
       const float I0 = 1.0f / s.inv_inertia[i][0], I1 = 1.0f / s.inv_inertia[i][1], I2 = 1.0f / s.inv_inertia[i][2];
-      const v3 ex = qrot(b.r, V(1, 0, 0)), ey = qrot(b.r, V(0, 1, 0)), ez = qrot(b.r, V(0, 0, 1));
+      const v3 ex = qrot(rf, V(1, 0, 0)), ey = qrot(rf, V(0, 1, 0)), ez = qrot(rf, V(0, 0, 1));
       const float e[3][3] = {{ex.x, ey.x, ez.x}, {ex.y, ey.y, ez.y}, {ex.z, ey.z, ez.z}};
       const float dc[3] = {d.x, d.y, d.z};
       int k = e0 + 10 * i;
@@ -619,8 +728,8 @@ static __device__ __forceinline__ void observe(const carl_brax_sys_t& s, const D
       for (int i = m.sub; i < na; i += kSub) m.at(m.lay.io + na + i) = m.at(m.lay.wrench + i);
       for (int j = m.sub; j < 3; j += kSub) {
         const int k = m.lay.io + 2 * na + j;
-        m.at(k) = m.at(m.lay.state + 13 * s.tip_link + j);
-        m.at(k + 3) = m.at(m.lay.state + 13 * s.push_link + j);
+        m.at(k) = (float)m.pd(7 * s.tip_link + j);
+        m.at(k + 3) = (float)m.pd(7 * s.push_link + j);
         m.at(k + 6) = m.at(m.lay.goal + j);
       }
     }
@@ -643,9 +752,9 @@ static __device__ __forceinline__ void observe(const carl_brax_sys_t& s, const D
       for (int i = m.sub; i < td; i += kSub) m.at(m.lay.io + tq + nq + i) = m.at(m.lay.wrench + nq + i);
       if (m.sub == 0) {
         const Body bt = m.body(s.tip_link), bg = m.body(s.target_link);
-        const v3 tip = bt.p + qrot(bt.r, f3(s.tip_offset) - f3(s.com[s.tip_link]));
-        const v3 d = tip - (bg.p - qrot(bg.r, f3(s.com[s.target_link])));
-        m.put3(m.lay.io + tq + nq + td, d);
+        const v3d tip = bt.p + qrot(bt.r, tod(f3(s.tip_offset) - f3(s.com[s.tip_link])));
+        const v3d d = tip - (bg.p - qrot(bg.r, tod(f3(s.com[s.target_link]))));
+        m.put3(m.lay.io + tq + nq + td, tof(d));
       }
     }
     phase_sync();
@@ -670,7 +779,8 @@ static __device__ __noinline__ void forward_kinematics(const carl_brax_sys_t& s,
         vel = V(m.at(d0), m.at(d0 + 1), m.at(d0 + 2));
         ang = V(m.at(d0 + 3), m.at(d0 + 4), m.at(d0 + 5));
       } else {
-        const Body bp = (P < 0) ? world_body() : m.body(P);
+        const Body bpd = (P < 0) ? world_body() : m.body(P);
+        struct { qt r; v3 w; } bp{tof(bpd.r), bpd.w};  // the reset pose is a draw: float32 kinematics, widened below
         const v3 o_p = (P < 0) ? V(0, 0, 0) : m.get3(m.lay.wrench + 12 * P);
         const v3 ov_p = (P < 0) ? V(0, 0, 0) : m.get3(m.lay.wrench + 12 * P + 3);
         const int ns = s.n_slide[i], nr = s.n_link_dof[i] - ns;
@@ -705,9 +815,9 @@ static __device__ __noinline__ void forward_kinematics(const carl_brax_sys_t& s,
       m.put3(m.lay.wrench + 12 * i + 3, vel);
       const v3 c = qrot(rot, f3(s.com[i]));
       Body b;
-      b.r = rot;
+      b.r = tod(rot);
       b.w = ang;
-      b.p = o + c;
+      b.p = tod(o + c);
       b.v = vel + cross(ang, c);
       m.put(i, b);
     }
@@ -824,6 +934,63 @@ static __device__ __forceinline__ void record_out(float* __restrict__ dst, size_
     for (int k = m.sub; k < W; k += kSub) dst[env * W + k] = m.at(m.lay.io + k);
 }
 
+// ---- the env's persistent record (Layout comment above: pose head | pose tail | velocities) <-> LDS --------
+// loads are issued four at a time before the first LDS write (a load-store loop pays one memory round trip per
+// element)
+static __device__ __forceinline__ void record_load(const float* __restrict__ src, const Lds& m, int L, bool go) {
+  if (!go) return;
+  const int NP = 7 * L, NV = 6 * L;
+  for (int k0 = m.sub; k0 < NP; k0 += 4 * kSub) {
+    float hi[4], lo[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = k0 + j * kSub;
+      hi[j] = (k < NP) ? src[k] : 0.0f;
+      lo[j] = (k < NP) ? src[NP + k] : 0.0f;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = k0 + j * kSub;
+      if (k < NP) m.pd(k) = (double)hi[j] + (double)lo[j];
+    }
+  }
+  for (int k0 = m.sub; k0 < NV; k0 += 4 * kSub) {
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = k0 + j * kSub;
+      v[j] = (k < NV) ? src[2 * NP + k] : 0.0f;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = k0 + j * kSub;
+      if (k < NV) m.at(m.lay.vel + k) = v[j];
+    }
+  }
+}
+static __device__ __forceinline__ void record_store(float* __restrict__ dst, const Lds& m, int L, bool go) {
+  if (!go) return;
+  const int NP = 7 * L, NV = 6 * L;
+  for (int k = m.sub; k < NP; k += kSub) {
+    const double d = m.pd(k);
+    const float hi = (float)d;
+    dst[k] = hi;
+    dst[NP + k] = (float)(d - (double)hi);
+  }
+  for (int k = m.sub; k < NV; k += kSub) dst[2 * NP + k] = m.at(m.lay.vel + k);
+}
+// Round the pose to what the record holds (head + tail, 48 bits).  Done at the end of EVERY env step, so a fused
+// rollout continues from exactly the state a per-call step would have stored and reloaded: rollout == repeated step,
+// bit for bit.
+static __device__ __forceinline__ void pose_round(const Lds& m, int L, bool go) {
+  if (!go) return;
+  for (int k = m.sub; k < 7 * L; k += kSub) {
+    const double d = m.pd(k);
+    const float hi = (float)d;
+    m.pd(k) = (double)hi + (double)(float)(d - (double)hi);
+  }
+}
+
 struct LaneState {
   float ep_return;
   int elapsed, cidx, n_new_calls, n_new_episodes;
@@ -879,7 +1046,7 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
   __shared__ carl_brax_sys_t s;
   __shared__ Topo tp;
   __shared__ Derived dv;
-  extern __shared__ float lds_dyn[];
+  extern __shared__ double lds_dyn[];  // pose rows (doubles) first, then the float rows
   {  // model table -> LDS, once per workgroup: every load in flight before the first LDS write (a
      // load-store loop paid one HBM/L2 round trip per 256 bytes: ~15 us of a per-call step)
     constexpr int kWords = (int)(sizeof(carl_brax_sys_t) / 4);
@@ -914,14 +1081,15 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
   // point at the last env's column, own no link (sub beyond every loop bound) and are never active
   const int tid = (int)threadIdx.x;
   const bool lane_ok = tid < kEnvs * kSub;
-  const Lds m{lds_dyn, Layout::make(s.n_links, s.n_dof, io_rows_of(s)), lane_ok ? tid / kSub : kEnvs - 1,
-              lane_ok ? tid % kSub : kLanes};
+  const Layout lay = Layout::make(s.n_links, s.n_dof, io_rows_of(s));
+  const Lds m{lds_dyn, reinterpret_cast<float*>(lds_dyn + (size_t)lay.pose_rows * kEnvs), lay,
+              lane_ok ? tid / kSub : kEnvs - 1, lane_ok ? tid % kSub : kLanes};
   const int env = (int)blockIdx.x * kEnvs + m.env;
   const bool active = lane_ok && env < b.n_lanes;
   const bool lead = active && m.sub == 0;  // the lane that writes the env's scalars
   const uint64_t genv = (uint64_t)(b.lane_offset + env);
   const size_t n = (size_t)b.n_lanes;
-  const int S = CARL_BRAX_LINK_STATE * s.n_links;
+  const int S = CARL_BRAX_LINK_RECORD * s.n_links;  // floats of the env's record in HBM
   LaneState r{};
   const bool goal = s.goal_mode != 0 && b.goal_pos != nullptr;
   if (active) {
@@ -942,9 +1110,9 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
     reset_state<TASK>(s, tp, b.seed, m, genv, r.episode, go);
     r.episode += 1u;
     if (go) {
-      for (int k = m.sub; k < S; k += kSub) b.state[(size_t)env * S + k] = m.at(m.lay.state + k);
+      record_store(b.state + (size_t)env * S, m, s.n_links, true);
       if (b.first_state != nullptr)  // what AUTORESET_FIRST_STATE puts a done env back to
-        for (int k = m.sub; k < S; k += kSub) b.first_state[(size_t)env * S + k] = m.at(m.lay.state + k);
+        record_store(b.first_state + (size_t)env * S, m, s.n_links, true);
       if (m.sub == 0) {
         b.elapsed[env] = 0;
         b.ep_return[env] = 0.0f;
@@ -963,23 +1131,7 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
     if (reset_obs != nullptr) record_out(reset_obs, (size_t)env, s.obs_dim, m, go);
     return;
   } else {
-    if (active) {  // the env's state record -> LDS, eight loads in flight at a time (a load-store loop pays
-                   // one memory round trip per element: 13 per lane for Ant)
-      const float* src = b.state + (size_t)env * S;
-      for (int k0 = m.sub; k0 < S; k0 += 8 * kSub) {
-        float tmp[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int k = k0 + j * kSub;
-          tmp[j] = (k < S) ? src[k] : 0.0f;
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int k = k0 + j * kSub;
-          if (k < S) m.at(m.lay.state + k) = tmp[j];
-        }
-      }
-    }
+    record_load(b.state + (size_t)env * S, m, s.n_links, active);
     r.ctx = load_ctx<TASK>(s, b, m, r.cidx, active);
     if (goal && active) {
       load_goal(s, b, r.cidx, r);
@@ -997,18 +1149,28 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
         ctrl += u * u;
       }
       for (int d = m.sub; d < s.n_dof; d += kSub) m.at(m.lay.tau + d) = 0.0f;
+      for (int k = m.sub; k < 2 * s.n_links; k += kSub) m.atu(m.lay.sig + k) = 0u;  // this step's branch record
       phase_sync();
       for (int k = m.sub; k < s.n_act; k += kSub)  // act_dof entries are distinct (checked by the host)
         m.at(m.lay.tau + s.act_dof[k]) += s.act_gear[k] * fminf(fmaxf(m.at(m.lay.io + k), s.act_lo[k]), s.act_hi[k]);
       phase_sync();
-      const Body b0 = m.body(0);
       float msum;
-      const float x0 = s.reward_on_com ? system_com(s, m, &msum).x : b0.p.x - qrot(b0.r, f3(s.com[0])).x;
+      // forward progress and root height: pose differences, float64
+      const double x0 = s.reward_on_com ? system_com(s, m, &msum).x : m.pos(0).x - qrot(m.rot(0), tod(f3(s.com[0]))).x;
       for (int f = 0; f < s.n_frames; ++f) substep<MULTI, TASK>(s, tp, dv, r.ctx, m);
-      const Body b1 = m.body(0);
-      const v3 c1 = qrot(b1.r, f3(s.com[0]));
-      const float x1 = s.reward_on_com ? system_com(s, m, &msum).x : b1.p.x - c1.x, z1 = b1.p.z - c1.z;
-      bool healthy = (z1 >= s.healthy_z_lo) && (z1 <= s.healthy_z_hi);
+      const v3d c1 = qrot(m.rot(0), tod(f3(s.com[0])));
+      const double x1 = s.reward_on_com ? system_com(s, m, &msum).x : m.pos(0).x - c1.x, z1d = m.pos(0).z - c1.z;
+      const float z1 = (float)z1d;
+      bool healthy = (z1d >= (double)s.healthy_z_lo) && (z1d <= (double)s.healthy_z_hi);
+      if (lead && io.branch_sig != nullptr) {  // the step's branch record: the per-link hashes combined in link order
+        uint32_t hc = 0u, hl = 0u;
+        for (int i = 0; i < s.n_links; ++i) {
+          hc = hc * 1000003u + m.atu(m.lay.sig + 2 * i);
+          hl = hl * 1000003u + m.atu(m.lay.sig + 2 * i + 1);
+        }
+        io.branch_sig[(step_off + env) * 2] = hc;
+        io.branch_sig[(step_off + env) * 2 + 1] = hl;
+      }
       r.elapsed += 1;
       const bool truncated = (b.max_episode_steps > 0) && (r.elapsed >= b.max_episode_steps);
       observe<MULTI, TASK>(s, dv, m, active, false);
@@ -1016,7 +1178,7 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
         const float qa = m.at(m.lay.io + s.healthy_q_index - s.exclude_current_positions);
         healthy = healthy && (qa >= s.healthy_q_lo) && (qa <= s.healthy_q_hi);
       }
-      float reward = s.forward_reward_weight * (s.reward_height ? z1 : (x1 - x0)) / dt_env +
+      float reward = s.forward_reward_weight * (s.reward_height ? z1 : (float)(x1 - x0)) / dt_env +
                      (s.terminate_when_unhealthy ? s.healthy_reward : (healthy ? s.healthy_reward : 0.0f)) -
                      s.ctrl_cost_weight * ctrl;
       bool terminated = s.terminate_when_unhealthy && !healthy;
@@ -1032,13 +1194,13 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
         reward = -sqrtf(dx * dx + dy * dy + dz * dz) - s.ctrl_cost_weight * ctrl;
         terminated = false;
       } else if (s.tip_link > 0) {  // brax.envs.inverted_double_pendulum: alive bonus - distance - velocity penalties
-        const Body bt = m.body(s.tip_link);
-        const v3 tip = bt.p + qrot(bt.r, f3(s.tip_offset) - f3(s.com[s.tip_link]));
+        const v3d tipd = m.pos(s.tip_link) + qrot(m.rot(s.tip_link), tod(f3(s.tip_offset) - f3(s.com[s.tip_link])));
+        const v3 tip = tof(tipd);
         const float dz = tip.z - s.tip_height;
         const float v0 = m.at(m.lay.wrench + s.tip_vel_dof[0]), v1 = m.at(m.lay.wrench + s.tip_vel_dof[1]);
         reward = s.healthy_reward - (s.tip_x_weight * tip.x * tip.x + dz * dz) -
                  (s.tip_vel_weight[0] * v0 * v0 + s.tip_vel_weight[1] * v1 * v1);
-        terminated = tip.z <= s.tip_min_height;
+        terminated = tipd.z <= (double)s.tip_min_height;
       }
       if (goal) {  // brax_walker_goal_wrapper.py:124-140: progress reward replaces the env reward
         const float nx = r.pos_x + m.at(m.lay.io + s.goal_obs_idx[0]) * s.goal_dt;
@@ -1077,9 +1239,8 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
           phase_sync();  // the io rows are rewritten below
           if ((b.flags & CARL_FLAG_AUTORESET_FIRST_STATE) && b.first_state != nullptr) {
             // brax AutoResetWrapper: the state of the last explicit reset, same context, nothing drawn
+            record_load(b.first_state + (size_t)env * S, m, s.n_links, done);
             if (done) {
-              const float* src = b.first_state + (size_t)env * S;
-              for (int k = m.sub; k < S; k += kSub) m.at(m.lay.state + k) = src[k];
               r.elapsed = 0;
               r.ep_return = 0.0f;
               if (goal) r.pos_x = r.pos_y = 0.0f;
@@ -1110,10 +1271,11 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
         }
       }
       record_out(io.obs + step_off * s.obs_dim, (size_t)env, s.obs_dim, m, active);
+      pose_round(m, s.n_links, active);
       phase_sync();  // the next step's actions overwrite the io rows
     }
     if (active) {
-      for (int k = m.sub; k < S; k += kSub) b.state[(size_t)env * S + k] = m.at(m.lay.state + k);
+      record_store(b.state + (size_t)env * S, m, s.n_links, true);
       if (m.sub == 0) {
         b.elapsed[env] = r.elapsed;
         b.ep_return[env] = r.ep_return;
@@ -1138,7 +1300,7 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
 // out, as MULTI = false does for the Euler-angle joints.  Task models always have a hinge-less last link,
 // so TASK implies MULTI.
 template <int MODE, bool MULTI, int K, bool TASK = false>
-__global__ void __launch_bounds__(kLanes) brax_kernel(const carl_batch_t b, const carl_brax_sys_t* __restrict__ sys_dev,
+__global__ void __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(2))) brax_kernel(const carl_batch_t b, const carl_brax_sys_t* __restrict__ sys_dev,
                                                       const Prepared prep, const carl_step_io_t io,
                                                       const uint8_t* __restrict__ mask, float* __restrict__ reset_obs,
                                                       const int n_steps) {

@@ -164,7 +164,7 @@ int launch_brax(const carl_batch_t* b, const carl_brax_sys_t* sd, const carl_bra
   const int K = brax_lanes_per_env(sh->n_links, multi, task, b->n_lanes, sh->lanes_per_env);
   const int envs = carl::brax::kLanes / K;  // one wavefront = envs x K lanes; LDS rows are `envs` floats wide
   const carl::brax::Layout lay = carl::brax::Layout::make(sh->n_links, sh->n_dof, carl::brax::io_rows_of(*sh));
-  const size_t sh_bytes = (size_t)lay.total * envs * sizeof(float);
+  const size_t sh_bytes = lay.bytes(envs);
   if (sh_bytes + sizeof(carl_brax_sys_t) + sizeof(carl::brax::Prepared) > 160 * 1024)
     return fail(CARL_ERR_UNSUPPORTED, "%s: model needs %zu B of LDS per wavefront", who, sh_bytes);
   using kern_t = void (*)(carl_batch_t, const carl_brax_sys_t*, carl::brax::Prepared, carl_step_io_t, const uint8_t*,

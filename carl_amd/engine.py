@@ -282,6 +282,7 @@ class VecEngine:
             io.terminated, io.truncated = _ptr(self.terminated), _ptr(self.truncated)
             io.final_obs = _ptr(self.final_obs)
             io.done = _ptr(self.done)
+            io.branch_sig = _ptr(getattr(self, "branch_sig", None))
 
     def _stream(self) -> int:
         return torch.cuda.current_stream(self.device).cuda_stream
@@ -424,6 +425,7 @@ class VecEngine:
         io.obs, io.reward = _ptr(out["obs"]), _ptr(out["reward"])
         io.terminated, io.truncated = _ptr(out["terminated"]), _ptr(out["truncated"])
         io.final_obs = _ptr(out.get("final_obs"))
+        io.branch_sig = _ptr(out.get("branch_sig"))
         with torch.cuda.device(self.device):
             _lib.check(self._c_rollout(io, T))
         return out

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define CARL_ABI_VERSION 4
+#define CARL_ABI_VERSION 5
 #define CARL_MAX_CTX_OBS 32
 
 #define CARL_ERR_INVALID_ARGUMENT (-1)
@@ -145,7 +145,7 @@ typedef struct carl_batch {
    * NULL otherwise */
   float* goal_pos;           /* [2][n_lanes] position integrated from the observed x/y velocities */
   uint8_t* success;          /* [n_lanes] (or [T][n_lanes] in a rollout): goal reached on this step */
-  /* Brax families, CARL_FLAG_AUTORESET_FIRST_STATE: [n_lanes][13 L], written by carl_brax_reset, read by the
+  /* Brax families, CARL_FLAG_AUTORESET_FIRST_STATE: [n_lanes][20 L] (records like `state`), written by carl_brax_reset, read by the
    * in-kernel auto-reset; NULL otherwise */
   float* first_state;
 } carl_batch_t;
@@ -166,6 +166,13 @@ typedef struct carl_step_io {
   uint8_t* done;        /* [n_lanes] or NULL: terminated | truncated, the done mask of this step (what
                            info["_final_observation"] of a vector env is); per-call carl_step / carl_brax_step
                            only, ignored by the rollout entry points */
+  uint32_t* branch_sig; /* Brax families: [n_lanes][2] or NULL.  Hash of the DISCRETE decisions the physics took in
+                           this env step: [0] which collision spheres delivered an impulse in which substep
+                           (discontinuous: an impulse appears when a point starts to approach), [1] which joint
+                           range limits were active (continuous: the limit spring starts at zero).  Two
+                           implementations of the same arithmetic can only be compared to rounding on lanes
+                           whose word [0] agrees; tests/test_gpu_brax.py uses it for exactly that.  Ignored by
+                           the classic-control entry points. */
 } carl_step_io_t;
 
 int carl_abi_version(void);
@@ -346,13 +353,20 @@ typedef struct carl_brax_sys {
   carl_brax_ctx_map_t ctx;
 } carl_brax_sys_t;
 
-/* floats of persistent state per lane: per link COM position 3, rotation 4 (w,x,y,z),
- * linear velocity 3, angular velocity 3 (world frame) */
+/* persistent state per link: COM position 3, rotation 4 (w,x,y,z), linear velocity 3, angular velocity 3
+ * (world frame) = 13 quantities.  The pose (the first 7) is carried to 48 significant bits as a float32 head
+ * plus a float32 tail -- the spring pipeline multiplies pose DIFFERENCES by k dt / m = 20 .. 50 per substep, so a
+ * pose rounded to float32 between steps costs 1e-5 of velocity per env step -- which makes
+ * CARL_BRAX_LINK_RECORD = 20 floats per link in HBM.  One env's record, L links:
+ *   [0, 7 L)      pose heads, link-major (p.x p.y p.z r.w r.x r.y r.z per link): the pose to float32
+ *   [7 L, 14 L)   pose tails: pose = (double)head + (double)tail
+ *   [14 L, 20 L)  velocities, link-major (v.x v.y v.z w.x w.y w.z per link) */
 #define CARL_BRAX_LINK_STATE 13
+#define CARL_BRAX_LINK_RECORD 20
 
 /* carl_batch_t is reused: family = CARL_N_FAMILIES + env_kind is ignored here (sys decides),
- * state is [n_lanes][13 * n_links] (env-major: the lanes that share an env move its 13 L floats as one
- * contiguous record; the classic-control families keep [S][n_lanes]), ctx_table rows follow the CARL
+ * state is [n_lanes][CARL_BRAX_LINK_RECORD * n_links] (env-major: the lanes that share an env move its 20 L
+ * floats as one contiguous record; the classic-control families keep [S][n_lanes]), ctx_table rows follow the CARL
  * class's feature table.
  * action is float32 [n_lanes][n_act] (lane-major, like obs).  `sys` is a DEVICE pointer to
  * one carl_brax_sys_t.  */

@@ -117,9 +117,10 @@ class Engine:
         term = np.empty(self.n, dtype=np.uint8)
         trunc = np.empty(self.n, dtype=np.uint8)
         final_obs = np.full((self.n, self.D), np.nan, dtype=np.float32)
+        self.branch_sig = np.zeros((self.n, 2), dtype=np.uint32)  # discrete decisions of this step (brax_spring.c: substep)
         O.lib().obx_engine_step(self.sys.ptr, C.byref(self.cfg), _p(self.ctx), C.c_int(self.F), _p(a),
                                 _p(self.state), _p(self.elapsed), _p(self.ctx_idx), _p(self.episode),
                                 _p(self.n_calls), _p(self.ep_return), _p(self.obs), _p(rew), _p(term), _p(trunc),
                                 _p(final_obs), _p(self.last_return), _p(self.last_length), _p(self.episodes_done),
-                                _p(self.goal_pos), _p(self.success), _p(self.first_state))
+                                _p(self.goal_pos), _p(self.success), _p(self.first_state), _p(self.branch_sig))
         return O.StepOut(self.obs.copy(), rew, term, trunc, final_obs)

@@ -295,8 +295,13 @@ static v3 apply_inv_inertia(const carl_brax_sys_t* s, int i, qt r, v3 t) {
   return qrot(r, V(l.x * s->inv_inertia[i][0], l.y * s->inv_inertia[i][1], l.z * s->inv_inertia[i][2]));
 }
 
-/* one brax.spring.pipeline.step */
-static void substep(const carl_brax_sys_t* s, const lane_ctx* c, const double* tau, body* b) {
+/* one brax.spring.pipeline.step.  hc / hl (nullable, per link): running hashes h <- 33 h + bits of the DISCRETE
+ * decisions taken -- hc: which of the link's collision spheres delivered an impulse (bit = ordinal of the sphere
+ * among the link's spheres), hl: which range limits of the link's joint were active (slides: bits 0-3, hinges: bits
+ * 4-9; below / above per dof).  A float32 implementation of the same arithmetic can only agree to rounding where
+ * it took the same contact decisions (an impulse is discontinuous in the state): tests compare these hashes with
+ * the kernel's (carl_step_io_t::branch_sig) and assert the tolerance on the agreeing lanes. */
+static void substep(const carl_brax_sys_t* s, const lane_ctx* c, const double* tau, body* b, uint32_t* hc, uint32_t* hl) {
   v3 F[L_MAX], T[L_MAX];
   const int L = s->n_links;
   for (int i = 0; i < L; ++i) { F[i] = V(0, 0, 0); T[i] = V(0, 0, 0); }
@@ -309,6 +314,7 @@ static void substep(const carl_brax_sys_t* s, const lane_ctx* c, const double* t
     const double kp = s->k_pos[i] * c->stiffness_scale;
     v3 e = vsub(g.A_p, g.A_c), ev = vsub(g.vA_p, g.vA_c);
     v3 f = V(0, 0, 0);
+    uint32_t lim = 0;
     const int ns = s->n_slide[i], d0 = s->dof_start[i];
     for (int k = 0; k < ns; ++k) { /* prismatic dofs: free along the axis, own spring/damper/force */
       const v3 ax = qrot(bp.r, f3(s->slide_axis[i][k]));
@@ -316,8 +322,8 @@ static void substep(const carl_brax_sys_t* s, const lane_ctx* c, const double* t
       e = vadd(e, vscale(ax, qk));
       ev = vadd(ev, vscale(ax, qdk));
       double fa = tau[d0 + k] - s->dof_damping[d0 + k] * qdk - s->dof_stiffness[d0 + k] * qk;
-      if (qk < s->dof_lo[d0 + k]) fa += s->k_limit[i] * (s->dof_lo[d0 + k] - qk); /* range of the slide */
-      if (qk > s->dof_hi[d0 + k]) fa -= s->k_limit[i] * (qk - s->dof_hi[d0 + k]);
+      if (qk < s->dof_lo[d0 + k]) { fa += s->k_limit[i] * (s->dof_lo[d0 + k] - qk); lim |= 1u << (2 * k); } /* range of the slide */
+      if (qk > s->dof_hi[d0 + k]) { fa -= s->k_limit[i] * (qk - s->dof_hi[d0 + k]); lim |= 2u << (2 * k); }
       f = vadd(f, vscale(ax, fa));
     }
     f = vadd(f, vadd(vscale(e, kp), vscale(ev, s->k_vel[i])));
@@ -328,8 +334,8 @@ static void substep(const carl_brax_sys_t* s, const lane_ctx* c, const double* t
     if (nr == 1) {
       t = vscale(vcross(g.x_c, g.x_p), kp); /* keep the hinge axes aligned */
       double ta = tau[d] - s->dof_damping[d] * g.thetadot - s->dof_stiffness[d] * g.theta;
-      if (g.theta < s->dof_lo[d]) ta += s->k_limit[i] * (s->dof_lo[d] - g.theta);
-      if (g.theta > s->dof_hi[d]) ta -= s->k_limit[i] * (g.theta - s->dof_hi[d]);
+      if (g.theta < s->dof_lo[d]) { ta += s->k_limit[i] * (s->dof_lo[d] - g.theta); lim |= 16u; }
+      if (g.theta > s->dof_hi[d]) { ta -= s->k_limit[i] * (g.theta - s->dof_hi[d]); lim |= 32u; }
       t = vadd(t, vscale(g.x_c, ta));
     } else { /* 2 or 3 stacked hinges: per-dof torques about the current axes; a missing third
                 dof is locked by the constraint spring on its Euler angle */
@@ -339,8 +345,8 @@ static void substep(const carl_brax_sys_t* s, const lane_ctx* c, const double* t
         if (k < nr) {
           const int dk = d + k;
           ta = tau[dk] - s->dof_damping[dk] * g.rate[k] - s->dof_stiffness[dk] * g.ang[k];
-          if (g.ang[k] < s->dof_lo[dk]) ta += s->k_limit[i] * (s->dof_lo[dk] - g.ang[k]);
-          if (g.ang[k] > s->dof_hi[dk]) ta -= s->k_limit[i] * (g.ang[k] - s->dof_hi[dk]);
+          if (g.ang[k] < s->dof_lo[dk]) { ta += s->k_limit[i] * (s->dof_lo[dk] - g.ang[k]); lim |= 16u << (2 * k); }
+          if (g.ang[k] > s->dof_hi[dk]) { ta -= s->k_limit[i] * (g.ang[k] - s->dof_hi[dk]); lim |= 32u << (2 * k); }
         } else {
           ta = -kp * g.ang[k];
         }
@@ -348,6 +354,7 @@ static void substep(const carl_brax_sys_t* s, const lane_ctx* c, const double* t
       }
     }
     t = vsub(t, vscale(g.wrel, s->k_ang_damp[i]));
+    if (hl) hl[i] = hl[i] * 33u + lim;
     T[i] = vadd(T[i], t);
     if (P >= 0) {
       F[P] = vsub(F[P], f);
@@ -384,11 +391,13 @@ static void substep(const carl_brax_sys_t* s, const lane_ctx* c, const double* t
   }
   /* --- spring.collisions.resolve: spheres vs the plane z = 0 ------------------------ */
   v3 dv[L_MAX], dw[L_MAX];
-  int cnt[L_MAX];
-  for (int i = 0; i < L; ++i) { dv[i] = V(0, 0, 0); dw[i] = V(0, 0, 0); cnt[i] = 0; }
+  int cnt[L_MAX], seen[L_MAX];
+  uint32_t hit[L_MAX];
+  for (int i = 0; i < L; ++i) { dv[i] = V(0, 0, 0); dw[i] = V(0, 0, 0); cnt[i] = 0; seen[i] = 0; hit[i] = 0; }
   const v3 n = V(0, 0, 1);
   for (int k = 0; k < s->n_coll; ++k) {
     const int i = s->coll_link[k];
+    const int ordinal = seen[i]++; /* of this sphere among its link's spheres */
     const v3 o = vsub(b[i].p, qrot(b[i].r, f3(s->com[i])));
     const v3 ctr = vadd(o, qrot(b[i].r, f3(s->coll_pos[k])));
     const double depth = s->coll_radius[k] - ctr.z; /* > 0: penetrating */
@@ -402,6 +411,7 @@ static void substep(const carl_brax_sys_t* s, const lane_ctx* c, const double* t
     const double baum = s->baumgarte_erp * depth / s->dt;
     const double imp = (-(1.0 + c->elasticity) * vn + baum) / (inv_m + ang);
     if (!(imp > 0) || !(vn < 0)) continue; /* only approaching contacts push */
+    hit[i] |= 1u << ordinal;
     v3 J = vscale(n, imp);
     const v3 vt = vsub(rel, vscale(n, vn));
     const double vt_len = sqrt(vdot(vt, vt));
@@ -420,6 +430,7 @@ static void substep(const carl_brax_sys_t* s, const lane_ctx* c, const double* t
   /* --- spring.integrator.integrate --------------------------------------------------- */
   const double dl = exp(s->vel_damping * s->dt), da = exp(c->ang_damping * s->dt);
   for (int i = 0; i < L; ++i) {
+    if (hc) hc[i] = hc[i] * 33u + hit[i];
     b[i].v = vscale(b[i].v, dl);
     b[i].w = vscale(b[i].w, da);
     if (cnt[i] > 0) {
@@ -630,7 +641,7 @@ void obx_substeps(const carl_brax_sys_t* s, const double* ctx_row, const double*
   body b[L_MAX];
   const lane_ctx c = make_ctx(s, ctx_row);
   load_bodies(s, state, b);
-  for (int k = 0; k < n_sub; ++k) substep(s, &c, tau, b);
+  for (int k = 0; k < n_sub; ++k) substep(s, &c, tau, b, NULL, NULL);
   store_bodies(s, b, state);
 }
 
@@ -662,7 +673,8 @@ void obx_engine_step(const carl_brax_sys_t* s, const oracle_cfg_t* cfg, const do
                      const float* action, double* state, int32_t* elapsed, int32_t* ctx_idx, uint32_t* episode,
                      int32_t* n_calls, double* ep_return, float* obs, float* reward, uint8_t* terminated,
                      uint8_t* truncated, float* final_obs, float* last_return, int32_t* last_length,
-                     int32_t* episodes_done, double* goal_pos, uint8_t* success, const double* first_state) {
+                     int32_t* episodes_done, double* goal_pos, uint8_t* success, const double* first_state,
+                     uint32_t* branch_sig /* [n_lanes][2] or NULL: see substep() */) {
   const int S = 13 * s->n_links, D = s->obs_dim;
   for (int i = 0; i < cfg->n_lanes; ++i) {
     const uint64_t g = (uint64_t)(cfg->lane_offset + i);
@@ -683,7 +695,15 @@ void obx_engine_step(const carl_brax_sys_t* s, const oracle_cfg_t* cfg, const do
     const v3 c0 = qrot(b[0].r, f3(s->com[0]));
     double M;
     double x0 = s->reward_on_com ? system_com(s, &c, b, &M).x : b[0].p.x - c0.x;
-    for (int k = 0; k < s->n_frames; ++k) substep(s, &c, tau, b);
+    uint32_t hc[L_MAX], hl[L_MAX];
+    for (int k = 0; k < s->n_links; ++k) hc[k] = hl[k] = 0;
+    for (int k = 0; k < s->n_frames; ++k) substep(s, &c, tau, b, hc, hl);
+    if (branch_sig) { /* the per-link hashes combined in link order */
+      uint32_t a = 0, l = 0;
+      for (int k = 0; k < s->n_links; ++k) { a = a * 1000003u + hc[k]; l = l * 1000003u + hl[k]; }
+      branch_sig[2 * i] = a;
+      branch_sig[2 * i + 1] = l;
+    }
     const v3 c1 = qrot(b[0].r, f3(s->com[0]));
     const double x1 = s->reward_on_com ? system_com(s, &c, b, &M).x : b[0].p.x - c1.x;
     const double z1 = b[0].p.z - c1.z;

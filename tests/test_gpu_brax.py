@@ -1,44 +1,32 @@
-"""HIP Brax-Ant lane engine (through the C ABI) against the fp64 oracle of the same
-specification (oracle/brax_spring.c).  PARITY WITH BRAX ITSELF IS UNPINNED (brax 0.12.1 is
-neither in the reference tree nor installable) -- these tests pin the
-fp32 LDS-resident kernel against an independent fp64 implementation, per transition.
+"""HIP Brax lane engine (through the C ABI) against the fp64 oracle of the same specification
+(oracle/brax_spring.c).  PARITY WITH BRAX ITSELF IS UNPINNED (brax 0.12.1 is neither in the reference tree nor
+installable) -- these tests pin the LDS-resident kernel against an independent fp64
+implementation, per transition.
 
-Tolerance -- north_star's bar is "within 1e-5 fp32", and for the Brax rows it is NOT MET on every entry; what is
-measured instead is stated here and asserted below.  Per env step (= n_frames substeps) from identical float32
-state, |d| / (1 + |x|) over observation entries and reward against the float64 restatement, 2 048 envs x 40 steps
-under BASELINE-style context variation and a full-range random policy (tools/brax_parity_percentiles.py on an
-MI355X, round 2, profiles/r02_brax_parity_percentiles.txt):
-
-    family                       p50      p99      p99.9    share > 1e-5   share > 1e-3
-    ant                          2.2e-6   7.1e-6   1.1e-5   0.2 %          0.006 %
-    halfcheetah                  2.8e-6   1.1e-5   1.5e-5   1.3 %          0.015 %
-    humanoid                     4.5e-6   2.4e-5   1.0e-3   17 %           0.10 %
-    hopper                       2.6e-6   1.2e-5   1.7e-5   2.4 %          0.007 %
-    walker2d                     4.1e-6   1.8e-5   9.6e-5   11 %           0.05 %
-    inverted (double) pendulum   <5e-7    <5e-6    <1e-5    <0.1 %         0
-    humanoidstandup              8.9e-6   2.7e-5   1.9e-3   39 %           0.15 %
-    reacher                      6e-8     2e-7     3e-7     0              0
-    pusher                       1.5e-5   8.3e-5   1.2e-4   65 %           0
-
-So: the 1e-5 bar holds at the 99th percentile for Ant, the inverted pendulums and Reacher, at the median for
-everything but Pusher, and FAILS beyond that.  Two mechanisms, neither removable in float32 state: (1) the pipeline
-is stiff -- a constraint spring turns an absolute error e in a relative position / orientation of two bodies into
-k dt e of velocity per substep (k dt = 20 for Ant, 30 for Humanoid, 47 for Halfcheetah), and float32 body poses
-carry e ~ 1e-7; round 2 moved the largest such term, the relative rotation of the joint frames and the axis-alignment
-torque, to float64 (Ant p99 2.2e-5 -> 7.1e-6, Humanoid p50 1.1e-5 -> 4.5e-6; brax_kernels.hip.h: joint_geometry), what
-is left is the rounding of the float32 state itself between substeps; (2) the contact rule is discontinuous (an
-impulse only while the point approaches, vn < 0; termination on a height threshold), so a lane whose vn or height
-crosses within rounding differs by O(erp depth / dt) -- the > 1e-3 tail.  Discrete outputs (truncation, counters,
-context ids) are exact."""
+Tolerance: north_star's "within 1e-5 fp32 (bit-exact for discrete done flags ...)", asserted as a MAXIMUM of
+|d| / (1 + |x|) over every observation entry and the reward of every lane-step whose DISCRETE decisions agree
+with the oracle's (tests/brax_parity_util.py: the contact set of every substep, hashed on both sides, and the
+`terminated` flag); lanes where a contact switched inside the rounding interval are excluded AND COUNTED
+(bound: 0.5 % of lane-steps), like the threshold-edge done flags of tests/test_gpu_parity.py.  Round 2 missed the
+bar (Humanoid: 11.7 % of entries beyond 1e-5) because a float32 pose carries ~1e-7 of rounding that the constraint
+springs multiply by k dt / m = 20 .. 47 per substep; since round 3 the kernel holds the pose, and forms every pose
+DIFFERENCE (anchor separation, relative joint rotation and its angles, contact depth, forward progress), in
+float64, and keeps forces / impulses / velocities in float32 (profiles/r03_brax_parity_percentiles.txt).
+Discrete outputs (truncation, counters, context ids) are exact."""
 import numpy as np
 import pytest
 import torch
 
 from carl_amd.envs.brax.models import ant_sys
+from brax_parity_util import Parity, assert_parity, step_both
 from oracle import brax as B
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
+
+# per-family tolerance of the every-width test where it is not north_star's 1e-5 (filled from the measured
+# profiles/r03_brax_parity_percentiles.txt; an entry here is a stated, failed bar)
+TOL: dict = {}
 
 NAMES = ["gravity", "friction", "elasticity", "ang_damping", "mass_torso", "viscosity", "target_distance",
          "target_direction", "target_radius"]
@@ -78,7 +66,7 @@ def test_reset_matches_oracle(device):
         want = ora.reset()
         np.testing.assert_array_equal(eng.ctx_idx.cpu().numpy(), ora.ctx_idx)
         np.testing.assert_array_equal(eng.n_calls.cpu().numpy(), ora.n_calls)
-        assert rel_err(eng.state.t().cpu().numpy(), ora.state).max() < 2e-6  # fp32 Box-Muller / kinematics
+        assert rel_err(eng.state_np(), ora.state).max() < 2e-6  # fp32 Box-Muller / kinematics
         assert rel_err(obs, want).max() < 5e-6
         np.testing.assert_array_equal(eng.ctx_obs.cpu().numpy(), rows[ora.ctx_idx].T.astype(np.float32))
     mask = (rng.random(n) < 0.25).astype(np.uint8)
@@ -87,7 +75,7 @@ def test_reset_matches_oracle(device):
     ora.reset(mask)
     keep = torch.as_tensor(mask == 0, device=device)
     assert torch.equal(eng.state[:, keep], before[:, keep])
-    assert rel_err(eng.state.t().cpu().numpy(), ora.state).max() < 2e-6
+    assert rel_err(eng.state_np(), ora.state).max() < 2e-6
 
 
 def test_stepwise_parity_with_resync(device):
@@ -96,36 +84,18 @@ def test_stepwise_parity_with_resync(device):
     n = 2048
     rows = context_rows(rng, n)
     kw = dict(selector=O.SEL_STATIC, seed=5, ctx_idx0=np.arange(n))
-    eng = engine(s, rows, n, device, max_episode_steps=40, **kw)
+    eng = engine(s, rows, n, device, max_episode_steps=40, branch_record=True, **kw)
     ora = B.Engine(s, rows, n, max_steps=40, **kw)
     eng.reset()
     ora.reset()
-    errs = []
+    par = Parity()
     for t in range(90):
-        ora.state[:] = eng.state.t().cpu().numpy()
         a = rng.uniform(-1.2, 1.2, (n, 8)).astype(np.float32)
-        obs, rew, term, trunc = eng.step(torch.as_tensor(a))
-        out = ora.step(a)
-        term, trunc = term.cpu().numpy(), trunc.cpu().numpy()
-        np.testing.assert_array_equal(trunc, out.truncated)
-        fd = term != out.terminated
-        assert fd.sum() <= 2, "termination differs away from the healthy-z threshold"
-        ok = ~fd
-        done = ((term | trunc) != 0) & ok
-        # compare the TERMINAL / regular observation of this transition
-        got_obs = np.where(done[:, None], eng.final_obs.cpu().numpy(), obs.cpu().numpy())
-        want_obs = np.where(done[:, None], out.final_obs, out.obs)
-        e = np.maximum(rel_err(got_obs, want_obs).max(1), rel_err(rew.cpu().numpy(), out.reward))[ok]
-        errs.append(e)
-        if fd.any():
-            break
-        np.testing.assert_array_equal(eng.elapsed.cpu().numpy(), ora.elapsed)
-        np.testing.assert_array_equal(eng.episodes_done.cpu().numpy(), ora.episodes_done)
-    e = np.concatenate(errs)
-    # measured 2.2e-6 / 7.1e-6 / 1.1e-5 (module docstring): the 1e-5 bar holds at p99, not beyond
-    assert np.percentile(e, 50) <= 5e-6 and np.percentile(e, 99) <= 1e-5 and np.percentile(e, 99.9) <= 5e-5, (
-        np.percentile(e, [50, 99, 99.9]))
-    assert (e > 1e-3).mean() < 1e-3
+        step_both(eng, ora, a, par, t)
+        if par.flag_mismatch == 0:
+            np.testing.assert_array_equal(eng.elapsed.cpu().numpy(), ora.elapsed)
+            np.testing.assert_array_equal(eng.episodes_done.cpu().numpy(), ora.episodes_done)
+    assert_parity(par, "ant")
     assert int(eng.episodes_done.sum()) >= n  # truncation at 40 + falls
 
 
@@ -260,32 +230,21 @@ def test_halfcheetah_stepwise_parity_and_reset(device):
     n = 2048
     rows = _cheetah_rows(rng, n, default, names)
     kw = dict(selector=O.SEL_STATIC, seed=6, ctx_idx0=np.arange(n))
-    eng = BraxVecEngine(s, len(names), rows, n, device, max_episode_steps=25, **kw)
+    eng = BraxVecEngine(s, len(names), rows, n, device, max_episode_steps=25, branch_record=True, **kw)
     ora = B.Engine(s, rows, n, max_steps=25, **kw)
     obs = eng.reset().cpu().numpy()
     want = ora.reset()
     assert obs.shape == (n, 17) and rel_err(obs, want).max() < 5e-6
-    assert rel_err(eng.state.t().cpu().numpy(), ora.state).max() < 2e-6
-    errs = []
+    assert rel_err(eng.state_np(), ora.state).max() < 2e-6
+    par = Parity()
     for t in range(60):
-        ora.state[:] = eng.state.t().cpu().numpy()
         a = rng.uniform(-1.2, 1.2, (n, 6)).astype(np.float32)
-        o, rew, term, trunc = eng.step(torch.as_tensor(a))
-        out = ora.step(a)
-        np.testing.assert_array_equal(trunc.cpu().numpy(), out.truncated)
+        o, rew, term, trunc, out = step_both(eng, ora, a, par, t)
         assert not term.any() and not out.terminated.any()
-        done = trunc.cpu().numpy() != 0
-        got = np.where(done[:, None], eng.final_obs.cpu().numpy(), o.cpu().numpy())
-        wnt = np.where(done[:, None], out.final_obs, out.obs)
-        errs.append(np.maximum(rel_err(got, wnt).max(1), rel_err(rew.cpu().numpy(), out.reward)))
         np.testing.assert_array_equal(eng.elapsed.cpu().numpy(), ora.elapsed)
-    e = np.concatenate(errs)
-    # stiffer constraint springs (k = 15000 x up to 2) and 16 substeps per env step; measured 2.8e-6 / 1.1e-5 /
-    # 1.5e-5 (module docstring): the 1e-5 bar is missed at p99 by ~10 %
-    assert np.percentile(e, 50) <= 8e-6 and np.percentile(e, 99) <= 4e-5 and (e > 1e-3).mean() < 1e-3, (
-        np.percentile(e, [50, 99, 99.9]))
+    assert_parity(par, "halfcheetah")  # k = 15000 x up to 2 (joint_stiffness context), 16 substeps per env step
     # planar: y and the roll / yaw quaternion components stay zero
-    st = eng.state.view(7, 13, n)
+    st = eng.state64().permute(1, 2, 0)  # [link, 13, env]
     assert float(st[:, 1].abs().max()) < 1e-5 and float(st[:, 4].abs().max()) < 1e-5
 
 
@@ -343,35 +302,33 @@ def test_goal_reward_epilogue_matches_oracle_and_reference_test(device):
     rows[:, 8] = rng.uniform(0.1, 0.5, n)         # target_radius
     rows = rows.astype(np.float32).astype(np.float64)
     kw = dict(selector=O.SEL_STATIC, seed=2, ctx_idx0=np.arange(n))
-    eng = BraxVecEngine(s, len(NAMES), rows, n, device, max_episode_steps=60, **kw)
+    eng = BraxVecEngine(s, len(NAMES), rows, n, device, max_episode_steps=60, branch_record=True, **kw)
     ora = B.Engine(s, rows, n, max_steps=60, **kw)
     eng.reset()
     ora.reset()
     n_success = 0
+    par = Parity()
     for t in range(100):
-        ora.state[:] = eng.state.t().cpu().numpy()
-        ora.goal_pos[:] = eng.goal_pos.t().cpu().numpy()
-        a = rng.uniform(-1, 1, (n, 8)).astype(np.float32)
-        o, rew, term, trunc = eng.step(torch.as_tensor(a))
-        out = ora.step(a)
+        pos0 = eng.goal_pos.t().cpu().numpy().astype(np.float64)
+        o, rew, term, trunc, out = step_both(eng, ora, rng.uniform(-1, 1, (n, 8)).astype(np.float32), par, t, sync_goal=True)
         assert float(rew.min()) >= 0.0  # the reference's own assertion
         ok = eng.success.cpu().numpy()
-        # lanes hit by a contact-rule discontinuity this step (see the module docstring) differ in
-        # their velocities, hence in the integrated position: judge the epilogue on the others
-        done = ((term | trunc) != 0).cpu().numpy()
-        got_obs = np.where(done[:, None], eng.final_obs.cpu().numpy(), o.cpu().numpy())
-        want_obs = np.where(done[:, None], out.final_obs, out.obs)
-        near = rel_err(got_obs, want_obs).max(1) < 1e-4
-        assert near.mean() > 0.98
+        # lanes where a contact switched within rounding this step differ in their velocities, hence in the
+        # integrated position: judge the epilogue on the lanes whose branch record agrees with the oracle's
+        sig = eng.branch_sig.cpu().numpy().view(np.uint32)
+        same = sig[:, 0] == ora.branch_sig[:, 0]
         agree = ok == ora.success
         assert agree.mean() > 0.995  # success flips only within rounding of the radius
-        assert rel_err(rew.cpu().numpy(), out.reward)[agree & near].max() < 1e-4
         n_success += int(ok.sum())
+        done = ((term | trunc) != 0).cpu().numpy()
+        live = same & agree & ~done  # (a done env's position is back at the origin on both sides)
+        assert rel_err(eng.goal_pos.t().cpu().numpy(), ora.goal_pos)[live].max() < 1e-5
         if not agree.all():
             break
-        np.testing.assert_array_equal(term.cpu().numpy(), out.terminated)
-        assert rel_err(eng.goal_pos.t().cpu().numpy(), ora.goal_pos)[near].max() < 1e-4
     assert n_success > 0  # some lanes with tiny target distances did reach their goal
+    # the progress reward replaces the env reward: it is part of the parity record.  A success flip shows up as a
+    # `terminated` mismatch and is excluded with the contact flips.
+    assert_parity(par, "ant goal mode", max_excluded=1e-2)
 
 
 def test_goal_mode_through_the_env_api(device):
@@ -427,41 +384,18 @@ def test_humanoid_stepwise_parity_and_reset(device):
     n = 1024
     rows = _humanoid_rows(rng, n, default, names)
     kw = dict(selector=O.SEL_STATIC, seed=8, ctx_idx0=np.arange(n))
-    eng = BraxVecEngine(s, len(names), rows, n, device, max_episode_steps=12, **kw)
+    eng = BraxVecEngine(s, len(names), rows, n, device, max_episode_steps=12, branch_record=True, **kw)
     ora = B.Engine(s, rows, n, max_steps=12, **kw)
     obs = eng.reset().cpu().numpy()
     want = ora.reset()
     assert obs.shape == (n, 244) and rel_err(obs, want).max() < 5e-6
-    assert rel_err(eng.state.t().cpu().numpy(), ora.state).max() < 2e-6
+    assert rel_err(eng.state_np(), ora.state).max() < 2e-6
     assert np.all(obs[:, -23:] == 0)
-    errs, n_term = [], 0
+    par = Parity()
     for t in range(30):
-        ora.state[:] = eng.state.t().cpu().numpy()
         a = rng.uniform(-0.5, 0.5, (n, 17)).astype(np.float32)
-        o, rew, term, trunc = eng.step(torch.as_tensor(a))
-        out = ora.step(a)
-        np.testing.assert_array_equal(trunc.cpu().numpy(), out.truncated)
-        term_g = term.cpu().numpy() != 0
-        # healthy-z threshold crossings within fp32 rounding may flip `terminated` on isolated lanes
-        flip = term_g != (out.terminated != 0)
-        assert flip.mean() < 2e-3
-        n_term += int(term_g.sum())
-        done = (term_g | (trunc.cpu().numpy() != 0)) & ~flip
-        got = np.where(done[:, None], eng.final_obs.cpu().numpy(), o.cpu().numpy())
-        wnt = np.where(done[:, None], out.final_obs, out.obs)
-        e = np.maximum(rel_err(got, wnt).max(1), rel_err(rew.cpu().numpy(), out.reward))
-        errs.append(e[~flip])
-        if flip.any():  # keep both sides on the same episode bookkeeping
-            ora.elapsed[:] = eng.elapsed.cpu().numpy()
-            ora.episode[:] = eng.episode.cpu().numpy()
-            ora.ep_return[:] = eng.ep_return.cpu().numpy()
-        else:
-            np.testing.assert_array_equal(eng.elapsed.cpu().numpy(), ora.elapsed)
-    e = np.concatenate(errs)
-    # k_pos 20000 at dt 0.0015, 10 substeps, contacts with terminations; measured 4.5e-6 / 2.4e-5 (module
-    # docstring): the 1e-5 bar holds at the median only
-    assert np.percentile(e, 50) <= 1e-5 and np.percentile(e, 99) <= 8e-5 and (e > 3e-3).mean() < 3e-3, (
-        np.percentile(e, [50, 99, 99.9]))
+        step_both(eng, ora, a, par, t)
+    assert_parity(par, "humanoid")  # k_pos 20000 at dt 0.0015, 10 substeps, 2- and 3-dof joints, contacts, terminations
 
 
 def test_humanoid_rollout_equals_step_and_env_api(device):
@@ -547,32 +481,26 @@ def test_every_lane_group_width_matches_oracle(device, model, lanes_per_env, mon
     rows[:, names.index("gravity")] = rng.uniform(-15, -5, n)
     rows = rows.astype(np.float32).astype(np.float64)
     kw = dict(selector=O.SEL_STATIC, seed=9, ctx_idx0=np.arange(n))
-    eng = BraxVecEngine(s, len(names), rows, n, device, max_episode_steps=4, **kw)
+    eng = BraxVecEngine(s, len(names), rows, n, device, max_episode_steps=4, branch_record=True, **kw)
     ora = B.Engine(s, rows, n, max_steps=4, **kw)
     obs = eng.reset().cpu().numpy()
     assert rel_err(obs, ora.reset()).max() < 5e-6
     if model == "pusher":  # even lanes: the fork sweeps into the puck within the first step (pair contacts)
         from test_brax_oracle import pusher_contact_state
 
-        eng.state.copy_(torch.as_tensor(pusher_contact_state(s, n).T.astype(np.float32)))
+        eng.set_state64(pusher_contact_state(s, n))
     lo = float(s.act_lo[0])
-    errs = []
+    par = Parity()
     for t in range(9):
-        ora.state[:] = eng.state.t().cpu().numpy()
         a = rng.uniform(lo, -lo, (n, s.n_act)).astype(np.float32)
-        o, rew, term, trunc = eng.step(torch.as_tensor(a))
-        out = ora.step(a)
-        np.testing.assert_array_equal(trunc.cpu().numpy(), out.truncated)
-        np.testing.assert_array_equal(term.cpu().numpy(), out.terminated)
+        o, rew, term, trunc, out = step_both(eng, ora, a, par, t)
         done = (term.cpu().numpy() | trunc.cpu().numpy()) != 0
-        got = np.where(done[:, None], eng.final_obs.cpu().numpy(), o.cpu().numpy())
-        wnt = np.where(done[:, None], out.final_obs, out.obs)
-        errs.append(np.maximum(rel_err(got, wnt).max(1), rel_err(rew.cpu().numpy(), out.reward)))
-        # the observation returned on a done step is the reset observation of the next episode
-        assert rel_err(o.cpu().numpy()[done], out.obs[done]).max(initial=0.0) < 5e-6
-        np.testing.assert_array_equal(eng.elapsed.cpu().numpy(), ora.elapsed)
-    e = np.concatenate(errs)
-    assert np.percentile(e, 50) <= 3e-5 and np.percentile(e, 99) <= 5e-4, np.percentile(e, [50, 99, 100])
+        if par.flag_mismatch == 0:
+            # the observation returned on a done step is the reset observation of the next episode
+            assert rel_err(o.cpu().numpy()[done], out.obs[done]).max(initial=0.0) < 5e-6
+            np.testing.assert_array_equal(eng.elapsed.cpu().numpy(), ora.elapsed)
+    # 1 827 lane-steps per case: a handful of contact flips is already > 0.5 %
+    assert_parity(par, f"{model}/{lanes_per_env}", tol=TOL.get(model, 1e-5), max_excluded=2e-2)
 
 
 def test_new_planar_families_env_api_and_rules(device):
@@ -602,10 +530,10 @@ def test_new_planar_families_env_api_and_rules(device):
     q[2] = 0.25
     qd = np.zeros(6)
     qd[0] = 50.0
-    st = eng.state.t().cpu().numpy().copy()
+    st = eng.state_np().copy()
     st[::2] = B.forward_kinematics(s, q, qd).reshape(-1)
-    eng.state.copy_(torch.as_tensor(st.T.astype(np.float32)))
-    ora.state[:] = eng.state.t().cpu().numpy()
+    eng.set_state64(st)
+    ora.state[:] = eng.state_np()
     a = np.zeros((n, 3), np.float32)
     o, r, te, tr = eng.step(torch.as_tensor(a))
     out = ora.step(a)
@@ -642,7 +570,7 @@ def test_config5_full_size_properties(device):
         assert int(out["truncated"][15].sum()) >= int(0.5 * n)  # TimeLimit(16) fires at step index 15 for survivors
         # the per-env joint_stiffness context acts: softer constraint springs let the joints separate
         # more under the same load -> larger anchor gap (measured on the final state, non-root joints)
-        st = eng.state.view(s.n_links, 13, n).permute(2, 0, 1).double().cpu().numpy()
+        st = eng.state64().cpu().numpy()
         soft, stiff = rows[:, js] < 0.7, rows[:, js] > 1.6
         gaps = []
         for sel in (soft, stiff):
@@ -760,14 +688,14 @@ def test_pusher_env_api_goal_context_and_contact(device):
     eng.reset()
     ora.reset()
     st = pusher_contact_state(s, m)
-    eng.state.copy_(torch.as_tensor(st.T.astype(np.float32)))
-    ora.state[:] = eng.state.t().cpu().numpy()
+    eng.set_state64(st)
+    ora.state[:] = eng.state_np()
     act = np.zeros((m, 7), np.float32)
     act[:, 0] = 2.0
     for t in range(8):
         eng.step(torch.as_tensor(act))
         ora.step(act)
-    got = eng.state.t().cpu().numpy().reshape(m, 8, 13)[:, 7, :3]
+    got = eng.state_np().reshape(m, 8, 13)[:, 7, :3]
     wnt = ora.state.reshape(m, 8, 13)[:, 7, :3]
     assert np.all(got[0::2, 1] - st.reshape(m, 8, 13)[0::2, 7, 1] > 0.08)
     np.testing.assert_allclose(got, wnt, atol=2e-4)

@@ -38,8 +38,8 @@ def _make(cls, n, device, rows_fn=None, **kw):
 
 
 def _bodies(eng, L):
-    """state [N, 13 L] -> p [N, L, 3], r [N, L, 4] (w, x, y, z), v [N, L, 3], w [N, L, 3]"""
-    st = eng.state.t().reshape(eng.n, L, 13)
+    """state [N, L, 13] -> p [N, L, 3], r [N, L, 4] (w, x, y, z), v [N, L, 3], w [N, L, 3] (float32 copies)"""
+    st = eng.state64().float()
     return st[..., 0:3], st[..., 3:7], st[..., 7:10], st[..., 10:13]
 
 
@@ -72,8 +72,9 @@ def test_free_flight_conserves_linear_and_angular_momentum(device):
     assert s.vel_damping == 0.0
     eng.reset()
     L = s.n_links
-    st = eng.state.t().reshape(n, L, 13)
-    st[..., 2] += 10.0  # (a view of the engine's env-major state record)
+    st = eng.state64()
+    st[..., 2] += 10.0
+    eng.set_state64(st)
     g = torch.Generator(device=device).manual_seed(0)
     # (the reset state is kinematically consistent -- joint anchors coincide -- so the spring forces of a joint
     # act at ONE point and exert no net moment; bodies torn apart by arbitrary velocities would, in this model
@@ -252,7 +253,7 @@ def test_first_state_autoreset_is_brax_autoresetwrapper(name, device):
     first_obs = eng.obs.clone()
     n_done = 0
     for t in range(T):
-        ora.state[:] = eng.state.t().cpu().numpy()
+        ora.state[:] = eng.state_np()
         a = rng.uniform(-1, 1, (n, s.n_act)).astype(np.float32) * float(max(s.act_hi[: s.n_act]))
         obs, rew, term, trunc = eng.step(torch.as_tensor(a))
         out = ora.step(a)

@@ -1,7 +1,9 @@
 """Per-env-step parity of the HIP Brax kernel against the fp64 restatement (oracle/brax_spring.c) for every
 Brax family: the oracle restarts every env step from the engine's float32 state (so only the arithmetic of
 ONE env step = n_frames substeps is compared), random actions, BASELINE-style context variation.
-Prints the percentiles of |d| / (1 + |x|) over observation entries and reward.  Run on the GPU box:
+Lanes are classified by their DISCRETE decisions (tests/brax_parity_util.py: contact set per substep, hashed on
+both sides; `terminated`): prints percentiles and the MAXIMUM of |d| / (1 + |x|) over observation entries and
+reward on the agreeing lanes, the excluded shares, and the all-lanes figures round 2 reported.  Run on the GPU box:
     python tools/brax_parity_percentiles.py [family ...]"""
 import sys
 
@@ -22,9 +24,8 @@ CLASSES = {"ant": E.CARLBraxAnt, "halfcheetah": E.CARLBraxHalfcheetahStiffness, 
            "humanoidstandup": E.CARLBraxHumanoidStandup, "reacher": E.CARLBraxReacher, "pusher": E.CARLBraxPusher}
 
 
-def rel(g, w):
-    g, w = np.asarray(g, np.float64), np.asarray(w, np.float64)
-    return np.abs(g - w) / (1 + np.abs(w))
+sys.path.insert(0, "tests")
+from brax_parity_util import Parity, step_both  # noqa: E402
 
 
 def measure(fam, n=2048, steps=40, seed=1):
@@ -41,23 +42,17 @@ def measure(fam, n=2048, steps=40, seed=1):
             rows[:, names.index(name)] = rng.uniform(lo, hi, n)
     rows = rows.astype(np.float32).astype(np.float64)
     kw = dict(selector=O.SEL_STATIC, seed=5, ctx_idx0=np.arange(n))
-    eng = BraxVecEngine(s, len(names), rows, n, "cuda", max_episode_steps=10_000, auto_reset=False, **kw)
+    eng = BraxVecEngine(s, len(names), rows, n, "cuda", max_episode_steps=10_000, auto_reset=False, branch_record=True, **kw)
     ora = B.Engine(s, rows, n, max_steps=10_000, autoreset=False, **kw)
     eng.reset()
     ora.reset()
     lo = np.array(s.act_lo[: s.n_act]) * 1.2
     hi = np.array(s.act_hi[: s.n_act]) * 1.2
-    errs = []
+    par = Parity()
     for t in range(steps):
-        ora.state[:] = eng.state.t().cpu().numpy()
         a = rng.uniform(lo, hi, (n, s.n_act)).astype(np.float32)
-        obs, rew, term, trunc = eng.step(torch.as_tensor(a))
-        out = ora.step(a)
-        errs.append(np.maximum(rel(obs.cpu().numpy(), out.obs).max(1), rel(rew.cpu().numpy(), out.reward)))
-    e = np.concatenate(errs)
-    p = np.percentile(e, [50, 99, 99.9, 100])
-    print(f"{fam:26s} n_frames {s.n_frames:3d}  p50 {p[0]:.2e}  p99 {p[1]:.2e}  p99.9 {p[2]:.2e}  max {p[3]:.2e}  "
-          f"frac>1e-5 {np.mean(e > 1e-5):.4f}  frac>1e-3 {np.mean(e > 1e-3):.5f}", flush=True)
+        step_both(eng, ora, a, par, t)
+    print(par.summary(f"{fam} ({s.n_frames} substeps)"), "worst agreeing (err, step, lane, col):", par.worst, flush=True)
 
 
 if __name__ == "__main__":
