@@ -68,6 +68,18 @@ def substeps(sys_struct, ctx_row, tau, n_sub, state) -> np.ndarray:
     return st.reshape(s.n_links, 13)
 
 
+def joint_wrenches(sys_struct, ctx_row, tau, state):
+    """net joint force / torque (about the COM, world frame) per link of one state: (F [L, 3], T [L, 3])"""
+    s = _Sys(sys_struct)
+    st = np.ascontiguousarray(state, dtype=np.float64).reshape(-1)
+    row = np.ascontiguousarray(ctx_row, dtype=np.float64)
+    tau = np.ascontiguousarray(tau, dtype=np.float64)
+    F = np.zeros((s.n_links, 3))
+    T = np.zeros((s.n_links, 3))
+    O.lib().obx_joint_wrenches(s.ptr, _p(row), _p(tau), _p(st), _p(F), _p(T))
+    return F, T
+
+
 class Engine:
     """Batched engine semantics for a Brax family (same contract as oracle.Engine)."""
 

@@ -301,11 +301,12 @@ static v3 apply_inv_inertia(const carl_brax_sys_t* s, int i, qt r, v3 t) {
  * 4-9; below / above per dof).  A float32 implementation of the same arithmetic can only agree to rounding where
  * it took the same contact decisions (an impulse is discontinuous in the state): tests compare these hashes with
  * the kernel's (carl_step_io_t::branch_sig) and assert the tolerance on the agreeing lanes. */
-static void substep(const carl_brax_sys_t* s, const lane_ctx* c, const double* tau, body* b, uint32_t* hc, uint32_t* hl) {
-  v3 F[L_MAX], T[L_MAX];
+/* spring.joints.resolve: net force F[i] and torque T[i] (about the COM, world frame) on every link from the joint
+ * springs, dampers, limits, actuators (and the push task's pair contacts) */
+static void joint_wrenches(const carl_brax_sys_t* s, const lane_ctx* c, const double* tau, const body* b, v3* F, v3* T,
+                           uint32_t* hl) {
   const int L = s->n_links;
   for (int i = 0; i < L; ++i) { F[i] = V(0, 0, 0); T[i] = V(0, 0, 0); }
-  /* --- spring.joints.resolve ------------------------------------------------------- */
   for (int i = 0; i < L; ++i) {
     const int P = s->parent[i];
     if (P < 0 && s->n_link_dof[i] == 6) continue;
@@ -384,6 +385,12 @@ static void substep(const carl_brax_sys_t* s, const lane_ctx* c, const double* t
       }
     }
   }
+}
+
+static void substep(const carl_brax_sys_t* s, const lane_ctx* c, const double* tau, body* b, uint32_t* hc, uint32_t* hl) {
+  v3 F[L_MAX], T[L_MAX];
+  const int L = s->n_links;
+  joint_wrenches(s, c, tau, b, F, T, hl);
   /* --- semi-implicit Euler: velocity update before the collision pass -------------- */
   for (int i = 0; i < L; ++i) {
     b[i].v = vadd(b[i].v, vscale(vadd(vscale(F[i], 1.0 / c->mass[i]), V(0, 0, c->gravity_z)), s->dt));
@@ -643,6 +650,20 @@ void obx_substeps(const carl_brax_sys_t* s, const double* ctx_row, const double*
   load_bodies(s, state, b);
   for (int k = 0; k < n_sub; ++k) substep(s, &c, tau, b, NULL, NULL);
   store_bodies(s, b, state);
+}
+
+/* the joint wrenches of one state (tests: compared with an independent NumPy restatement, oracle/spring_ref.py) */
+void obx_joint_wrenches(const carl_brax_sys_t* s, const double* ctx_row, const double* tau, const double* state,
+                        double* F_out, double* T_out) {
+  body b[L_MAX];
+  v3 F[L_MAX], T[L_MAX];
+  const lane_ctx c = make_ctx(s, ctx_row);
+  load_bodies(s, state, b);
+  joint_wrenches(s, &c, tau, b, F, T, NULL);
+  for (int i = 0; i < s->n_links; ++i) {
+    F_out[3 * i] = F[i].x; F_out[3 * i + 1] = F[i].y; F_out[3 * i + 2] = F[i].z;
+    T_out[3 * i] = T[i].x; T_out[3 * i + 1] = T[i].y; T_out[3 * i + 2] = T[i].z;
+  }
 }
 
 void obx_engine_reset(const carl_brax_sys_t* s, const oracle_cfg_t* cfg, const double* ctx_table, int n_feat,

@@ -632,3 +632,53 @@ def test_goal_epilogue_against_the_reference_wrapper_run(golden_dir):
         d = np.asarray(g["direction_values"][str(case["target_direction"])]) * np.float32(case["target_distance"])
         np.testing.assert_allclose(d, case["goal_position"], rtol=1e-6)
     assert saw_success > 20
+
+
+@pytest.mark.parametrize("model", ["ant", "halfcheetah", "humanoid", "hopper", "walker2d", "inverted_pendulum",
+                                   "inverted_double_pendulum", "humanoidstandup", "reacher", "pusher"])
+def test_joint_wrenches_agree_with_the_independent_numpy_restatement(model):
+    """oracle/spring_ref.py: the joint pass written a second time, from the specification, with rotation matrices
+    instead of quaternions (1-, 2-, 3-dof and locked joints, slides, limits, actuator torques, parent reactions).
+    Random perturbed states of every model: both restatements give the same net force / torque per link."""
+    from carl_amd import envs as E
+    from carl_amd.envs.brax.models import SYSTEMS
+    from oracle import spring_ref as R
+
+    cls = {"ant": E.CARLBraxAnt, "halfcheetah": E.CARLBraxHalfcheetahStiffness, "humanoid": E.CARLBraxHumanoidStiffness,
+           "hopper": E.CARLBraxHopper, "walker2d": E.CARLBraxWalker2d, "inverted_pendulum": E.CARLBraxInvertedPendulum,
+           "inverted_double_pendulum": E.CARLBraxInvertedDoublePendulum, "humanoidstandup": E.CARLBraxHumanoidStandup,
+           "reacher": E.CARLBraxReacher, "pusher": E.CARLBraxPusher}[model]
+    feats = cls.get_context_features()
+    names = list(feats)
+    row = np.array([float(f.default_value) for f in feats.values()])
+    scale = 1.0
+    if "joint_stiffness" in names:
+        scale = 1.7
+        row[names.index("joint_stiffness")] = scale
+    s = SYSTEMS[cls.env_name](names)
+    rng = np.random.default_rng(sum(map(ord, model)))
+    worst = 0.0
+    for trial in range(12):
+        # a consistent pose with joints pushed around (also beyond their ranges), then every body knocked off it
+        q = np.array(s.init_q[: s.n_q], dtype=np.float64) + rng.uniform(-0.6, 0.6, s.n_q)
+        if s.parent[0] < 0 and s.n_link_dof[0] == 6:
+            q[3:7] = rng.normal(size=4)
+            q[3:7] /= np.linalg.norm(q[3:7])
+        qd = rng.normal(0, 2.0, s.n_dof)
+        st = B.forward_kinematics(s, q, qd)
+        st[:, 0:3] += rng.normal(0, 0.01, (s.n_links, 3))
+        dq = rng.normal(0, 0.02, (s.n_links, 4))
+        st[:, 3:7] += dq
+        st[:, 3:7] /= np.linalg.norm(st[:, 3:7], axis=1, keepdims=True)
+        st[:, 7:13] += rng.normal(0, 0.5, (s.n_links, 6))
+        if s.n_pair > 0:
+            st[s.push_link, 0:2] += 5.0  # the puck far from the gripper: no pair contact (not part of the joint pass)
+        tau = rng.normal(0, 5.0, s.n_dof)
+        F_c, T_c = B.joint_wrenches(s, row, tau, st)
+        F_n, T_n = R.joint_wrenches(s, st, tau, stiffness_scale=float(np.float32(scale)))
+        size = 1.0 + max(np.abs(F_c).max(), np.abs(T_c).max())
+        worst = max(worst, np.abs(F_c - F_n).max() / size, np.abs(T_c - T_n).max() / size)
+        assert np.abs(F_c).max() > 1.0  # a real load
+    # the table's float32 quaternions are unit to ~3e-8 only; the two restatements treat that differently
+    # (quaternion products as stored vs normalised bases): agreement to that level, relative to the wrench scale
+    assert worst < 2e-6, worst
