@@ -1,14 +1,16 @@
 #!/usr/bin/env python
-"""Headline benchmark: env-steps/sec at 65 536 parallel contexts per MI355X.
+"""Headline benchmark: env-steps/sec (whole node) at 65 536 parallel contexts (BASELINE.json's metric).
 
     python bench.py --gpus 1 --steps 20 --warmup 5           (what the driver runs)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1]): CARLPendulum, 65 536 contexts per GPU sampled over
-the features `g ~ U(1,20)` and `l ~ U(0.5,2)` (CARL's feature literally
-called "gravity" is inert, Quirk P1), lane i <-> context i (StaticSelector), auto-reset
-on, synthetic actions U(-2,2) resident in HBM.
+Workload: north_star's target -- CARLCartPole with 65 536 sampled contexts (gravity, length, masspole;
+carl/envs/gymnasium/classic_control/carl_cartpole.py:11-66), lane i <-> context i (StaticSelector), auto-reset on,
+synthetic actions resident in HBM.  BASELINE.json configs[1] (CARLPendulum x 65 536 over g / l) and configs 3-5
+follow under `also`.  With N GPUs the 65 536 contexts are SPLIT over the node (strong scaling: the letter of the
+metric, "at 65k parallel contexts"); the same JSON line carries the weak-scaling run (65 536 contexts per GPU)
+under `weak`.
 
 One "step" of this benchmark = ONE PASS of the hot path over one batch of synthetic input:
 one fused `carl_rollout` launch that advances every lane by `--chunk` (250) env steps and
@@ -27,9 +29,13 @@ Also in the same JSON line:
   also          the same launch train for north_star's target env (CARLCartPole x 65 536) and
                 BASELINE configs 3-5 (Acrobot+MountainCar mixed batch, Ant, Halfcheetah+Humanoid)
 
-Multi-GPU: lanes sharded by contiguous global-id ranges, no data-path collective (weak
-scaling: 65 536 lanes per GPU); one RCCL all-gather of the per-lane episodic returns after
-the timed region (the reporting collective of SURVEY.md 8e), timed separately.
+  sustained     the same launch train for >= 0.3 s (the K-launch region of the driver's command is ~1.5 ms: burst
+                clocks; sustained runs clock ~8 % lower)
+  weak          (N > 1) 65 536 contexts PER GPU, same launch train
+
+Multi-GPU: lanes sharded by contiguous global-id ranges, no data-path collective; one RCCL all-gather of the
+per-lane episodic returns after the timed region (the reporting collective of SURVEY.md 8e), timed separately
+(`--rccl` builds the one-rank RCCL group on a single GPU too, so that librccl runs on the one-GPU boxes).
 """
 from __future__ import annotations
 
@@ -58,16 +64,18 @@ IO_PER_STEP = {"pendulum": 4 + 12 + 4 + 2, "cartpole": 4 + 16 + 4 + 2, "acrobot"
 PER_LAUNCH = {"pendulum": 8 + 4 + 16 + 4 + 4 + 8 + 4 + 4, "cartpole": 16 + 4 + 20 + 4 + 4 + 16 + 4 + 4,
               "acrobot": 16 + 4 + 36 + 4 + 4 + 4 + 16 + 4 + 4, "mountaincar": 8 + 4 + 28 + 4 + 4 + 8 + 4 + 4,
               "mountaincar_cont": 8 + 4 + 24 + 4 + 4 + 8 + 4 + 4,
-              "ant": 2 * 13 * 9 * 4 + 4 + 5 * 4 + 4 + 4 + 4 + 4,
-              "halfcheetah": 2 * 13 * 7 * 4 + 4 + 12 * 4 + 4 + 4 + 4 + 4,
-              "humanoid": 2 * 13 * 11 * 4 + 4 + 15 * 4 + 4 + 4 + 4 + 4}
+              # Brax: the env's 20 L-float record (pose head + tail + velocities, include/carl_amd.h) in and out
+              "ant": 2 * 20 * 9 * 4 + 4 + 5 * 4 + 4 + 4 + 4 + 4,
+              "halfcheetah": 2 * 20 * 7 * 4 + 4 + 12 * 4 + 4 + 4 + 4 + 4,
+              "humanoid": 2 * 20 * 11 * 4 + 4 + 15 * 4 + 4 + 4 + 4 + 4}
 
 BRAX_ENVS = ("ant", "halfcheetah", "humanoid")
 DEFAULT_CHUNK = {e: (20 if e in BRAX_ENVS else 250) for e in BYTES_8D}
 # the other BASELINE workloads, run after the headline one (same launch train, fewer words):
 #   name -> (families, total lanes per family, "weak" = per GPU / "strong" = split over the GPUs)
 ALSO = {
-    "cartpole": (("cartpole",), 65536, "weak"),                      # north_star's target env
+    "cartpole": (("cartpole",), 65536, "weak"),                      # north_star's target env (the default headline)
+    "pendulum": (("pendulum",), 65536, "weak"),                      # BASELINE config 2
     "config3": (("acrobot", "mountaincar"), 65536, "weak"),          # 131 072-context mixed batch per GPU
     "config4": (("ant",), 32768, "strong"),                          # 32 768 contexts over the node
     "config5": (("halfcheetah", "humanoid"), 32768, "strong"),       # 65 536 contexts over the node
@@ -79,21 +87,26 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=200, help="timed fused launches (each = --chunk env steps of every lane)")
     p.add_argument("--warmup", type=int, default=20, help="untimed launches before them")
-    p.add_argument("--env", default="pendulum",
+    p.add_argument("--env", default="cartpole",
                    help="family, or a+b for a mixed batch (e.g. acrobot+mountaincar); one of " + ", ".join(BYTES_8D))
     p.add_argument("--lanes", type=int, default=65536, help="lanes (= contexts) per family per GPU")
     p.add_argument("--chunk", type=int, default=0, help="env steps per fused launch (default 250; Brax 20)")
     p.add_argument("--buffer-sets", type=int, default=2, help="action/output buffer sets the launches rotate through")
-    p.add_argument("--strong", action="store_true",
-                   help="strong scaling: --lanes is the TOTAL number of contexts per family, split over the GPUs "
-                        "(default: weak scaling, --lanes per GPU)")
-    p.add_argument("--also", default="cartpole,config3,config4,config5",
+    p.add_argument("--weak", action="store_true",
+                   help="headline value = weak scaling (--lanes contexts PER GPU).  Default: strong -- --lanes is the "
+                        "TOTAL number of contexts, split over the GPUs (BASELINE's metric); the weak run is reported "
+                        "under 'weak' either way")
+    p.add_argument("--rccl", action="store_true",
+                   help="single GPU: build a one-rank RCCL process group and run the reporting all-gather through it")
+    p.add_argument("--sustained-seconds", type=float, default=0.3)
+    p.add_argument("--also", default="pendulum,config3,config4,config5",
                    help="comma list of extra workloads reported under 'also' (" + ", ".join(ALSO) + "), or 'none'")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-per-call", action="store_true")
     p.add_argument("--cpu-envs-per-core", type=int, default=256)
     p.add_argument("--cpu-steps-per-env", type=int, default=1000)
     a = p.parse_args()
+    a.strong = not a.weak
     a.families = tuple(a.env.split("+"))
     for f in a.families:
         if f not in BYTES_8D:
@@ -117,7 +130,7 @@ def context_dists(env):
         # (not mass_torso: below ~0.75 x its default the torso's effective mass makes the explicit spring
         #  integration of this model unstable -- CARLBraxEnv refuses such contexts)
         "halfcheetah": [U("joint_stiffness", 0.5, 2.0), U("gravity", -15, -5)],
-        "humanoid": [U("mass_torso", 5, 15), U("gravity", -15, -5), U("friction", 0.3, 1.5)],
+        "humanoid": [U("joint_stiffness", 0.5, 2.0), U("gravity", -15, -5)],
     }[env]
 
 
@@ -131,12 +144,13 @@ def make_env(env, n, rank, world, device, lane_base=0):
 
     cls = {"pendulum": E.CARLPendulum, "cartpole": E.CARLCartPole, "acrobot": E.CARLAcrobot,
            "mountaincar": E.CARLMountainCar, "mountaincar_cont": E.CARLMountainCarContinuous,
-           "ant": E.CARLBraxAnt, "halfcheetah": E.CARLBraxHalfcheetahStiffness, "humanoid": E.CARLBraxHumanoid}[env]
+           "ant": E.CARLBraxAnt, "halfcheetah": E.CARLBraxHalfcheetahStiffness,
+           "humanoid": E.CARLBraxHumanoidStiffness}[env]  # config 5: the classes WITH the joint_stiffness feature
     table = ContextSampler(context_dists(env), cls.get_context_space(), seed=0).sample_context_table(n * world)
     local = ContextTable(table.names, table.values_2d[rank * n:(rank + 1) * n])
     size_kw = {"batch_size": n, "autotune": False} if env in BRAX_ENVS else {"num_envs": n}
     carl_env = cls(contexts=local, device=device, context_selector=StaticSelector, seed=0,
-                   lane_offset=lane_base + rank * n, fin_capacity=0, **size_kw)
+                   lane_offset=lane_base + rank * n, context_offset=lane_base + rank * n, fin_capacity=0, **size_kw)
     return carl_env, table
 
 
@@ -442,10 +456,11 @@ def main():
     device = torch.device("cuda", local_rank)
     coll_dev = device if backend == "nccl" else torch.device("cpu")
     dist = None
-    if world > 1:
+    if world > 1 or args.rccl:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29400 + os.getpid() % 500))
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
@@ -483,6 +498,15 @@ def main():
     roofline = roofline_of(wl, avg_launch_s)
     per_rank_launch_ms = gather_over_ranks(avg_launch_s * 1e3)
 
+    # ---- the same launch train, sustained: the K-launch region above is ~1-2 ms (burst clocks) ----
+    import math
+
+    Ks = max(K, int(math.ceil(args.sustained_seconds / max(avg_launch_s, 1e-6))))
+    wall_s, avg_s = wl.train(Ks, 0, barrier)
+    el_s = max_over_ranks(wall_s)
+    sustained = {"steps": Ks, "seconds": el_s, "value": n * world * T * Ks / el_s, "unit": "env-steps/s",
+                 "ms_per_step": el_s / Ks * 1e3, "avg_launch_ms": avg_s * 1e3, "frac": roofline_of(wl, avg_s)["frac"]}
+
     # ---- reporting collective: episodic returns all-gathered over RCCL ------------
     gather_ms, rccl_ranks = None, None
     if dist is not None:
@@ -512,7 +536,7 @@ def main():
         eng = wl.eng
         a1 = wl.acts[0][0][0].contiguous()
         per_call = per_call_record(eng, a1, n * world, Kc, device, world, barrier)
-        if world == 1:
+        if world == 1 and dist is None:
             try:
                 graph_per_call(per_call, eng, a1, args.families[0], n, Kc, device)
             except Exception as e:  # graph capture is an optimisation of the measurement, not the product
@@ -556,6 +580,7 @@ def main():
             "avg_launch_ms": avg2 * 1e3, "frac": r2["frac"], "achieved_GBs": r2["achieved"],
             "bytes_per_unit": r2["bytes_per_unit"], "traffic": r2["traffic"],
             "mean_last_episode_return": w2.mean_last_return(), "lanes_per_env": w2.launch_shape(),
+            "classes": [type(e).__name__ for e in w2.envs],
         }
         if name == "cartpole" and rank == 0 and world == 1 and not args.no_cpu_baseline:
             # north_star: the CartPole number "next to the reference Python step() timed on the host cores (core
@@ -564,25 +589,37 @@ def main():
         del w2
         torch.cuda.empty_cache()
 
+    # ---- N > 1: the weak-scaling run of the headline workload (65 536 contexts PER GPU) ----
+    weak = None
+    if world > 1 and args.strong:
+        w3 = Workload(args.families, args.lanes, T, args.buffer_sets, rank, world, device)
+        wall3, avg3 = w3.train(K, W, barrier)
+        el3 = max_over_ranks(wall3)
+        weak = {"scaling": "weak", "lanes_per_gpu": w3.n, "total_lanes": w3.n * world, "value": w3.n * world * T * K / el3,
+                "unit": "env-steps/s", "ms_per_step": el3 / K * 1e3, "avg_launch_ms": avg3 * 1e3,
+                "frac_per_gpu": roofline_of(w3, avg3)["frac"]}
+        del w3
+        torch.cuda.empty_cache()
+
     if rank == 0:
         fam_txt = " + ".join(f"CARL{f} x {n_fam}" for f in args.families)
         line = {
-            "metric": "env-steps/sec (whole node) at 65k parallel contexts per GPU",
+            "metric": "env-steps/sec (whole node) at 65k parallel contexts, 1/2/4/8 MI355X",  # BASELINE.json, verbatim
             "value": n * world * T * K / elapsed, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
             "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
             # arithmetic type of the path (state in HBM is float32 throughout): Acrobot's RK4 runs in float64
             "dtype": ("f32" if "acrobot" not in args.families else "f64" if set(args.families) == {"acrobot"} else "f32/f64"),
             "data": "synthetic",
-            "config": {"workload": f"{fam_txt} contexts/GPU, StaticSelector lane<->context, auto-reset; one step = one "
+            "config": {"workload": f"{fam_txt} contexts/GPU ({n * world} over the node), StaticSelector lane<->context, auto-reset; one step = one "
                                    f"fused carl_rollout launch of {T} env steps of every lane, full transition written "
                                    f"per env step; {args.buffer_sets} rotating action/output buffer sets",
                        "lanes_per_gpu": n, "total_lanes": n * world, "chunk": T,
                        "env_steps_per_step": n * world * T, "buffer_sets": args.buffer_sets,
                        "parallelism": f"lane-shard x{world}", "lanes_per_env": shape},
-            "roofline": roofline, "cpu_baseline": cpu, "per_call": per_call, "also": also,
+            "roofline": roofline, "cpu_baseline": cpu, "sustained": sustained, "weak": weak, "per_call": per_call, "also": also,
             "mean_last_episode_return": mean_return, "return_allgather_ms": gather_ms, "rccl_ranks": rccl_ranks,
-            "collective_backend": (backend if world > 1 else None),
+            "collective_backend": (backend if dist is not None else None),
             "per_rank_avg_launch_ms": per_rank_launch_ms,
         }
         print(json.dumps(line), flush=True)

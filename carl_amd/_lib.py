@@ -26,6 +26,8 @@ FLAG_AUTORESET = 1
 FLAG_CARTPOLE_RECOMPUTE = 2
 FLAG_ACROBOT_FP32 = 4
 FLAG_AUTORESET_FIRST_STATE = 8
+FLAG_ROLLOUT_DIRECT = 16
+ROLLOUT_STAGED, ROLLOUT_DIRECT_SHAPE, ROLLOUT_DIRECT_FLAG = range(3)
 ACTION_I32, ACTION_I64, ACTION_F32 = range(3)
 
 _vp = C.c_void_p
@@ -73,6 +75,7 @@ EXPORTS = {
     "carl_reset_indexed": (C.c_int, [C.POINTER(Batch), _vp, _vp, _vp, _vp]),
     "carl_step": (C.c_int, [C.POINTER(Batch), C.POINTER(StepIO), _vp]),
     "carl_rollout": (C.c_int, [C.POINTER(Batch), C.POINTER(StepIO), C.c_int32, _vp]),
+    "carl_rollout_variant": (C.c_int, [C.POINTER(Batch)]),
     "carl_done_compact": (C.c_int, [_vp, _vp, C.c_int32, _vp, _vp, _vp, _vp]),
     "carl_done_compact_scratch_elems": (C.c_int32, [C.c_int32]),
 }
@@ -150,7 +153,7 @@ class BraxCtxMap(C.Structure):
         ("joint_stiffness_scale", _i), ("target_distance", _i), ("target_direction", _i), ("target_radius", _i),
         ("n_mass", _i),
         ("mass_row", _i * BRAX_MAX_CTX_MASS), ("mass_link", _i * BRAX_MAX_CTX_MASS),
-        ("mass_nominal", _f * BRAX_MAX_CTX_MASS),
+        ("mass_nominal", _f * BRAX_MAX_CTX_MASS), ("mass_ratio_floor", _f * BRAX_MAX_CTX_MASS),
         ("goal_position", _i * 3),
     ]
 

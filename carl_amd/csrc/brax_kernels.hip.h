@@ -917,7 +917,8 @@ static __device__ __forceinline__ LaneCtx load_ctx(const carl_brax_sys_t& s, con
   if (go)
     for (int k = m.sub; k < cm.n_mass; k += kSub)
       m.at(m.lay.mass + cm.mass_link[k]) =
-          s.mass[cm.mass_link[k]] * (b.ctx_table[(size_t)cm.mass_row[k] * b.ctx_stride + c] / cm.mass_nominal[k]);
+          s.mass[cm.mass_link[k]] *
+          fmaxf(b.ctx_table[(size_t)cm.mass_row[k] * b.ctx_stride + c] / cm.mass_nominal[k], cm.mass_ratio_floor[k]);
   phase_sync();
   return lc;
 }

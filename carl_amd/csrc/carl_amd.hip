@@ -1,6 +1,8 @@
 // carl_amd.hip -- C-ABI entry points (include/carl_amd.h) and kernel dispatch: classic control,
 // context sets, done compaction.  The Brax entry points live in carl_brax.hip (own compile flags).
-// gfx950 only.  No persistent device allocations, no global mutable state.
+// gfx950 only.  No persistent device allocations.  The one piece of process-wide state is ensure_dynamic_lds's
+// record of which kernels were already granted > 48 KiB of dynamic LDS (an idempotent driver attribute per
+// (device, kernel), guarded by a mutex: it only saves a ~2 us driver call per launch).
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
@@ -35,6 +37,9 @@ int check_launch(const char* what) {
   return 0;
 }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (device, kernel, size).  The map below is the library's
+// only mutable process-wide state (include/carl_amd.h "Conventions"): a cache of an idempotent attribute, never
+// read by the kernels, safe under concurrent callers.
 int ensure_dynamic_lds(const void* kernel, size_t bytes, const char* who) {
   static std::mutex mu;
   static std::map<std::pair<int, const void*>, size_t> granted;
@@ -110,6 +115,11 @@ bool use_lds_ctx(const carl_batch_t* b) {
   return bytes <= 32 * 1024 && (int64_t)b->n_contexts * 8 <= (int64_t)b->n_lanes;
 }
 
+int rollout_variant(const carl_batch_t* b) {
+  if (b->flags & CARL_FLAG_ROLLOUT_DIRECT) return CARL_ROLLOUT_DIRECT_FLAG;
+  return (b->n_lanes % 16 == 0) ? CARL_ROLLOUT_STAGED : CARL_ROLLOUT_DIRECT_SHAPE;
+}
+
 // 64-thread workgroups spread a small batch over all 256 CUs x 4 SIMDs (65 536
 // lanes = 1024 waves = one per SIMD); large batches use 256.
 int pick_block(int n, bool lds) { return (lds || n > 256 * 1024) ? 256 : 64; }
@@ -156,12 +166,12 @@ int launch_step(const carl_batch_t* b, const carl_step_io_t* io, int n_steps, hi
     CARL_LAUNCH(step_kernel, *b, *io);
     return check_launch("carl_step");
   }
-  // n_lanes % 16 == 0 + global context table: records are staged in LDS and written out by the
-  // workgroup's storer wave with 16-byte stores (see rollout_staged_kernel)
-  static const bool no_staged = getenv("CARL_AMD_NO_STAGED") != nullptr;
+  // n_lanes % 16 == 0: records are staged in LDS and written out by the workgroup's storer waves with 16-byte
+  // stores (rollout_staged_kernel).  Other shapes -- and CARL_FLAG_ROLLOUT_DIRECT, the A/B switch -- take
+  // rollout_kernel (per-lane stores, ~50 % slower); carl_rollout_variant() tells a caller which one it gets.
   // (also for tables small enough for LDS: a fused rollout gathers parameters once per launch and on
   // resets, so the global table costs nothing there; the LDS copy pays off in the per-call kernel)
-  if (!no_staged && b->n_lanes % 16 == 0) {  // 16-byte pieces of every output row stay inside the batch
+  if (rollout_variant(b) == CARL_ROLLOUT_STAGED) {  // 16-byte pieces of every output row stay inside the batch
     size_t sh_staged = carl::rollout_staged_lds_bytes<Fam>();
     using kern_t = void (*)(carl_batch_t, carl_step_io_t, int);
     kern_t kern = a64 ? static_cast<kern_t>(carl::rollout_staged_kernel<Fam, true>)
@@ -172,7 +182,9 @@ int launch_step(const carl_batch_t* b, const carl_step_io_t* io, int n_steps, hi
       const bool keeps_context = b->selector == CARL_SEL_STATIC || b->selector == CARL_SEL_HOST;
       const size_t table_bytes = (size_t)Fam::F * b->n_contexts * sizeof(float);
       const bool lean = b->fin_count == nullptr && io->final_obs == nullptr;
-      const bool table_fits = lds && sh_staged + table_bytes <= 160 * 1024;
+      // static LDS of the kernel (Acrobot's fp64 kernels carry the 8 KiB sin/cos table) counts against the 160 KiB too
+      constexpr size_t static_lds = carl::has_tables<Fam>::value ? sizeof(double) * 2 * CARL_SINCOS_TAB_N : 0;
+      const bool table_fits = lds && sh_staged + table_bytes + static_lds <= 160 * 1024;
       bool picked = false;
       if (keeps_context && lean) {
         // none of the optional features is on: the done path compiled without them
@@ -306,6 +318,14 @@ int carl_rollout(const carl_batch_t* batch, const carl_step_io_t* io, int32_t n_
 #define CALL(F) launch_step<F>(batch, io, n_steps, (hipStream_t)stream)
   CARL_DISPATCH(batch->family, CALL)
 #undef CALL
+}
+
+int carl_rollout_variant(const carl_batch_t* batch) {
+  if (batch == nullptr) {
+    fail(CARL_ERR_INVALID_ARGUMENT, "carl_rollout_variant: batch is NULL");
+    return CARL_ERR_INVALID_ARGUMENT;
+  }
+  return rollout_variant(batch);
 }
 
 int32_t carl_done_compact_scratch_elems(int32_t n) {

@@ -60,13 +60,22 @@ def default_context_index(n_lanes: int, lane_offset: int, n_contexts: int, round
     off = context_offset
     if off is None:
         off = int(lane_offset) if int(n_contexts) == int(n_lanes) else 0
+        if int(lane_offset) > 0 and int(n_contexts) == int(n_lanes):
+            # a guess from the shapes: a REPLICATED table that happens to have one row per local lane would be
+            # misread as this rank's shard.  The env layer passes context_offset explicitly; direct engine users
+            # should too.
+            import warnings
+
+            warnings.warn("default_context_index: context_offset not given and the table has one row per local lane -- "
+                          f"assuming it is this rank's shard of a lane <-> context identity (row 0 = context {lane_offset}); "
+                          "pass context_offset=0 for a replicated table", RuntimeWarning, stacklevel=3)
     g = np.arange(int(n_lanes), dtype=np.int64) + int(lane_offset) - int(off)
     if round_robin:
         g = g - int(stride)
     return np.mod(g, int(n_contexts))
 
 
-def _all_gather_1d(t: torch.Tensor, counts: list[int] | None = None) -> torch.Tensor:
+def _all_gather_1d(t: torch.Tensor, counts: list[int] | None = None, padded: bool = False) -> torch.Tensor:
     import torch.distributed as dist
 
     world = dist.get_world_size()
@@ -75,7 +84,7 @@ def _all_gather_1d(t: torch.Tensor, counts: list[int] | None = None) -> torch.Te
         ns = [torch.zeros_like(n) for _ in range(world)]
         dist.all_gather(ns, n)
         counts = [int(x.item()) for x in ns]
-    if len(set(counts)) == 1:
+    if len(set(counts)) == 1 and not padded:
         out = torch.empty(world * counts[0], dtype=t.dtype, device=t.device)
         dist.all_gather_into_tensor(out, t.contiguous())
         return out
@@ -87,21 +96,24 @@ def _all_gather_1d(t: torch.Tensor, counts: list[int] | None = None) -> torch.Te
     return torch.cat([p[:c] for p, c in zip(parts, counts)])
 
 
-def all_gather_episode_stats(engine_or_stats, counts: list[int] | None = None) -> dict[str, torch.Tensor]:
+def all_gather_episode_stats(engine_or_stats, counts: list[int] | None = None, padded: bool = False) -> dict[str, torch.Tensor]:
     """All ranks receive the global, lane-ordered ``last_return`` / ``last_length`` /
     ``episodes_done`` vectors (rank order == global lane order by construction).
 
     ``engine_or_stats`` is a ``VecEngine`` or a dict with those three tensors (the CPU
-    tests pass plain tensors over gloo)."""
+    tests pass plain tensors over gloo).  Equal shard sizes take one ``all_gather_into_tensor`` per vector;
+    uneven ones (``counts``) -- or ``padded=True`` -- the padded list form.  Under an initialised process group
+    the collective RUNS even with one rank (a world-1 RCCL communicator is how the one-GPU boxes exercise
+    librccl); without a group it is the identity."""
     import torch.distributed as dist
 
     if not isinstance(engine_or_stats, dict):
         e = engine_or_stats
         engine_or_stats = {"last_return": e.last_return, "last_length": e.last_length,
                            "episodes_done": e.episodes_done}
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_available() or not dist.is_initialized():
         return {k: v.clone() for k, v in engine_or_stats.items()}
-    return {k: _all_gather_1d(v, counts) for k, v in engine_or_stats.items()}
+    return {k: _all_gather_1d(v, counts, padded) for k, v in engine_or_stats.items()}
 
 
 def reduce_episode_summary(engine_or_stats) -> dict[str, float]:
@@ -119,7 +131,7 @@ def reduce_episode_summary(engine_or_stats) -> dict[str, float]:
         fin.double().sum(),
         engine_or_stats["episodes_done"].double().sum(),
     ])
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.all_reduce(v)
     n = max(float(v[2]), 1.0)
     return {"mean_return": float(v[0]) / n, "mean_length": float(v[1]) / n, "lanes_finished": float(v[2]),

@@ -165,6 +165,8 @@ class VecEngine:
         self._b_ref, self._io_ref = C.byref(self.b), C.byref(self._io)
         self._step_fn = self.lib.carl_step
         self._last_action = None
+        self._last_action_meta = None
+        self._warned_direct = False
 
     # ------------------------------------------------------------------ contexts
     def default_ctx_idx(self, n_contexts: int) -> torch.Tensor:
@@ -364,13 +366,15 @@ class VecEngine:
         raw stream handle comes from torch's C binding; the ctypes function and its two by-reference arguments
         are prepared once; the device guard is only entered when another device is current."""
         io = self._io
-        if action is self._last_action and action.data_ptr() == io.action:
-            pass
+        if (action is self._last_action and action.data_ptr() == io.action
+                and (action.dtype, action.numel()) == self._last_action_meta):
+            pass  # (dtype and element count are re-checked: resize_ / set_ / .data = keep the object and its address)
         else:
             a, dt = self._action_tensor(action, ())
             io.action, io.action_dtype = a.data_ptr(), dt
             # only a tensor used as-is can take the fast path next time (a converted copy is a temporary)
             self._last_action = action if a is action else None
+            self._last_action_meta = (a.dtype, a.numel())
         if _current_device() == self._dev_index:
             code = self._c_step_fast(_raw_stream(self._dev_index))
         else:
@@ -416,6 +420,13 @@ class VecEngine:
         transition is written to ``out`` (see ``alloc_rollout``)."""
         T = int(actions.shape[0])
         a, dt = self._action_tensor(actions, (T,))
+        if not self._warned_direct and self.rollout_variant() == _lib.ROLLOUT_DIRECT_SHAPE:
+            import warnings
+
+            self._warned_direct = True
+            warnings.warn(f"carl_rollout: {self.n} lanes is not a multiple of 16 -- this batch takes the direct-store "
+                          "kernel (~50 % slower than the staged one; same results).  Pad the batch to a multiple of 16 "
+                          "lanes for the fast path.", RuntimeWarning, stacklevel=2)
         if out is None:
             out = self.alloc_rollout(T)
         if out["reward"].shape[0] < T:
@@ -429,6 +440,11 @@ class VecEngine:
         with torch.cuda.device(self.device):
             _lib.check(self._c_rollout(io, T))
         return out
+
+    def rollout_variant(self) -> int:
+        """Which kernel ``rollout`` launches for this batch: ``_lib.ROLLOUT_STAGED`` (fast path, needs
+        ``n_lanes % 16 == 0``), ``ROLLOUT_DIRECT_SHAPE`` or ``ROLLOUT_DIRECT_FLAG`` (carl_rollout_variant)."""
+        return int(self.lib.carl_rollout_variant(C.byref(self.b)))
 
     def drain_finished(self):
         """Finished-episode log since the last drain -> (global lane ids, returns, lengths,

@@ -70,10 +70,20 @@ class CARLBraxEnv(CARLEnv):
         fin_capacity: int = 0,
         autotune: bool | None = None,
         autoreset: str = "redraw",
+        mass_check: str = "warn",
         **kwargs,
     ) -> None:
         """Reference parameters (carl_brax_env.py:119-131) plus the lane-engine ones.
-        ``batch_size`` is the reference's name for the number of parallel envs (:164)."""
+        ``batch_size`` is the reference's name for the number of parallel envs (:164).
+
+        ``mass_check``: what happens to ``mass_<link>`` contexts below the model's stability floor
+        (``feature_tables.MASS_RATIO_FLOOR``) -- every value inside the reference's bounds (0.1, inf) constructs:
+        "warn" (default): the EFFECTIVE mass is clamped at the floor per env inside the kernel (the context
+        observation keeps the sampled value) and one warning names the features; "error": raise ``ValueError``
+        (round 2's behaviour); "off": no clamp, no warning (such envs go non-finite within a few steps)."""
+        if mass_check not in ("warn", "error", "off"):
+            raise ValueError("mass_check must be 'warn', 'error' or 'off'")
+        self._mass_check = mass_check
         goal_mode = False
         if contexts is not None and len(contexts):
             first = contexts[list(contexts.keys())[0]]
@@ -89,6 +99,13 @@ class CARLBraxEnv(CARLEnv):
             # goals vary across contexts -> the reference wraps the env with BraxWalkerGoalWrapper
             # (:195-223); here the wrapper's step/reset are an epilogue fused into the kernels
             sys_table.goal_mode = 1 if goal_mode else 0
+            if mass_check != "off":  # per-env clamp of the effective mass ratio (carl_brax_ctx_map_t::mass_ratio_floor)
+                from carl_amd.envs.brax.feature_tables import DEFAULT_MASS_RATIO_FLOOR, MASS_RATIO_FLOOR
+
+                floors = MASS_RATIO_FLOOR.get(self.env_name, {})
+                cm = sys_table.ctx
+                for k in range(cm.n_mass):
+                    cm.mass_ratio_floor[k] = floors.get(names[cm.mass_row[k]], DEFAULT_MASS_RATIO_FLOOR)
             n_auto = batch_size > 1
             env = BraxVecEngine(
                 sys_table, len(names),
@@ -121,16 +138,21 @@ class CARLBraxEnv(CARLEnv):
             self.env.autotune()
 
     def _check_mass_stability(self) -> None:
-        """Refuse link masses below the measured stability floor of the model's explicit spring integration
-        (``feature_tables.MASS_RATIO_FLOOR``): such an env goes non-finite within a few steps.  Not applied with
-        ``reference_compat=True``, where -- as in the reference (Quirk B1) -- masses never reach the physics."""
-        if getattr(self, "_reference_compat", False):
+        """Link masses below the measured stability floor of the model's explicit spring integration
+        (``feature_tables.MASS_RATIO_FLOOR``): the reference accepts any mass in (0.1, inf)
+        (carl/envs/brax/carl_halfcheetah.py:37-57) -- there they never reach the physics (Quirk B1).  Here the
+        kernel clamps the effective mass at the floor (``mass_check="warn"``, default: one warning), or the
+        constructor refuses (``"error"``).  Not applied with ``reference_compat=True``."""
+        if getattr(self, "_reference_compat", False) or getattr(self, "_mass_check", "warn") == "off":
             return
+        import warnings
+
         from carl_amd.envs.brax.feature_tables import DEFAULT_MASS_RATIO_FLOOR, MASS_RATIO_FLOOR
 
         floors = MASS_RATIO_FLOOR.get(self.env_name, {})
         feats = self.get_context_features()
         names = list(self._table.names)
+        low = []
         for j, name in enumerate(names):
             if not name.startswith("mass_") or name not in feats:
                 continue
@@ -138,11 +160,16 @@ class CARLBraxEnv(CARLEnv):
             lowest = float(col.min())
             floor = floors.get(name, DEFAULT_MASS_RATIO_FLOOR) * float(feats[name].default_value)
             if lowest < floor:
-                raise ValueError(
-                    f"{type(self).__name__}: context feature {name} = {lowest:g} is below {floor:g}, the smallest value "
-                    f"for which this model's explicit spring integration stays stable (measured: "
-                    f"tools/mass_stability_sweep.py); pass reference_compat=True to ignore physics contexts as the "
-                    f"reference effectively does")
+                low.append(f"{name} = {lowest:g} < {floor:g}")
+        if not low:
+            return
+        msg = (f"{type(self).__name__}: context values below the smallest effective mass for which this model's explicit "
+               f"spring integration stays stable (measured: tools/mass_stability_sweep.py): {'; '.join(low)}")
+        if self._mass_check == "error":
+            raise ValueError(msg + "; pass mass_check='warn' to clamp the effective mass per env, or reference_compat=True "
+                             "to ignore physics contexts as the reference effectively does")
+        warnings.warn(msg + " -- the physics runs these envs at the floor (the context observation keeps the sampled "
+                      "value); mass_check='error' refuses instead", RuntimeWarning, stacklevel=3)
 
     def _base_observation_space(self) -> spaces.Space:
         obs = np.inf * np.ones(self.env.D, dtype=np.float32)

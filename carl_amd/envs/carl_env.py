@@ -309,7 +309,12 @@ class CARLEnv(abc.ABC):
         c = self._views()
         _, reward, _, _ = self.env.step(action)
         info = dict(c["info_auto"] if self.env.auto_reset else c["info_plain"])
-        return c["obs"], reward, c["term"], c["trunc"], info
+        # the observation dict (and its nested context dict) is a fresh shallow copy per call, like `info` and
+        # like reset(): a caller that replaces or pops an entry does not corrupt later returns; the tensors inside
+        # are the cached views
+        ctx = c["obs"]["context"]
+        obs = {"obs": c["obs"]["obs"], "context": dict(ctx) if isinstance(ctx, dict) else ctx}
+        return obs, reward, c["term"], c["trunc"], info
 
     def _views(self) -> dict:
         eng = self.env

@@ -13,8 +13,10 @@
  *    allocates them as PyTorch-ROCm tensors and passes tensor.data_ptr()).  The
  *    library never allocates persistent device memory and never frees caller
  *    memory; scratch is caller-provided.
- *  - Calls enqueue on `stream` and return without synchronising; no global mutable
- *    state; one carl_batch_t per device, caller serialises calls per batch.
+ *  - Calls enqueue on `stream` and return without synchronising; one carl_batch_t per
+ *    device, caller serialises calls per batch.  No global mutable state that a result
+ *    depends on: the only process-wide data is a mutex-guarded record of which kernels
+ *    were already granted > 48 KiB of dynamic LDS (an idempotent driver attribute).
  *  - Return value: 0 on success, otherwise a hipError_t value or CARL_ERR_*;
  *    carl_last_error() returns a thread-local message.  Nothing throws or exits.
  *  - Layouts: per-lane state is struct-of-arrays  state[s * n_lanes + lane];
@@ -72,6 +74,8 @@ enum {
   CARL_FLAG_ACROBOT_FP32 = 4,       /* evaluate Acrobot's _dsdt/rk4 in fp32 instead of
                                        fp64 (faster; up to ~1e-3 relative error on
                                        states near the velocity bounds) */
+  CARL_FLAG_ROLLOUT_DIRECT = 16,    /* carl_rollout: launch the direct-store kernel even where the staged one
+                                       applies (A/B measurements and tests; ~50 % slower, same results) */
   CARL_FLAG_AUTORESET_FIRST_STATE = 8 /* Brax families, with AUTORESET: a done env is put back to the state
                                        its last explicit reset produced -- no new draw, no selector advance,
                                        no context change: brax.envs.wrappers.training.AutoResetWrapper as the
@@ -208,6 +212,13 @@ int carl_step(const carl_batch_t* batch, const carl_step_io_t* io, void* stream)
  * lanes is shorter than a kernel launch. */
 int carl_rollout(const carl_batch_t* batch, const carl_step_io_t* io, int32_t n_steps, void* stream);
 
+/* Which kernel carl_rollout launches for this batch (classic-control families).  The staged kernel (transition
+ * records assembled in LDS, written with 16-byte stores by dedicated waves) needs n_lanes % 16 == 0; any other
+ * lane count silently took the ~50 % slower direct-store kernel in ABI <= 4 -- now a caller can ask (and the
+ * Python engine warns once). */
+enum { CARL_ROLLOUT_STAGED = 0, CARL_ROLLOUT_DIRECT_SHAPE = 1, CARL_ROLLOUT_DIRECT_FLAG = 2 };
+int carl_rollout_variant(const carl_batch_t* batch);
+
 /* done-mask compaction: ascending lane ids with terminated|truncated set.
  * idx_out [n], count_out [1], scratch >= carl_done_compact_scratch_elems(n) int32.
  * No reference counterpart (the gymnasium path has no auto-reset; the user calls
@@ -245,7 +256,14 @@ typedef struct carl_brax_ctx_map {
   int32_t n_mass;                               /* mass_<link> features */
   int32_t mass_row[CARL_BRAX_MAX_CTX_MASS];     /* table row */
   int32_t mass_link[CARL_BRAX_MAX_CTX_MASS];    /* link it scales */
-  float mass_nominal[CARL_BRAX_MAX_CTX_MASS];   /* CARL default: value / nominal scales the link's effective mass */
+  float mass_nominal[CARL_BRAX_MAX_CTX_MASS];   /* CARL default: value / nominal scales the link's effective mass
+                                                 * (an EXTENSION of this build, like joint_stiffness: with brax's
+                                                 * spring_mass_scale = 1 the spring backend runs every link at
+                                                 * m**(1 - 1) = 1, so upstream a mass context would not move it) */
+  float mass_ratio_floor[CARL_BRAX_MAX_CTX_MASS]; /* the ratio is clamped from below at this value per env (0 = no
+                                                 * clamp): lighter links make k dt^2 / m of the joint springs exceed
+                                                 * the explicit integrator's stability bound (NaNs within a few
+                                                 * steps); the context OBSERVATION keeps the unclamped value */
   int32_t goal_position[3];                     /* push task: goal_position_x / _y / _z rows (carl_pusher.py:80-103) */
 } carl_brax_ctx_map_t;
 

@@ -774,3 +774,50 @@ def test_language_goals_as_the_reference_tests_them(device):
     env = CARLBraxAnt(contexts=same, use_language_goals=True)
     state, _ = env.reset()
     assert not isinstance(state["obs"], dict) and env.position is None
+
+
+def test_every_mass_feature_at_the_reference_lower_bound_constructs_and_stays_finite(device):
+    """The reference accepts any ``mass_<link>`` in (0.1, inf) (carl/envs/brax/carl_halfcheetah.py:37-57) -- there
+    the value never reaches the physics (Quirk B1); here it does, and below a model-specific fraction of its
+    default the explicit spring integration would blow up.  Default ``mass_check="warn"``: every such context
+    CONSTRUCTS, the kernel runs the env at the stability floor (carl_brax_ctx_map_t::mass_ratio_floor), the
+    context observation keeps the sampled value, one RuntimeWarning names the features; "error" refuses."""
+    import inspect
+    import warnings
+
+    import carl_amd.envs.brax as brax_envs
+    from carl_amd.envs.brax.feature_tables import MASS_BOUNDS
+
+    lower = float(MASS_BOUNDS[0])
+    n_classes = 0
+    for env_name, cls in inspect.getmembers(brax_envs):
+        if not (inspect.isclass(cls) and "CARL" in env_name and env_name != "CARLBraxEnv"):
+            continue
+        feats = cls.get_context_features()
+        mass = [k for k in feats if k.startswith("mass_")]
+        if not mass:
+            continue
+        n_classes += 1
+        default = {k: float(f.default_value) for k, f in feats.items() if k not in ("target_distance", "target_direction", "target_radius")}
+        # one context per mass feature at the bound, plus one with ALL of them there
+        contexts = {i: dict(default, **{m: lower * 1.001}) for i, m in enumerate(mass)}
+        contexts[len(mass)] = dict(default, **{m: lower * 1.001 for m in mass})
+        n = len(contexts)
+        with pytest.warns(RuntimeWarning, match="stays stable"):
+            env = cls(contexts=contexts, batch_size=n, device=device, seed=0)
+        with pytest.raises(ValueError):
+            cls(contexts=contexts, batch_size=n, device=device, seed=0, mass_check="error")
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")  # contexts at the defaults: silent
+            cls(batch_size=2, device=device)
+        obs, info = env.reset(seed=0)
+        cid = info["context_id"].cpu().numpy()
+        for i, m in enumerate(mass):  # the observation shows what was sampled, not the clamp
+            assert float(obs["context"][m][cid == i][0]) == pytest.approx(lower * 1.001, rel=1e-6)
+        g = torch.Generator(device="cpu").manual_seed(1)
+        lo, hi = env.action_space.low[0], env.action_space.high[0]
+        for t in range(60):
+            a = torch.rand((n, env.action_space.shape[1]), generator=g) * float(hi[0] - lo[0]) + float(lo[0])
+            o, r, te, tr, _ = env.step(a.to(device))
+            assert bool(torch.isfinite(o["obs"]).all()) and bool(torch.isfinite(r).all()), (env_name, t)
+    assert n_classes >= 10

@@ -276,3 +276,64 @@ def test_uneven_lane_shards_through_the_env_api_keep_their_contexts(selector_nam
         assert torch.equal(obs, f_obs[:, sh.slice]) and torch.equal(rew, f_rew[:, sh.slice]), (r, sh)
         want = f_idx[sh.slice] - (sh.offset if identity else 0)  # sharded rows are numbered from the shard's first
         assert torch.equal(idx, want.to(idx.dtype)), (r, idx, want)
+
+
+_RCCL_WORLD1 = r"""
+import os, sys, time
+sys.path.insert(0, os.environ["CARL_ROOT"])
+import numpy as np, torch, torch.distributed as dist
+from carl_amd.engine import VecEngine
+from carl_amd.distributed import all_gather_episode_stats, reduce_episode_summary
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)   # backend "nccl" IS librccl on ROCm
+d = np.load(os.environ["CARL_CASE"])
+N = int(d["acts"].shape[1])
+eng = VecEngine(int(d["fam"]), d["table"], N, dev, selector=0, seed=13, ctx_idx0=np.arange(N), max_episode_steps=int(d["max_steps"]))
+eng.reset()
+eng.rollout(torch.as_tensor(d["acts"], device=dev))
+torch.cuda.synchronize()
+assert eng.last_return.is_cuda
+equal = all_gather_episode_stats(eng)                       # all_gather_into_tensor of DEVICE tensors
+padded = all_gather_episode_stats(eng, counts=[N], padded=True)  # the uneven-shard form: pad + all_gather(list)
+summary = reduce_episode_summary(eng)                        # all_reduce of four device scalars
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(20):
+    all_gather_episode_stats(eng)
+torch.cuda.synchronize()
+ms = (time.perf_counter() - t0) / 20 * 1e3
+loaded = [l.split()[-1] for l in open("/proc/self/maps") if "librccl" in l or "libnccl" in l]
+np.savez(os.environ["CARL_OUT"], ms=ms, rccl_loaded=len(loaded) > 0, world=dist.get_world_size(),
+         backend=dist.get_backend(), summary_mean=summary["mean_return"], episodes=summary["episodes"],
+         **{"eq_" + k: v.cpu().numpy() for k, v in equal.items()}, **{"pad_" + k: v.cpu().numpy() for k, v in padded.items()},
+         **{"ref_" + k: getattr(eng, k).cpu().numpy() for k in ("last_return", "last_length", "episodes_done")})
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_rccl_collectives_run_on_this_gpu_with_a_world_of_one(device, tmp_path):
+    """RCCL had never executed on hardware (two ranks on one device are refused).  A ONE-rank
+    `nccl` process group on the one GPU: librccl is loaded, a communicator is built, and the engine's DEVICE tensors
+    go through the reporting collectives -- the equal-count `all_gather_into_tensor` path, the padded list path of
+    uneven shards, and the 4-scalar all-reduce.  With one rank every collective is the identity, so the results
+    must equal the engine's own vectors bit for bit.  (Own process: the group must not leak into pytest's.)"""
+    fam, N, T, max_steps = O.CARTPOLE, 8192, 64, 17
+    rng = np.random.default_rng(22)
+    case, out = tmp_path / "case.npz", tmp_path / "out.npz"
+    np.savez(case, fam=fam, table=random_table(fam, rng, N), acts=random_actions(fam, rng, (T, N)), max_steps=max_steps)
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(29500 + (os.getpid() % 2000) + 11), CARL_ROOT=ROOT, CARL_CASE=str(case), CARL_OUT=str(out),
+               CARL_AMD_NO_BUILD="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, "-c", _RCCL_WORLD1], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    got = np.load(out)
+    assert str(got["backend"]) == "nccl" and int(got["world"]) == 1 and bool(got["rccl_loaded"])
+    for k in ("last_return", "last_length", "episodes_done"):
+        np.testing.assert_array_equal(got["eq_" + k], got["ref_" + k])
+        np.testing.assert_array_equal(got["pad_" + k], got["ref_" + k])
+    fin = got["ref_episodes_done"] > 0
+    assert fin.any() and abs(float(got["summary_mean"]) - float(got["ref_last_return"][fin].mean())) < 1e-4
+    assert float(got["episodes"]) == float(got["ref_episodes_done"].sum())
+    print(f"RCCL world-1 all-gather of 3 x {N} device values: {float(got['ms']):.3f} ms per call")

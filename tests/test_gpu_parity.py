@@ -650,3 +650,64 @@ def test_cartpole_dense_rollout_with_moving_contexts_equals_repeated_step(select
         assert torch.equal(getattr(e1, name), getattr(e2, name)), name
     assert int(e1.episodes_done.sum()) > n  # contexts did move
     assert len(torch.unique(e1.ctx_idx)) > min(n_ctx, n) // 4
+
+
+@pytest.mark.parametrize("n_ctx", [290, 400, 450])
+def test_acrobot_rollout_with_a_context_table_near_the_lds_budget(n_ctx, device):
+    """the fp64 Acrobot kernels carry an 8 KiB static LDS sin/cos table, and the host's
+    "does the context table fit in LDS behind the record buffers" test ignored it -- tables of 16 385 .. 24 576 B
+    (293 .. 438 contexts at F = 14) with a moving selector were admitted into the LDS-table kernel and overflowed the
+    160 KiB at launch.  Now the static part counts (carl_amd.hip: table_fits): such a batch launches (LDS table
+    where it fits, the global table otherwise) and equals repeated per-call steps bit for bit."""
+    fam = O.ACROBOT
+    rng = np.random.default_rng(n_ctx)
+    n, T = 4096, 24
+    table = random_table(fam, rng, n_ctx)
+    acts = torch.as_tensor(random_actions(fam, rng, (T, n)), device=device)
+    kw = dict(selector=O.SEL_ROUND_ROBIN, selector_stride=3, seed=19, max_episode_steps=7)
+    e1 = _engine(fam, table, n, device, **kw)
+    e2 = _engine(fam, table, n, device, **kw)
+    e1.reset()
+    e2.reset()
+    out = e1.rollout(acts)
+    for t in range(T):
+        obs, rew, term, trunc = e2.step(acts[t])
+        assert torch.equal(out["obs"][t], obs) and torch.equal(out["reward"][t], rew), t
+        assert torch.equal(out["terminated"][t], term) and torch.equal(out["truncated"][t], trunc), t
+    for name in ("state", "elapsed", "ctx_idx", "episode", "n_calls", "ep_return", "episodes_done", "ctx_obs"):
+        assert torch.equal(getattr(e1, name), getattr(e2, name)), name
+    assert int(e1.episodes_done.sum()) >= 3 * n
+
+
+def test_rollout_variant_is_visible_and_odd_lane_counts_warn(device):
+    """`n_lanes % 16 != 0` silently took the ~50 % slower direct-store rollout kernel.  The
+    library now answers which kernel a batch gets (carl_rollout_variant), the engine warns once, and the A/B
+    switch is a flag bit (CARL_FLAG_ROLLOUT_DIRECT) instead of an environment variable read in the launch path --
+    with identical results."""
+    from carl_amd import _lib
+
+    fam = O.PENDULUM
+    rng = np.random.default_rng(5)
+    T = 20
+    for n, want in ((4096, _lib.ROLLOUT_STAGED), (4100, _lib.ROLLOUT_DIRECT_SHAPE)):
+        table = random_table(fam, rng, n)
+        acts = torch.as_tensor(random_actions(fam, rng, (T, n)), device=device)
+        e = _engine(fam, table, n, device, selector=O.SEL_STATIC, seed=2, ctx_idx0=np.arange(n))
+        assert e.rollout_variant() == want
+        e.reset()
+        if want == _lib.ROLLOUT_DIRECT_SHAPE:
+            with pytest.warns(RuntimeWarning, match="multiple of 16"):
+                e.rollout(acts)
+        else:
+            import warnings
+
+            with warnings.catch_warnings():
+                warnings.simplefilter("error")
+                ref = e.rollout(acts)
+            d = _engine(fam, table, n, device, selector=O.SEL_STATIC, seed=2, ctx_idx0=np.arange(n))
+            d.b.flags |= _lib.FLAG_ROLLOUT_DIRECT
+            assert d.rollout_variant() == _lib.ROLLOUT_DIRECT_FLAG
+            d.reset()
+            got = d.rollout(acts)
+            for k in ("obs", "reward", "terminated", "truncated"):
+                assert torch.equal(ref[k], got[k]), k
