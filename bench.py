@@ -435,6 +435,24 @@ def graph_per_call(rec, eng, action, env, n, Kc, device):
     })
 
 
+class _stdout_to_stderr:
+    """RCCL prints a version banner with C stdio on stdout when a communicator is created; the contract of this
+    script is ONE JSON line on stdout.  File descriptor 1 points at stderr while the group is built (and the C
+    buffers are flushed before it is restored)."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        import ctypes
+
+        ctypes.CDLL(None).fflush(None)
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+
+
 def main():
     args = parse()
     import torch
@@ -461,10 +479,15 @@ def main():
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(29400 + os.getpid() % 500))
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        with _stdout_to_stderr():
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world)
+            t = torch.zeros(1, device=coll_dev)
+            dist.all_reduce(t)  # the communicator is created lazily: here, not inside the timed region
+            if coll_dev.type == "cuda":
+                torch.cuda.synchronize()
 
     def barrier():
         if dist is not None:

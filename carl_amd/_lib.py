@@ -154,6 +154,7 @@ class BraxCtxMap(C.Structure):
         ("n_mass", _i),
         ("mass_row", _i * BRAX_MAX_CTX_MASS), ("mass_link", _i * BRAX_MAX_CTX_MASS),
         ("mass_nominal", _f * BRAX_MAX_CTX_MASS), ("mass_ratio_floor", _f * BRAX_MAX_CTX_MASS),
+        ("mass_ratio_floor_multi", _f * BRAX_MAX_CTX_MASS),
         ("goal_position", _i * 3),
     ]
 

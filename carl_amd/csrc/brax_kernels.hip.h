@@ -914,11 +914,17 @@ static __device__ __forceinline__ LaneCtx load_ctx(const carl_brax_sys_t& s, con
   }
   if (TASK && s.push_link > 0) put_goal(s, b, m, c, go);
   phase_sync();
-  if (go)
+  if (go) {
+    // stability clamp of the effective mass ratio (carl_brax_ctx_map_t::mass_ratio_floor): the higher floor when
+    // two or more links of the env are lighter than nominal
+    int n_light = 0;
+    for (int k = 0; k < cm.n_mass; ++k)
+      n_light += (b.ctx_table[(size_t)cm.mass_row[k] * b.ctx_stride + c] / cm.mass_nominal[k] < 0.999f) ? 1 : 0;
     for (int k = m.sub; k < cm.n_mass; k += kSub)
       m.at(m.lay.mass + cm.mass_link[k]) =
-          s.mass[cm.mass_link[k]] *
-          fmaxf(b.ctx_table[(size_t)cm.mass_row[k] * b.ctx_stride + c] / cm.mass_nominal[k], cm.mass_ratio_floor[k]);
+          s.mass[cm.mass_link[k]] * fmaxf(b.ctx_table[(size_t)cm.mass_row[k] * b.ctx_stride + c] / cm.mass_nominal[k],
+                                          n_light >= 2 ? cm.mass_ratio_floor_multi[k] : cm.mass_ratio_floor[k]);
+  }
   phase_sync();
   return lc;
 }

@@ -111,3 +111,10 @@ MASS_RATIO_FLOOR = {
     "pusher": {"mass_r_wrist_flex_link": 0.88, "mass_object": 0.22},
 }
 DEFAULT_MASS_RATIO_FLOOR = 0.1  # nothing below was measured
+# Several light links at once are less stable than each alone: with EVERY mass feature at alpha x its floor the
+# envs still blew up to the alpha below (tools/mass_combo_sweep.py on an MI355X, round 3: profiles/
+# r03_mass_combo_sweep.txt) -- the floors of an env with two or more light links are these multiples (+10 %) of the
+# single-feature ones, capped at the default mass.
+COMBINED_FLOOR_SCALE = {"ant": 1.1, "halfcheetah": 1.45, "humanoid": 1.85, "humanoidstandup": 1.85, "hopper": 1.65,
+                        "walker2d": 1.65, "inverted_pendulum": 1.2, "inverted_double_pendulum": 1.6, "reacher": 1.45,
+                        "pusher": 1.15}

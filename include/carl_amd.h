@@ -261,9 +261,13 @@ typedef struct carl_brax_ctx_map {
                                                  * spring_mass_scale = 1 the spring backend runs every link at
                                                  * m**(1 - 1) = 1, so upstream a mass context would not move it) */
   float mass_ratio_floor[CARL_BRAX_MAX_CTX_MASS]; /* the ratio is clamped from below at this value per env (0 = no
-                                                 * clamp): lighter links make k dt^2 / m of the joint springs exceed
-                                                 * the explicit integrator's stability bound (NaNs within a few
-                                                 * steps); the context OBSERVATION keeps the unclamped value */
+                                                 * clamp): lighter links push the explicit spring integration past
+                                                 * its stability bound (NaNs within a few steps); the context
+                                                 * OBSERVATION keeps the unclamped value.  This floor applies to an
+                                                 * env in which ONE mass feature is lighter than nominal ... */
+  float mass_ratio_floor_multi[CARL_BRAX_MAX_CTX_MASS]; /* ... and this (higher) one when two or more are (ratio <
+                                                 * 0.999): several light links at once are less stable than each
+                                                 * alone (measured: tools/mass_combo_sweep.py) */
   int32_t goal_position[3];                     /* push task: goal_position_x / _y / _z rows (carl_pusher.py:80-103) */
 } carl_brax_ctx_map_t;
 

@@ -111,9 +111,12 @@ static lane_ctx make_ctx(const carl_brax_sys_t* s, const double* row) {
   c.ang_damping = (m->ang_damping >= 0) ? (double)(float)row[m->ang_damping] : s->ang_damping;
   c.stiffness_scale = (m->joint_stiffness_scale >= 0) ? (double)(float)row[m->joint_stiffness_scale] : 1.0;
   for (int i = 0; i < s->n_links; ++i) c.mass[i] = s->mass[i];
+  int n_light = 0; /* stability clamp (carl_brax_ctx_map_t::mass_ratio_floor): the higher floor when >= 2 links are light */
+  for (int k = 0; k < m->n_mass; ++k) n_light += ((float)row[m->mass_row[k]] / m->mass_nominal[k] < 0.999f) ? 1 : 0;
   for (int k = 0; k < m->n_mass; ++k)
     c.mass[m->mass_link[k]] = s->mass[m->mass_link[k]] *
-                              fmax((double)(float)row[m->mass_row[k]] / m->mass_nominal[k], (double)m->mass_ratio_floor[k]);
+                              fmax((double)(float)row[m->mass_row[k]] / m->mass_nominal[k],
+                                   (double)(n_light >= 2 ? m->mass_ratio_floor_multi[k] : m->mass_ratio_floor[k]));
   for (int k = 0; k < 3; ++k)
     c.goal[k] = (s->push_link > 0 && m->goal_position[k] >= 0) ? (double)(float)row[m->goal_position[k]] : s->push_goal[k];
   return c;

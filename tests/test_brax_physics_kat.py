@@ -41,7 +41,7 @@ def test_k1_free_fall_follows_the_scheme_and_the_gravity_context(runner):
     dtf = float(np.float32(dt))  # the model table is float32
     t = n * dtf
     np.testing.assert_allclose(st[:, 7:9], v0[:, :2], rtol=tol(runner, 1e-13, 1e-6))
-    np.testing.assert_allclose(st[:, 9], v0[:, 2] + g * t, rtol=tol(runner, 1e-12, 2e-6))
+    np.testing.assert_allclose(st[:, 9], v0[:, 2] + g * t, rtol=tol(runner, 1e-12, 5e-6))  # 50 float32 additions
     np.testing.assert_allclose(st[:, 0:2], v0[:, :2] * t, rtol=tol(runner, 1e-12, 2e-6), atol=1e-12)
     # semi-implicit Euler: z_n = z0 + dt (n v0 + g dt n (n + 1) / 2)  -- NOT the continuous v0 t + g t^2 / 2
     z = 100.0 + dtf * (n * v0[:, 2] + g * dtf * n * (n + 1) / 2)
@@ -211,8 +211,8 @@ def test_k7_coulomb_friction_stops_a_sliding_sphere_after_v0_squared_over_2_mu_g
         k = np.arange(1, n_stop[lane] + 1)
         # every substep the normal impulse is m |g| dt, the friction impulse mu times that, until what is left of
         # the tangential velocity is smaller: then the sphere stops dead
-        np.testing.assert_allclose(vs[: n_stop[lane], lane], v0[lane] - k * dec, rtol=tol(runner, 1e-10, 2e-5), atol=tol(runner, 1e-12, 2e-6))
-        assert np.all(vs[n_stop[lane] + 1:, lane] == 0.0)
+        np.testing.assert_allclose(vs[: n_stop[lane], lane], v0[lane] - k * dec, rtol=tol(runner, 1e-10, 2e-5), atol=tol(runner, 1e-12, 5e-6))
+        assert np.all(np.abs(vs[n_stop[lane] + 1:, lane]) <= tol(runner, 0.0, 1e-6))  # (v_rcp_f32 on the kernel: zero to an ulp)
         dist = dtf * np.sum(v0[lane] - k * dec)
         assert xs[-1, lane] == pytest.approx(dist, rel=tol(runner, 1e-10, 1e-5))
         assert xs[-1, lane] == pytest.approx(v0[lane] ** 2 / (2 * mu[lane] * abs(g[lane])), rel=2.5 * dec / v0[lane])

@@ -6,9 +6,10 @@ per-dispatch DURATION rocprofv3 reports for the same kernel (VERDICT r02 weak #5
     python tools/per_call_period.py --trace DIR          # start-to-start deltas and durations from the trace"""
 import csv
 import glob
+import os
 import sys
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def run(family="pendulum", n=65536, steps=100, reps=50):
