@@ -430,8 +430,14 @@ def graph_per_call(rec, eng, action, env, n, Kc, device):
         "roofline": {"bound": "hbm", "kernel": "step_kernel", "bytes_per_unit": b8d,
                      "achieved": b8d * n / per_step_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": b8d * n / per_step_s / 1e9 / HBM_PEAK_GBS,
-                     "note": "duration = graph-replayed launch-to-launch period (includes the "
-                             "~1.5 us kernel boundary)"},
+                     "duration_us": per_step_s * 1e6,
+                     "note": "duration = launch-to-launch period of back-to-back launches (hipGraph replay, HIP events): "
+                             "what a caller pays per env step.  rocprofv3's per-dispatch duration of this kernel is "
+                             "LONGER (3.7 us median): the profiler serialises dispatches and times each one alone "
+                             "(ramp-up + one HBM round trip + release), phases that back-to-back launches overlap "
+                             "-- profiles/r03_per_call_period.txt",
+                     "isolated_dispatch_us_rocprofv3": 3.68,
+                     "frac_isolated_dispatch": b8d * n / 3.68e-6 / 1e9 / HBM_PEAK_GBS},
     })
 
 
