@@ -35,10 +35,36 @@
 #include "carl_device.hip.h"
 #include "fast_math.hip.h"
 
+// CARL_EXP_BRAX_* switches compile MEASUREMENT-ONLY kernels (a cost attribution: what a piece of the substep costs
+// by leaving it out or replacing it with the float32 form -- results differ); refused without -DCARL_ABLATION, which
+// carl_amd/build.py never passes (tools/build_variant.sh writes such libraries to gpurun_in/).
+#if (defined(CARL_EXP_BRAX_FAST_ATAN) || defined(CARL_EXP_BRAX_NO_CONTACTS) || defined(CARL_EXP_BRAX_NO_PHASE_A) || \
+     defined(CARL_EXP_BRAX_NO_PHASE_B) || defined(CARL_EXP_BRAX_LDS_PAD) || defined(CARL_EXP_BRAX_NO_CHILDREN) || defined(CARL_EXP_BRAX_F32_INTEGRATE)) &&              \
+    !defined(CARL_ABLATION)
+#error "CARL_EXP_BRAX_* build measurement-only kernels; pass -DCARL_ABLATION to confirm (never for the product library)"
+#endif
+
 namespace carl {
 namespace brax {
 
-constexpr int kLanes = 64;  // lanes per workgroup = one wavefront
+constexpr int kLanes = 64;  // lanes per wavefront: one wavefront works on floor(64 / kSub) envs, on its own
+// Wavefronts per workgroup.  The wavefronts of a workgroup are INDEPENDENT (own envs, own slice of the dynamic LDS,
+// no workgroup barrier after the start-up copy); they only share the one LDS copy of the model table, topology and
+// derived constants (5.5 KB).  With one wavefront per workgroup that copy made LDS, not registers, the occupancy
+// limit: Ant 10.7 KB of rows + 5.5 KB static = 9 wavefronts per CU.
+// The host picks the number of wavefronts per workgroup (<= kMaxWavesPerWg; 8 keeps the 256-VGPR budget under
+// __launch_bounds__) that puts the most wavefronts on a CU's 160 KB (carl_brax.hip: launch_brax).
+#ifndef CARL_BRAX_WAVES_PER_WG
+#define CARL_BRAX_WAVES_PER_WG 8
+#endif
+constexpr int kMaxWavesPerWg = CARL_BRAX_WAVES_PER_WG;
+constexpr int kMaxThreads = kLanes * kMaxWavesPerWg;
+// Register budget: two wavefronts per SIMD (256 VGPRs each).  The MULTI instantiations need 267 without the bound
+// (occupancy 1); with it the allocator spills 8 dwords of cold-path values.  Three / four waves per SIMD (168 / 128
+// VGPRs) were measured and lose to the spills (profiles/r03_brax_occupancy.txt).
+#ifndef CARL_BRAX_WAVES_PER_EU
+#define CARL_BRAX_WAVES_PER_EU 2
+#endif
 // kSub = lanes per env is a template parameter of everything below (Group<kSub>): 2, 4, 7, 9, 11 or
 // 16, chosen per model and batch size by the host (carl_amd.hip: brax_lanes_per_env)
 constexpr float kPiF = 3.14159265358979323846f;
@@ -181,7 +207,9 @@ struct Layout {
     return l;
   }
   // bytes of dynamic LDS for `envs` envs per workgroup
-  __host__ __device__ size_t bytes(int envs) const { return ((size_t)pose_rows * 8 + (size_t)total * 4) * envs; }
+  __host__ __device__ size_t bytes(int envs) const {  // per wavefront, rounded up to 8 (the next wavefront's doubles)
+    return (((size_t)pose_rows * 8 + (size_t)total * 4) * envs + 7) & ~(size_t)7;
+  }
 };
 
 // Persistent state record of one env in HBM (carl_batch_t::state, ::first_state): CARL_BRAX_LINK_RECORD = 20
@@ -271,7 +299,7 @@ struct Prepared {
 
 template <int kSub>
 struct Group {
-static constexpr int kEnvs = kLanes / kSub;  // envs per workgroup
+static constexpr int kEnvs = kLanes / kSub;  // envs per wavefront
 
 struct Lds {
   double* pose;  // [7 L][kEnvs]
@@ -306,9 +334,16 @@ struct Lds {
   __device__ __forceinline__ v3 get3(int row) const { return V(at(row), at(row + 1), at(row + 2)); }
 };
 
-// hand-over between lockstep phases: the workgroup is ONE wavefront, so this is an LDS
-// drain (s_waitcnt) plus a compiler fence; s_barrier itself is trivially satisfied
-static __device__ __forceinline__ void phase_sync() { __syncthreads(); }
+// hand-over between lockstep phases: producer and consumer lanes are in the SAME wavefront, whose LDS instructions
+// execute in program order -- so no s_barrier and no s_waitcnt are needed, only that the compiler keeps the order
+// (from one thread's point of view the rows written before and read after are different addresses).  A
+// wavefront-scope fence pair around a scheduling barrier is exactly that; the other wavefronts of the workgroup are
+// not involved.
+static __device__ __forceinline__ void phase_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 static __device__ __forceinline__ v3 apply_inv_inertia(const carl_brax_sys_t& s, int i, qt r, v3 t, bool iso) {
   if (iso) return t * s.inv_inertia[i][0];  // every shipped model: spring_inertia_scale = 1
@@ -372,7 +407,11 @@ static __device__ __forceinline__ JointGeom joint_geometry(const carl_brax_sys_t
     g.axx = qrot(rp, V(0.0f, (float)a2, (float)-a1));
   }
   if (rel.w < 0.0) { rel.w = -rel.w; rel.x = -rel.x; }
+#ifdef CARL_EXP_BRAX_FAST_ATAN
+  g.theta = 2.0f * atan2_fast((float)rel.x, (float)rel.w);
+#else
   g.theta = (float)(2.0 * atan2_f64(rel.x, rel.w));  // twist about the hinge (joint frame x)
+#endif
   g.wrel = bc.w - bp.w;
   g.thetadot = dot(g.x_c, g.wrel);
   const int nr = MULTI ? s.n_link_dof[i] - s.n_slide[i] : 1;
@@ -459,7 +498,11 @@ static __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const T
                                         const Lds& m) {
   const int L = s.n_links;
   // phase A -- spring.joints.resolve, one joint per lane
+#ifdef CARL_EXP_BRAX_NO_PHASE_A
+  for (int i = L; i < L; i += kSub) {
+#else
   for (int i = tp.first_joint + m.sub; i < L; i += kSub) {
+#endif
     const int P = s.parent[i];
     if (is_free_root(s, i)) continue;
     const Body bc = m.body(i);
@@ -529,7 +572,11 @@ static __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const T
   const float dl = __expf(s.vel_damping * s.dt), da = __expf(c.ang_damping * s.dt);
   const float inv_dt = __builtin_amdgcn_rcpf(s.dt);
   const v3 n = V(0, 0, 1);
+#ifdef CARL_EXP_BRAX_NO_PHASE_B
+  for (int i = L; i < L; i += kSub) {
+#else
   for (int i = m.sub; i < L; i += kSub) {
+#endif
     Body b = m.body(i);
     const qt rf = tof(b.r);
     v3 F = V(0, 0, 0), T = V(0, 0, 0);
@@ -537,11 +584,13 @@ static __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const T
       F = m.get3(m.lay.wrench + 12 * i);
       T = m.get3(m.lay.wrench + 12 * i + 3);
     }
+#ifndef CARL_EXP_BRAX_NO_CHILDREN
     for (int cc = tp.child_begin[i]; cc < tp.child_begin[i + 1]; ++cc) {
       const int wr = m.lay.wrench + 12 * tp.child_idx[cc];
       F = F + m.get3(wr + 6);
       T = T + m.get3(wr + 9);
     }
+#endif
     const float inv_m = __builtin_amdgcn_rcpf(m.at(m.lay.mass + i));  // v_rcp_f32 (1 ulp): the phase is issue-bound
     b.v = b.v + (F * inv_m + V(0, 0, c.gravity_z)) * s.dt;
     b.w = b.w + apply_inv_inertia(s, i, rf, T, dv.iso[i] != 0) * s.dt;
@@ -551,7 +600,11 @@ static __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const T
     uint32_t hit = 0u;
     const bool iso = dv.iso[i] != 0;
     // no sphere of this link can reach the plane while its COM is higher than the farthest sphere surface
+#ifdef CARL_EXP_BRAX_NO_CONTACTS
+    const int k_end = 0;
+#else
     const int k_end = ((float)b.p.z < dv.reach[i]) ? tp.coll_begin[i + 1] : 0;
+#endif
     // third row of the rotation matrix in float64: a sphere's height -- hence its depth, which the Baumgarte
     // term multiplies by erp / dt -- is a pose difference
     const double R20 = 2.0 * (b.r.x * b.r.z - b.r.w * b.r.y), R21 = 2.0 * (b.r.y * b.r.z + b.r.w * b.r.x),
@@ -592,6 +645,17 @@ static __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const T
       b.v = b.v + cdv * ic;
       b.w = b.w + cdw * ic;
     }
+#ifdef CARL_EXP_BRAX_F32_INTEGRATE
+    {
+      const v3 pf = tof(b.p) + b.v * s.dt;
+      const qt dqf = qmul(qt{0.0f, b.w.x, b.w.y, b.w.z}, rf);
+      const float hf = 0.5f * s.dt;
+      b.p = tod(pf);
+      b.r = tod(qnormalize(qt{rf.w + hf * dqf.w, rf.x + hf * dqf.x, rf.y + hf * dqf.y, rf.z + hf * dqf.z}));
+      m.put(i, b);
+      continue;
+    }
+#endif
     const double dtd = (double)s.dt;
     b.p = D(fma((double)b.v.x, dtd, b.p.x), fma((double)b.v.y, dtd, b.p.y), fma((double)b.v.z, dtd, b.p.z));
     const qtd dq = qmul(qtd{0.0, (double)b.w.x, (double)b.w.y, (double)b.w.z}, b.r);
@@ -1057,18 +1121,19 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
   {  // model table -> LDS, once per workgroup: every load in flight before the first LDS write (a
      // load-store loop paid one HBM/L2 round trip per 256 bytes: ~15 us of a per-call step)
     constexpr int kWords = (int)(sizeof(carl_brax_sys_t) / 4);
-    constexpr int kPer = (kWords + kLanes - 1) / kLanes;
+    constexpr int kPer = (kWords + kLanes - 1) / kLanes;  // (sized for a one-wavefront workgroup)
+    const int kThreads = (int)blockDim.x;
     const uint32_t* src = reinterpret_cast<const uint32_t*>(sys_dev);
     uint32_t* dst = reinterpret_cast<uint32_t*>(&s);
     uint32_t tmp[kPer];
 #pragma unroll
     for (int j = 0; j < kPer; ++j) {
-      const int k = j * kLanes + (int)threadIdx.x;
+      const int k = j * kThreads + (int)threadIdx.x;
       tmp[j] = (k < kWords) ? src[k] : 0u;
     }
 #pragma unroll
     for (int j = 0; j < kPer; ++j) {
-      const int k = j * kLanes + (int)threadIdx.x;
+      const int k = j * kThreads + (int)threadIdx.x;
       if (k < kWords) dst[k] = tmp[j];
     }
   }
@@ -1080,18 +1145,21 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
     const uint32_t* sd = reinterpret_cast<const uint32_t*>(&prep.derived);
     uint32_t* dt = reinterpret_cast<uint32_t*>(&tp);
     uint32_t* dd = reinterpret_cast<uint32_t*>(&dv);
-    for (int k = (int)threadIdx.x; k < kWordsT; k += kLanes) dt[k] = st[k];
-    for (int k = (int)threadIdx.x; k < kWordsD; k += kLanes) dd[k] = sd[k];
+    for (int k = (int)threadIdx.x; k < kWordsT; k += (int)blockDim.x) dt[k] = st[k];
+    for (int k = (int)threadIdx.x; k < kWordsD; k += (int)blockDim.x) dd[k] = sd[k];
   }
   __syncthreads();
   // kSub need not divide 64 (one lane per link: 7, 9, 11): the wavefront's spare lanes idle -- they
   // point at the last env's column, own no link (sub beyond every loop bound) and are never active
-  const int tid = (int)threadIdx.x;
+  const int tid = (int)threadIdx.x & (kLanes - 1), wave = (int)threadIdx.x >> 6;
   const bool lane_ok = tid < kEnvs * kSub;
   const Layout lay = Layout::make(s.n_links, s.n_dof, io_rows_of(s));
-  const Lds m{lds_dyn, reinterpret_cast<float*>(lds_dyn + (size_t)lay.pose_rows * kEnvs), lay,
+  double* const my_lds = lds_dyn + (size_t)wave * (lay.bytes(kEnvs) / 8);  // this wavefront's rows (bytes(): multiple of 8)
+  const Lds m{my_lds, reinterpret_cast<float*>(my_lds + (size_t)lay.pose_rows * kEnvs), lay,
               lane_ok ? tid / kSub : kEnvs - 1, lane_ok ? tid % kSub : kLanes};
-  const int env = (int)blockIdx.x * kEnvs + m.env;
+  const int gwave = (int)blockIdx.x * ((int)blockDim.x >> 6) + wave;  // global wavefront = group of kEnvs envs
+  const int env = gwave * kEnvs + m.env;
+  if (gwave * kEnvs >= b.n_lanes) return;  // a wavefront past the end of the batch
   const bool active = lane_ok && env < b.n_lanes;
   const bool lead = active && m.sub == 0;  // the lane that writes the env's scalars
   const uint64_t genv = (uint64_t)(b.lane_offset + env);
@@ -1307,7 +1375,7 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
 // out, as MULTI = false does for the Euler-angle joints.  Task models always have a hinge-less last link,
 // so TASK implies MULTI.
 template <int MODE, bool MULTI, int K, bool TASK = false>
-__global__ void __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(2))) brax_kernel(const carl_batch_t b, const carl_brax_sys_t* __restrict__ sys_dev,
+__global__ void __launch_bounds__(kMaxThreads) __attribute__((amdgpu_waves_per_eu(CARL_BRAX_WAVES_PER_EU))) brax_kernel(const carl_batch_t b, const carl_brax_sys_t* __restrict__ sys_dev,
                                                       const Prepared prep, const carl_step_io_t io,
                                                       const uint8_t* __restrict__ mask, float* __restrict__ reset_obs,
                                                       const int n_steps) {

@@ -164,9 +164,31 @@ int launch_brax(const carl_batch_t* b, const carl_brax_sys_t* sd, const carl_bra
   const int K = brax_lanes_per_env(sh->n_links, multi, task, b->n_lanes, sh->lanes_per_env);
   const int envs = carl::brax::kLanes / K;  // one wavefront = envs x K lanes; LDS rows are `envs` floats wide
   const carl::brax::Layout lay = carl::brax::Layout::make(sh->n_links, sh->n_dof, carl::brax::io_rows_of(*sh));
-  const size_t sh_bytes = lay.bytes(envs);
-  if (sh_bytes + sizeof(carl_brax_sys_t) + sizeof(carl::brax::Prepared) > 160 * 1024)
-    return fail(CARL_ERR_UNSUPPORTED, "%s: model needs %zu B of LDS per wavefront", who, sh_bytes);
+  // independent wavefronts per workgroup, sharing the LDS copy of the static tables: as many (<= kMaxWavesPerWg) as fit
+  const size_t static_lds = sizeof(carl_brax_sys_t) + sizeof(carl::brax::Prepared);
+#ifdef CARL_EXP_BRAX_LDS_PAD  // measurement only (needs -DCARL_ABLATION): fewer resident wavefronts per SIMD through LDS
+  const size_t wave_bytes = lay.bytes(envs) > (size_t)CARL_EXP_BRAX_LDS_PAD ? lay.bytes(envs) : (size_t)CARL_EXP_BRAX_LDS_PAD;
+#else
+  const size_t wave_bytes = lay.bytes(envs);
+#endif
+  if (wave_bytes + static_lds > 160 * 1024)
+    return fail(CARL_ERR_UNSUPPORTED, "%s: model needs %zu B of LDS per wavefront", who, wave_bytes);
+  // Registers allow 2 wavefronts per SIMD = 8 per CU (brax_kernels.hip.h: CARL_BRAX_WAVES_PER_EU): take the SMALLEST
+  // workgroup that gets there LDS-wise (or as close as LDS allows) -- small workgroups retire independently, larger
+  // ones cost the launch's tail (Ant, 4 wavefronts per workgroup: 2.97e8 -> 2.57e8 env-steps/s)
+  int W = 1, best = 0;
+  for (int w = 1; w <= carl::brax::kMaxWavesPerWg; ++w) {
+    const size_t wg = (size_t)w * wave_bytes + static_lds;
+    if (wg > 160 * 1024) break;
+    if (w > 1 && (long long)(w - 1) * envs >= b->n_lanes) break;  // a small batch: no empty wavefronts
+    int per_cu = (int)((160 * 1024) / wg) * w;                     // resident wavefronts per CU, LDS-wise
+    if (per_cu > 4 * CARL_BRAX_WAVES_PER_EU) per_cu = 4 * CARL_BRAX_WAVES_PER_EU;
+    if (per_cu > best) {
+      best = per_cu;
+      W = w;
+    }
+  }
+  const size_t sh_bytes = (size_t)W * wave_bytes;
   using kern_t = void (*)(carl_batch_t, const carl_brax_sys_t*, carl::brax::Prepared, carl_step_io_t, const uint8_t*,
                           float*, int);
   kern_t kern = nullptr;
@@ -191,13 +213,13 @@ int launch_brax(const carl_batch_t* b, const carl_brax_sys_t* sd, const carl_bra
   if (sh_bytes > 48 * 1024) {
     if (int e = carl_host::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), sh_bytes, who)) return e;
   }
-  const int grid = (b->n_lanes + envs - 1) / envs;
+  const int grid = (b->n_lanes + envs * W - 1) / (envs * W);
   carl_step_io_t io_v{};
   if (io != nullptr) io_v = *io;
   carl::brax::Prepared prep{};  // topology + derived per-link constants, host-side (microseconds)
   carl::brax::build_topo_host(*sh, prep.topo);
   for (int i = 0; i < sh->n_links; ++i) carl::brax::build_derived_host(*sh, prep.derived, i);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(carl::brax::kLanes), sh_bytes, st, *b, sd, prep, io_v, mask, reset_obs,
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(carl::brax::kLanes * W), sh_bytes, st, *b, sd, prep, io_v, mask, reset_obs,
                      n_steps);
   return check_launch(who);
 }
