@@ -112,7 +112,9 @@ __host__ __device__ __forceinline__ qt f4(const float* p) { return qt{p[0], p[1]
 // observation entries beyond north_star's 1e-5).  So everything that is a DIFFERENCE OF POSES -- anchor
 // separation, relative rotation and the joint angles read from it, contact depth, the step's forward progress --
 // is formed in float64 from a float64 pose; forces, torques, impulses and velocities (relative errors, never
-// amplified) stay float32.  v_fma_f64 issues at the v_fma_f32 rate on gfx950 (profiles/r03_fp64_rate.txt).
+// amplified) stay float32.  Cost: at two wavefronts per SIMD a float64 instruction issues at 0.63 x the float32 rate
+// (profiles/r03_fp64_rate.txt); about a third of the substep's vector instructions are float64, -10 % throughput
+// against the all-float32 kernel of round 2 (profiles/r03_brax_occupancy.txt has the attribution).
 struct v3d {
   double x, y, z;
 };

@@ -9,8 +9,11 @@ brax 0.12.1's ``ant.xml`` (a Gym-Ant derivative with brax ``<custom>`` numerics)
 
 Spring backend conventions restated here: ``spring_mass_scale = spring_inertia_scale = 1``
 in the asset, i.e. the pipeline runs every link with effective mass ``m**(1-1) = 1`` and
-identity inertia (what keeps its stiff joint springs stable at dt = 0.005); contexts scale
-the effective mass RELATIVE to CARL's default (``mass_torso`` 10 -> factor 1).
+identity inertia (what keeps its stiff joint springs stable at dt = 0.005).  Hence upstream a
+``mass_<link>`` context would NOT move the spring dynamics even with the reference's Quirk B1
+fixed; scaling the effective mass RELATIVE to CARL's default (``mass_torso`` 10 -> factor 1) is an
+EXTENSION of this build (north_star asks for per-instance mass), like ``joint_stiffness`` --
+clamped per env at the measured stability floor (``carl_brax_ctx_map_t::mass_ratio_floor``).
 """
 from __future__ import annotations
 
