@@ -821,3 +821,45 @@ def test_every_mass_feature_at_the_reference_lower_bound_constructs_and_stays_fi
             o, r, te, tr, _ = env.step(a.to(device))
             assert bool(torch.isfinite(o["obs"]).all()) and bool(torch.isfinite(r).all()), (env_name, t)
     assert n_classes >= 10
+
+
+def test_config4_and_config5_full_size_step_parity(device):
+    """BASELINE configs 4 and 5 at their full sizes (Ant x 32 768; Halfcheetah + Humanoid x 32 768 each with the
+    joint_stiffness classes): the engines run the whole batch; the fp64 oracle re-computes every lane (Ant) or every
+    fourth lane (config 5) of one env step from the engine's own state after a few free-running steps -- north_star's
+    1e-5 as a maximum on the lanes whose contact decisions agree, the excluded share bounded."""
+    from carl_amd.brax_engine import BraxVecEngine
+
+    n = 32768
+    rng = np.random.default_rng(60)
+    cases = [("ant", ant_sys(NAMES), NAMES, context_rows(rng, n), 1, 1.0)]
+    s, names, default = _cheetah()
+    cases.append(("halfcheetah", s, names, _cheetah_rows(rng, n, default, names), 4, 1.0))
+    s, names, default = _humanoid()
+    rows = np.tile(default, (n, 1))
+    rows[:, names.index("joint_stiffness")] = rng.uniform(0.5, 2.0, n)
+    rows[:, names.index("gravity")] = rng.uniform(-15, -5, n)
+    cases.append(("humanoid", s, names, rows.astype(np.float32).astype(np.float64), 4, 0.4))
+    for label, s, names, rows, stride, amp in cases:
+        eng = BraxVecEngine(s, len(names), rows, n, device, selector=O.SEL_STATIC, seed=1, ctx_idx0=np.arange(n),
+                            auto_reset=False, max_episode_steps=10_000, branch_record=True)
+        eng.reset()
+        g = torch.Generator(device=device).manual_seed(3)
+        for _ in range(5):  # away from the reset pose: contacts, limits, motion
+            eng.step((torch.rand((n, s.n_act), generator=g, device=device) * 2 - 1) * amp)
+        sel = np.arange(0, n, stride)
+        ora = B.Engine(s, rows[sel], len(sel), selector=O.SEL_STATIC, ctx_idx0=np.arange(len(sel)), autoreset=False,
+                       max_steps=10_000)
+        ora.reset()
+        ora.state[:] = eng.state_np()[sel]
+        ora.elapsed[:] = eng.elapsed.cpu().numpy()[sel]
+        a = (rng.uniform(-1, 1, (n, s.n_act)) * amp).astype(np.float32)
+        obs, rew, term, trunc = eng.step(torch.as_tensor(a))
+        out = ora.step(a[sel])
+        sig = eng.branch_sig.cpu().numpy().view(np.uint32)[sel]
+        flag = (term.cpu().numpy()[sel] != 0) != (out.terminated != 0)
+        agree = (sig[:, 0] == ora.branch_sig[:, 0]) & ~flag
+        e = np.maximum(rel_err(obs.cpu().numpy()[sel], out.obs).max(1), rel_err(rew.cpu().numpy()[sel], out.reward))
+        print(f"{label}: {len(sel)} lanes, agreeing max {e[agree].max():.2e}, excluded {1 - agree.mean():.5f}")
+        assert agree.mean() >= 0.995 and e[agree].max() <= 1e-5, (label, e[agree].max(), agree.mean())
+        assert bool(torch.isfinite(obs).all())
