@@ -59,11 +59,18 @@ constexpr int kLanes = 64;  // lanes per wavefront: one wavefront works on floor
 #endif
 constexpr int kMaxWavesPerWg = CARL_BRAX_WAVES_PER_WG;
 constexpr int kMaxThreads = kLanes * kMaxWavesPerWg;
-// Register budget: two wavefronts per SIMD (256 VGPRs each).  The MULTI instantiations need 267 without the bound
-// (occupancy 1); with it the allocator spills 8 dwords of cold-path values.  Three / four waves per SIMD (168 / 128
-// VGPRs) were measured and lose to the spills (profiles/r03_brax_occupancy.txt).
+// Register budget.  Single-hinge models (MULTI = false: Ant, Halfcheetah, Hopper, Walker2d): THREE wavefronts per SIMD
+// (168 VGPRs) -- the kernel is bound by the latency of its own dependent chains (one -> two wavefronts per SIMD: 1.7 x),
+// the hot substep loop fits 168 registers without a spill (ISA checked) and what spills (62 dwords) sits in observe and
+// in the done path, once per env step or rarer: Ant 2.98e8 -> 3.55e8 env-steps/s.  The reset path is INLINED there: with
+// reset_state / forward_kinematics as non-inlined calls the 168-register Ant build faulted on the device
+// (HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION in the spilled call path).  Multi-hinge / task models (Humanoid, ...):
+// two wavefronts (256 VGPRs; they are LDS-bound at 2.5 and lose 4-28 % at 168 / 128).  profiles/r03_brax_occupancy.txt.
 #ifndef CARL_BRAX_WAVES_PER_EU
-#define CARL_BRAX_WAVES_PER_EU 2
+#define CARL_BRAX_WAVES_PER_EU(MULTI) ((MULTI) ? 2 : 3)
+#endif
+#ifndef CARL_BRAX_RESET_INLINE
+#define CARL_BRAX_RESET_INLINE __forceinline__
 #endif
 // kSub = lanes per env is a template parameter of everything below (Group<kSub>): 2, 4, 7, 9, 11 or
 // 16, chosen per model and batch size by the host (carl_amd.hip: brax_lanes_per_env)
@@ -705,7 +712,7 @@ static __device__ __forceinline__ void observe(const carl_brax_sys_t& s, const D
   };
   float M = 1.0f;
   v3d com = D(0, 0, 0);
-  if (s.obs_extended && go) com = system_com(s, m, &M);
+  if (MULTI && s.obs_extended && go) com = system_com(s, m, &M);
   for (int i = m.sub; i < L; i += kSub) {
     if (!go) continue;
     const int P = s.parent[i];
@@ -743,7 +750,7 @@ static __device__ __forceinline__ void observe(const carl_brax_sys_t& s, const D
           }
       }
     }
-    if (s.obs_extended) {  // inertia about the system com, world axes, row-major, then mass; com velocity
+    if (MULTI && s.obs_extended) {  // inertia about the system com, world axes, row-major, then mass; com velocity
       const int e0 = m.lay.io + qd0 + s.n_dof;
       const v3 d = tof(b.p - com);
       const qt rf = tof(b.r);
@@ -770,7 +777,7 @@ static __device__ __forceinline__ void observe(const carl_brax_sys_t& s, const D
       m.at(k + 3) = b.w.x; m.at(k + 4) = b.w.y; m.at(k + 5) = b.w.z;
     }
   }
-  if (s.obs_extended && go) {
+  if (MULTI && s.obs_extended && go) {
     const int k0 = m.lay.io + qd0 + s.n_dof + 16 * L;
     for (int d = m.sub; d < s.n_dof; d += kSub) m.at(k0 + d) = zero_frc ? 0.0f : m.at(m.lay.tau + d);
   }
@@ -831,7 +838,7 @@ static __device__ __forceinline__ void observe(const carl_brax_sys_t& s, const D
 // [0, n_q), qd at rows [n_q, n_q + n_dof)); writes the state rows.  The tree is walked level by
 // level (links of one depth in parallel); link-frame origins and their velocities are kept in
 // the wrench rows (free at this point).  Wavefront-uniform call; `go`: envs that take part.
-static __device__ __noinline__ void forward_kinematics(const carl_brax_sys_t& s, const Topo& tp, const Lds& m, bool go) {
+static __device__ CARL_BRAX_RESET_INLINE void forward_kinematics(const carl_brax_sys_t& s, const Topo& tp, const Lds& m, bool go) {
   for (int lvl = 0; lvl <= tp.max_depth; ++lvl) {
     for (int i = m.sub; i < s.n_links; i += kSub) {
       if (!go || tp.depth[i] != lvl) continue;
@@ -910,10 +917,10 @@ static __device__ __forceinline__ void put_goal(const carl_brax_sys_t& s, const 
 }
 
 // wavefront-uniform call; `go`: envs that are reset.  Push task: the caller has put the envs' goal rows
-// (put_goal + phase_sync) -- the batch descriptor stays out of this non-inlined function's arguments: by
-// reference it would have to live in scratch memory for the whole kernel.
+// (put_goal + phase_sync) -- the batch descriptor stays out of this function's arguments (it was a non-inlined call
+// until round 3: by reference the descriptor would have lived in scratch memory for the whole kernel).
 template <bool TASK>
-static __device__ __noinline__ void reset_state(const carl_brax_sys_t& s, const Topo& tp, uint64_t seed, const Lds& m,
+static __device__ CARL_BRAX_RESET_INLINE void reset_state(const carl_brax_sys_t& s, const Topo& tp, uint64_t seed, const Lds& m,
                                          uint64_t genv, uint32_t episode, bool go) {
   if (go) {
     const int tl = !TASK ? 0 : s.target_link > 0 ? s.target_link : s.push_link;  // reach / push task: the last link's
@@ -1377,7 +1384,7 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
 // out, as MULTI = false does for the Euler-angle joints.  Task models always have a hinge-less last link,
 // so TASK implies MULTI.
 template <int MODE, bool MULTI, int K, bool TASK = false>
-__global__ void __launch_bounds__(kMaxThreads) __attribute__((amdgpu_waves_per_eu(CARL_BRAX_WAVES_PER_EU))) brax_kernel(const carl_batch_t b, const carl_brax_sys_t* __restrict__ sys_dev,
+__global__ void __launch_bounds__(kMaxThreads) __attribute__((amdgpu_waves_per_eu(CARL_BRAX_WAVES_PER_EU(MULTI)))) brax_kernel(const carl_batch_t b, const carl_brax_sys_t* __restrict__ sys_dev,
                                                       const Prepared prep, const carl_step_io_t io,
                                                       const uint8_t* __restrict__ mask, float* __restrict__ reset_obs,
                                                       const int n_steps) {

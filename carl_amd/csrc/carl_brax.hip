@@ -173,7 +173,8 @@ int launch_brax(const carl_batch_t* b, const carl_brax_sys_t* sd, const carl_bra
 #endif
   if (wave_bytes + static_lds > 160 * 1024)
     return fail(CARL_ERR_UNSUPPORTED, "%s: model needs %zu B of LDS per wavefront", who, wave_bytes);
-  // Registers allow 2 wavefronts per SIMD = 8 per CU (brax_kernels.hip.h: CARL_BRAX_WAVES_PER_EU): take the SMALLEST
+  // Registers allow 2 (multi-hinge / task models) or 3 wavefronts per SIMD = 8 / 12 per CU (brax_kernels.hip.h:
+  // CARL_BRAX_WAVES_PER_EU): take the SMALLEST
   // workgroup that gets there LDS-wise (or as close as LDS allows) -- small workgroups retire independently, larger
   // ones cost the launch's tail (Ant, 4 wavefronts per workgroup: 2.97e8 -> 2.57e8 env-steps/s)
   int W = 1, best = 0;
@@ -182,7 +183,7 @@ int launch_brax(const carl_batch_t* b, const carl_brax_sys_t* sd, const carl_bra
     if (wg > 160 * 1024) break;
     if (w > 1 && (long long)(w - 1) * envs >= b->n_lanes) break;  // a small batch: no empty wavefronts
     int per_cu = (int)((160 * 1024) / wg) * w;                     // resident wavefronts per CU, LDS-wise
-    if (per_cu > 4 * CARL_BRAX_WAVES_PER_EU) per_cu = 4 * CARL_BRAX_WAVES_PER_EU;
+    if (per_cu > 4 * CARL_BRAX_WAVES_PER_EU(multi)) per_cu = 4 * CARL_BRAX_WAVES_PER_EU(multi);
     if (per_cu > best) {
       best = per_cu;
       W = w;
