@@ -16,7 +16,8 @@ GPU runs the same kernel sequence".
   caller (it also captures into a hipGraph as one fork/join); the launches of a fused
   ``rollout`` go back to back on the caller's stream -- each fills the chip by itself (two
   families' workgroups need more LDS than a CU has, so they could not co-reside) and the
-  fork/join only added ~75 us of gaps per mixed launch (measured, round 2);
+  fork/join only added ~75 us of gaps per mixed launch (measured, round 2; round 3 tried it for the Brax families,
+  whose small one-wavefront workgroups could co-reside: config 5 7.69 ms back to back vs 7.82-8.26 ms concurrent);
 * re-homes the parts' episodic-return bookkeeping (``ep_return``, ``last_return``,
   ``last_length``, ``episodes_done``) and per-step ``reward`` / ``terminated`` /
   ``truncated`` into contiguous ``[N_total]`` buffers, so the reporting all-gather
