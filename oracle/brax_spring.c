@@ -13,10 +13,14 @@
  * brax==0.12.1 (pyproject.toml:62-65) is NOT vendored in /root/reference and not
  * installable here; neither are jax/mujoco.  Everything below is [upstream-memory]:
  * the structure follows SURVEY.md section 8a "Brax restatement"; coefficients and the exact
- * form of the joint constraint are this build's reconstruction.  PARITY UNPINNED -- the
- * reference's tests hold no Brax step value (test/test_brax_env.py:8-23 is a smoke test).
+ * form of the joint constraint are this build's reconstruction.  PARITY UNPINNED against brax --
+ * the reference's tests hold no Brax step value (test/test_brax_env.py:8-23 is a smoke test).
  * What this file pins is the HIP kernel against an independent fp64 implementation of the
- * same specification, plus physical invariants (tests/test_brax_oracle.py).
+ * same specification; what pins THIS file: eight analytic known-answer cases (closed forms of the
+ * scheme and of the physics: free fall, restitution, the reduced-mass oscillator, the physical
+ * pendulum's period, actuator + damping series, limit equilibrium, Coulomb stop, torque-free spin:
+ * tests/test_brax_physics_kat.py), a second, independently written NumPy restatement of the joint
+ * pass (oracle/spring_ref.py) and physical invariants (tests/test_brax_oracle.py).
  *
  * Specification (per substep dt, all vectors in the world frame, state per link =
  * COM position p, rotation r, linear velocity v, angular velocity w):
