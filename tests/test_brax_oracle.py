@@ -682,3 +682,24 @@ def test_joint_wrenches_agree_with_the_independent_numpy_restatement(model):
     # the table's float32 quaternions are unit to ~3e-8 only; the two restatements treat that differently
     # (quaternion products as stored vs normalised bases): agreement to that level, relative to the wrench scale
     assert worst < 2e-6, worst
+
+
+@pytest.mark.parametrize("fam", ["ant", "halfcheetah", "humanoid"])
+def test_committed_brax_transitions_are_reproduced_by_the_oracle(fam, golden_dir):
+    """tests/golden/transitions_brax_<family>.npz (made by make_brax_transition_golden.py FROM this oracle: self-derived,
+    not brax output) pin the restatement against drift: one env step from each committed (context, state, action) row."""
+    from carl_amd.envs.brax.models import SYSTEMS
+
+    g = np.load(os.path.join(golden_dir, f"transitions_brax_{fam}.npz"))
+    names = [str(x) for x in g["names"]]
+    s = SYSTEMS[fam](names)
+    rows = g["ctx"].astype(np.float64)
+    n = len(rows)
+    eng = B.Engine(s, rows, n, selector=O.SEL_STATIC, ctx_idx0=np.arange(n), autoreset=False, max_steps=1 << 30)
+    eng.reset()
+    eng.state[:] = g["state"]
+    out = eng.step(g["action"])
+    np.testing.assert_allclose(out.obs, g["obs"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(out.reward, g["reward"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_array_equal(out.terminated, g["terminated"])
+    np.testing.assert_array_equal(eng.branch_sig, g["branch_sig"])

@@ -863,3 +863,31 @@ def test_config4_and_config5_full_size_step_parity(device):
         print(f"{label}: {len(sel)} lanes, agreeing max {e[agree].max():.2e}, excluded {1 - agree.mean():.5f}")
         assert agree.mean() >= 0.995 and e[agree].max() <= 1e-5, (label, e[agree].max(), agree.mean())
         assert bool(torch.isfinite(obs).all())
+
+
+@pytest.mark.parametrize("fam", ["ant", "halfcheetah", "humanoid"])
+def test_committed_brax_transitions(fam, device, golden_dir):
+    """The committed (self-derived: made from the fp64 restatement, NOT brax output) transition fixtures of BASELINE
+    configs 4 / 5 through the HIP kernel: observation and reward within north_star's 1e-5 on the rows whose contact
+    record equals the fixture's, flags exact."""
+    import os
+
+    from carl_amd.brax_engine import BraxVecEngine
+    from carl_amd.envs.brax.models import SYSTEMS
+
+    g = np.load(os.path.join(golden_dir, f"transitions_brax_{fam}.npz"))
+    names = [str(x) for x in g["names"]]
+    s = SYSTEMS[fam](names)
+    rows = g["ctx"].astype(np.float64)
+    n = len(rows)
+    eng = BraxVecEngine(s, len(names), rows, n, device, selector=O.SEL_STATIC, ctx_idx0=np.arange(n), auto_reset=False,
+                        max_episode_steps=1 << 30, branch_record=True)
+    eng.reset()
+    eng.set_state64(g["state"].reshape(n, s.n_links, 13))
+    obs, rew, term, trunc = eng.step(torch.as_tensor(g["action"]))
+    sig = eng.branch_sig.cpu().numpy().view(np.uint32)
+    same = sig[:, 0] == g["branch_sig"][:, 0]
+    assert same.mean() >= 0.95
+    np.testing.assert_array_equal(term.cpu().numpy()[same], g["terminated"][same])
+    e = np.maximum(rel_err(obs.cpu().numpy(), g["obs"]).max(1), rel_err(rew.cpu().numpy(), g["reward"]))
+    assert e[same].max() <= 1e-5, e[same].max()
