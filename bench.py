@@ -230,6 +230,32 @@ class Workload:
         wall = time.perf_counter() - t0
         return wall, e0.elapsed_time(e1) * 1e-3 / K
 
+    def train_free_running(self, K, W, barrier):
+        """The same K launches per part, each part on its OWN stream, joined only at the end
+        (`MixedVecEngine.rollout(free_running=True)` + `join()`): consecutive launches of different parts overlap (the
+        tail of one fills the head of the other).  What a double-buffered collector does (half-batch A steps while the
+        policy looks at half-batch B); NOT the one-stream launch train `value` is quoted on -- reported beside it for
+        the Brax workloads, whose workgroups live for a whole launch and leave the last 'round' of SIMD slots half
+        empty."""
+        import torch
+
+        def go(n):
+            for _ in range(n):
+                s = self._i % len(self.acts)
+                self._i += 1
+                self.eng.rollout(self.acts[s], self.outs[s], free_running=True)
+            self.eng.join()
+
+        torch.cuda.synchronize()
+        go(W)
+        torch.cuda.synchronize()
+        barrier()
+        t0 = time.perf_counter()
+        go(K)
+        torch.cuda.synchronize()
+        barrier()
+        return time.perf_counter() - t0
+
     def launch_shape(self):
         """Brax families: the autotuned lane-group width per part (a pure scheduling choice)"""
         parts = self.eng.parts if self.mixed else [self.eng]
@@ -243,6 +269,14 @@ class Workload:
 
     def mean_last_return(self):
         return float(self.eng.last_return.mean())
+
+
+class SplitWorkload(Workload):
+    """ONE family's contexts as two independent engines of half the lanes each, stepped as one `MixedVecEngine`: the
+    parts of a free-running, double-buffered launch train."""
+
+    def __init__(self, family, lanes_each, T, sets, rank, world, device):
+        super().__init__((family, family), lanes_each, T, sets, rank, world, device)
 
 
 def traffic_record(key):
@@ -611,6 +645,17 @@ def main():
             "mean_last_episode_return": w2.mean_last_return(), "lanes_per_env": w2.launch_shape(),
             "classes": [type(e).__name__ for e in w2.envs],
         }
+        if all(f in BRAX_ENVS for f in fams):
+            # double-buffered use: the same contexts as two free-running half-batches (one family: two engines of half
+            # the lanes; two families: one engine each), launches overlapping across streams
+            w4 = SplitWorkload(fams[0], lanes // 2, Ta, args.buffer_sets, rank, world, device) if len(fams) == 1 else w2
+            wall4 = max_over_ranks(w4.train_free_running(K, W, barrier))
+            also[name]["free_running_two_streams"] = {
+                "value": w4.n * world * Ta * K / wall4, "unit": "env-steps/s", "ms_per_step": wall4 / K * 1e3,
+                "note": "the same contexts as two half-batches on two HIP streams, joined only at the end of the train "
+                        "(double-buffered collection): consecutive launches overlap; not the one-stream figure above"}
+            if w4 is not w2:
+                del w4
         if name == "cartpole" and rank == 0 and world == 1 and not args.no_cpu_baseline:
             # north_star: the CartPole number "next to the reference Python step() timed on the host cores (core
             # count stated) in the same run" -- the restatement of that loop (kind "port"), same context set

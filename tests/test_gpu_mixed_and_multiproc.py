@@ -337,3 +337,40 @@ def test_rccl_collectives_run_on_this_gpu_with_a_world_of_one(device, tmp_path):
     assert fin.any() and abs(float(got["summary_mean"]) - float(got["ref_last_return"][fin].mean())) < 1e-4
     assert float(got["episodes"]) == float(got["ref_episodes_done"].sum())
     print(f"RCCL world-1 all-gather of 3 x {N} device values: {float(got['ms']):.3f} ms per call")
+
+
+def test_free_running_half_batches_equal_the_one_stream_rollouts(device):
+    """`MixedVecEngine.rollout(free_running=True)` + `join()`: one family's contexts as two half-batches whose launch
+    trains run on their own streams and overlap across calls (the double-buffered collector; bench.py's
+    `free_running_two_streams` record).  Three consecutive free-running rollouts, one join: every output of every
+    launch and the final engine state equal the same launches enqueued back to back on one stream."""
+    from carl_amd.context.selection import StaticSelector
+    from carl_amd.envs import CARLBraxAnt
+    from carl_amd.mixed import MixedVecEngine
+
+    n, T, R = 2048, 6, 3
+
+    def mk():
+        return [CARLBraxAnt(batch_size=n, device=device, context_selector=StaticSelector, seed=4, lane_offset=k * n,
+                            autotune=False) for k in range(2)]
+    a, b = mk(), mk()
+    ma, mb = MixedVecEngine([p.env for p in a], ["ant", "ant"]), MixedVecEngine([p.env for p in b], ["ant", "ant"])
+    for m_ in (ma, mb):
+        m_.seed(4)
+        m_.reset()
+    g = torch.Generator(device=device).manual_seed(1)
+    acts = [[torch.rand((T, n, 8), generator=g, device=device) * 2 - 1 for _ in range(2)] for _ in range(R)]
+    outs_a = [ma.alloc_rollout(T) for _ in range(R)]
+    outs_b = [mb.alloc_rollout(T) for _ in range(R)]
+    for r in range(R):
+        ma.rollout(acts[r], outs_a[r], free_running=True)   # no join between the calls
+        mb.rollout(acts[r], outs_b[r])
+    ma.join()
+    torch.cuda.synchronize()
+    for r in range(R):
+        for k in range(2):
+            for name in ("obs", "reward", "terminated", "truncated"):
+                assert torch.equal(outs_a[r][k][name], outs_b[r][k][name]), (r, k, name)
+    for k in range(2):
+        assert torch.equal(ma.parts[k].state, mb.parts[k].state)
+    assert torch.equal(ma.ep_return, mb.ep_return) and torch.equal(ma.episodes_done, mb.episodes_done)
