@@ -211,9 +211,17 @@ class Workload:
         seconds from one HIP-event pair on the launch stream)."""
         import torch
 
+        import gc
+
         for _ in range(W):
             self.launch()
         torch.cuda.synchronize()
+        # The timed region is ~1.5 ms of host time: a generation-2 garbage collection landing inside it (the context
+        # sets of the workloads are 65 536-row Python-side objects) stalls the launch loop for tens of milliseconds --
+        # seen as a wall-clock value 10 x below the HIP-event figure of the same launches.  Collect now, and keep the
+        # collector off while the clock runs.
+        gc.collect()
+        gc.disable()
         # one HIP-event pair around the whole launch train, on the stream the kernels run on (torch's
         # current stream): launches are back-to-back, so elapsed / K is the kernel's average duration
         # plus the ~1-2 us kernel boundary
@@ -228,6 +236,7 @@ class Workload:
         torch.cuda.synchronize()
         barrier()
         wall = time.perf_counter() - t0
+        gc.enable()
         return wall, e0.elapsed_time(e1) * 1e-3 / K
 
     def train_free_running(self, K, W, barrier):
@@ -246,15 +255,21 @@ class Workload:
                 self.eng.rollout(self.acts[s], self.outs[s], free_running=True)
             self.eng.join()
 
+        import gc
+
         torch.cuda.synchronize()
         go(W)
         torch.cuda.synchronize()
+        gc.collect()
+        gc.disable()
         barrier()
         t0 = time.perf_counter()
         go(K)
         torch.cuda.synchronize()
         barrier()
-        return time.perf_counter() - t0
+        wall = time.perf_counter() - t0
+        gc.enable()
+        return wall
 
     def launch_shape(self):
         """Brax families: the autotuned lane-group width per part (a pure scheduling choice)"""
@@ -595,9 +610,13 @@ def main():
     # ---- per-call path (one launch per env step) -----------------------------------
     per_call = None
     if not args.no_per_call and not wl.mixed:
+        import gc
+
         Kc = 1000
         eng = wl.eng
         a1 = wl.acts[0][0][0].contiguous()
+        gc.collect()
+        gc.disable()  # (see Workload.train)
         per_call = per_call_record(eng, a1, n * world, Kc, device, world, barrier)
         if world == 1 and dist is None:
             try:
@@ -616,6 +635,7 @@ def main():
                 dt = time.perf_counter() - t0
                 per_call["captured_value"] = n * Kc / dt
                 per_call["captured_ms_per_step"] = dt / Kc * 1e3
+        gc.enable()
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
