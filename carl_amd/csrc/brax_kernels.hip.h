@@ -39,7 +39,7 @@
 // by leaving it out or replacing it with the float32 form -- results differ); refused without -DCARL_ABLATION, which
 // carl_amd/build.py never passes (tools/build_variant.sh writes such libraries to gpurun_in/).
 #if (defined(CARL_EXP_BRAX_FAST_ATAN) || defined(CARL_EXP_BRAX_NO_CONTACTS) || defined(CARL_EXP_BRAX_NO_PHASE_A) || \
-     defined(CARL_EXP_BRAX_NO_PHASE_B) || defined(CARL_EXP_BRAX_LDS_PAD) || defined(CARL_EXP_BRAX_NO_CHILDREN) || defined(CARL_EXP_BRAX_F32_INTEGRATE)) &&              \
+     defined(CARL_EXP_BRAX_NO_PHASE_B) || defined(CARL_EXP_BRAX_EULER_F32) || defined(CARL_EXP_BRAX_LDS_PAD) || defined(CARL_EXP_BRAX_NO_CHILDREN) || defined(CARL_EXP_BRAX_F32_INTEGRATE)) &&              \
     !defined(CARL_ABLATION)
 #error "CARL_EXP_BRAX_* build measurement-only kernels; pass -DCARL_ABLATION to confirm (never for the product library)"
 #endif
@@ -428,7 +428,11 @@ static __device__ __forceinline__ JointGeom joint_geometry(const carl_brax_sys_t
     const double R00 = 1.0 - 2.0 * (rel.y * rel.y + rel.z * rel.z), R01 = 2.0 * (rel.x * rel.y - rel.w * rel.z);
     const double R02 = fmin(fmax(2.0 * (rel.x * rel.z + rel.w * rel.y), -1.0), 1.0);
     const double R12 = 2.0 * (rel.y * rel.z - rel.w * rel.x), R22 = 1.0 - 2.0 * (rel.x * rel.x + rel.y * rel.y);
+#ifdef CARL_EXP_BRAX_EULER_F32
+    const float al = atan2_fast((float)-R12, (float)R22), be = asinf((float)R02), ga = atan2_fast((float)-R01, (float)R00);
+#else
     const float al = (float)atan2_f64(-R12, R22), be = (float)asin_f64(R02), ga = (float)atan2_f64(-R01, R00);
+#endif
     const float sg = (nr == 3) ? s.dof_sign3[i] : 1.0f;
     g.ang[0] = al; g.ang[1] = be; g.ang[2] = sg * ga;
     g.axis[0] = g.x_p;
