@@ -1,6 +1,8 @@
 #!/bin/bash
+# Brax throughput of the product library and of measurement-only variants built by tools/build_variant.sh (gpurun_in/):
+#   VARIANTS="product w4" [TEST_LIB=w4] tools/brax_variants.sh      (on the GPU box; profiles/r03_brax_occupancy.txt was made with it)
 export CARL_AMD_NO_BUILD=1 TMPDIR=/tmp
-O=gpurun_out/r03i; mkdir -p $O
+O=gpurun_out/brax_variants; mkdir -p $O
 run() { # name libpath env
   CARL_AMD_LIB_PATH=$2 timeout 120 python bench.py --env $3 --lanes 32768 --steps 10 --warmup 3 --no-cpu-baseline --no-per-call --also none 2>/tmp/bench_err.txt > /tmp/bench_out.txt
   python - "$1" "$3" <<'PY'
