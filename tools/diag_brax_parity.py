@@ -17,11 +17,11 @@ for nf in (1,10):
     eng.reset(); ora.reset()
     errs=[]; errr=[]
     for t in range(60 if nf==10 else 300):
-        ora.state[:]=eng.state.t().cpu().numpy()
+        ora.state[:]=eng.state_np()
         a=rng.uniform(-1.2,1.2,(n,8)).astype(np.float32)
         obs,rew,term,trunc=eng.step(torch.as_tensor(a)); out=ora.step(a)
         errs.append(rel(obs.cpu().numpy(),out.obs).max(1)); errr.append(rel(rew.cpu().numpy(),out.reward))
-        es=rel(eng.state.t().cpu().numpy(), ora.state)
+        es=rel(eng.state_np(), ora.state)
     e=np.concatenate(errs); r=np.concatenate(errr)
     print("n_frames",nf,"obs err pct 50/99/99.9/max: %.2e %.2e %.2e %.2e"%tuple(np.percentile(e,[50,99,99.9,100])), " reward: %.2e %.2e %.2e %.2e"%tuple(np.percentile(r,[50,99,99.9,100])), "state max %.2e"%es.max())
     # which obs column is worst

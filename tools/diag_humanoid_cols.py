@@ -16,7 +16,7 @@ eng.reset(); ora.reset()
 lo = np.array(s.act_lo[: s.n_act]); hi = np.array(s.act_hi[: s.n_act])
 E = []
 for t in range(30):
-    ora.state[:] = eng.state.t().cpu().numpy()
+    ora.state[:] = eng.state_np()
     a = rng.uniform(lo, hi, (n, s.n_act)).astype(np.float32)
     obs, rew, term, trunc = eng.step(torch.as_tensor(a)); out = ora.step(a)
     E.append(rel(obs.cpu().numpy(), out.obs))
