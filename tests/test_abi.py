@@ -163,3 +163,21 @@ def test_first_state_flag_needs_its_buffer():
     s = ant_sys(["gravity", "friction", "elasticity", "ang_damping", "mass_torso", "viscosity"])
     rc = lib.carl_brax_reset(C.byref(b), 0x1000, C.byref(s), None, None, None)
     assert rc == -1 and b"first_state" in lib.carl_last_error()
+
+
+def test_rollout_variant_is_answered_on_the_host():
+    """carl_rollout_variant (ABI 5): which kernel a fused rollout of this batch launches -- pure host logic"""
+    from carl_amd import _lib
+
+    lib = _lib.load()
+    b = _lib.Batch()
+    b.n_lanes = 65536
+    assert lib.carl_rollout_variant(C.byref(b)) == _lib.ROLLOUT_STAGED
+    b.n_lanes = 65520  # a multiple of 16: still the staged kernel (ragged last workgroup)
+    assert lib.carl_rollout_variant(C.byref(b)) == _lib.ROLLOUT_STAGED
+    b.n_lanes = 65000
+    assert lib.carl_rollout_variant(C.byref(b)) == _lib.ROLLOUT_DIRECT_SHAPE
+    b.n_lanes = 65536
+    b.flags = _lib.FLAG_ROLLOUT_DIRECT
+    assert lib.carl_rollout_variant(C.byref(b)) == _lib.ROLLOUT_DIRECT_FLAG
+    assert lib.carl_rollout_variant(None) == -1 and b"NULL" in lib.carl_last_error()

@@ -703,3 +703,40 @@ def test_committed_brax_transitions_are_reproduced_by_the_oracle(fam, golden_dir
     np.testing.assert_allclose(out.reward, g["reward"], rtol=1e-6, atol=1e-6)
     np.testing.assert_array_equal(out.terminated, g["terminated"])
     np.testing.assert_array_equal(eng.branch_sig, g["branch_sig"])
+
+
+def test_mass_ratio_floor_clamps_the_effective_mass_per_env():
+    """carl_brax_ctx_map_t::mass_ratio_floor / _multi (round 3): a mass context below the stability floor runs at the
+    floor -- the single-feature floor when it is the env's only light link, the higher combined floor when two or
+    more links are lighter than nominal.  Free fall of the torso under a constant joint-less push shows the mass."""
+    from carl_amd.envs.brax.models import halfcheetah_sys
+    from carl_amd.envs import CARLBraxHalfcheetah
+
+    feats = CARLBraxHalfcheetah.get_context_features()
+    names = list(feats)
+    default = np.array([float(f.default_value) for f in feats.values()])
+    s = halfcheetah_sys(names)
+    cm = s.ctx
+    k_torso = [k for k in range(cm.n_mass) if names[cm.mass_row[k]] == "mass_torso"][0]
+    k_foot = [k for k in range(cm.n_mass) if names[cm.mass_row[k]] == "mass_bfoot"][0]
+    for k in range(cm.n_mass):
+        cm.mass_ratio_floor[k] = 0.5
+        cm.mass_ratio_floor_multi[k] = 0.8
+    st0 = B.forward_kinematics(s, np.array(s.init_q[: s.n_q], dtype=np.float64) + np.array([0, 5.0] + [0] * (s.n_q - 2)),
+                               np.zeros(s.n_dof))  # lifted 5 m: no contacts, joints at rest
+
+    def torso_dv(row):
+        F0, _ = B.joint_wrenches(s, row, np.zeros(s.n_dof), st0)
+        tau = np.zeros(s.n_dof)
+        tau[0] = 100.0  # a force on the root's x slide
+        out = B.substeps(s, row, tau, 1, st0)
+        return out[0, 7] - st0[0, 7]
+
+    base = torso_dv(default)                       # effective mass ratio 1
+    row = default.copy()
+    row[cm.mass_row[k_torso]] = 0.7 * default[cm.mass_row[k_torso]]
+    assert torso_dv(row) == pytest.approx(base / 0.7, rel=1e-9)        # above the floor: the context value
+    row[cm.mass_row[k_torso]] = 0.2 * default[cm.mass_row[k_torso]]
+    assert torso_dv(row) == pytest.approx(base / 0.5, rel=1e-9)        # one light link: the single-feature floor
+    row[cm.mass_row[k_foot]] = 0.9 * default[cm.mass_row[k_foot]]
+    assert torso_dv(row) == pytest.approx(base / float(np.float32(0.8)), rel=1e-9)  # two light links: the combined floor
