@@ -131,3 +131,39 @@ def test_default_lane_context_assignment_is_shard_aware():
     assert seen == list(range(N))                                             # every global context exactly once
     # an explicit offset: the rank holds rows [8, 16) of the global set and lanes [10, 14)
     np.testing.assert_array_equal(default_context_index(4, 10, 8, context_offset=8), [2, 3, 4, 5])
+
+
+def _world1_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        stats = {"last_return": torch.arange(10, dtype=torch.float32), "last_length": torch.arange(10, dtype=torch.int32),
+                 "episodes_done": torch.tensor([0, 1, 2, 0, 1, 0, 0, 3, 1, 1], dtype=torch.int32)}
+        eq = all_gather_episode_stats(stats)                               # all_gather_into_tensor, one rank
+        pad = all_gather_episode_stats(stats, counts=[10], padded=True)    # the padded list form
+        summ = reduce_episode_summary(stats)                               # all_reduce, one rank
+        q.put({"eq": {k: v.numpy() for k, v in eq.items()}, "pad": {k: v.numpy() for k, v in pad.items()}, "summ": summ})
+    finally:
+        dist.destroy_process_group()
+
+
+def test_collectives_run_under_a_one_rank_group():
+    """Round 3: the reporting collectives no longer short-circuit when world_size == 1 -- under an initialised group
+    they RUN (that is how the one-GPU boxes exercise librccl: tests/test_gpu_mixed_and_multiproc.py does this with
+    backend nccl on device tensors).  Here: gloo, one rank, both all-gather forms and the all-reduce are the identity."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_world1_worker, args=(0, 1, _free_port(), q))
+    p.start()
+    got = q.get(timeout=120)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    want = {"last_return": np.arange(10, dtype=np.float32), "last_length": np.arange(10, dtype=np.int32),
+            "episodes_done": np.array([0, 1, 2, 0, 1, 0, 0, 3, 1, 1], dtype=np.int32)}
+    for form in ("eq", "pad"):
+        for k, v in want.items():
+            np.testing.assert_array_equal(got[form][k], v)
+    fin = want["episodes_done"] > 0
+    assert got["summ"]["mean_return"] == pytest.approx(float(want["last_return"][fin].mean()))
+    assert got["summ"]["episodes"] == float(want["episodes_done"].sum())
