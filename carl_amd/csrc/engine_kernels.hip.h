@@ -19,7 +19,7 @@
 #if (defined(CARL_EXP_NO_REWARD_STORE) || defined(CARL_EXP_NO_FLAG_STORES) || defined(CARL_EXP_NO_DONE) ||      \
      defined(CARL_EXP_NO_OBS_STORE) || defined(CARL_EXP_NO_ACTIONS) || defined(CARL_EXP_NO_LOADER) ||            \
      defined(CARL_EXP_NO_DRAIN) || defined(CARL_EXP_TEMPORAL) || defined(CARL_STORERS) ||                        \
-     defined(CARL_EXP_DENSE_ROLLED)) &&                                                                          \
+     defined(CARL_EXP_DENSE_ROLLED) || defined(CARL_EXP_NO_FLAG_DRAIN)) &&                                                                          \
     !defined(CARL_ABLATION)
 #error "CARL_EXP_* / CARL_STORERS build profiling-only kernels; pass -DCARL_ABLATION to confirm (never for the product library)"
 #endif
@@ -889,7 +889,9 @@ __device__ __forceinline__ void drain_records(char* buf, const carl_step_io_t& i
 #pragma unroll
       for (int off = 0; off < SK::kObsBytes; off += 1024) put(g_obs + off + 16 * l, rec + off + 16 * l);
       put(reinterpret_cast<char*>(io.reward + row) + 16 * l, rec + SK::kObsBytes + 16 * l);
+#ifndef CARL_EXP_NO_FLAG_DRAIN  // measurement only: the terminated / truncated rows never reach HBM
       if (l < 32) put(reinterpret_cast<char*>(fl_dst), fl);
+#endif
     } else {  // ragged last workgroup: per-piece guards (each guard is its own block with its own LDS wait:
               // slower, but only this one workgroup pays it)
 #pragma unroll
