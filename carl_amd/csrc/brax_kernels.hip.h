@@ -1189,7 +1189,7 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
 
   if constexpr (MODE == 0) {
     const bool go = active && (mask == nullptr || mask[env] != 0);
-    if (__ballot(go) == 0ull) return;
+    if (ballot(go) == 0ull) return;
     if (go) r.cidx = select_context(b, r.cidx, genv, r.episode);
     if (TASK && s.push_link > 0) {  // the object is placed relative to the env's goal
       put_goal(s, b, m, r.cidx, go);
@@ -1310,7 +1310,7 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
         io.truncated[step_off + env] = (uint8_t)truncated;
         if (io.done != nullptr && n_steps == 1) io.done[env] = (uint8_t)(terminated | truncated);  // per-call step
       }
-      if (__ballot(done) != 0ull) {
+      if (ballot(done) != 0ull) {
         const float fin_ret = r.ep_return;
         const int fin_len = r.elapsed;
         if (done) {

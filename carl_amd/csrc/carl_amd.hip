@@ -190,6 +190,12 @@ int launch_step(const carl_batch_t* b, const carl_step_io_t* io, int n_steps, hi
         // none of the optional features is on: the done path compiled without them
         kern = a64 ? static_cast<kern_t>(carl::rollout_staged_kernel<Fam, true, true>)
                    : static_cast<kern_t>(carl::rollout_staged_kernel<Fam, false, true>);
+        if constexpr (carl::dense_done_of<Fam>::value) {
+          // ... and, for the short-episode family, with auto-reset a compile-time fact (step_dense: AR)
+          if (b->flags & CARL_FLAG_AUTORESET)
+            kern = a64 ? static_cast<kern_t>(carl::rollout_staged_kernel<Fam, true, true, false, false, false, true>)
+                       : static_cast<kern_t>(carl::rollout_staged_kernel<Fam, false, true, false, false, false, true>);
+        }
         picked = true;
       }
       if constexpr (carl::dense_done_of<Fam>::value) {

@@ -102,6 +102,12 @@ __device__ __forceinline__ int select_context(const carl_batch_t& b, int idx, ui
 // ---- wave-level helpers --------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
 
+// The wave's mask of a per-lane predicate.  HIP's `__ballot(int)` widens the predicate to an int and compares it
+// with zero through an opaque intrinsic, so a predicate that already IS a lane mask (the OR of two compares) comes
+// out as v_cndmask 0/1 + v_cmp_ne: two vector instructions per call in a loop that is bound by the instruction
+// stream of one wave.  The ballot builtin takes the i1 and costs nothing.
+__device__ __forceinline__ unsigned long long ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
 // number of set bits of `mask` below this lane (v_mbcnt_lo/hi)
 __device__ __forceinline__ int prefix_popc(unsigned long long mask) {
   return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
@@ -113,7 +119,7 @@ __device__ __forceinline__ int prefix_popc(unsigned long long mask) {
 __device__ __forceinline__ void log_finished(const carl_batch_t& b, bool done, uint64_t glane,
                                              float ret, int len) {
   if (b.fin_count == nullptr) return;
-  const unsigned long long m = __ballot(done);
+  const unsigned long long m = ballot(done);
   if (m == 0ull) return;
   int base = 0;
   if (lane_id() == __builtin_ctzll(m)) base = atomicAdd(b.fin_count, __popcll(m));

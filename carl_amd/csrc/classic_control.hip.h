@@ -418,7 +418,7 @@ struct AcrobotT {
     y0 = y0 < -pi ? y0 + diff : y0;
     y1 = y1 < -pi ? y1 + diff : y1;
     const bool more = !(y0 <= pi && y0 >= -pi && y1 <= pi && y1 >= -pi);  // several turns, or non-finite
-    if (__builtin_expect(__ballot(more) != 0ull, 0)) {
+    if (__builtin_expect(ballot(more) != 0ull, 0)) {
       y0 = wrap_pi(x0);
       y1 = wrap_pi(x1);
     }

@@ -19,7 +19,8 @@
 #if (defined(CARL_EXP_NO_REWARD_STORE) || defined(CARL_EXP_NO_FLAG_STORES) || defined(CARL_EXP_NO_DONE) ||      \
      defined(CARL_EXP_NO_OBS_STORE) || defined(CARL_EXP_NO_ACTIONS) || defined(CARL_EXP_NO_LOADER) ||            \
      defined(CARL_EXP_NO_DRAIN) || defined(CARL_EXP_TEMPORAL) || defined(CARL_STORERS) ||                        \
-     defined(CARL_EXP_DENSE_ROLLED) || defined(CARL_EXP_NO_FLAG_DRAIN)) &&                                                                          \
+     defined(CARL_EXP_DENSE_ROLLED) || defined(CARL_EXP_NO_FLAG_DRAIN) || defined(CARL_EXP_NO_DRAW) ||             \
+     defined(CARL_EXP_XCD_SWIZZLE)) &&          \
     !defined(CARL_ABLATION)
 #error "CARL_EXP_* / CARL_STORERS build profiling-only kernels; pass -DCARL_ABLATION to confirm (never for the product library)"
 #endif
@@ -201,14 +202,20 @@ struct LdsSink {
   int t;              // global step index of this record
   int tid;
   __device__ __forceinline__ void put_reward(float r) const {
+#ifndef CARL_EXP_NO_REWARD_STORE
     reinterpret_cast<float*>(step_base + kObsBytes)[tid] = r;
+#endif
   }
   __device__ __forceinline__ void put_flags(bool te, bool tr) const {
+#ifndef CARL_EXP_NO_FLAG_STORES
     reinterpret_cast<uint8_t*>(step_base + kFlagOff)[tid] = (uint8_t)te;
     reinterpret_cast<uint8_t*>(step_base + kFlagOff + 256)[tid] = (uint8_t)tr;
+#endif
   }
   __device__ __forceinline__ void put_obs(const float (&o)[Fam::D]) const {
+#ifndef CARL_EXP_NO_OBS_STORE
     store_obs<Fam::D>(reinterpret_cast<float*>(step_base), (size_t)tid, o);
+#endif
   }
   // only evaluated on the done path (the terminal observation is stored to HBM directly)
   __device__ __forceinline__ float* final_obs_ptr() const {
@@ -230,7 +237,7 @@ struct predraw_of<Fam, std::void_t<decltype(Fam::kPredraw)>> : std::bool_constan
 
 template <class Fam>
 __device__ __forceinline__ void predraw(const carl_batch_t& b, uint64_t glane, LaneRegs<Fam>& r) {
-  if (__ballot(!r.next_ok) != 0ull) {
+  if (ballot(!r.next_ok) != 0ull) {
     const u32x4 w = lane_words(b.seed, glane, r.episode, kSubInit);
     if (!r.next_ok) r.next_w = w;
     r.next_ok = true;
@@ -313,7 +320,7 @@ template <class Fam>
 __device__ __forceinline__ void finish_plain(const carl_batch_t& b, uint64_t glane, bool done, float (&o)[Fam::D],
                                              LaneRegs<Fam>& r) {
   u32x4 w = r.next_w;
-  if (__ballot(done && !r.next_ok) != 0ull) {
+  if (ballot(done && !r.next_ok) != 0ull) {
     const u32x4 wi = lane_words(b.seed, glane, r.episode, kSubInit);
     w = select_words(r.next_ok, w, wi);
   }
@@ -382,13 +389,17 @@ __device__ __forceinline__ void dense_draw(const carl_batch_t& b, const Ctx& ctx
   typename Fam::Params pn = r.p;
   if constexpr (MOVES) {
     cn = select_context(b, r.cidx, glane, r.episode);  // carl/context/selection.py rules, as reset_lane applies them
-    if (__ballot(cn != r.cidx) != 0ull) {
+    if (ballot(cn != r.cidx) != 0ull) {
       typename Fam::Params q = Fam::load(ctx, cn, b.flags);
       settle(q);
       pn = select_words(cn != r.cidx, q, r.p);
     }
   }
+#ifndef CARL_EXP_NO_DRAW
   const u32x4 w = lane_words(b.seed, glane, r.episode, kSubInit);
+#else  // profiling only: the chunk's init-state draw without its Philox block
+  const u32x4 w{(uint32_t)glane * 2654435761u, r.episode * 40503u, (uint32_t)glane, r.episode};
+#endif
   float fresh[Fam::S];
   typename Fam::Aux fa;
   Fam::reset(pn, w, fresh);
@@ -405,20 +416,29 @@ __device__ __forceinline__ void dense_draw(const carl_batch_t& b, const Ctx& ctx
 
 // FINAL: terminal observations requested (io.final_obs): a finishing lane stores its pre-reset observation straight
 // to HBM (one exec-masked store; compute waves issue no loads, so nothing queues behind it).
-template <class Fam, class Ctx, bool MOVES, bool FINAL, class Sink>
-__device__ __forceinline__ void step_dense(const carl_batch_t& b, const Ctx& ctx, const Sink& cur, int max_steps,
-                                           bool autoreset, uint64_t glane, typename Fam::Action action,
+// AR: the launch is known to run with CARL_FLAG_AUTORESET (the host picks the specialisation): `done` IS the reset
+// mask, and -- `ENTRY` false: any step but the launch's first -- the step function is told elapsed = 0.  Of the step
+// functions only CartPole's reads `elapsed`, to recognise a lane that is stepped AGAIN after terminating (reward 0,
+// gymnasium's steps_beyond_terminated): `elapsed > 0 && out_of_bounds(pre-step state)`.  Under auto-reset a lane
+// that went out of bounds was reset in that same step, so past the launch's first step (whose loaded state may
+// date from a launch without auto-reset) the pre-step state is either fresh (elapsed 0) or in bounds: the rule
+// never fires, and with the constant the compiler drops its seven instructions and the reward select.
+// `max_steps_eff`: max_episode_steps, or INT_MAX for "no TimeLimit" (one compare instead of compare + mask AND).
+template <class Fam, class Ctx, bool MOVES, bool FINAL, bool AR, bool ENTRY, class Sink>
+__device__ __forceinline__ void step_dense(const carl_batch_t& b, const Ctx& ctx, const Sink& cur, int max_steps_eff,
+                                           bool autoreset_in, uint64_t glane, typename Fam::Action action,
                                            LaneRegs<Fam>& r, DenseNext<Fam>& nx) {
   static_assert(!Fam::kNeedsStepNoise, "dense done handling: families without per-step noise");
+  const bool autoreset = AR || autoreset_in;
   float reward;
-  const bool terminated = Fam::step(r.p, r.s, r.aux, action, 0.0f, r.elapsed, reward);
+  const bool terminated = Fam::step(r.p, r.s, r.aux, action, 0.0f, (AR && !ENTRY) ? 0 : r.elapsed, reward);
   r.elapsed += 1;
-  const bool truncated = (max_steps > 0) && (r.elapsed >= max_steps);  // gymnasium TimeLimit.step
+  const bool truncated = r.elapsed >= max_steps_eff;  // gymnasium TimeLimit.step
   r.ep_return += reward;
   cur.put_reward(reward);
   cur.put_flags(terminated, truncated);  // every step (the lazy flag rows only save work when done is rare)
   const bool done = terminated | truncated;
-  const unsigned long long dm = __ballot(done);
+  const unsigned long long dm = ballot(done);
   const unsigned long long again = dm & ~nx.ok_mask;
   if (__builtin_expect(again != 0ull, 0)) dense_draw<Fam, Ctx, MOVES>(b, ctx, glane, r, again, nx);
   const bool rs = done && autoreset;
@@ -442,7 +462,7 @@ __device__ __forceinline__ void step_dense(const carl_batch_t& b, const Ctx& ctx
   r.elapsed = rs ? 0 : r.elapsed;
   r.ep_return = rs ? 0.0f : r.ep_return;
   r.episode += rs ? 1u : 0u;
-  r.n_new_calls += rs ? 1 : 0;
+  if constexpr (!AR) r.n_new_calls += rs ? 1 : 0;  // (AR: = n_new_episodes, taken from it after the last step)
   nx.ok_mask &= autoreset ? ~dm : ~0ull;
   float o[Fam::D];
   Fam::observe(r.s, r.aux, o);
@@ -485,7 +505,7 @@ __device__ __forceinline__ void step_lane(const carl_batch_t& b, const Ctx& ctx,
     done = false;
 #endif
   }
-  if (__builtin_expect(__ballot(done) != 0ull, 0)) {
+  if (__builtin_expect(ballot(done) != 0ull, 0)) {
 #ifndef CARL_EXP_NO_FLAG_STORES
     if constexpr (Sink::kLazyFlags) {  // the flag rows are pre-zeroed: only waves with a finished lane write
       if (active) cur.put_flags(te, tr);
@@ -922,7 +942,9 @@ __device__ __forceinline__ void zero_flag_rows(char* out_buf, int l, int which) 
 // read instead of an HBM / L2 round trip the whole wave waits for.
 // MOVES (with PLAIN, kDenseDone families): the dense done handling with context changes on reset (see dense_draw).
 // FINAL (with PLAIN, kDenseDone families): ... and with terminal observations written (see step_dense).
-template <class Fam, bool A64, bool PLAIN = false, bool LDSCTX = false, bool MOVES = false, bool FINAL = false>
+// AR (with PLAIN, kDenseDone families): compiled for launches with CARL_FLAG_AUTORESET set (see step_dense).
+template <class Fam, bool A64, bool PLAIN = false, bool LDSCTX = false, bool MOVES = false, bool FINAL = false,
+          bool AR = false>
 __global__ void __launch_bounds__(kStagedThreads) rollout_staged_kernel(const carl_batch_t b, const carl_step_io_t io,
                                                                         const int n_steps) {
   extern __shared__ float lds_dyn[];
@@ -942,7 +964,12 @@ __global__ void __launch_bounds__(kStagedThreads) rollout_staged_kernel(const ca
   const bool compute = wave < kRolloutLanes / kWave;
   const bool loader = wave == kRolloutLanes / kWave;
   const int hl = threadIdx.x % kWave;    // lane within a helper wave
+#ifdef CARL_EXP_XCD_SWIZZLE  // measurement only: workgroup i runs on XCD i % 8 -- give every XCD one contiguous lane range
+  const int wg = (gridDim.x % 8 == 0) ? (int)((blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8) : (int)blockIdx.x;
+  const int lane_base = wg * kRolloutLanes;
+#else
   const int lane_base = blockIdx.x * kRolloutLanes;
+#endif
   const int lane = lane_base + (compute ? (int)threadIdx.x : 0);
   const bool active = compute && lane < b.n_lanes;
   const uint64_t glane = (uint64_t)(b.lane_offset + lane);
@@ -974,6 +1001,7 @@ __global__ void __launch_bounds__(kStagedThreads) rollout_staged_kernel(const ca
   int buf = 0;
   [[maybe_unused]] DenseNext<Fam> nx{};  // dense done handling (PLAIN, kDenseDone families): nothing drawn yet
   [[maybe_unused]] const bool autoreset = (b.flags & CARL_FLAG_AUTORESET) != 0;
+  [[maybe_unused]] const int max_steps_eff = max_steps > 0 ? max_steps : 0x7fffffff;
   for (int t0 = 0; t0 < n_steps; t0 += kStageChunk, buf ^= 1) {
     const int steps = min(kStageChunk, n_steps - t0);
     if (compute) {
@@ -994,11 +1022,18 @@ __global__ void __launch_bounds__(kStagedThreads) rollout_staged_kernel(const ca
 #else
         if (steps == kStageChunk) {  // fully unrolled: record addresses are immediates, no loop control
 #endif
+          // (AR: the chunk's first step is the launch's first step when t0 == 0; two copies of the unrolled chunk
+          // would double the kernel for one step's worth of instructions, so that step always takes ENTRY)
 #pragma unroll
           for (int u = 0; u < kStageChunk; ++u) {
             const SK sink{rec + (size_t)u * SK::kStepBytes, FINAL ? final_base : nullptr, n * Fam::D, t0 + u,
                           (int)threadIdx.x};
-            step_dense<Fam, ctx_t<LDSCTX>, MOVES, FINAL, SK>(b, ctx, sink, max_steps, autoreset, glane, acts[u], r, nx);
+            if (u == 0)
+              step_dense<Fam, ctx_t<LDSCTX>, MOVES, FINAL, AR, true, SK>(b, ctx, sink, max_steps_eff, autoreset, glane,
+                                                                         acts[u], r, nx);
+            else
+              step_dense<Fam, ctx_t<LDSCTX>, MOVES, FINAL, AR, false, SK>(b, ctx, sink, max_steps_eff, autoreset, glane,
+                                                                          acts[u], r, nx);
           }
         } else {  // the rollout's last, ragged chunk
 #pragma unroll 1
@@ -1008,9 +1043,11 @@ __global__ void __launch_bounds__(kStagedThreads) rollout_staged_kernel(const ca
             Action a = acts[0];
 #pragma unroll
             for (int k = 1; k < kStageChunk; ++k) a = (u == k) ? acts[k] : a;
-            step_dense<Fam, ctx_t<LDSCTX>, MOVES, FINAL, SK>(b, ctx, sink, max_steps, autoreset, glane, a, r, nx);
+            step_dense<Fam, ctx_t<LDSCTX>, MOVES, FINAL, AR, true, SK>(b, ctx, sink, max_steps_eff, autoreset, glane, a, r,
+                                                                       nx);
           }
         }
+        if constexpr (AR) r.n_new_calls = r.n_new_episodes;
       }
       if constexpr (!(PLAIN && dense_done_of<Fam>::value)) {
       if constexpr (predraw_of<Fam>::value) predraw<Fam>(b, glane, r);
@@ -1074,7 +1111,7 @@ __global__ void __launch_bounds__(kCompactBlock) done_count_kernel(const uint8_t
   __shared__ int wave_counts[kCompactBlock / kWave];
   const int i = blockIdx.x * kCompactBlock + threadIdx.x;
   const bool done = (i < n) && ((term[i] | trunc[i]) != 0);
-  const unsigned long long m = __ballot(done);
+  const unsigned long long m = ballot(done);
   if (lane_id() == 0) wave_counts[threadIdx.x / kWave] = __popcll(m);
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -1101,7 +1138,7 @@ __global__ void __launch_bounds__(kCompactBlock) done_write_kernel(const uint8_t
   if (lane_id() == 0) partial[threadIdx.x / kWave] = acc;
   const int i = blockIdx.x * kCompactBlock + threadIdx.x;
   const bool done = (i < n) && ((term[i] | trunc[i]) != 0);
-  const unsigned long long m = __ballot(done);
+  const unsigned long long m = ballot(done);
   if (lane_id() == 0) wave_counts[threadIdx.x / kWave] = __popcll(m);
   __syncthreads();
   if (threadIdx.x == 0) {

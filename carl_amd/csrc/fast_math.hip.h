@@ -13,6 +13,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include "carl_device.hip.h"  // ballot()
+
 namespace carl {
 
 __device__ __forceinline__ void sincos_fast(float x, float& sn, float& cs) {
@@ -40,7 +42,7 @@ __device__ __forceinline__ void sincos_fast(float x, float& sn, float& cs) {
   // ~8 scalar instructions per call, which matters when a single wave issues one
   // instruction per 4-cycle slot.
   const bool big = !(fabsf(x) <= 1.0e5f);  // also catches NaN/inf
-  if (__builtin_expect(__ballot(big) != 0ull, 0)) {
+  if (__builtin_expect(ballot(big) != 0ull, 0)) {
     if (big) sincosf(x, &sn, &cs);
   }
 }
@@ -48,12 +50,12 @@ __device__ __forceinline__ void sincos_fast(float x, float& sn, float& cs) {
 // For arguments that are small in practice (CartPole's pole angle: an episode ends at 0.21 rad): when EVERY lane
 // of the wave has |x| <= 0.78 the reduction finds k = 0, r = x and quadrant 0, so the polynomials alone give the
 // same bits as sincos_fast -- without the multiply / round / three-fma reduction and the quadrant swap and sign
-// logic (14 of its 34 instructions); any larger |x| in the wave takes sincos_fast itself.
+// logic (14 of its 34 instructions); any larger |x| in the wave takes sincos_fast itself.  The polynomials come
+// FIRST and unconditionally, the wave-uniform test after them: as `if (any large) {general; return;} polynomials`
+// the structurizer gave the hot path five control-flow instructions per call (a flag move, two branches and their
+// mask arithmetic) and cut the caller's step into three basic blocks; this way it is a compare and one
+// branch-not-taken to an out-of-line block, and the polynomials schedule with the code around them.
 __device__ __forceinline__ void sincos_fast_smallarg(float x, float& sn, float& cs) {
-  if (__builtin_expect(__ballot(!(fabsf(x) <= 0.78f)) != 0ull, 0)) {
-    sincos_fast(x, sn, cs);
-    return;
-  }
   const float z = x * x;
   float ps = __fmaf_rn(z, 2.7557314297e-06f, -1.9841270114e-04f);
   ps = __fmaf_rn(z, ps, 8.3333337680e-03f);
@@ -63,6 +65,7 @@ __device__ __forceinline__ void sincos_fast_smallarg(float x, float& sn, float& 
   pc = __fmaf_rn(z, pc, -1.3888889225e-03f);
   pc = __fmaf_rn(z, pc, 4.1666667908e-02f);
   cs = __fmaf_rn(z * z, pc, __fmaf_rn(z, -0.5f, 1.0f));
+  if (__builtin_expect(ballot(!(fabsf(x) <= 0.78f)) != 0ull, 0)) sincos_fast(x, sn, cs);
 }
 
 // A double constant pinned in a scalar register pair.  The fp64 Horner steps below are `p = fma(z, p, c)` with a
