@@ -187,6 +187,7 @@ __device__ __forceinline__ double asin_f64(double x) { return atan2_f64(x, sqrt(
 // per-env context scalars: carl_brax_env.py:255-292 in its intended form
 struct LaneCtx {
   float gravity_z, friction, elasticity, ang_damping, stiffness_scale;
+  float da;  // exp(ang_damping dt): the substep's angular velocity decay
 };
 
 // LDS layout of a workgroup.  Pose rows are doubles (7 per link: COM position 3, rotation 4) in a region of their
@@ -198,6 +199,7 @@ struct Layout {
   int wrench;  // 12 * L rows: per joint (f, t) on the child, (-f, -t') on the parent; reused by FK
   int mass;    // L rows (effective mass per link, context-scaled)
   int sig;     // 2 * L rows (uint32): per-link hash of the step's contact / limit branch decisions
+  int zero;    // 6 rows kept at zero: what a link without a k-th child reads in the body phase's child loop
   int goal;    // 3 rows: push task, the env's goal position (context or model default)
   int tau;     // n_dof rows
   int io;      // staging of the env's action / observation record, and of (q, qd) in reset
@@ -209,7 +211,8 @@ struct Layout {
     l.wrench = l.vel + 6 * L;
     l.mass = l.wrench + 12 * L;
     l.sig = l.mass + L;
-    l.goal = l.sig + 2 * L;
+    l.zero = l.sig + 2 * L;
+    l.goal = l.zero + 6;
     l.tau = l.goal + 3;
     l.io = l.tau + n_dof;
     l.total = l.io + io_rows;
@@ -269,41 +272,103 @@ inline void build_topo_host(const carl_brax_sys_t& s, Topo& t) {
   t.first_joint = (s.parent[0] < 0 && s.n_link_dof[0] == 6) ? 1 : 0;
 }
 
-// per-link constants derived from the model table (on the host, once per launch)
-struct Derived {
-  float ac[CARL_BRAX_MAX_LINKS][3];   // joint anchor relative to the child's COM (child frame)
-  float ap[CARL_BRAX_MAX_LINKS][3];   // ... relative to the parent's COM (parent frame; world: origin), zero slide
-  float rpl[CARL_BRAX_MAX_LINKS][4];  // parent-side joint frame in the parent frame: link_rot (x) joint_rot
-  float reach[CARL_BRAX_MAX_LINKS];   // max over the link's spheres of |centre - COM| + radius (-1: none)
-  uint8_t iso[CARL_BRAX_MAX_LINKS];   // isotropic inertia: R diag(c) R^T = c
+// Per-link records laid out for the substep's two phases (built on the host, once per launch).  A phase used to pick its
+// constants out of a dozen arrays of carl_brax_sys_t / Topo indexed one after the other -- parent -> body rows,
+// n_slide -> dof_start -> tau row, child_begin -> child_idx -> wrench rows, coll_begin -> coll_idx -> sphere -- each a
+// dependent LDS round trip the wavefront waits for; here a phase reads ONE 16-byte-aligned block per link with
+// ds_read_b128s issued together, and every index it needs is a bit field of a word of that block.
+typedef float vf4 __attribute__((ext_vector_type(4)));
+struct alignas(16) LinkA {  // joint phase (spring.joints.resolve) and inverse kinematics: 24 words
+  float ac[3];              // joint anchor relative to the child's COM (child frame)
+  uint32_t word;            // parent + 1 (5 bits; 0: the world) | free root (1) | n_slide (2) | hinges (3) | dof_start (5)
+  float ap[3];              // ... relative to the parent's COM (parent frame; world: origin), zero slide
+  float k_pos;
+  float rpl[4];             // parent-side joint frame in the parent frame: link_rot (x) joint_rot
+  float jrot[4];            // child-side joint frame in the child frame: joint_rot
+  float k_vel, k_limit, k_ang_damp;
+  float damping;            // the link's FIRST hinge (dof_start + n_slide): dof_damping, dof_stiffness, dof_lo, dof_hi
+  float stiffness, lo, hi, pad;
+};
+constexpr uint32_t kWaFree = 1u << 5;
+__host__ __device__ inline int wa_parent(uint32_t w) { return (int)(w & 31u) - 1; }
+__host__ __device__ inline int wa_slides(uint32_t w) { return (int)((w >> 6) & 3u); }
+__host__ __device__ inline int wa_hinges(uint32_t w) { return (int)((w >> 8) & 7u); }
+__host__ __device__ inline int wa_dof(uint32_t w) { return (int)((w >> 11) & 31u); }
+struct alignas(16) LinkB {  // body phase: 4 words
+  uint32_t word;            // free root (1) | isotropic inertia (1) | children (4) | first sphere (6) | spheres (6)
+  uint32_t children;        // the first 8 children, 4 bits each, ascending (the oracle's summation order)
+  float inv_i0;             // inv_inertia[0] (all there is to an isotropic inertia: R diag(c) R^T = c)
+  float reach;              // max over the link's spheres of |centre - COM| + radius (-1: none)
+};
+constexpr uint32_t kWbFree = 1u, kWbIso = 2u;
+__host__ __device__ inline int wb_children(uint32_t w) { return (int)((w >> 2) & 15u); }
+__host__ __device__ inline int wb_first_sphere(uint32_t w) { return (int)((w >> 6) & 63u); }
+__host__ __device__ inline int wb_spheres(uint32_t w) { return (int)((w >> 12) & 63u); }
+struct alignas(16) Sphere {  // a link's spheres are consecutive, in Topo::coll_idx order
+  float off[3];              // centre - COM of its link (link frame)
+  float radius;
+};
+struct Packed {
+  LinkA a[CARL_BRAX_MAX_LINKS];
+  LinkB b[CARL_BRAX_MAX_LINKS];
+  Sphere sph[CARL_BRAX_MAX_COLL];
+  int max_children;  // over the links (bound of the body phase's wavefront-uniform child loop)
+  int pad[3];
 };
 
-inline void build_derived_host(const carl_brax_sys_t& s, Derived& d, int i) {
-  const int P = s.parent[i];
-  const v3 a = f3(s.joint_pos[i]);
-  const qt lrot = f4(s.link_rot[i]);
-  const v3 com_p = (P < 0) ? V(0, 0, 0) : f3(s.com[P]);
-  const v3 ac = a - f3(s.com[i]);
-  const v3 ap = f3(s.link_pos[i]) + qrot(lrot, a) - com_p;
-  const qt rpl = qmul(lrot, f4(s.joint_rot[i]));
-  d.ac[i][0] = ac.x; d.ac[i][1] = ac.y; d.ac[i][2] = ac.z;
-  d.ap[i][0] = ap.x; d.ap[i][1] = ap.y; d.ap[i][2] = ap.z;
-  d.rpl[i][0] = rpl.w; d.rpl[i][1] = rpl.x; d.rpl[i][2] = rpl.y; d.rpl[i][3] = rpl.z;
-  float reach = -1.0f;
-  for (int k = 0; k < s.n_coll; ++k)
-    if (s.coll_link[k] == i) {
+inline void build_packed_host(const carl_brax_sys_t& s, const Topo& t, Packed& pk) {
+  int mc = 0;
+  for (int i = 0; i < s.n_links; ++i) {
+    const int P = s.parent[i];
+    const v3 a = f3(s.joint_pos[i]);
+    const qt lrot = f4(s.link_rot[i]);
+    const v3 com_p = (P < 0) ? V(0, 0, 0) : f3(s.com[P]);
+    const v3 ac = a - f3(s.com[i]);
+    const v3 ap = f3(s.link_pos[i]) + qrot(lrot, a) - com_p;
+    const qt rpl = qmul(lrot, f4(s.joint_rot[i]));
+    LinkA& A = pk.a[i];
+    A.ac[0] = ac.x; A.ac[1] = ac.y; A.ac[2] = ac.z;
+    A.ap[0] = ap.x; A.ap[1] = ap.y; A.ap[2] = ap.z;
+    A.rpl[0] = rpl.w; A.rpl[1] = rpl.x; A.rpl[2] = rpl.y; A.rpl[3] = rpl.z;
+    for (int k = 0; k < 4; ++k) A.jrot[k] = s.joint_rot[i][k];
+    const bool free_root = P < 0 && s.n_link_dof[i] == 6;
+    const int ns = free_root ? 0 : s.n_slide[i], nr = free_root ? 0 : s.n_link_dof[i] - ns, d = s.dof_start[i] + ns;
+    A.word = (uint32_t)(P + 1) | (free_root ? kWaFree : 0u) | ((uint32_t)ns << 6) | ((uint32_t)nr << 8) |
+             ((uint32_t)s.dof_start[i] << 11);
+    A.k_pos = s.k_pos[i]; A.k_vel = s.k_vel[i]; A.k_limit = s.k_limit[i]; A.k_ang_damp = s.k_ang_damp[i];
+    const bool hinge = !free_root && nr >= 1 && d < CARL_BRAX_MAX_DOF;
+    A.damping = hinge ? s.dof_damping[d] : 0.0f;
+    A.stiffness = hinge ? s.dof_stiffness[d] : 0.0f;
+    A.lo = hinge ? s.dof_lo[d] : 0.0f;
+    A.hi = hinge ? s.dof_hi[d] : 0.0f;
+    A.pad = 0.0f;
+    LinkB& B = pk.b[i];
+    const int nch = t.child_begin[i + 1] - t.child_begin[i], nsp = t.coll_begin[i + 1] - t.coll_begin[i];
+    mc = nch > mc ? nch : mc;
+    const bool iso = s.inv_inertia[i][0] == s.inv_inertia[i][1] && s.inv_inertia[i][1] == s.inv_inertia[i][2];
+    B.word = (free_root ? kWbFree : 0u) | (iso ? kWbIso : 0u) | ((uint32_t)nch << 2) | ((uint32_t)t.coll_begin[i] << 6) |
+             ((uint32_t)nsp << 12);
+    B.children = 0u;
+    for (int k = 0; k < nch && k < 8; ++k) B.children |= (uint32_t)t.child_idx[t.child_begin[i] + k] << (4 * k);
+    B.inv_i0 = s.inv_inertia[i][0];
+    float reach = -1.0f;
+    for (int kk = t.coll_begin[i]; kk < t.coll_begin[i + 1]; ++kk) {
+      const int k = t.coll_idx[kk];
       const v3 c = f3(s.coll_pos[k]) - f3(s.com[i]);
       const float rk = sqrtf(dot(c, c)) + s.coll_radius[k];
       reach = rk > reach ? rk : reach;
+      pk.sph[kk].off[0] = c.x; pk.sph[kk].off[1] = c.y; pk.sph[kk].off[2] = c.z;
+      pk.sph[kk].radius = s.coll_radius[k];
     }
-  d.reach[i] = reach;
-  d.iso[i] = (s.inv_inertia[i][0] == s.inv_inertia[i][1] && s.inv_inertia[i][1] == s.inv_inertia[i][2]) ? 1 : 0;
+    B.reach = reach;
+  }
+  pk.max_children = mc;
 }
 
-// what the host precomputes per launch (kernel argument, ~830 bytes)
+// what the host precomputes per launch (kernel argument, ~2.6 KB)
 struct Prepared {
   Topo topo;
-  Derived derived;
+  Packed packed;
 };
 
 template <int kSub>
@@ -354,8 +419,8 @@ static __device__ __forceinline__ void phase_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-static __device__ __forceinline__ v3 apply_inv_inertia(const carl_brax_sys_t& s, int i, qt r, v3 t, bool iso) {
-  if (iso) return t * s.inv_inertia[i][0];  // every shipped model: spring_inertia_scale = 1
+static __device__ __forceinline__ v3 apply_inv_inertia(const carl_brax_sys_t& s, int i, qt r, v3 t, bool iso, float inv_i0) {
+  if (iso) return t * inv_i0;  // every shipped model: spring_inertia_scale = 1 (inv_i0 = inv_inertia[i][0])
   const v3 l = qrot(qconj(r), t);
   return qrot(r, V(l.x * s.inv_inertia[i][0], l.y * s.inv_inertia[i][1], l.z * s.inv_inertia[i][2]));
 }
@@ -389,12 +454,18 @@ struct JointGeom {
 // path out (Ant, Halfcheetah: fewer registers, shorter joint phase).
 // Everything that is a difference of the two poses is formed in float64 and rounded ONCE: the anchor
 // separation `ed`, the relative rotation of the joint frames, the axis-alignment term and the joint angles.
+// `la`: the link's joint record, already in registers (vector LDS reads of the caller).
+struct JointRec {
+  v3 ac, ap;
+  qt rpl, jrot;
+  uint32_t word;
+};
 template <bool MULTI>
-static __device__ __forceinline__ JointGeom joint_geometry(const carl_brax_sys_t& s, const Derived& dv, int i, const Body& bc,
+static __device__ __forceinline__ JointGeom joint_geometry(const carl_brax_sys_t& s, const JointRec& la, int i, const Body& bc,
                                                     const Body& bp) {
   JointGeom g;
   {
-    const v3d rc_off = qrot(bc.r, tod(f3(dv.ac[i]))), rp_off = qrot(bp.r, tod(f3(dv.ap[i])));
+    const v3d rc_off = qrot(bc.r, tod(la.ac)), rp_off = qrot(bp.r, tod(la.ap));
     g.ed = (bp.p - bc.p) + (rp_off - rc_off);  // A_p - A_c (at zero slide)
     g.rc_off = tof(rc_off);
     g.rp_off = tof(rp_off);
@@ -407,7 +478,7 @@ static __device__ __forceinline__ JointGeom joint_geometry(const carl_brax_sys_t
   qtd rel;
   qt rp;
   {
-    const qtd rcd = qmul(bc.r, tod(f4(s.joint_rot[i]))), rpd = qmul(bp.r, tod(f4(dv.rpl[i])));
+    const qtd rcd = qmul(bc.r, tod(la.jrot)), rpd = qmul(bp.r, tod(la.rpl));
     rel = qmul(qconj(rpd), rcd);
     rp = tof(rpd);
     const double a1 = 2.0 * (rel.x * rel.y + rel.w * rel.z), a2 = 2.0 * (rel.x * rel.z - rel.w * rel.y);
@@ -423,7 +494,7 @@ static __device__ __forceinline__ JointGeom joint_geometry(const carl_brax_sys_t
 #endif
   g.wrel = bc.w - bp.w;
   g.thetadot = dot(g.x_c, g.wrel);
-  const int nr = MULTI ? s.n_link_dof[i] - s.n_slide[i] : 1;
+  const int nr = MULTI ? wa_hinges(la.word) : 1;
   if (MULTI && nr != 1) {  // rel = Rx(al) Ry(be) Rz(ga): decompose, ga = sign * theta_3 (nr = 0: all locked)
     const double R00 = 1.0 - 2.0 * (rel.y * rel.y + rel.z * rel.z), R01 = 2.0 * (rel.x * rel.y - rel.w * rel.z);
     const double R02 = fmin(fmax(2.0 * (rel.x * rel.z + rel.w * rel.y), -1.0), 1.0);
@@ -506,27 +577,76 @@ static __device__ __forceinline__ double rsqrt_f64(double x) {
 // bits 0-3, hinges: bits 4-9; below / above per dof).  The step's combination of the rows is an optional output
 // (carl_step_io_t::branch_sig): a parity check can then separate lanes that took the same branches as the
 // reference arithmetic from lanes where a contact switched within rounding -- an impulse is discontinuous there.
+// Launch-invariant scalars of the substep.  The model table sits in LDS and every phase hand-over is a fence, so the
+// compiler may not carry a value it read from the table across a phase: left in the substep, `dt`, exp(damping dt),
+// 1 / dt ... were re-read and re-derived in every one of the n_frames substeps.  Wave-uniform ones are pinned in
+// scalar registers (readfirstlane), which also takes them out of the vector-register budget.
+struct SubK {
+  float dt, dl, inv_dt, erp;
+  int L, first_joint, max_children;
+};
+// The index words of the lane's FIRST joint / body (link first_joint + sub / sub), read once per launch: with one lane
+// per link -- the shape every large batch runs in -- a phase then starts with every address it needs in registers and
+// issues all its loads at once; a lane that owns a second link (kSub < n_links) reads that link's words at the end
+// of its first round.
+struct LinkWords {
+  uint32_t wa, wb, wch;
+};
+static __device__ __forceinline__ LinkWords load_words(const Packed& pk, const SubK& K, int sub) {
+  LinkWords w;
+  const int ia = K.first_joint + sub;
+  w.wa = ia < K.L ? pk.a[ia].word : kWaFree;
+  w.wb = sub < K.L ? pk.b[sub].word : 0u;
+  w.wch = sub < K.L ? pk.b[sub].children : 0u;
+  return w;
+}
+static __device__ __forceinline__ float uniform(float x) {
+  return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x)));
+}
+static __device__ __forceinline__ SubK make_subk(const carl_brax_sys_t& s, const Topo& tp, const Packed& pk) {
+  SubK k;
+  k.dt = uniform(s.dt);
+  k.dl = uniform(__expf(s.vel_damping * s.dt));
+  k.inv_dt = uniform(__builtin_amdgcn_rcpf(s.dt));
+  k.erp = uniform(s.baumgarte_erp);
+  k.L = __builtin_amdgcn_readfirstlane(s.n_links);
+  k.first_joint = __builtin_amdgcn_readfirstlane(tp.first_joint);
+  k.max_children = __builtin_amdgcn_readfirstlane(pk.max_children);
+  return k;
+}
+static __device__ __forceinline__ vf4 ld4(const void* p) { return *reinterpret_cast<const vf4*>(p); }
+
 template <bool MULTI, bool TASK>
-static __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const Topo& tp, const Derived& dv, const LaneCtx& c,
-                                        const Lds& m) {
-  const int L = s.n_links;
+static __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const Topo& tp, const Packed& pk, const SubK& K,
+                                        const LinkWords& W, const LaneCtx& c, const Lds& m) {
+  const int L = K.L;
   // phase A -- spring.joints.resolve, one joint per lane
+  uint32_t wa = W.wa;
 #ifdef CARL_EXP_BRAX_NO_PHASE_A
   for (int i = L; i < L; i += kSub) {
 #else
-  for (int i = tp.first_joint + m.sub; i < L; i += kSub) {
+  for (int i = K.first_joint + m.sub; i < L; i += kSub, wa = (i < L) ? pk.a[min(i, L - 1)].word : wa) {
 #endif
-    const int P = s.parent[i];
-    if (is_free_root(s, i)) continue;
+    if (wa & kWaFree) continue;
+    const LinkA& rec = pk.a[i];
+    const int P = wa_parent(wa);
+    const int ns = wa_slides(wa), d0 = wa_dof(wa);
+    const int d = d0 + ns, nr = MULTI ? wa_hinges(wa) : 1;
+    // every load of the phase whose address is known here, in one batch
+    const vf4 q0 = ld4(&rec.ac[0]), q1 = ld4(&rec.ap[0]), q2 = ld4(&rec.rpl[0]), q3 = ld4(&rec.jrot[0]);
     const Body bc = m.body(i);
     const Body bp = (P < 0) ? world_body() : m.body(P);
-    const JointGeom g = joint_geometry<MULTI>(s, dv, i, bc, bp);
-    const float kp = s.k_pos[i] * c.stiffness_scale;
+    const vf4 q4 = ld4(&rec.k_vel), q5 = ld4(&rec.stiffness);  // k_vel k_limit k_ang_damp damping | stiffness lo hi
+    const float tau1 = (!MULTI || nr == 1) ? m.at(m.lay.tau + d) : 0.0f;
+    const uint32_t sig_lim = m.atu(m.lay.sig + 2 * i + 1);
+    const JointRec la{V(q0.x, q0.y, q0.z), V(q1.x, q1.y, q1.z), qt{q2.x, q2.y, q2.z, q2.w}, qt{q3.x, q3.y, q3.z, q3.w}, wa};
+    const JointGeom g = joint_geometry<MULTI>(s, la, i, bc, bp);
+    const float k_limit = q4.y;
+    const float kp = q1.w * c.stiffness_scale;
     v3d ed = g.ed;
     v3 ev = g.vA_p - g.vA_c;
     v3 f = V(0, 0, 0);
     uint32_t lim = 0u;
-    const int ns = s.n_slide[i], d0 = s.dof_start[i];
     for (int k = 0; k < ns; ++k) {  // prismatic dofs: free along the axis, own spring/damper/force
       const v3d axd = qrot(bp.r, tod(f3(s.slide_axis[i][k])));
       const double qkd = -dot(ed, axd);
@@ -535,18 +655,17 @@ static __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const T
       const float qk = (float)qkd, qdk = -dot(ev, ax);
       ev = ev + ax * qdk;
       float fa = m.at(m.lay.tau + d0 + k) - s.dof_damping[d0 + k] * qdk - s.dof_stiffness[d0 + k] * qk;
-      if (qk < s.dof_lo[d0 + k]) { fa += s.k_limit[i] * (s.dof_lo[d0 + k] - qk); lim |= 1u << (2 * k); }  // range of the slide
-      if (qk > s.dof_hi[d0 + k]) { fa -= s.k_limit[i] * (qk - s.dof_hi[d0 + k]); lim |= 2u << (2 * k); }
+      if (qk < s.dof_lo[d0 + k]) { fa += k_limit * (s.dof_lo[d0 + k] - qk); lim |= 1u << (2 * k); }  // range of the slide
+      if (qk > s.dof_hi[d0 + k]) { fa -= k_limit * (qk - s.dof_hi[d0 + k]); lim |= 2u << (2 * k); }
       f = f + ax * fa;
     }
-    f = f + tof(ed) * kp + ev * s.k_vel[i];
+    f = f + tof(ed) * kp + ev * q4.x;
     v3 t;
-    const int d = d0 + ns, nr = MULTI ? s.n_link_dof[i] - ns : 1;
     if (!MULTI || nr == 1) {
       t = g.axx * kp;  // keep the hinge axes aligned
-      float ta = m.at(m.lay.tau + d) - s.dof_damping[d] * g.thetadot - s.dof_stiffness[d] * g.theta;
-      if (g.theta < s.dof_lo[d]) { ta += s.k_limit[i] * (s.dof_lo[d] - g.theta); lim |= 16u; }
-      if (g.theta > s.dof_hi[d]) { ta -= s.k_limit[i] * (g.theta - s.dof_hi[d]); lim |= 32u; }
+      float ta = tau1 - q4.w * g.thetadot - q5.x * g.theta;
+      if (g.theta < q5.y) { ta += k_limit * (q5.y - g.theta); lim |= 16u; }
+      if (g.theta > q5.z) { ta -= k_limit * (g.theta - q5.z); lim |= 32u; }
       t = t + g.x_c * ta;
     } else {  // 2 or 3 stacked hinges: per-dof torques about the current axes; a missing third
               // dof is locked by the constraint spring on its Euler angle
@@ -557,16 +676,16 @@ static __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const T
         if (k < nr) {
           const int dk = d + k;
           ta = m.at(m.lay.tau + dk) - s.dof_damping[dk] * g.rate[k] - s.dof_stiffness[dk] * g.ang[k];
-          if (g.ang[k] < s.dof_lo[dk]) { ta += s.k_limit[i] * (s.dof_lo[dk] - g.ang[k]); lim |= 16u << (2 * k); }
-          if (g.ang[k] > s.dof_hi[dk]) { ta -= s.k_limit[i] * (g.ang[k] - s.dof_hi[dk]); lim |= 32u << (2 * k); }
+          if (g.ang[k] < s.dof_lo[dk]) { ta += k_limit * (s.dof_lo[dk] - g.ang[k]); lim |= 16u << (2 * k); }
+          if (g.ang[k] > s.dof_hi[dk]) { ta -= k_limit * (g.ang[k] - s.dof_hi[dk]); lim |= 32u << (2 * k); }
         } else {
           ta = -kp * g.ang[k];
         }
         t = t + g.axis[k] * ta;
       }
     }
-    t = t - g.wrel * s.k_ang_damp[i];
-    m.atu(m.lay.sig + 2 * i + 1) = m.atu(m.lay.sig + 2 * i + 1) * 33u + lim;
+    t = t - g.wrel * q4.z;
+    m.atu(m.lay.sig + 2 * i + 1) = sig_lim * 33u + lim;
     const int wr = m.lay.wrench + 12 * i;
     v3 pf = f * -1.0f, pt = (cross(g.rp_off, f) + t) * -1.0f;  // on the parent
     if (TASK && s.n_pair > 0 && i == s.push_link) {
@@ -582,74 +701,90 @@ static __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const T
   }
   phase_sync();
   // phase B -- per body: wrench sum, semi-implicit Euler, its contacts, integrate
-  const float dl = __expf(s.vel_damping * s.dt), da = __expf(c.ang_damping * s.dt);
-  const float inv_dt = __builtin_amdgcn_rcpf(s.dt);
+  const float dl = K.dl, da = c.da, inv_dt = K.inv_dt, dt = K.dt;
   const v3 n = V(0, 0, 1);
+  uint32_t wb = W.wb, wch = W.wch;
 #ifdef CARL_EXP_BRAX_NO_PHASE_B
   for (int i = L; i < L; i += kSub) {
 #else
-  for (int i = m.sub; i < L; i += kSub) {
+  for (int i = m.sub; i < L; i += kSub, wb = (i < L) ? pk.b[min(i, L - 1)].word : wb,
+           wch = (i < L) ? pk.b[min(i, L - 1)].children : wch) {
 #endif
+    const vf4 qb = ld4(&pk.b[i]);  // .z inv_inertia[0], .w reach (the index words are in registers)
+    const bool iso = (wb & kWbIso) != 0u;
     Body b = m.body(i);
+    const float mass_i = m.at(m.lay.mass + i);
+    const uint32_t sig_hit = m.atu(m.lay.sig + 2 * i);
     const qt rf = tof(b.r);
-    v3 F = V(0, 0, 0), T = V(0, 0, 0);
-    if (!is_free_root(s, i)) {
-      F = m.get3(m.lay.wrench + 12 * i);
-      T = m.get3(m.lay.wrench + 12 * i + 3);
-    }
+    // own joint's wrench (a free root has none: it reads the zero rows)
+    const int own = (wb & kWbFree) ? m.lay.zero : m.lay.wrench + 12 * i;
+    v3 F = m.get3(own), T = m.get3(own + 3);
 #ifndef CARL_EXP_BRAX_NO_CHILDREN
-    for (int cc = tp.child_begin[i]; cc < tp.child_begin[i + 1]; ++cc) {
-      const int wr = m.lay.wrench + 12 * tp.child_idx[cc];
-      F = F + m.get3(wr + 6);
-      T = T + m.get3(wr + 9);
+    {  // children's reactions, ascending: a wavefront-uniform trip count and loads whose addresses come from a
+       // register (a link with fewer children reads the zero rows), so a pass is one batch of independent LDS reads
+      const int nch = wb_children(wb);
+      for (int k0 = 0; k0 < K.max_children && k0 < 8; k0 += 2) {
+        const int r0 = (k0 < nch) ? m.lay.wrench + 12 * (int)((wch >> (4 * k0)) & 15u) + 6 : m.lay.zero;
+        const int r1 = (k0 + 1 < nch) ? m.lay.wrench + 12 * (int)((wch >> (4 * k0 + 4)) & 15u) + 6 : m.lay.zero;
+        const v3 f0 = m.get3(r0), t0 = m.get3(r0 + 3), f1 = m.get3(r1), t1 = m.get3(r1 + 3);
+        F = (F + f0) + f1;
+        T = (T + t0) + t1;
+      }
+      if (K.max_children > 8)  // (no shipped model; wavefront-uniform)
+        for (int cc = tp.child_begin[i] + 8; cc < tp.child_begin[i + 1]; ++cc) {
+          const int wr = m.lay.wrench + 12 * tp.child_idx[cc];
+          F = F + m.get3(wr + 6);
+          T = T + m.get3(wr + 9);
+        }
     }
 #endif
-    const float inv_m = __builtin_amdgcn_rcpf(m.at(m.lay.mass + i));  // v_rcp_f32 (1 ulp): the phase is issue-bound
-    b.v = b.v + (F * inv_m + V(0, 0, c.gravity_z)) * s.dt;
-    b.w = b.w + apply_inv_inertia(s, i, rf, T, dv.iso[i] != 0) * s.dt;
+    const float inv_m = __builtin_amdgcn_rcpf(mass_i);  // v_rcp_f32 (1 ulp): the phase is issue-bound
+    b.v = b.v + (F * inv_m + V(0, 0, c.gravity_z)) * dt;
+    b.w = b.w + apply_inv_inertia(s, i, rf, T, iso, qb.z) * dt;
     // spring.collisions.resolve: this body's spheres vs the plane z = 0
     v3 cdv = V(0, 0, 0), cdw = V(0, 0, 0);
     float cnt = 0.0f;
     uint32_t hit = 0u;
-    const bool iso = dv.iso[i] != 0;
     // no sphere of this link can reach the plane while its COM is higher than the farthest sphere surface
 #ifdef CARL_EXP_BRAX_NO_CONTACTS
-    const int k_end = 0;
+    const int n_sph = 0;
 #else
-    const int k_end = ((float)b.p.z < dv.reach[i]) ? tp.coll_begin[i + 1] : 0;
+    const int n_sph = ((float)b.p.z < qb.w) ? wb_spheres(wb) : 0;
 #endif
     // third row of the rotation matrix in float64: a sphere's height -- hence its depth, which the Baumgarte
     // term multiplies by erp / dt -- is a pose difference
     const double R20 = 2.0 * (b.r.x * b.r.z - b.r.w * b.r.y), R21 = 2.0 * (b.r.y * b.r.z + b.r.w * b.r.x),
                  R22 = 1.0 - 2.0 * (b.r.x * b.r.x + b.r.y * b.r.y);
-    for (int kk = tp.coll_begin[i]; kk < k_end; ++kk) {
-      const int k = tp.coll_idx[kk];
-      const v3 off = f3(s.coll_pos[k]) - f3(s.com[i]);
+    const Sphere* sph = pk.sph + wb_first_sphere(wb);
+    for (int j = 0; j < n_sph; ++j) {
+      const vf4 sp = ld4(&sph[j]);
+      const v3 off = V(sp.x, sp.y, sp.z);
+      const float radius = sp.w;
       const float depth =
-          (float)((double)s.coll_radius[k] - (b.p.z + (R20 * (double)off.x + R21 * (double)off.y + R22 * (double)off.z)));
+          (float)((double)radius - (b.p.z + (R20 * (double)off.x + R21 * (double)off.y + R22 * (double)off.z)));
       if (!(depth > 0.0f)) continue;
       const v3 ro = qrot(rf, off);
-      const v3 r = V(ro.x, ro.y, ro.z - s.coll_radius[k]);
+      const v3 r = V(ro.x, ro.y, ro.z - radius);
       const v3 rel = b.v + cross(b.w, r);
       const float vn = dot(n, rel);
-      const float ang = dot(n, cross(apply_inv_inertia(s, i, rf, cross(r, n), iso), r));
-      const float imp = div_fast(-(1.0f + c.elasticity) * vn + s.baumgarte_erp * depth * inv_dt, inv_m + ang);
+      const float ang = dot(n, cross(apply_inv_inertia(s, i, rf, cross(r, n), iso, qb.z), r));
+      const float imp = div_fast(-(1.0f + c.elasticity) * vn + K.erp * depth * inv_dt, inv_m + ang);
       if (!(imp > 0.0f) || !(vn < 0.0f)) continue;
-      hit |= 1u << (kk - tp.coll_begin[i]);
+      hit |= 1u << j;
       v3 J = n * imp;
       const v3 vt = rel - n * vn;
       const float vt_len = sqrtf(dot(vt, vt));
       if (vt_len > 1e-9f) {
         const v3 dir = vt * __builtin_amdgcn_rcpf(vt_len);
-        const float ang_d = dot(dir, cross(apply_inv_inertia(s, i, rf, cross(r, dir), iso), r));
+        const float ang_d = dot(dir, cross(apply_inv_inertia(s, i, rf, cross(r, dir), iso, qb.z), r));
         const float imp_d = fminf(div_fast(vt_len, inv_m + ang_d), c.friction * imp);
         J = J - dir * imp_d;
       }
       cdv = cdv + J * inv_m;
-      cdw = cdw + apply_inv_inertia(s, i, rf, cross(r, J), iso);
+      cdw = cdw + apply_inv_inertia(s, i, rf, cross(r, J), iso, qb.z);
       cnt += 1.0f;
     }
-    m.atu(m.lay.sig + 2 * i) = m.atu(m.lay.sig + 2 * i) * 33u + hit;
+    m.atu(m.lay.sig + 2 * i) = sig_hit * 33u + hit;
     // spring.integrator.integrate
     b.v = b.v * dl;
     b.w = b.w * da;
@@ -660,16 +795,16 @@ static __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const T
     }
 #ifdef CARL_EXP_BRAX_F32_INTEGRATE
     {
-      const v3 pf = tof(b.p) + b.v * s.dt;
+      const v3 pf = tof(b.p) + b.v * dt;
       const qt dqf = qmul(qt{0.0f, b.w.x, b.w.y, b.w.z}, rf);
-      const float hf = 0.5f * s.dt;
+      const float hf = 0.5f * dt;
       b.p = tod(pf);
       b.r = tod(qnormalize(qt{rf.w + hf * dqf.w, rf.x + hf * dqf.x, rf.y + hf * dqf.y, rf.z + hf * dqf.z}));
       m.put(i, b);
       continue;
     }
 #endif
-    const double dtd = (double)s.dt;
+    const double dtd = (double)dt;
     b.p = D(fma((double)b.v.x, dtd, b.p.x), fma((double)b.v.y, dtd, b.p.y), fma((double)b.v.z, dtd, b.p.z));
     const qtd dq = qmul(qtd{0.0, (double)b.w.x, (double)b.w.y, (double)b.w.z}, b.r);
     const double h = 0.5 * dtd;
@@ -700,7 +835,7 @@ static __device__ __forceinline__ v3d system_com(const carl_brax_sys_t& s, const
 // qfrc_actuator (the tau rows; `zero_frc`: reset observations see a zero action).  `go`: envs
 // that take part (the calls are wavefront-uniform).  Ends with a phase_sync.
 template <bool MULTI, bool TASK>
-static __device__ __forceinline__ void observe(const carl_brax_sys_t& s, const Derived& dv, const Lds& m, bool go,
+static __device__ __forceinline__ void observe(const carl_brax_sys_t& s, const Packed& pk, const Lds& m, bool go,
                                         bool zero_frc) {
   const int skip = s.exclude_current_positions;
   // q[from:] as sin ++ cos (inverted double pendulum): the raw angles are written to the sin rows and
@@ -734,7 +869,11 @@ static __device__ __forceinline__ void observe(const carl_brax_sys_t& s, const D
       for (int k = 0; k < 6; ++k) put_qd(s.dof_start[i] + k, dvv[k]);
     } else {
       const Body bp = (P < 0) ? world_body() : m.body(P);
-      const JointGeom g = joint_geometry<MULTI>(s, dv, i, b, bp);
+      const LinkA& rec = pk.a[i];
+      const vf4 q0 = ld4(&rec.ac[0]), q1 = ld4(&rec.ap[0]), q2 = ld4(&rec.rpl[0]), q3 = ld4(&rec.jrot[0]);
+      const JointRec la{V(q0.x, q0.y, q0.z), V(q1.x, q1.y, q1.z), qt{q2.x, q2.y, q2.z, q2.w}, qt{q3.x, q3.y, q3.z, q3.w},
+                        __float_as_uint(q0.w)};
+      const JointGeom g = joint_geometry<MULTI>(s, la, i, b, bp);
       const int ns = s.n_slide[i];
       for (int k = 0; k < ns; ++k) {
         const v3d axd = qrot(bp.r, tod(f3(s.slide_axis[i][k])));
@@ -987,6 +1126,7 @@ static __device__ __forceinline__ LaneCtx load_ctx(const carl_brax_sys_t& s, con
     lc.elasticity = get(cm.elasticity, s.elasticity);
     lc.ang_damping = get(cm.ang_damping, s.ang_damping);
     lc.stiffness_scale = get(cm.joint_stiffness_scale, 1.0f);
+    lc.da = __expf(lc.ang_damping * s.dt);
     for (int i = m.sub; i < s.n_links; i += kSub) m.at(m.lay.mass + i) = s.mass[i];
   }
   if (TASK && s.push_link > 0) put_goal(s, b, m, c, go);
@@ -1129,7 +1269,7 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
                                            const int n_steps) {
   __shared__ carl_brax_sys_t s;
   __shared__ Topo tp;
-  __shared__ Derived dv;
+  __shared__ Packed pk;
   extern __shared__ double lds_dyn[];  // pose rows (doubles) first, then the float rows
   {  // model table -> LDS, once per workgroup: every load in flight before the first LDS write (a
      // load-store loop paid one HBM/L2 round trip per 256 bytes: ~15 us of a per-call step)
@@ -1152,12 +1292,12 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
   }
   __syncthreads();
   {  // topology + derived constants: kernel argument -> LDS (per-lane indexed in the phases)
-    constexpr int kWordsT = (int)(sizeof(Topo) / 4), kWordsD = (int)(sizeof(Derived) / 4);
-    static_assert(sizeof(Topo) % 4 == 0 && sizeof(Derived) % 4 == 0, "word copies");
+    constexpr int kWordsT = (int)(sizeof(Topo) / 4), kWordsD = (int)(sizeof(Packed) / 4);
+    static_assert(sizeof(Topo) % 4 == 0 && sizeof(Packed) % 4 == 0, "word copies");
     const uint32_t* st = reinterpret_cast<const uint32_t*>(&prep.topo);
-    const uint32_t* sd = reinterpret_cast<const uint32_t*>(&prep.derived);
+    const uint32_t* sd = reinterpret_cast<const uint32_t*>(&prep.packed);
     uint32_t* dt = reinterpret_cast<uint32_t*>(&tp);
-    uint32_t* dd = reinterpret_cast<uint32_t*>(&dv);
+    uint32_t* dd = reinterpret_cast<uint32_t*>(&pk);
     for (int k = (int)threadIdx.x; k < kWordsT; k += (int)blockDim.x) dt[k] = st[k];
     for (int k = (int)threadIdx.x; k < kWordsD; k += (int)blockDim.x) dd[k] = sd[k];
   }
@@ -1215,7 +1355,7 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
       write_ctx_obs(b, m, n, env, r.cidx);
     }
     if (s.obs_extended) load_ctx<TASK>(s, b, m, r.cidx, go);  // com inertia / velocity use the env's masses
-    observe<MULTI, TASK>(s, dv, m, go, true);
+    observe<MULTI, TASK>(s, pk, m, go, true);
     if (reset_obs != nullptr) record_out(reset_obs, (size_t)env, s.obs_dim, m, go);
     return;
   } else {
@@ -1227,6 +1367,10 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
       r.pos_y = b.goal_pos[n + env];
     }
     const float dt_env = s.dt * (float)s.n_frames;
+    const SubK K = make_subk(s, tp, pk);
+    const LinkWords W = load_words(pk, K, m.sub);
+    const int n_frames = __builtin_amdgcn_readfirstlane(s.n_frames);
+    for (int k = m.sub; k < 6; k += kSub) m.at(m.lay.zero + k) = 0.0f;  // (the first phase_sync below orders it)
     for (int t = 0; t < n_steps; ++t) {
       const size_t step_off = (size_t)t * n;
       record_in(static_cast<const float*>(io.action) + step_off * s.n_act, (size_t)env, s.n_act, m, active);
@@ -1245,7 +1389,7 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
       float msum;
       // forward progress and root height: pose differences, float64
       const double x0 = s.reward_on_com ? system_com(s, m, &msum).x : m.pos(0).x - qrot(m.rot(0), tod(f3(s.com[0]))).x;
-      for (int f = 0; f < s.n_frames; ++f) substep<MULTI, TASK>(s, tp, dv, r.ctx, m);
+      for (int f = 0; f < n_frames; ++f) substep<MULTI, TASK>(s, tp, pk, K, W, r.ctx, m);
       const v3d c1 = qrot(m.rot(0), tod(f3(s.com[0])));
       const double x1 = s.reward_on_com ? system_com(s, m, &msum).x : m.pos(0).x - c1.x, z1d = m.pos(0).z - c1.z;
       const float z1 = (float)z1d;
@@ -1261,7 +1405,7 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
       }
       r.elapsed += 1;
       const bool truncated = (b.max_episode_steps > 0) && (r.elapsed >= b.max_episode_steps);
-      observe<MULTI, TASK>(s, dv, m, active, false);
+      observe<MULTI, TASK>(s, pk, m, active, false);
       if (s.healthy_q_index >= 0) {  // torso pitch (hopper, walker2d) / pole angle: read from the observation
         const float qa = m.at(m.lay.io + s.healthy_q_index - s.exclude_current_positions);
         healthy = healthy && (qa >= s.healthy_q_lo) && (qa <= s.healthy_q_hi);
@@ -1355,7 +1499,7 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
             write_ctx_obs(b, m, n, env, r.cidx);
           }
           }
-          observe<MULTI, TASK>(s, dv, m, done, true);
+          observe<MULTI, TASK>(s, pk, m, done, true);
         }
       }
       record_out(io.obs + step_off * s.obs_dim, (size_t)env, s.obs_dim, m, active);

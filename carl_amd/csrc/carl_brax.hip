@@ -219,7 +219,7 @@ int launch_brax(const carl_batch_t* b, const carl_brax_sys_t* sd, const carl_bra
   if (io != nullptr) io_v = *io;
   carl::brax::Prepared prep{};  // topology + derived per-link constants, host-side (microseconds)
   carl::brax::build_topo_host(*sh, prep.topo);
-  for (int i = 0; i < sh->n_links; ++i) carl::brax::build_derived_host(*sh, prep.derived, i);
+  carl::brax::build_packed_host(*sh, prep.topo, prep.packed);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(carl::brax::kLanes * W), sh_bytes, st, *b, sd, prep, io_v, mask, reset_obs,
                      n_steps);
   return check_launch(who);
