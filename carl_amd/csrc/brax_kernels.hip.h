@@ -190,12 +190,18 @@ struct LaneCtx {
   float da;  // exp(ang_damping dt): the substep's angular velocity decay
 };
 
-// LDS layout of a workgroup.  Pose rows are doubles (7 per link: COM position 3, rotation 4) in a region of their
-// own at the start of the dynamic LDS; every other row is a float row.  Each row = kEnvs consecutive elements, one
-// per env.
+// LDS layout of a wavefront's slice.  First the BODY RECORDS, one per (env, link), [env][link] x 80 bytes:
+//   pose, 7 doubles (COM position 3, rotation w x y z) | linear, angular velocity, 6 floats
+// read and written as five 16-byte accesses per body.  (Round 3 measured the [row][env] layout these replace:
+// the LDS array was busy 74 % of the kernel's CU-cycles, 40 % of that bank conflicts (SQ_LDS_IDX_ACTIVE /
+// SQ_LDS_BANK_CONFLICT, profiles/r03_brax_lds_counters.txt) -- the substep was bound by the LDS pipe, not by
+// issue: a body took four 8-byte and three 4-byte two-address reads at 128 B/clk with 2-3-way conflicts (row stride
+// of 7 or 9 envs); the 80-byte record is 5 x 4 banks wide and 5 is coprime to 16, so the 16 lanes of a
+// ds_read_b128 group land on 16 different bank quads at 256 B/clk.)  Then the float rows: each row = kEnvs
+// consecutive floats, one per env.
+constexpr int kBodyBytes = 80;
 struct Layout {
-  int pose_rows;  // 7 * L DOUBLE rows (separate region)
-  int vel;     // 6 * L rows: linear, angular velocity
+  int L;       // links: body records per env
   int wrench;  // 12 * L rows: per joint (f, t) on the child, (-f, -t') on the parent; reused by FK
   int mass;    // L rows (effective mass per link, context-scaled)
   int sig;     // 2 * L rows (uint32): per-link hash of the step's contact / limit branch decisions
@@ -206,9 +212,8 @@ struct Layout {
   int total;   // float rows
   __host__ __device__ static Layout make(int L, int n_dof, int io_rows) {
     Layout l;
-    l.pose_rows = 7 * L;
-    l.vel = 0;
-    l.wrench = l.vel + 6 * L;
+    l.L = L;
+    l.wrench = 0;
     l.mass = l.wrench + 12 * L;
     l.sig = l.mass + L;
     l.zero = l.sig + 2 * L;
@@ -219,8 +224,9 @@ struct Layout {
     return l;
   }
   // bytes of dynamic LDS for `envs` envs per workgroup
-  __host__ __device__ size_t bytes(int envs) const {  // per wavefront, rounded up to 8 (the next wavefront's doubles)
-    return (((size_t)pose_rows * 8 + (size_t)total * 4) * envs + 7) & ~(size_t)7;
+  __host__ __device__ size_t body_bytes(int envs) const { return (size_t)kBodyBytes * L * envs; }
+  __host__ __device__ size_t bytes(int envs) const {  // per wavefront, rounded up to 16 (the next wavefront's records)
+    return (body_bytes(envs) + (size_t)total * 4 * envs + 15) & ~(size_t)15;
   }
 };
 
@@ -376,31 +382,45 @@ struct Group {
 static constexpr int kEnvs = kLanes / kSub;  // envs per wavefront
 
 struct Lds {
-  double* pose;  // [7 L][kEnvs]
+  char* rec;     // this wavefront's body records
   float* base;   // float rows
   Layout lay;
-  int env;  // env within the workgroup (0..kEnvs-1)
+  int env;  // env within the wavefront (0..kEnvs-1)
   int sub;  // lane within the env (0..kSub-1)
   __device__ __forceinline__ float& at(int row) const { return base[row * kEnvs + env]; }
   __device__ __forceinline__ uint32_t& atu(int row) const { return reinterpret_cast<uint32_t*>(base)[row * kEnvs + env]; }
-  __device__ __forceinline__ double& pd(int row) const { return pose[row * kEnvs + env]; }
-  __device__ __forceinline__ v3d pos(int i) const { return D(pd(7 * i), pd(7 * i + 1), pd(7 * i + 2)); }
-  __device__ __forceinline__ qtd rot(int i) const { return qtd{pd(7 * i + 3), pd(7 * i + 4), pd(7 * i + 5), pd(7 * i + 6)}; }
+  __device__ __forceinline__ char* body_ptr(int i) const { return rec + (env * lay.L + i) * kBodyBytes; }
+  __device__ __forceinline__ double& pd(int i, int c) const { return reinterpret_cast<double*>(body_ptr(i))[c]; }
+  __device__ __forceinline__ float& vel(int i, int c) const { return reinterpret_cast<float*>(body_ptr(i) + 56)[c]; }
+  // flat element k of the env's pose [7 L] / velocity [6 L] block (the record copies: once per env step)
+  __device__ __forceinline__ double& pdk(int k) const { return pd(k / 7, k % 7); }
+  __device__ __forceinline__ float& velk(int k) const { return vel(k / 6, k % 6); }
+  __device__ __forceinline__ v3d pos(int i) const { return D(pd(i, 0), pd(i, 1), pd(i, 2)); }
+  __device__ __forceinline__ qtd rot(int i) const { return qtd{pd(i, 3), pd(i, 4), pd(i, 5), pd(i, 6)}; }
   __device__ __forceinline__ Body body(int i) const {
-    const int r0 = lay.vel + 6 * i;
+    typedef double vd2 __attribute__((ext_vector_type(2)));
+    const char* q = body_ptr(i);
+    const vd2 a = *reinterpret_cast<const vd2*>(q), b2 = *reinterpret_cast<const vd2*>(q + 16),
+              c2 = *reinterpret_cast<const vd2*>(q + 32);
+    const vf4 d = *reinterpret_cast<const vf4*>(q + 48), e = *reinterpret_cast<const vf4*>(q + 64);
+    typedef float vf2 __attribute__((ext_vector_type(2)));
     Body b;
-    b.p = pos(i);
-    b.r = rot(i);
-    b.v = V(at(r0), at(r0 + 1), at(r0 + 2));
-    b.w = V(at(r0 + 3), at(r0 + 4), at(r0 + 5));
+    b.p = D(a.x, a.y, b2.x);
+    b.r = qtd{b2.y, c2.x, c2.y, __builtin_bit_cast(double, vf2{d.x, d.y})};
+    b.v = V(d.z, d.w, e.x);
+    b.w = V(e.y, e.z, e.w);
     return b;
   }
   __device__ __forceinline__ void put(int i, const Body& b) const {
-    const int r0 = lay.vel + 6 * i;
-    pd(7 * i) = b.p.x; pd(7 * i + 1) = b.p.y; pd(7 * i + 2) = b.p.z;
-    pd(7 * i + 3) = b.r.w; pd(7 * i + 4) = b.r.x; pd(7 * i + 5) = b.r.y; pd(7 * i + 6) = b.r.z;
-    at(r0) = b.v.x; at(r0 + 1) = b.v.y; at(r0 + 2) = b.v.z;
-    at(r0 + 3) = b.w.x; at(r0 + 4) = b.w.y; at(r0 + 5) = b.w.z;
+    typedef double vd2 __attribute__((ext_vector_type(2)));
+    typedef float vf2 __attribute__((ext_vector_type(2)));
+    char* q = body_ptr(i);
+    *reinterpret_cast<vd2*>(q) = vd2{b.p.x, b.p.y};
+    *reinterpret_cast<vd2*>(q + 16) = vd2{b.p.z, b.r.w};
+    *reinterpret_cast<vd2*>(q + 32) = vd2{b.r.x, b.r.y};
+    const vf2 rz = __builtin_bit_cast(vf2, b.r.z);
+    *reinterpret_cast<vf4*>(q + 48) = vf4{rz.x, rz.y, b.v.x, b.v.y};
+    *reinterpret_cast<vf4*>(q + 64) = vf4{b.v.z, b.w.x, b.w.y, b.w.z};
   }
   __device__ __forceinline__ void put3(int row, v3 a) const {
     at(row) = a.x; at(row + 1) = a.y; at(row + 2) = a.z;
@@ -944,8 +964,8 @@ static __device__ __forceinline__ void observe(const carl_brax_sys_t& s, const P
       for (int i = m.sub; i < na; i += kSub) m.at(m.lay.io + na + i) = m.at(m.lay.wrench + i);
       for (int j = m.sub; j < 3; j += kSub) {
         const int k = m.lay.io + 2 * na + j;
-        m.at(k) = (float)m.pd(7 * s.tip_link + j);
-        m.at(k + 3) = (float)m.pd(7 * s.push_link + j);
+        m.at(k) = (float)m.pd(s.tip_link, j);
+        m.at(k + 3) = (float)m.pd(s.push_link, j);
         m.at(k + 6) = m.at(m.lay.goal + j);
       }
     }
@@ -1175,7 +1195,7 @@ static __device__ __forceinline__ void record_load(const float* __restrict__ src
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int k = k0 + j * kSub;
-      if (k < NP) m.pd(k) = (double)hi[j] + (double)lo[j];
+      if (k < NP) m.pdk(k) = (double)hi[j] + (double)lo[j];
     }
   }
   for (int k0 = m.sub; k0 < NV; k0 += 4 * kSub) {
@@ -1188,7 +1208,7 @@ static __device__ __forceinline__ void record_load(const float* __restrict__ src
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int k = k0 + j * kSub;
-      if (k < NV) m.at(m.lay.vel + k) = v[j];
+      if (k < NV) m.velk(k) = v[j];
     }
   }
 }
@@ -1196,12 +1216,12 @@ static __device__ __forceinline__ void record_store(float* __restrict__ dst, con
   if (!go) return;
   const int NP = 7 * L, NV = 6 * L;
   for (int k = m.sub; k < NP; k += kSub) {
-    const double d = m.pd(k);
+    const double d = m.pdk(k);
     const float hi = (float)d;
     dst[k] = hi;
     dst[NP + k] = (float)(d - (double)hi);
   }
-  for (int k = m.sub; k < NV; k += kSub) dst[2 * NP + k] = m.at(m.lay.vel + k);
+  for (int k = m.sub; k < NV; k += kSub) dst[2 * NP + k] = m.velk(k);
 }
 // Round the pose to what the record holds (head + tail, 48 bits).  Done at the end of EVERY env step, so a fused
 // rollout continues from exactly the state a per-call step would have stored and reloaded: rollout == repeated step,
@@ -1209,9 +1229,9 @@ static __device__ __forceinline__ void record_store(float* __restrict__ dst, con
 static __device__ __forceinline__ void pose_round(const Lds& m, int L, bool go) {
   if (!go) return;
   for (int k = m.sub; k < 7 * L; k += kSub) {
-    const double d = m.pd(k);
+    const double d = m.pdk(k);
     const float hi = (float)d;
-    m.pd(k) = (double)hi + (double)(float)(d - (double)hi);
+    m.pdk(k) = (double)hi + (double)(float)(d - (double)hi);
   }
 }
 
@@ -1270,7 +1290,7 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
   __shared__ carl_brax_sys_t s;
   __shared__ Topo tp;
   __shared__ Packed pk;
-  extern __shared__ double lds_dyn[];  // pose rows (doubles) first, then the float rows
+  extern __shared__ vf4 lds_dyn[];  // per wavefront: body records, then the float rows (16-byte aligned slices)
   {  // model table -> LDS, once per workgroup: every load in flight before the first LDS write (a
      // load-store loop paid one HBM/L2 round trip per 256 bytes: ~15 us of a per-call step)
     constexpr int kWords = (int)(sizeof(carl_brax_sys_t) / 4);
@@ -1307,8 +1327,8 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
   const int tid = (int)threadIdx.x & (kLanes - 1), wave = (int)threadIdx.x >> 6;
   const bool lane_ok = tid < kEnvs * kSub;
   const Layout lay = Layout::make(s.n_links, s.n_dof, io_rows_of(s));
-  double* const my_lds = lds_dyn + (size_t)wave * (lay.bytes(kEnvs) / 8);  // this wavefront's rows (bytes(): multiple of 8)
-  const Lds m{my_lds, reinterpret_cast<float*>(my_lds + (size_t)lay.pose_rows * kEnvs), lay,
+  char* const my_lds = reinterpret_cast<char*>(lds_dyn) + (size_t)wave * lay.bytes(kEnvs);  // this wavefront's slice
+  const Lds m{my_lds, reinterpret_cast<float*>(my_lds + lay.body_bytes(kEnvs)), lay,
               lane_ok ? tid / kSub : kEnvs - 1, lane_ok ? tid % kSub : kLanes};
   const int gwave = (int)blockIdx.x * ((int)blockDim.x >> 6) + wave;  // global wavefront = group of kEnvs envs
   const int env = gwave * kEnvs + m.env;
