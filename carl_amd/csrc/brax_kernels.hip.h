@@ -59,6 +59,11 @@ constexpr int kLanes = 64;  // lanes per wavefront: one wavefront works on floor
 #endif
 constexpr int kMaxWavesPerWg = CARL_BRAX_WAVES_PER_WG;
 constexpr int kMaxThreads = kLanes * kMaxWavesPerWg;
+// The single-hinge kernels run THREE wavefronts per SIMD (168 VGPRs), so a workgroup of theirs may be a CU's whole
+// 12 wavefronts -- what the balanced fragment schedule of a large batch wants (run(): the fewer, larger workgroups
+// the groups are dealt to, the smaller the rounding loss between workgroups).
+constexpr int kMaxWavesPerWg3 = 12;
+__host__ __device__ constexpr int max_waves_per_wg(bool multi) { return multi ? kMaxWavesPerWg : kMaxWavesPerWg3; }
 // Register budget.  Single-hinge models (MULTI = false: Ant, Halfcheetah, Hopper, Walker2d): THREE wavefronts per SIMD
 // (168 VGPRs) -- the kernel is bound by the latency of its own dependent chains (one -> two wavefronts per SIMD: 1.7 x),
 // the hot substep loop fits 168 registers without a spill (ISA checked) and what spills (62 dwords) sits in observe and
@@ -584,8 +589,10 @@ static __device__ __forceinline__ PairOut pair_contact(const carl_brax_sys_t& s,
 
 // 1 / sqrt(x), x near 1 (a quaternion's squared norm after one integration step): v_rsq_f64 + two Newton steps
 static __device__ __forceinline__ double rsqrt_f64(double x) {
-  double y = __builtin_amdgcn_rsq(x);
-  y = y * fma(-0.5 * x, y * y, 1.5);
+  // seed: v_rsq_f32 of the rounded argument (1 ulp of float32, 6e-8); one Newton step squares the error: 5e-15, under the
+  // 48 bits the pose record keeps.  (v_rsq_f64 + two steps: twice the dependent float64 chain at the end of the body
+  // phase, the longest latency chain of the substep.)
+  double y = (double)__builtin_amdgcn_rsqf((float)x);
   y = y * fma(-0.5 * x, y * y, 1.5);
   return y;
 }
@@ -743,6 +750,16 @@ static __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const T
     {  // children's reactions, ascending: a wavefront-uniform trip count and loads whose addresses come from a
        // register (a link with fewer children reads the zero rows), so a pass is one batch of independent LDS reads
       const int nch = wb_children(wb);
+      if (K.max_children > 2 && K.max_children <= 4) {  // (Ant's torso, Humanoid's pelvis: all four slots in ONE batch of loads)
+        int r[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r[k] = (k < nch) ? m.lay.wrench + 12 * (int)((wch >> (4 * k)) & 15u) + 6 : m.lay.zero;
+        v3 f[4], t[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { f[k] = m.get3(r[k]); t[k] = m.get3(r[k] + 3); }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { F = F + f[k]; T = T + t[k]; }
+      } else
       for (int k0 = 0; k0 < K.max_children && k0 < 8; k0 += 2) {
         const int r0 = (k0 < nch) ? m.lay.wrench + 12 * (int)((wch >> (4 * k0)) & 15u) + 6 : m.lay.zero;
         const int r1 = (k0 + 1 < nch) ? m.lay.wrench + 12 * (int)((wch >> (4 * k0 + 4)) & 15u) + 6 : m.lay.zero;
@@ -1290,6 +1307,8 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
   __shared__ carl_brax_sys_t s;
   __shared__ Topo tp;
   __shared__ Packed pk;
+  __shared__ int head_done[kMaxWavesPerWg3];  // fragment hand-over flags (MODE 1, see below)
+  if (threadIdx.x < kMaxWavesPerWg3) head_done[threadIdx.x] = 0;
   extern __shared__ vf4 lds_dyn[];  // per wavefront: body records, then the float rows (16-byte aligned slices)
   {  // model table -> LDS, once per workgroup: every load in flight before the first LDS write (a
      // load-store loop paid one HBM/L2 round trip per 256 bytes: ~15 us of a per-call step)
@@ -1330,24 +1349,22 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
   char* const my_lds = reinterpret_cast<char*>(lds_dyn) + (size_t)wave * lay.bytes(kEnvs);  // this wavefront's slice
   const Lds m{my_lds, reinterpret_cast<float*>(my_lds + lay.body_bytes(kEnvs)), lay,
               lane_ok ? tid / kSub : kEnvs - 1, lane_ok ? tid % kSub : kLanes};
-  const int gwave = (int)blockIdx.x * ((int)blockDim.x >> 6) + wave;  // global wavefront = group of kEnvs envs
-  const int env = gwave * kEnvs + m.env;
-  if (gwave * kEnvs >= b.n_lanes) return;  // a wavefront past the end of the batch
-  const bool active = lane_ok && env < b.n_lanes;
-  const bool lead = active && m.sub == 0;  // the lane that writes the env's scalars
-  const uint64_t genv = (uint64_t)(b.lane_offset + env);
   const size_t n = (size_t)b.n_lanes;
   const int S = CARL_BRAX_LINK_RECORD * s.n_links;  // floats of the env's record in HBM
-  LaneState r{};
   const bool goal = s.goal_mode != 0 && b.goal_pos != nullptr;
-  if (active) {
-    r.cidx = b.ctx_idx[env];
-    r.episode = b.episode[env];
-    r.elapsed = b.elapsed[env];
-    r.ep_return = b.ep_return[env];
-  }
+  const int n_waves = (int)blockDim.x >> 6;
 
   if constexpr (MODE == 0) {
+    const int gwave = (int)blockIdx.x * n_waves + wave;  // global wavefront = group of kEnvs envs
+    const int env = gwave * kEnvs + m.env;
+    if (gwave * kEnvs >= b.n_lanes) return;  // a wavefront past the end of the batch
+    const bool active = lane_ok && env < b.n_lanes;
+    const uint64_t genv = (uint64_t)(b.lane_offset + env);
+    LaneState r{};
+    if (active) {
+      r.cidx = b.ctx_idx[env];
+      r.episode = b.episode[env];
+    }
     const bool go = active && (mask == nullptr || mask[env] != 0);
     if (ballot(go) == 0ull) return;
     if (go) r.cidx = select_context(b, r.cidx, genv, r.episode);
@@ -1379,6 +1396,69 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
     if (reset_obs != nullptr) record_out(reset_obs, (size_t)env, s.obs_dim, m, go);
     return;
   } else {
+    // ---- which (group, step range) fragments this wavefront runs.  A group = kEnvs envs = one wavefront's worth.
+    // The workgroup owns the groups [g_lo, g_hi); with no more groups than wavefronts each wavefront runs one group for
+    // all n_steps steps.  With more (a batch larger than the chip holds at once: the host then launches exactly
+    // the resident number of workgroups) every wavefront lives for a whole launch and its latency-bound step
+    // chain sets the pace, so "1.52 groups per wavefront" used to cost TWO full rounds (Ant, 32 768 envs: 4 682 groups on
+    // 3 072 resident wavefronts).  Here the workgroup's G x n_steps group-steps, laid out group-major, are cut into
+    // one contiguous piece per wavefront: whole groups, plus at most the TAIL of one group at the piece's start and
+    // the HEAD of one at its end.  A wavefront runs its head fragment FIRST (then stores the group exactly as at the
+    // end of a launch and raises its LDS flag), its whole groups, and its tail fragment LAST (after the previous
+    // wavefront's flag: that head was the first thing it did, n_steps <= piece length earlier).  A fragment
+    // boundary is what a launch boundary is -- state record and episode scalars through HBM, pose rounded at every
+    // env step -- so results are bit-identical to one launch per group; both wavefronts are in one workgroup,
+    // i.e. co-resident on one CU, so the wait cannot deadlock.
+    const int T = n_steps;
+    const int n_groups = ((int)b.n_lanes + kEnvs - 1) / kEnvs;
+    const int g_lo = (int)(((long long)blockIdx.x * n_groups) / (long long)gridDim.x);
+    const int G = (int)(((long long)(blockIdx.x + 1) * n_groups) / (long long)gridDim.x) - g_lo;
+    long long p0, p1;  // this wavefront's piece of the workgroup's G * T group-steps
+    if (G <= n_waves) {
+      p0 = (long long)wave * T;
+      p1 = wave < G ? p0 + T : p0;
+    } else {
+      p0 = ((long long)wave * G * T) / n_waves;
+      p1 = ((long long)(wave + 1) * G * T) / n_waves;
+    }
+    const int k0 = (int)(p0 / T), s0 = (int)(p0 % T), k1 = (int)(p1 / T), s1 = (int)(p1 % T);
+    const int ka = k0 + (s0 > 0 ? 1 : 0), n_whole = k1 > ka ? k1 - ka : 0;
+    const int n_frag = (s1 > 0 ? 1 : 0) + n_whole + (s0 > 0 ? 1 : 0);
+    const float dt_env = s.dt * (float)s.n_frames;
+    const SubK K = make_subk(s, tp, pk);
+    const LinkWords W = load_words(pk, K, m.sub);
+    const int n_frames = __builtin_amdgcn_readfirstlane(s.n_frames);
+    for (int k = m.sub; k < 6; k += kSub) m.at(m.lay.zero + k) = 0.0f;  // (the first phase_sync below orders it)
+    for (int fi = 0; fi < n_frag; ++fi) {
+    int grp, t_lo = 0, t_hi = T;
+    bool wait_head = false, signal_head = false;
+    {
+      int ff = fi;
+      if (s1 > 0 && ff == 0) {
+        grp = k1; t_hi = s1; signal_head = true;
+      } else {
+        ff -= (s1 > 0 ? 1 : 0);
+        if (ff < n_whole) grp = ka + ff;
+        else { grp = k0; t_lo = s0; wait_head = true; }
+      }
+    }
+    const int gwave = g_lo + grp;
+    const int env = gwave * kEnvs + m.env;
+    const bool active = lane_ok && env < b.n_lanes;
+    const bool lead = active && m.sub == 0;  // the lane that writes the env's scalars
+    const uint64_t genv = (uint64_t)(b.lane_offset + env);
+    if (wait_head) {  // the head of this group: the previous wavefront's first fragment
+      while (__hip_atomic_load(&head_done[wave - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0)
+        __builtin_amdgcn_s_sleep(16);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    LaneState r{};
+    if (active) {
+      r.cidx = b.ctx_idx[env];
+      r.episode = b.episode[env];
+      r.elapsed = b.elapsed[env];
+      r.ep_return = b.ep_return[env];
+    }
     record_load(b.state + (size_t)env * S, m, s.n_links, active);
     r.ctx = load_ctx<TASK>(s, b, m, r.cidx, active);
     if (goal && active) {
@@ -1386,12 +1466,7 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
       r.pos_x = b.goal_pos[env];
       r.pos_y = b.goal_pos[n + env];
     }
-    const float dt_env = s.dt * (float)s.n_frames;
-    const SubK K = make_subk(s, tp, pk);
-    const LinkWords W = load_words(pk, K, m.sub);
-    const int n_frames = __builtin_amdgcn_readfirstlane(s.n_frames);
-    for (int k = m.sub; k < 6; k += kSub) m.at(m.lay.zero + k) = 0.0f;  // (the first phase_sync below orders it)
-    for (int t = 0; t < n_steps; ++t) {
+    for (int t = t_lo; t < t_hi; ++t) {
       const size_t step_off = (size_t)t * n;
       record_in(static_cast<const float*>(io.action) + step_off * s.n_act, (size_t)env, s.n_act, m, active);
       // actuator.to_tau: tau = 0, then every actuator adds gear * clip(action) to its dof
@@ -1543,6 +1618,12 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
         }
       }
     }
+    if (signal_head) {  // the group continues in the next wavefront: everything above is in memory before the flag
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      if (tid == 0) __hip_atomic_store(&head_done[wave], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    phase_sync();  // the next fragment reloads this wavefront's rows
+    }  // fragments
   }
 }
 
@@ -1552,7 +1633,7 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
 // out, as MULTI = false does for the Euler-angle joints.  Task models always have a hinge-less last link,
 // so TASK implies MULTI.
 template <int MODE, bool MULTI, int K, bool TASK = false>
-__global__ void __launch_bounds__(kMaxThreads) __attribute__((amdgpu_waves_per_eu(CARL_BRAX_WAVES_PER_EU(MULTI)))) brax_kernel(const carl_batch_t b, const carl_brax_sys_t* __restrict__ sys_dev,
+__global__ void __launch_bounds__(kLanes * max_waves_per_wg(MULTI)) __attribute__((amdgpu_waves_per_eu(CARL_BRAX_WAVES_PER_EU(MULTI)))) brax_kernel(const carl_batch_t b, const carl_brax_sys_t* __restrict__ sys_dev,
                                                       const Prepared prep, const carl_step_io_t io,
                                                       const uint8_t* __restrict__ mask, float* __restrict__ reset_obs,
                                                       const int n_steps) {

@@ -177,16 +177,48 @@ int launch_brax(const carl_batch_t* b, const carl_brax_sys_t* sd, const carl_bra
   // CARL_BRAX_WAVES_PER_EU): take the SMALLEST
   // workgroup that gets there LDS-wise (or as close as LDS allows) -- small workgroups retire independently, larger
   // ones cost the launch's tail (Ant, 4 wavefronts per workgroup: 2.97e8 -> 2.57e8 env-steps/s)
+  // MODE 1 (step / rollout) with more groups (a group = one wavefront's `envs` envs) than the chip holds at once:
+  // launch exactly the resident number of workgroups; each deals its share of the groups to its wavefronts in
+  // equal (group, step-range) pieces (brax_kernels.hip.h: run(), "fragments").  Then fewer, larger workgroups
+  // lose less to the rounding of groups per workgroup: take the size with the smallest ceil(groups per
+  // workgroup) / wavefronts.
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+      n_cu = v;
+    else
+      n_cu = 256;
+  }
+  const int max_w = carl::brax::max_waves_per_wg(multi);
+  const int n_groups = (b->n_lanes + envs - 1) / envs;
+  int per_cu_of[16] = {0};
   int W = 1, best = 0;
-  for (int w = 1; w <= carl::brax::kMaxWavesPerWg; ++w) {
+  for (int w = 1; w <= max_w; ++w) {
     const size_t wg = (size_t)w * wave_bytes + static_lds;
     if (wg > 160 * 1024) break;
     if (w > 1 && (long long)(w - 1) * envs >= b->n_lanes) break;  // a small batch: no empty wavefronts
     int per_cu = (int)((160 * 1024) / wg) * w;                     // resident wavefronts per CU, LDS-wise
     if (per_cu > 4 * CARL_BRAX_WAVES_PER_EU(multi)) per_cu = 4 * CARL_BRAX_WAVES_PER_EU(multi);
+    per_cu -= per_cu % w;  // whole workgroups
+    per_cu_of[w] = per_cu;
     if (per_cu > best) {
       best = per_cu;
       W = w;
+    }
+  }
+  int grid = (n_groups + W - 1) / W;
+  if (MODE == 1 && (long long)n_groups > (long long)n_cu * best) {  // more than one "round": the balanced schedule
+    double best_cost = 1e30;
+    for (int w = 1; w <= max_w; ++w) {
+      if (per_cu_of[w] != best) continue;
+      const int n_wg = n_cu * (best / w);
+      const double cost = (double)((n_groups + n_wg - 1) / n_wg) / (double)w;
+      if (cost < best_cost - 1e-9) {
+        best_cost = cost;
+        W = w;
+        grid = n_wg;
+      }
     }
   }
   const size_t sh_bytes = (size_t)W * wave_bytes;
@@ -214,7 +246,6 @@ int launch_brax(const carl_batch_t* b, const carl_brax_sys_t* sd, const carl_bra
   if (sh_bytes > 48 * 1024) {
     if (int e = carl_host::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), sh_bytes, who)) return e;
   }
-  const int grid = (b->n_lanes + envs * W - 1) / (envs * W);
   carl_step_io_t io_v{};
   if (io != nullptr) io_v = *io;
   carl::brax::Prepared prep{};  // topology + derived per-link constants, host-side (microseconds)

@@ -124,6 +124,42 @@ def test_rollout_equals_repeated_step_bit_exact(device):
     assert l1.numel() == int(e1.episodes_done.sum()) > 0
 
 
+@pytest.mark.parametrize("width", [0, 16])
+def test_large_batch_fragment_schedule_equals_repeated_step_bit_exact(device, width):
+    """More env groups than the chip holds wavefronts: the rollout kernel then runs as many workgroups as are resident
+    and cuts each workgroup's (group, step) work into one piece per wavefront -- groups are split between two wavefronts
+    at a step boundary and handed over through the state record (brax_kernels.hip.h: run(), "fragments").  A fused
+    rollout must still be, bit for bit, the sequence of per-call steps (which never split a group), with episodes
+    ending and auto-resetting inside the launch, and every env's counters must come out the same."""
+    s = ant_sys(NAMES)
+    if width:
+        s.lanes_per_env = width  # 4 envs per wavefront: 7 500 groups for 30 000 envs
+    rng = np.random.default_rng(12)
+    n, T = 30000, 7  # 30 000 / 7 envs per wavefront = 4 286 groups > 3 072 resident wavefronts; T not a divisor of anything
+    rows = context_rows(rng, 64)
+    acts = torch.as_tensor(rng.uniform(-1, 1, (T, n, 8)).astype(np.float32), device=device)
+    kw = dict(selector=O.SEL_ROUND_ROBIN, seed=5, max_episode_steps=5)
+    e1, e2 = engine(s, rows, n, device, **kw), engine(s, rows, n, device, **kw)
+    e1.reset()
+    e2.reset()
+    out = e1.rollout(acts, e1.alloc_rollout(T, final_obs=True))
+    for t in range(T):
+        obs, rew, term, trunc = e2.step(acts[t])
+        assert torch.equal(out["obs"][t], obs) and torch.equal(out["reward"][t], rew), t
+        assert torch.equal(out["terminated"][t], term) and torch.equal(out["truncated"][t], trunc), t
+        d = (term | trunc).bool()
+        assert torch.equal(out["final_obs"][t][d], e2.final_obs[d]), t
+    for name in ("state", "elapsed", "ctx_idx", "episode", "n_calls", "ep_return", "episodes_done", "ctx_obs", "last_return",
+                 "last_length"):
+        assert torch.equal(getattr(e1, name), getattr(e2, name)), name
+    assert int(e1.episodes_done.min()) >= 1  # TimeLimit 5 < T: every env finished an episode inside the launch
+    # ... and a second launch continues from the first one's records
+    out2 = e1.rollout(acts[:3].contiguous())
+    for t in range(3):
+        obs, rew, term, trunc = e2.step(acts[t])
+        assert torch.equal(out2["obs"][t], obs) and torch.equal(out2["reward"][t], rew)
+
+
 def test_lane_sharding_is_invariant(device):
     s = ant_sys(NAMES)
     rng = np.random.default_rng(4)

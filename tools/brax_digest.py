@@ -71,7 +71,7 @@ if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[1] == "--dump":
         DUMP = {}
     for f in FAMS:
-        for n, w in ((1024, 0), (200, 16)):
+        for n, w in ((1024, 0), (200, 16), (40000, 0)):
             try:
                 d, ok = digest(f, n, w)
                 print(f"{f:32s} n {n:5d} width {w:2d}  {d}  finite {ok}", flush=True)
