@@ -512,22 +512,32 @@ static __device__ __forceinline__ JointGeom joint_geometry(const carl_brax_sys_t
     g.axx = qrot(rp, V(0.0f, (float)a2, (float)-a1));
   }
   if (rel.w < 0.0) { rel.w = -rel.w; rel.x = -rel.x; }
+  const int nr = MULTI ? wa_hinges(la.word) : 1;
+  // The first float64 arctangent serves both kinds of joint: the twist about the hinge (theta / 2, joint frame x) on a
+  // single-hinge lane, the first Euler angle on a stacked-hinge lane.  A wavefront of a multi-hinge model holds both
+  // kinds, so two separate calls under complementary lane masks cost it two evaluations (~30 float64 instructions each).
+  [[maybe_unused]] double R00 = 0.0, R01 = 0.0, R02 = 0.0;
+  double a_y = rel.x, a_x = rel.w;
+  if (MULTI && nr != 1) {  // rel = Rx(al) Ry(be) Rz(ga): decompose, ga = sign * theta_3 (nr = 0: all locked)
+    R00 = 1.0 - 2.0 * (rel.y * rel.y + rel.z * rel.z);
+    R01 = 2.0 * (rel.x * rel.y - rel.w * rel.z);
+    R02 = fmin(fmax(2.0 * (rel.x * rel.z + rel.w * rel.y), -1.0), 1.0);
+    a_y = -(2.0 * (rel.y * rel.z - rel.w * rel.x));  // -R12
+    a_x = 1.0 - 2.0 * (rel.x * rel.x + rel.y * rel.y);  // R22
+  }
 #ifdef CARL_EXP_BRAX_FAST_ATAN
-  g.theta = 2.0f * atan2_fast((float)rel.x, (float)rel.w);
+  const double a1 = (double)atan2_fast((float)a_y, (float)a_x);
 #else
-  g.theta = (float)(2.0 * atan2_f64(rel.x, rel.w));  // twist about the hinge (joint frame x)
+  const double a1 = atan2_f64(a_y, a_x);
 #endif
+  g.theta = (float)(2.0 * a1);  // (meaningful on single-hinge lanes)
   g.wrel = bc.w - bp.w;
   g.thetadot = dot(g.x_c, g.wrel);
-  const int nr = MULTI ? wa_hinges(la.word) : 1;
-  if (MULTI && nr != 1) {  // rel = Rx(al) Ry(be) Rz(ga): decompose, ga = sign * theta_3 (nr = 0: all locked)
-    const double R00 = 1.0 - 2.0 * (rel.y * rel.y + rel.z * rel.z), R01 = 2.0 * (rel.x * rel.y - rel.w * rel.z);
-    const double R02 = fmin(fmax(2.0 * (rel.x * rel.z + rel.w * rel.y), -1.0), 1.0);
-    const double R12 = 2.0 * (rel.y * rel.z - rel.w * rel.x), R22 = 1.0 - 2.0 * (rel.x * rel.x + rel.y * rel.y);
+  if (MULTI && nr != 1) {
 #ifdef CARL_EXP_BRAX_EULER_F32
-    const float al = atan2_fast((float)-R12, (float)R22), be = asinf((float)R02), ga = atan2_fast((float)-R01, (float)R00);
+    const float al = (float)a1, be = asinf((float)R02), ga = atan2_fast((float)-R01, (float)R00);
 #else
-    const float al = (float)atan2_f64(-R12, R22), be = (float)asin_f64(R02), ga = (float)atan2_f64(-R01, R00);
+    const float al = (float)a1, be = (float)asin_f64(R02), ga = (float)atan2_f64(-R01, R00);
 #endif
     const float sg = (nr == 3) ? s.dof_sign3[i] : 1.0f;
     g.ang[0] = al; g.ang[1] = be; g.ang[2] = sg * ga;
