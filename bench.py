@@ -191,7 +191,8 @@ class Workload:
         for e in self.envs:
             e.reset(seed=0)
         if any(f in BRAX_ENVS for f in self.families):  # launch shape chosen by timing on this batch
-            self.eng.autotune()                          # (results do not depend on it)
+            self.eng.autotune(n_steps=T)                 # (results do not depend on it; probed at the launch length:
+                                                         #  the best width for 20-step launches is not the 2-step one)
         torch.cuda.synchronize()
         self._i = 0
         self.units_per_launch = self.n * T

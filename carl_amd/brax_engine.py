@@ -137,9 +137,12 @@ class BraxVecEngine(VecEngine):
         """Time ``carl_brax_rollout`` on THIS batch for every launchable lane-group width and keep
         the fastest (``sys.lanes_per_env``).  The width is a pure scheduling choice -- results are
         bit-identical across widths (tests/test_gpu_brax.py) -- but the best one depends on the
-        batch size: workgroups live for the whole launch, so what matters is how evenly
-        ceil(N / envs_per_wave) workgroups fill the 2 048 resident wave slots of the chip as well as
-        the instruction count per wave.  All engine state is saved and restored around the probe."""
+        batch size AND on the launch length: what matters is how evenly ceil(N / envs_per_wave) groups
+        fill the resident wave slots of the chip, the instruction count per wave, and -- for batches
+        larger than the chip holds at once -- how the kernel's (group, step-range) fragments divide
+        (Halfcheetah x 32 768: width 4 wins a 2-step probe, width 7 is 10 % faster at 20 steps:
+        ``tools/autotune_probe.py``).  Pass the ``n_steps`` the launches will have (per-call stepping:
+        the default).  All engine state is saved and restored around the probe."""
         saved = {k: getattr(self, k).clone() for k in ("state", "elapsed", "ctx_idx", "episode", "n_calls", "ep_return",
                                                       "last_return", "last_length", "episodes_done", "obs", "ctx_obs")}
         if self.goal_pos is not None:

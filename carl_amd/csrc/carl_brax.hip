@@ -208,7 +208,10 @@ int launch_brax(const carl_batch_t* b, const carl_brax_sys_t* sd, const carl_bra
     }
   }
   int grid = (n_groups + W - 1) / W;
-  if (MODE == 1 && (long long)n_groups > (long long)n_cu * best) {  // more than one "round": the balanced schedule
+  // (launches of fewer than 4 env steps keep one wavefront per group, dispatched as slots free up: a fragment
+  // boundary costs about one env step, which such a launch cannot amortise -- measured, tools/brax_per_call.py:
+  // Ant x 32 768, 2-step launches 205 us as groups vs 226 us as fragments; 5-step launches 452 vs 411 us)
+  if (MODE == 1 && n_steps >= 4 && (long long)n_groups > (long long)n_cu * best) {  // more than one "round": the balanced schedule
     double best_cost = 1e30;
     for (int w = 1; w <= max_w; ++w) {
       if (per_cu_of[w] != best) continue;

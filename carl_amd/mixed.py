@@ -136,10 +136,10 @@ class MixedVecEngine:
             j.record(s)
             cur.wait_event(j)
 
-    def autotune(self) -> None:
+    def autotune(self, n_steps: int = 2) -> None:
         for p in self.parts:
             if hasattr(p, "autotune"):
-                p.autotune()
+                p.autotune(n_steps=n_steps)
 
     @property
     def ctx_idx(self) -> list[torch.Tensor]:
