@@ -15,10 +15,10 @@
 // second round with one busy lane per env costs a whole round: one lane per link keeps every phase
 // to a single round.  32 768 Ant envs are 4 682 wavefronts = 4.6 per SIMD, where the earlier
 // one-lane-per-env kernel (r01c) had 512 wavefronts for 1 024 SIMDs, each walking all links
-// serially through LDS.  An env's maximal-coordinate state (13 floats per link), the per-joint
-// wrenches, masses, joint torques and the action / observation record live in LDS for the whole
-// launch ([row][8 envs]); the n_frames substeps -- and in the fused rollout all T env steps --
-// never touch HBM for state.  A substep is two lockstep phases with a wavefront-wide LDS
+// serially through LDS.  An env's maximal-coordinate state (one 80-byte record per link: pose 7
+// doubles, velocity 6 floats), the per-joint wrenches, masses, joint torques and the action /
+// observation record ([row][envs] float rows) live in LDS for the whole launch; the n_frames substeps
+// -- and in the fused rollout all T env steps of a fragment -- never touch HBM for state.  A substep is two lockstep phases with a wavefront-wide LDS
 // hand-over between them:
 //   A  per joint:  joint geometry -> spring/damper/limit/actuator wrench on the child and the
 //                  reaction on the parent, written to the joint's own wrench rows (no atomics);
