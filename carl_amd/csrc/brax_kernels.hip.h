@@ -751,7 +751,6 @@ static __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const T
   phase_sync();
   // phase B -- per body: wrench sum, semi-implicit Euler, its contacts, integrate
   const float dl = K.dl, da = c.da, inv_dt = K.inv_dt, dt = K.dt;
-  const v3 n = V(0, 0, 1);
   uint32_t wb = W.wb, wch = W.wch;
 #ifdef CARL_EXP_BRAX_NO_PHASE_B
   for (int i = L; i < L; i += kSub) {
@@ -822,23 +821,29 @@ static __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const T
       const float depth =
           (float)((double)radius - (b.p.z + (R20 * (double)off.x + R21 * (double)off.y + R22 * (double)off.z)));
       if (!(depth > 0.0f)) continue;
+      // (the plane normal n = e_z is folded in by hand: `dot(n, x)`, `cross(r, n)`, `n * imp` spelled with n as a
+      // vector leave the multiplications by its zeros in the instruction stream -- 0 * x is not 0 for IEEE)
       const v3 ro = qrot(rf, off);
       const v3 r = V(ro.x, ro.y, ro.z - radius);
       const v3 rel = b.v + cross(b.w, r);
-      const float vn = dot(n, rel);
-      const float ang = dot(n, cross(apply_inv_inertia(s, i, rf, cross(r, n), iso, qb.z), r));
+      const float vn = rel.z;  // n . rel
+      const v3 in = apply_inv_inertia(s, i, rf, V(r.y, -r.x, 0.0f), iso, qb.z);  // I^-1 (r x n)
+      const float ang = in.x * r.y - in.y * r.x;                                  // n . (I^-1 (r x n) x r)
       const float imp = div_fast(-(1.0f + c.elasticity) * vn + K.erp * depth * inv_dt, inv_m + ang);
       if (!(imp > 0.0f) || !(vn < 0.0f)) continue;
       hit |= 1u << j;
-      v3 J = n * imp;
-      const v3 vt = rel - n * vn;
-      const float vt_len = sqrtf(dot(vt, vt));
+      float Jx = 0.0f, Jy = 0.0f;  // J = n imp - dir imp_d, dir = the tangential velocity's direction (dir.z = 0)
+      const float vt_len = sqrtf(rel.x * rel.x + rel.y * rel.y);
       if (vt_len > 1e-9f) {
-        const v3 dir = vt * __builtin_amdgcn_rcpf(vt_len);
-        const float ang_d = dot(dir, cross(apply_inv_inertia(s, i, rf, cross(r, dir), iso, qb.z), r));
+        const float il = __builtin_amdgcn_rcpf(vt_len), dx = rel.x * il, dy = rel.y * il;
+        const v3 id = apply_inv_inertia(s, i, rf, V(-r.z * dy, r.z * dx, r.x * dy - r.y * dx), iso, qb.z);  // I^-1 (r x dir)
+        const v3 c2 = cross(id, r);
+        const float ang_d = dx * c2.x + dy * c2.y;
         const float imp_d = fminf(div_fast(vt_len, inv_m + ang_d), c.friction * imp);
-        J = J - dir * imp_d;
+        Jx = -dx * imp_d;
+        Jy = -dy * imp_d;
       }
+      const v3 J = V(Jx, Jy, imp);
       cdv = cdv + J * inv_m;
       cdw = cdw + apply_inv_inertia(s, i, rf, cross(r, J), iso, qb.z);
       cnt += 1.0f;
