@@ -109,6 +109,11 @@ __host__ __device__ __forceinline__ v3 qrot(qt q, v3 v) {
   const v3 t = cross(u, v) * 2.0f;
   return v + t * q.w + cross(u, t);
 }
+// q rotating (0, y, z)
+__host__ __device__ __forceinline__ v3 qrot_yz(qt q, float y, float z) {
+  const v3 t = V(q.y * z - q.z * y, -(q.x * z), q.x * y) * 2.0f;  // 2 u x v
+  return V(t.x * q.w + (q.y * t.z - q.z * t.y), y + t.y * q.w + (q.z * t.x - q.x * t.z), z + t.z * q.w + (q.x * t.y - q.y * t.x));
+}
 __device__ __forceinline__ qt qaxis(int k, float angle) {
   float s, c;
   sincos_fast(0.5f * angle, s, c);
@@ -146,6 +151,11 @@ __device__ __forceinline__ qtd qmul(qtd a, qtd b) {
              a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x, a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w};
 }
 __device__ __forceinline__ qtd qconj(qtd a) { return qtd{a.w, -a.x, -a.y, -a.z}; }
+// (0, w) (x) b: the quaternion product with a pure-vector left factor, without the four multiplications by its zero
+__device__ __forceinline__ qtd qmul_vec(v3d w, qtd b) {
+  return qtd{-(w.x * b.x) - w.y * b.y - w.z * b.z, w.x * b.w + w.y * b.z - w.z * b.y,
+             w.y * b.w - w.x * b.z + w.z * b.x, w.z * b.w + w.x * b.y - w.y * b.x};
+}
 __device__ __forceinline__ v3d qrot(qtd q, v3d v) {
   const v3d u = D(q.x, q.y, q.z);
   const v3d t = cross(u, v) * 2.0;
@@ -509,7 +519,7 @@ static __device__ __forceinline__ JointGeom joint_geometry(const carl_brax_sys_t
     const double a1 = 2.0 * (rel.x * rel.y + rel.w * rel.z), a2 = 2.0 * (rel.x * rel.z - rel.w * rel.y);
     g.x_c = xaxis(tof(rcd));
     g.x_p = xaxis(rp);
-    g.axx = qrot(rp, V(0.0f, (float)a2, (float)-a1));
+    g.axx = qrot_yz(rp, (float)a2, (float)-a1);
   }
   if (rel.w < 0.0) { rel.w = -rel.w; rel.x = -rel.x; }
   const int nr = MULTI ? wa_hinges(la.word) : 1;
@@ -554,7 +564,7 @@ static __device__ __forceinline__ JointGeom joint_geometry(const carl_brax_sys_t
       const bool pole = !(h2 > 1e-20f);
       const float ih = pole ? 0.0f : __builtin_amdgcn_rsqf(h2);
       const float ca = pole ? 1.0f : cacb * ih, sa = sacb * ih;
-      g.axis[1] = qrot(rp, V(0.0f, ca, sa));
+      g.axis[1] = qrot_yz(rp, ca, sa);
       g.axis[2] = qrot(rp, V(sb, -sacb, cacb)) * sg;
     }
     const float w0 = dot(g.wrel, g.axis[0]), w1 = dot(g.wrel, g.axis[1]), w2 = dot(g.wrel, g.axis[2]);
@@ -870,7 +880,7 @@ static __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const T
 #endif
     const double dtd = (double)dt;
     b.p = D(fma((double)b.v.x, dtd, b.p.x), fma((double)b.v.y, dtd, b.p.y), fma((double)b.v.z, dtd, b.p.z));
-    const qtd dq = qmul(qtd{0.0, (double)b.w.x, (double)b.w.y, (double)b.w.z}, b.r);
+    const qtd dq = qmul_vec(D((double)b.w.x, (double)b.w.y, (double)b.w.z), b.r);
     const double h = 0.5 * dtd;
     qtd r2 = qtd{fma(h, dq.w, b.r.w), fma(h, dq.x, b.r.x), fma(h, dq.y, b.r.y), fma(h, dq.z, b.r.z)};
     const double inv = rsqrt_f64(r2.w * r2.w + r2.x * r2.x + r2.y * r2.y + r2.z * r2.z);
