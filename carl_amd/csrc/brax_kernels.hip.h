@@ -392,6 +392,61 @@ struct Prepared {
   Packed packed;
 };
 
+// ---- the fragment schedule of a step / rollout launch (Group::run, MODE 1), as plain integer functions shared by the
+// kernel and the host (carl_brax_fragment_plan: the CPU tests check coverage, order and hand-over on it).
+// A group = one wavefront's worth of envs.  Workgroup `wg` of `n_wg` owns the groups [g_lo, g_lo + G).
+struct WgShare {
+  int g_lo, G;
+};
+__host__ __device__ inline WgShare wg_share(int n_groups, int n_wg, int wg) {
+  const int lo = (int)(((long long)wg * n_groups) / n_wg);
+  return WgShare{lo, (int)(((long long)(wg + 1) * n_groups) / n_wg) - lo};
+}
+// With no more groups than wavefronts each wavefront runs one group for all T steps.  With more, the workgroup's
+// G x T group-steps, laid out group-major, are cut into one contiguous piece [p0, p1) per wavefront (G >= n_waves
+// makes every piece at least T long): whole groups, plus at most the TAIL [s0, T) of group k0 at its start and the
+// HEAD [0, s1) of group k1 at its end.
+struct Piece {
+  int k0, s0, k1, s1, ka, n_whole, n_frag;
+};
+__host__ __device__ inline Piece make_piece(int G, int T, int n_waves, int wave) {
+  long long p0, p1;
+  if (G <= n_waves) {
+    p0 = (long long)wave * T;
+    p1 = wave < G ? p0 + T : p0;
+  } else {
+    p0 = ((long long)wave * G * T) / n_waves;
+    p1 = ((long long)(wave + 1) * G * T) / n_waves;
+  }
+  Piece p;
+  p.k0 = (int)(p0 / T); p.s0 = (int)(p0 % T); p.k1 = (int)(p1 / T); p.s1 = (int)(p1 % T);
+  p.ka = p.k0 + (p.s0 > 0 ? 1 : 0);
+  p.n_whole = p.k1 > p.ka ? p.k1 - p.ka : 0;
+  p.n_frag = (p.s1 > 0 ? 1 : 0) + p.n_whole + (p.s0 > 0 ? 1 : 0);
+  return p;
+}
+// Fragment fi of a piece, in the order the wavefront runs them: the head fragment FIRST (the group is then stored as at
+// the end of a launch and the wavefront's flag raised), the whole groups, the tail fragment LAST (after the previous
+// wavefront's flag).  `grp` is relative to the workgroup's first group.
+struct Fragment {
+  int grp, t_lo, t_hi;
+  bool wait_head, signal_head;
+};
+__host__ __device__ inline Fragment fragment_of(const Piece& p, int T, int fi) {
+  Fragment f{0, 0, T, false, false};
+  if (p.s1 > 0 && fi == 0) {
+    f.grp = p.k1; f.t_hi = p.s1; f.signal_head = true;
+    return f;
+  }
+  const int ff = fi - (p.s1 > 0 ? 1 : 0);
+  if (ff < p.n_whole) {
+    f.grp = p.ka + ff;
+  } else {
+    f.grp = p.k0; f.t_lo = p.s0; f.wait_head = true;
+  }
+  return f;
+}
+
 template <int kSub>
 struct Group {
 static constexpr int kEnvs = kLanes / kSub;  // envs per wavefront
@@ -1448,37 +1503,19 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
     // i.e. co-resident on one CU, so the wait cannot deadlock.
     const int T = n_steps;
     const int n_groups = ((int)b.n_lanes + kEnvs - 1) / kEnvs;
-    const int g_lo = (int)(((long long)blockIdx.x * n_groups) / (long long)gridDim.x);
-    const int G = (int)(((long long)(blockIdx.x + 1) * n_groups) / (long long)gridDim.x) - g_lo;
-    long long p0, p1;  // this wavefront's piece of the workgroup's G * T group-steps
-    if (G <= n_waves) {
-      p0 = (long long)wave * T;
-      p1 = wave < G ? p0 + T : p0;
-    } else {
-      p0 = ((long long)wave * G * T) / n_waves;
-      p1 = ((long long)(wave + 1) * G * T) / n_waves;
-    }
-    const int k0 = (int)(p0 / T), s0 = (int)(p0 % T), k1 = (int)(p1 / T), s1 = (int)(p1 % T);
-    const int ka = k0 + (s0 > 0 ? 1 : 0), n_whole = k1 > ka ? k1 - ka : 0;
-    const int n_frag = (s1 > 0 ? 1 : 0) + n_whole + (s0 > 0 ? 1 : 0);
+    const WgShare share = wg_share(n_groups, (int)gridDim.x, (int)blockIdx.x);
+    const int g_lo = share.g_lo;
+    const Piece piece = make_piece(share.G, T, n_waves, wave);
+    const int n_frag = piece.n_frag;
     const float dt_env = s.dt * (float)s.n_frames;
     const SubK K = make_subk(s, tp, pk);
     const LinkWords W = load_words(pk, K, m.sub);
     const int n_frames = __builtin_amdgcn_readfirstlane(s.n_frames);
     for (int k = m.sub; k < 6; k += kSub) m.at(m.lay.zero + k) = 0.0f;  // (the first phase_sync below orders it)
     for (int fi = 0; fi < n_frag; ++fi) {
-    int grp, t_lo = 0, t_hi = T;
-    bool wait_head = false, signal_head = false;
-    {
-      int ff = fi;
-      if (s1 > 0 && ff == 0) {
-        grp = k1; t_hi = s1; signal_head = true;
-      } else {
-        ff -= (s1 > 0 ? 1 : 0);
-        if (ff < n_whole) grp = ka + ff;
-        else { grp = k0; t_lo = s0; wait_head = true; }
-      }
-    }
+    const Fragment frag = fragment_of(piece, T, fi);
+    const int grp = frag.grp, t_lo = frag.t_lo, t_hi = frag.t_hi;
+    const bool wait_head = frag.wait_head, signal_head = frag.signal_head;
     const int gwave = g_lo + grp;
     const int env = gwave * kEnvs + m.env;
     const bool active = lane_ok && env < b.n_lanes;

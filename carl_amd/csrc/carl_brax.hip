@@ -295,6 +295,23 @@ int carl_brax_rollout(const carl_batch_t* batch, const carl_brax_sys_t* sys_dev,
                         "carl_brax_rollout");
 }
 
+int carl_brax_fragment_plan(int32_t n_groups, int32_t n_workgroups, int32_t waves_per_workgroup, int32_t n_steps,
+                            int32_t workgroup, int32_t wave, int32_t* out, int32_t cap) {
+  if (n_groups < 1 || n_workgroups < 1 || waves_per_workgroup < 1 || n_steps < 1 || workgroup < 0 ||
+      workgroup >= n_workgroups || wave < 0 || wave >= waves_per_workgroup || (cap > 0 && out == nullptr)) {
+    fail(CARL_ERR_INVALID_ARGUMENT, "carl_brax_fragment_plan: argument out of range");
+    return -1;
+  }
+  const carl::brax::WgShare sh = carl::brax::wg_share(n_groups, n_workgroups, workgroup);
+  const carl::brax::Piece p = carl::brax::make_piece(sh.G, n_steps, waves_per_workgroup, wave);
+  for (int fi = 0; fi < p.n_frag && fi < cap; ++fi) {
+    const carl::brax::Fragment f = carl::brax::fragment_of(p, n_steps, fi);
+    int32_t* o = out + 5 * fi;
+    o[0] = sh.g_lo + f.grp; o[1] = f.t_lo; o[2] = f.t_hi; o[3] = f.wait_head ? 1 : 0; o[4] = f.signal_head ? 1 : 0;
+  }
+  return p.n_frag;
+}
+
 int carl_brax_lane_widths(const carl_brax_sys_t* sys_host, int32_t* widths_out, int32_t cap) {
   if (sys_host == nullptr || widths_out == nullptr || cap < 1) {
     fail(CARL_ERR_INVALID_ARGUMENT, "carl_brax_lane_widths: NULL argument");

@@ -402,6 +402,16 @@ int carl_brax_rollout(const carl_batch_t* batch, const carl_brax_sys_t* sys_dev,
  * ascending; returns their number (<= cap).  Results do not depend on the width: it is a pure
  * scheduling choice (carl_amd.brax_engine.BraxVecEngine.autotune times them on the real batch). */
 int carl_brax_lane_widths(const carl_brax_sys_t* sys_host, int32_t* widths_out, int32_t cap);
+/* How a step / rollout launch of a batch larger than the chip holds at once is divided (no reference counterpart: the
+ * reference steps its envs in vmapped lock-step, carl/envs/brax/carl_brax_env.py:163-190).  A "group" is one
+ * wavefront's worth of envs; workgroup w of n_workgroups owns a contiguous share of the n_groups groups and cuts its
+ * groups x n_steps group-steps into one contiguous piece per wavefront.  Writes, for (workgroup, wave), the fragments
+ * in the order the wavefront runs them -- five int32 each: global group, first step, one-past-last step, waits for the
+ * previous wavefront's hand-over (0/1), hands over to the next wavefront (0/1) -- and returns their number (-1: bad
+ * argument).  Pure integer arithmetic, no device access: it is the same code the kernel runs (tests/test_abi.py checks
+ * that every group-step is run exactly once, in step order, and that no hand-over can wait on a later one). */
+int carl_brax_fragment_plan(int32_t n_groups, int32_t n_workgroups, int32_t waves_per_workgroup, int32_t n_steps,
+                            int32_t workgroup, int32_t wave, int32_t* fragments_out, int32_t cap);
 
 /* ======================= context sets on the device =======================
  * Replaces ContextSampler.sample_contexts (carl/context/sampler.py:45-61: per-feature draws from

@@ -6,6 +6,7 @@ import re
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -181,3 +182,61 @@ def test_rollout_variant_is_answered_on_the_host():
     b.flags = _lib.FLAG_ROLLOUT_DIRECT
     assert lib.carl_rollout_variant(C.byref(b)) == _lib.ROLLOUT_DIRECT_FLAG
     assert lib.carl_rollout_variant(None) == -1 and b"NULL" in lib.carl_last_error()
+
+
+def _plan(lib, n_groups, n_wg, n_waves, T, wg, wave):
+    out = (C.c_int32 * (5 * 1024))()
+    k = lib.carl_brax_fragment_plan(n_groups, n_wg, n_waves, T, wg, wave, out, 1024)
+    assert 0 <= k <= 1024
+    return [tuple(out[5 * i: 5 * i + 5]) for i in range(k)]
+
+
+def test_brax_fragment_schedule_covers_every_group_step_once_and_cannot_deadlock():
+    """The (group, step-range) schedule of a Brax step / rollout launch (include/carl_amd.h: carl_brax_fragment_plan --
+    the integer functions the kernel itself runs).  For many (groups, workgroups, wavefronts, steps): every group-step
+    is run exactly once; a group is split between at most two wavefronts of ONE workgroup, head before tail; a
+    wavefront raises its hand-over flag in its FIRST fragment and waits only in its LAST, for the PREVIOUS wavefront
+    (so no wait can depend on a later one: no deadlock among co-resident wavefronts); pieces of a workgroup with more
+    groups than wavefronts differ by at most one step (balance)."""
+    from carl_amd import _lib
+
+    lib = _lib.load()
+    rng = np.random.default_rng(0)
+    cases = [(4682, 256, 12, 20), (6554, 256, 8, 20), (4286, 256, 12, 7), (7500, 256, 12, 7), (3, 1, 4, 5), (13, 1, 12, 2),
+             (100, 7, 3, 1), (18, 1, 12, 4), (12, 1, 12, 9), (5, 5, 1, 3)]
+    cases += [(int(rng.integers(1, 400)), int(rng.integers(1, 9)), int(rng.integers(1, 13)), int(rng.integers(1, 40)))
+              for _ in range(200)]
+    for n_groups, n_wg, n_waves, T in cases:
+        n_wg = min(n_wg, n_groups)
+        seen = np.zeros((n_groups, T), np.int32)
+        for wg in range(n_wg):
+            g_lo, g_hi = wg * n_groups // n_wg, (wg + 1) * n_groups // n_wg
+            G = g_hi - g_lo
+            plans = [_plan(lib, n_groups, n_wg, n_waves, T, wg, w) for w in range(n_waves)]
+            lengths = []
+            for w, frags in enumerate(plans):
+                lengths.append(sum(t1 - t0 for _, t0, t1, _, _ in frags))
+                for i, (g, t0, t1, wait, signal) in enumerate(frags):
+                    assert g_lo <= g < g_hi and 0 <= t0 < t1 <= T, (n_groups, n_wg, n_waves, T, wg, w, frags)
+                    seen[g, t0:t1] += 1
+                    if signal:  # a head: first thing the wavefront does, starts at step 0, continues in wavefront w + 1
+                        assert i == 0 and t0 == 0 and t1 < T and w + 1 < n_waves
+                        nxt = plans[w + 1][-1]
+                        assert nxt[0] == g and nxt[1] == t1 and nxt[2] == T and nxt[3] == 1
+                    if wait:    # a tail: last thing the wavefront does, ends at T, its head ran in wavefront w - 1
+                        assert i == len(frags) - 1 and t1 == T and t0 > 0 and w > 0
+                        prv = plans[w - 1][0]
+                        assert prv[0] == g and prv[1] == 0 and prv[2] == t0 and prv[4] == 1
+                    if not wait and not signal:
+                        assert (t0, t1) == (0, T)
+                # timing: the head this wavefront waits for (t0 steps long, run first by w - 1) is over before this
+                # wavefront gets to its last fragment, if all wavefronts advance at the same rate
+                if frags and frags[-1][3]:
+                    assert frags[-1][1] <= lengths[-1] - (T - frags[-1][1])
+            if G > n_waves:
+                assert max(lengths) - min(lengths) <= 1 and sum(lengths) == G * T
+            else:
+                assert sorted(lengths, reverse=True) == [T] * G + [0] * (n_waves - G)
+        assert (seen == 1).all(), (n_groups, n_wg, n_waves, T)
+    assert lib.carl_brax_fragment_plan(0, 1, 1, 1, 0, 0, None, 0) == -1
+    assert lib.carl_brax_fragment_plan(10, 2, 4, 5, 2, 0, None, 0) == -1
