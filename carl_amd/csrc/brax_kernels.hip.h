@@ -964,8 +964,10 @@ static __device__ __forceinline__ v3d system_com(const carl_brax_sys_t& s, const
 // qfrc_actuator (the tau rows; `zero_frc`: reset observations see a zero action).  `go`: envs
 // that take part (the calls are wavefront-uniform).  Ends with a phase_sync.
 template <bool MULTI, bool TASK>
+// `com_in` / `mass_in`: the whole-body centre of mass and total mass when the caller has just formed them at this very
+// state (the step's forward reward of reward_on_com models: one 11-link pass less per Humanoid env step).
 static __device__ __forceinline__ void observe(const carl_brax_sys_t& s, const Packed& pk, const Lds& m, bool go,
-                                        bool zero_frc) {
+                                        bool zero_frc, const v3d* com_in = nullptr, float mass_in = 0.0f) {
   const int skip = s.exclude_current_positions;
   // q[from:] as sin ++ cos (inverted double pendulum): the raw angles are written to the sin rows and
   // converted in a second pass below; everything behind them moves back by n_trig rows
@@ -980,7 +982,14 @@ static __device__ __forceinline__ void observe(const carl_brax_sys_t& s, const P
   };
   float M = 1.0f;
   v3d com = D(0, 0, 0);
-  if (MULTI && s.obs_extended && go) com = system_com(s, m, &M);
+  if (MULTI && s.obs_extended) {
+    if (com_in != nullptr) {
+      com = *com_in;
+      M = mass_in;
+    } else if (go) {
+      com = system_com(s, m, &M);
+    }
+  }
   for (int i = m.sub; i < L; i += kSub) {
     if (!go) continue;
     const int P = s.parent[i];
@@ -1560,7 +1569,9 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
       const double x0 = s.reward_on_com ? system_com(s, m, &msum).x : m.pos(0).x - qrot(m.rot(0), tod(f3(s.com[0]))).x;
       for (int f = 0; f < n_frames; ++f) substep<MULTI, TASK>(s, tp, pk, K, W, r.ctx, m);
       const v3d c1 = qrot(m.rot(0), tod(f3(s.com[0])));
-      const double x1 = s.reward_on_com ? system_com(s, m, &msum).x : m.pos(0).x - c1.x, z1d = m.pos(0).z - c1.z;
+      v3d com1 = D(0, 0, 0);
+      if (s.reward_on_com) com1 = system_com(s, m, &msum);
+      const double x1 = s.reward_on_com ? com1.x : m.pos(0).x - c1.x, z1d = m.pos(0).z - c1.z;
       const float z1 = (float)z1d;
       bool healthy = (z1d >= (double)s.healthy_z_lo) && (z1d <= (double)s.healthy_z_hi);
       if (lead && io.branch_sig != nullptr) {  // the step's branch record: the per-link hashes combined in link order
@@ -1574,7 +1585,7 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
       }
       r.elapsed += 1;
       const bool truncated = (b.max_episode_steps > 0) && (r.elapsed >= b.max_episode_steps);
-      observe<MULTI, TASK>(s, pk, m, active, false);
+      observe<MULTI, TASK>(s, pk, m, active, false, s.reward_on_com ? &com1 : nullptr, msum);
       if (s.healthy_q_index >= 0) {  // torso pitch (hopper, walker2d) / pole angle: read from the observation
         const float qa = m.at(m.lay.io + s.healthy_q_index - s.exclude_current_positions);
         healthy = healthy && (qa >= s.healthy_q_lo) && (qa <= s.healthy_q_hi);
