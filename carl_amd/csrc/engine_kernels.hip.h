@@ -959,7 +959,13 @@ __global__ void __launch_bounds__(kStagedThreads) rollout_staged_kernel(const ca
   // 0..3 compute, 4 loader, 5.. storers (wave-uniform).  Eight waves = two per SIMD: every
   // compute wave shares its SIMD with exactly one light helper wave, so no compute wave is
   // slowed more than the others before the chunk barrier.
+#ifdef CARL_TRY_VECTOR_WAVE_ID
   const int wave = threadIdx.x / kWave;
+#else
+  // (readfirstlane: the compiler then KNOWS the role tests below are wavefront-uniform -- scalar branches and scalar
+  // loop control / address arithmetic in the helper waves instead of exec-mask loops over per-lane counters)
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+#endif
   const int storer = wave - (kRolloutLanes / kWave + 1);  // 0..kStorers-1 on storer waves
   const bool compute = wave < kRolloutLanes / kWave;
   const bool loader = wave == kRolloutLanes / kWave;
@@ -998,13 +1004,21 @@ __global__ void __launch_bounds__(kStagedThreads) rollout_staged_kernel(const ca
     r.valid = active;
   }
   __syncthreads();
+  // One chunk loop PER ROLE (the roles are wavefront-uniform: `wave` comes from readfirstlane), each with its own
+  // barrier per chunk -- every wavefront of the workgroup executes the same number of s_barriers.  With one shared
+  // loop body the compiler's wait-count analysis merged the roles' paths at the loop header: the storer block
+  // then waited on vmcnt for loads only the LOADER path has in flight (`s_waitcnt vmcnt(3)` inside the drain loop:
+  // a storer stalled until all but three of ITS stores had completed), and all roles shared one register
+  // allocation.
+  auto run_role = [&](auto role_tag) -> int {
+  constexpr int ROLE = decltype(role_tag)::value;  // 0 compute, 1 loader, 2 storer
   int buf = 0;
   [[maybe_unused]] DenseNext<Fam> nx{};  // dense done handling (PLAIN, kDenseDone families): nothing drawn yet
   [[maybe_unused]] const bool autoreset = (b.flags & CARL_FLAG_AUTORESET) != 0;
   [[maybe_unused]] const int max_steps_eff = max_steps > 0 ? max_steps : 0x7fffffff;
   for (int t0 = 0; t0 < n_steps; t0 += kStageChunk, buf ^= 1) {
     const int steps = min(kStageChunk, n_steps - t0);
-    if (compute) {
+    if constexpr (ROLE == 0) {
       const Action* my = act_buf + buf * kBufActs + threadIdx.x;
       char* rec = out_buf + (size_t)buf * kStageChunk * SK::kStepBytes;
       if constexpr (PLAIN && dense_done_of<Fam>::value) {
@@ -1075,7 +1089,7 @@ __global__ void __launch_bounds__(kStagedThreads) rollout_staged_kernel(const ca
       }
       }
       }
-    } else if (loader) {
+    } else if constexpr (ROLE == 1) {
 #ifndef CARL_EXP_NO_LOADER
       // chunk c+1 (loads issued one iteration ago) -> LDS; then start chunk c+2
       pipe.commit(act_buf + (buf ^ 1) * kBufActs, act, n, lane_base, hl, n_steps);
@@ -1089,6 +1103,10 @@ __global__ void __launch_bounds__(kStagedThreads) rollout_staged_kernel(const ca
     }
     __syncthreads();
   }
+  return buf;
+  };
+  const int buf = compute ? run_role(std::integral_constant<int, 0>{})
+                          : loader ? run_role(std::integral_constant<int, 1>{}) : run_role(std::integral_constant<int, 2>{});
   if (compute) {
     if (active) store_lane<Fam>(b, ctx, lane, r);
   } else if (!loader) {  // records of the last chunk
