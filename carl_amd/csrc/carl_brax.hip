@@ -182,13 +182,11 @@ int launch_brax(const carl_batch_t* b, const carl_brax_sys_t* sd, const carl_bra
   // equal (group, step-range) pieces (brax_kernels.hip.h: run(), "fragments").  Then fewer, larger workgroups
   // lose less to the rounding of groups per workgroup: take the size with the smallest ceil(groups per
   // workgroup) / wavefronts.
-  static int n_cu = 0;
-  if (n_cu == 0) {
+  int n_cu = 256;  // (asked of the current device at every launch: no process-wide cache to go stale in a multi-device process)
+  {
     int dev = 0, v = 0;
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
       n_cu = v;
-    else
-      n_cu = 256;
   }
   const int max_w = carl::brax::max_waves_per_wg(multi);
   const int n_groups = (b->n_lanes + envs - 1) / envs;
