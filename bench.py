@@ -667,6 +667,10 @@ def main():
             "classes": [type(e).__name__ for e in w2.envs],
         }
         if all(f in BRAX_ENVS for f in fams):
+            # the Brax path moves ~1 % of what HBM could: its bound is the vector ALU (committed counters, not measured here)
+            also[name]["bound"] = ("vector ALU: SQ_ACTIVE_INST_VALU per resident wavefront x wavefronts per SIMD = 1.1 (Ant, three per "
+                                   "SIMD) / 0.9 (Humanoid, two) of a SIMD's issue capacity -- profiles/r03_brax_sq_counters.txt; `frac` "
+                                   "above is the HBM fraction of the same launch")
             # double-buffered use: the same contexts as two free-running half-batches (one family: two engines of half
             # the lanes; two families: one engine each), launches overlapping across streams
             w4 = SplitWorkload(fams[0], lanes // 2, Ta, args.buffer_sets, rank, world, device) if len(fams) == 1 else w2
