@@ -681,6 +681,14 @@ def main():
                         "(double-buffered collection): consecutive launches overlap; not the one-stream figure above"}
             if w4 is not w2:
                 del w4
+        elif len(fams) > 1:
+            # a mixed classic-control batch (BASELINE config 3): each family's launch train on its own stream, joined at
+            # the end of the train -- the tail of one family's launch overlaps the head of the other's
+            wall4 = max_over_ranks(w2.train_free_running(K, W, barrier))
+            also[name]["free_running_two_streams"] = {
+                "value": w2.n * world * Ta * K / wall4, "unit": "env-steps/s", "ms_per_step": wall4 / K * 1e3,
+                "note": "each family's launch train on its own HIP stream, joined only at the end of the train: consecutive "
+                        "launches of the two families overlap; not the one-stream figure above"}
         if name == "cartpole" and rank == 0 and world == 1 and not args.no_cpu_baseline:
             # north_star: the CartPole number "next to the reference Python step() timed on the host cores (core
             # count stated) in the same run" -- the restatement of that loop (kind "port"), same context set
