@@ -27,6 +27,7 @@ FLAG_CARTPOLE_RECOMPUTE = 2
 FLAG_ACROBOT_FP32 = 4
 FLAG_AUTORESET_FIRST_STATE = 8
 FLAG_ROLLOUT_DIRECT = 16
+FLAG_BRAX_GENERIC = 32
 ROLLOUT_STAGED, ROLLOUT_DIRECT_SHAPE, ROLLOUT_DIRECT_FLAG = range(3)
 ACTION_I32, ACTION_I64, ACTION_F32 = range(3)
 

@@ -42,7 +42,10 @@ class BraxVecEngine(VecEngine):
         self.goal_pos = self.success = self.first_state = self.branch_sig = None
         self.autoreset_mode = autoreset_mode
         branch_record = bool(kw.pop("branch_record", False))
+        generic = bool(kw.pop("generic_substep", False))  # planar models: step with the general 3-D substep (A/B, tests)
         super().__init__(-1, ctx_table, n_lanes, device, **kw)
+        if generic:
+            self.b.flags |= _lib.FLAG_BRAX_GENERIC
         if autoreset_mode == "first_state":
             self.b.flags |= _lib.FLAG_AUTORESET_FIRST_STATE
             self.first_state = torch.zeros((self.n, self.S), dtype=torch.float32, device=self.device)

@@ -308,7 +308,8 @@ struct alignas(16) LinkA {  // joint phase (spring.joints.resolve) and inverse k
   float jrot[4];            // child-side joint frame in the child frame: joint_rot
   float k_vel, k_limit, k_ang_damp;
   float damping;            // the link's FIRST hinge (dof_start + n_slide): dof_damping, dof_stiffness, dof_lo, dof_hi
-  float stiffness, lo, hi, pad;
+  float stiffness, lo, hi;
+  float axis_sign;          // planar models: +-1, the joint frame's x axis is +-y of the link frame (else 0)
 };
 constexpr uint32_t kWaFree = 1u << 5;
 __host__ __device__ inline int wa_parent(uint32_t w) { return (int)(w & 31u) - 1; }
@@ -362,7 +363,7 @@ inline void build_packed_host(const carl_brax_sys_t& s, const Topo& t, Packed& p
     A.stiffness = hinge ? s.dof_stiffness[d] : 0.0f;
     A.lo = hinge ? s.dof_lo[d] : 0.0f;
     A.hi = hinge ? s.dof_hi[d] : 0.0f;
-    A.pad = 0.0f;
+    A.axis_sign = (s.joint_rot[i][1] == 0.0f && s.joint_rot[i][2] == 0.0f) ? (s.joint_rot[i][3] > 0.0f ? 1.0f : (s.joint_rot[i][3] < 0.0f ? -1.0f : 0.0f)) : 0.0f;
     LinkB& B = pk.b[i];
     const int nch = t.child_begin[i + 1] - t.child_begin[i], nsp = t.coll_begin[i + 1] - t.coll_begin[i];
     mc = nch > mc ? nch : mc;
@@ -945,6 +946,150 @@ static __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const T
   phase_sync();
 }
 
+// ---- the same substep for PLANAR models (Halfcheetah, Hopper, Walker2d: a root on two world slides x, z and a hinge
+// about y, every other link on a hinge about y, all geometry in the y = 0 plane; carl_brax.hip: brax_is_planar).
+// Their state never leaves the plane: rotations are (w, 0, y, 0) -- the half-angle complex number u = w + i y --,
+// angular velocities (0, omega, 0), nothing moves in y.  The general substep still pays for the full 3-D algebra:
+// three float64 quaternion products and two float64 vector rotations per joint, 3-vector cross products everywhere.
+// Here the SAME records, the SAME two phases and the SAME formulas are evaluated with the zero components left
+// out: rotating (ax, ., az) by u is (c ax + s az, -s ax + c az) with c = w^2 - y^2, s = 2 w y; the relative joint
+// rotation is conj(u_p) u_c (with link_rot = identity and joint_rot = "x -> y", the joint-frame products cancel:
+// rel = (W, +-Y, 0, 0), the sign that of the hinge axis); a torque is its y component; the first-order quaternion update is w += -h omega y,
+// y += h omega w.  Pose differences stay float64.  Results agree with the general substep to rounding
+// (tests/test_gpu_brax.py: both paths against each other and against the float64 restatement of the 3-D pipeline).
+template <bool TASK>
+static __device__ __forceinline__ void substep_planar(const carl_brax_sys_t& s, const Topo& tp, const Packed& pk, const SubK& K,
+                                               const LinkWords& W, const LaneCtx& c, const Lds& m) {
+  static_assert(!TASK, "planar models are not task models");
+  const int L = K.L;
+  // phase A -- spring.joints.resolve
+  uint32_t wa = W.wa;
+  for (int i = K.first_joint + m.sub; i < L; i += kSub, wa = (i < L) ? pk.a[min(i, L - 1)].word : wa) {
+    const LinkA& rec = pk.a[i];
+    const int P = wa_parent(wa);
+    const int ns = wa_slides(wa), d0 = wa_dof(wa), d = d0 + ns;
+    const vf4 q0 = ld4(&rec.ac[0]), q1 = ld4(&rec.ap[0]);
+    const Body bc = m.body(i);
+    const Body bp = (P < 0) ? world_body() : m.body(P);
+    const vf4 q4 = ld4(&rec.k_vel), q5 = ld4(&rec.stiffness);  // k_vel k_limit k_ang_damp damping | stiffness lo hi
+    const float tau1 = m.at(m.lay.tau + d);
+    const float tau_s0 = ns > 0 ? m.at(m.lay.tau + d0) : 0.0f, tau_s1 = ns > 0 ? m.at(m.lay.tau + d0 + 1) : 0.0f;
+    const uint32_t sig_lim = m.atu(m.lay.sig + 2 * i + 1);
+    const float k_limit = q4.y, kp = q1.w * c.stiffness_scale;
+    // rotation of both bodies as (cos, sin) of the full angle, float64
+    const double cc = bc.r.w * bc.r.w - bc.r.y * bc.r.y, sc = 2.0 * (bc.r.w * bc.r.y);
+    const double cp = bp.r.w * bp.r.w - bp.r.y * bp.r.y, sp = 2.0 * (bp.r.w * bp.r.y);
+    const double acx = (double)q0.x, acz = (double)q0.z, apx = (double)q1.x, apz = (double)q1.z;
+    const double rcx = cc * acx + sc * acz, rcz = cc * acz - sc * acx;  // anchor - COM, child side, world
+    const double rpx = cp * apx + sp * apz, rpz = cp * apz - sp * apx;  // ... parent side
+    double edx = (bp.p.x - bc.p.x) + (rpx - rcx), edz = (bp.p.z - bc.p.z) + (rpz - rcz);  // A_p - A_c
+    const float rcxf = (float)rcx, rczf = (float)rcz, rpxf = (float)rpx, rpzf = (float)rpz;
+    // anchor velocities v + omega x r, omega = (0, w.y, 0)
+    const float vcx = bc.v.x + bc.w.y * rczf, vcz = bc.v.z - bc.w.y * rcxf;
+    const float vpx = bp.v.x + bp.w.y * rpzf, vpz = bp.v.z - bp.w.y * rpxf;
+    float evx = vpx - vcx, evz = vpz - vcz;
+    // relative rotation conj(u_p) u_c: the hinge angle is twice its argument
+    double Wr = bp.r.w * bc.r.w + bp.r.y * bc.r.y, Yr = bp.r.w * bc.r.y - bp.r.y * bc.r.w;
+    if (Wr < 0.0) { Wr = -Wr; Yr = -Yr; }
+    const float sg = q5.w;  // +-1: the hinge axis is +-y (joint_rot maps x to +-y)
+    const float theta = sg * (float)(2.0 * atan2_f64(Yr, Wr));
+    const float wrel = bc.w.y - bp.w.y, thetadot = sg * wrel;
+    uint32_t lim = 0u;
+    float fx = 0.0f, fz = 0.0f;
+    if (ns > 0) {  // the root: slides along world x and z (the parent is the world), unlimited
+      const float qx = (float)(-edx), qz = (float)(-edz), qdx = -evx, qdz = -evz;
+      edx = 0.0; edz = 0.0; evx = 0.0f; evz = 0.0f;
+      fx = tau_s0 - s.dof_damping[d0] * qdx - s.dof_stiffness[d0] * qx;
+      fz = tau_s1 - s.dof_damping[d0 + 1] * qdz - s.dof_stiffness[d0 + 1] * qz;
+      if (qx < s.dof_lo[d0]) { fx += k_limit * (s.dof_lo[d0] - qx); lim |= 1u; }
+      if (qx > s.dof_hi[d0]) { fx -= k_limit * (qx - s.dof_hi[d0]); lim |= 2u; }
+      if (qz < s.dof_lo[d0 + 1]) { fz += k_limit * (s.dof_lo[d0 + 1] - qz); lim |= 4u; }
+      if (qz > s.dof_hi[d0 + 1]) { fz -= k_limit * (qz - s.dof_hi[d0 + 1]); lim |= 8u; }
+    }
+    fx = fx + (float)edx * kp + evx * q4.x;
+    fz = fz + (float)edz * kp + evz * q4.x;
+    float ta = tau1 - q4.w * thetadot - q5.x * theta;
+    if (theta < q5.y) { ta += k_limit * (q5.y - theta); lim |= 16u; }
+    if (theta > q5.z) { ta -= k_limit * (theta - q5.z); lim |= 32u; }
+    const float ty = sg * ta - wrel * q4.z;  // about y: hinge torque, angular damping (the axes are parallel: no alignment term)
+    m.atu(m.lay.sig + 2 * i + 1) = sig_lim * 33u + lim;
+    const int wr = m.lay.wrench + 12 * i;
+    // (a x f).y = a.z f.x - a.x f.z
+    m.at(wr) = fx; m.at(wr + 2) = fz; m.at(wr + 4) = (rczf * fx - rcxf * fz) + ty;
+    m.at(wr + 6) = -fx; m.at(wr + 8) = -fz; m.at(wr + 10) = -((rpzf * fx - rpxf * fz) + ty);
+  }
+  phase_sync();
+  // phase B -- per body: wrench sum, semi-implicit Euler, its contacts, integrate
+  const float dl = K.dl, da = c.da, inv_dt = K.inv_dt, dt = K.dt;
+  uint32_t wb = W.wb, wch = W.wch;
+  for (int i = m.sub; i < L; i += kSub, wb = (i < L) ? pk.b[min(i, L - 1)].word : wb,
+           wch = (i < L) ? pk.b[min(i, L - 1)].children : wch) {
+    const vf4 qb = ld4(&pk.b[i]);  // .z inv_inertia[0], .w reach
+    Body b = m.body(i);
+    const float mass_i = m.at(m.lay.mass + i);
+    const uint32_t sig_hit = m.atu(m.lay.sig + 2 * i);
+    const int own = m.lay.wrench + 12 * i;
+    float Fx = m.at(own), Fz = m.at(own + 2), Ty = m.at(own + 4);
+    {
+      const int nch = wb_children(wb);
+      for (int k0 = 0; k0 < K.max_children && k0 < 8; k0 += 2) {
+        const int r0 = (k0 < nch) ? m.lay.wrench + 12 * (int)((wch >> (4 * k0)) & 15u) + 6 : m.lay.zero;
+        const int r1 = (k0 + 1 < nch) ? m.lay.wrench + 12 * (int)((wch >> (4 * k0 + 4)) & 15u) + 6 : m.lay.zero;
+        const float fx0 = m.at(r0), fz0 = m.at(r0 + 2), t0 = m.at(r0 + 4), fx1 = m.at(r1), fz1 = m.at(r1 + 2), t1 = m.at(r1 + 4);
+        Fx = (Fx + fx0) + fx1; Fz = (Fz + fz0) + fz1; Ty = (Ty + t0) + t1;
+      }
+    }
+    const float inv_m = __builtin_amdgcn_rcpf(mass_i), inv_i = qb.z;
+    float vx = b.v.x + (Fx * inv_m) * dt, vz = b.v.z + (Fz * inv_m + c.gravity_z) * dt;
+    float om = b.w.y + (Ty * inv_i) * dt;
+    // spring.collisions.resolve: this body's spheres vs the plane z = 0
+    float cdvx = 0.0f, cdvz = 0.0f, cdw = 0.0f, cnt = 0.0f;
+    uint32_t hit = 0u;
+    const int n_sph = ((float)b.p.z < qb.w) ? wb_spheres(wb) : 0;
+    const double cth = 1.0 - 2.0 * (b.r.y * b.r.y), sth = 2.0 * (b.r.w * b.r.y);  // R22, -R20 of the general form
+    const float cf = (float)cth, sf = (float)sth;
+    const Sphere* sph = pk.sph + wb_first_sphere(wb);
+    for (int j = 0; j < n_sph; ++j) {
+      const vf4 sp = ld4(&sph[j]);
+      const float radius = sp.w;
+      const float depth = (float)((double)radius - (b.p.z + (cth * (double)sp.z - sth * (double)sp.x)));
+      if (!(depth > 0.0f)) continue;
+      const float rx = cf * sp.x + sf * sp.z, rz = (cf * sp.z - sf * sp.x) - radius;  // sphere's lowest point - COM
+      const float relx = vx + om * rz, relz = vz - om * rx;
+      const float vn = relz;
+      const float imp = div_fast(-(1.0f + c.elasticity) * vn + K.erp * depth * inv_dt, inv_m + inv_i * (rx * rx));
+      if (!(imp > 0.0f) || !(vn < 0.0f)) continue;
+      hit |= 1u << j;
+      float Jx = 0.0f;
+      const float vt_len = fabsf(relx);
+      if (vt_len > 1e-9f) {
+        const float dx = relx > 0.0f ? 1.0f : -1.0f;
+        const float imp_d = fminf(div_fast(vt_len, inv_m + inv_i * (rz * rz)), c.friction * imp);
+        Jx = -dx * imp_d;
+      }
+      cdvx += Jx * inv_m;
+      cdvz += imp * inv_m;
+      cdw += inv_i * (rz * Jx - rx * imp);  // (r x J).y
+      cnt += 1.0f;
+    }
+    m.atu(m.lay.sig + 2 * i) = sig_hit * 33u + hit;
+    vx *= dl; vz *= dl; om *= da;
+    if (cnt > 0.0f) {
+      const float ic = __builtin_amdgcn_rcpf(cnt);
+      vx += cdvx * ic; vz += cdvz * ic; om += cdw * ic;
+    }
+    const double dtd = (double)dt, h = 0.5 * dtd, omd = (double)om;
+    b.p.x = fma((double)vx, dtd, b.p.x);
+    b.p.z = fma((double)vz, dtd, b.p.z);
+    const double w2 = fma(h, -(omd * b.r.y), b.r.w), y2 = fma(h, omd * b.r.w, b.r.y);  // r + h (0, omega) (x) r
+    const double inv = rsqrt_f64(w2 * w2 + y2 * y2);
+    b.r.w = w2 * inv; b.r.y = y2 * inv;
+    b.v.x = vx; b.v.z = vz; b.w.y = om;
+    m.put(i, b);
+  }
+  phase_sync();
+}
+
 // whole-body centre of mass (brax.envs.humanoid.Humanoid._com), float64 (the forward reward is the difference
 // of two of these over one env step); *mass_sum = total mass
 static __device__ __forceinline__ v3d system_com(const carl_brax_sys_t& s, const Lds& m, float* mass_sum) {
@@ -1400,7 +1545,7 @@ static __device__ __forceinline__ void write_ctx_obs(const carl_batch_t& b, cons
 }
 
 // mode 0: reset (mask optional), mode 1: n_steps env steps (1 = per call, T = fused rollout)
-template <int MODE, bool MULTI, bool TASK>
+template <int MODE, bool MULTI, bool TASK, bool PLANAR = false>
 static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_brax_sys_t* __restrict__ sys_dev,
                                            const Prepared& prep, const carl_step_io_t& io,
                                            const uint8_t* __restrict__ mask, float* __restrict__ reset_obs,
@@ -1567,7 +1712,11 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
       float msum;
       // forward progress and root height: pose differences, float64
       const double x0 = s.reward_on_com ? system_com(s, m, &msum).x : m.pos(0).x - qrot(m.rot(0), tod(f3(s.com[0]))).x;
-      for (int f = 0; f < n_frames; ++f) substep<MULTI, TASK>(s, tp, pk, K, W, r.ctx, m);
+      if constexpr (PLANAR) {
+        for (int f = 0; f < n_frames; ++f) substep_planar<TASK>(s, tp, pk, K, W, r.ctx, m);
+      } else {
+        for (int f = 0; f < n_frames; ++f) substep<MULTI, TASK>(s, tp, pk, K, W, r.ctx, m);
+      }
       const v3d c1 = qrot(m.rot(0), tod(f3(s.com[0])));
       v3d com1 = D(0, 0, 0);
       if (s.reward_on_com) com1 = system_com(s, m, &msum);
@@ -1717,12 +1866,13 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
 // TASK: the model is a reach / push task (target_link / push_link / pair contacts); false compiles that code
 // out, as MULTI = false does for the Euler-angle joints.  Task models always have a hinge-less last link,
 // so TASK implies MULTI.
-template <int MODE, bool MULTI, int K, bool TASK = false>
+// PLANAR: substep_planar (step / rollout of a planar single-hinge model; the host checks the model, carl_brax.hip).
+template <int MODE, bool MULTI, int K, bool TASK = false, bool PLANAR = false>
 __global__ void __launch_bounds__(kLanes * max_waves_per_wg(MULTI)) __attribute__((amdgpu_waves_per_eu(CARL_BRAX_WAVES_PER_EU(MULTI)))) brax_kernel(const carl_batch_t b, const carl_brax_sys_t* __restrict__ sys_dev,
                                                       const Prepared prep, const carl_step_io_t io,
                                                       const uint8_t* __restrict__ mask, float* __restrict__ reset_obs,
                                                       const int n_steps) {
-  Group<K>::template run<MODE, MULTI, TASK>(b, sys_dev, prep, io, mask, reset_obs, n_steps);
+  Group<K>::template run<MODE, MULTI, TASK, PLANAR>(b, sys_dev, prep, io, mask, reset_obs, n_steps);
 }
 
 }  // namespace brax

@@ -122,6 +122,35 @@ bool brax_is_multi(const carl_brax_sys_t* sh) {  // any link with 0, 2 or 3 hing
   }
   return multi;
 }
+// Planar single-hinge model (Halfcheetah, Hopper, Walker2d as this package builds them): the root hangs on the world by
+// two slides along x and z and a hinge about y, every other link by one hinge about +-y; link frames are unrotated, the
+// joint frame is "x -> +-y", and anchors, centres of mass and spheres all lie in the y = 0 plane.  Then a state produced
+// by reset never leaves that plane and brax_kernels.hip.h's substep_planar computes the same substep without the
+// zero components.  Anything else -- and any batch with CARL_FLAG_BRAX_GENERIC -- takes the general substep.
+bool brax_is_planar(const carl_brax_sys_t* sh) {
+  if (brax_is_task(sh) || brax_is_multi(sh) || sh->n_links < 1 || sh->n_pair > 0) return false;
+  const float r = 0.70710678f;
+  auto near = [](float a, float b) { return a - b < 1e-6f && b - a < 1e-6f; };
+  for (int i = 0; i < sh->n_links; ++i) {
+    const bool root = i == 0;
+    if (root ? sh->parent[i] >= 0 : (sh->parent[i] < 0 || sh->parent[i] >= i)) return false;
+    if (sh->n_slide[i] != (root ? 2 : 0) || sh->n_link_dof[i] != (root ? 3 : 1)) return false;
+    if (!(sh->link_rot[i][0] == 1.0f && sh->link_rot[i][1] == 0.0f && sh->link_rot[i][2] == 0.0f && sh->link_rot[i][3] == 0.0f))
+      return false;
+    if (!(near(sh->joint_rot[i][0], r) && sh->joint_rot[i][1] == 0.0f && sh->joint_rot[i][2] == 0.0f &&
+          (near(sh->joint_rot[i][3], r) || near(sh->joint_rot[i][3], -r))))  // x -> +y or x -> -y
+      return false;
+    if (sh->link_pos[i][1] != 0.0f || sh->joint_pos[i][1] != 0.0f || sh->com[i][1] != 0.0f) return false;
+    if (!(sh->inv_inertia[i][0] == sh->inv_inertia[i][1] && sh->inv_inertia[i][1] == sh->inv_inertia[i][2])) return false;
+    if (root && !(sh->slide_axis[i][0][0] == 1.0f && sh->slide_axis[i][0][1] == 0.0f && sh->slide_axis[i][0][2] == 0.0f &&
+                  sh->slide_axis[i][1][0] == 0.0f && sh->slide_axis[i][1][1] == 0.0f && sh->slide_axis[i][1][2] == 1.0f))
+      return false;
+  }
+  for (int k = 0; k < sh->n_coll; ++k)
+    if (sh->coll_pos[k][1] != 0.0f) return false;
+  return true;
+}
+
 int brax_lanes_per_env(int n_links, bool multi, bool task, int n_lanes, int hint) {
   int want = n_links;
   bool pinned = false;
@@ -162,6 +191,7 @@ int launch_brax(const carl_batch_t* b, const carl_brax_sys_t* sd, const carl_bra
   if (b->n_lanes == 0 || (MODE == 1 && n_steps == 0)) return 0;
   const bool multi = brax_is_multi(sh), task = brax_is_task(sh);  // task models have a hinge-less last link: multi
   const int K = brax_lanes_per_env(sh->n_links, multi, task, b->n_lanes, sh->lanes_per_env);
+  const bool planar = MODE == 1 && !(b->flags & CARL_FLAG_BRAX_GENERIC) && brax_is_planar(sh);
   const int envs = carl::brax::kLanes / K;  // one wavefront = envs x K lanes; LDS rows are `envs` floats wide
   const carl::brax::Layout lay = carl::brax::Layout::make(sh->n_links, sh->n_dof, carl::brax::io_rows_of(*sh));
   // independent wavefronts per workgroup, sharing the LDS copy of the static tables: as many (<= kMaxWavesPerWg) as fit
@@ -241,6 +271,16 @@ int launch_brax(const carl_batch_t* b, const carl_brax_sys_t* sd, const carl_bra
   CARL_PICK(8, false);
   CARL_PICK(9, false);
   CARL_PICK(16, false);
+  if constexpr (MODE == 1) {
+#define CARL_PICK_PLANAR(KK) \
+  if (planar && K == KK) kern = static_cast<kern_t>(carl::brax::brax_kernel<1, false, KK, false, true>)
+    CARL_PICK_PLANAR(4);
+    CARL_PICK_PLANAR(7);
+    CARL_PICK_PLANAR(8);
+    CARL_PICK_PLANAR(9);
+    CARL_PICK_PLANAR(16);
+#undef CARL_PICK_PLANAR
+  }
 #undef CARL_PICK
 #undef CARL_PICK_TASK
   if (kern == nullptr) return fail(CARL_ERR_UNSUPPORTED, "%s: no kernel for %d lanes per env", who, K);

@@ -81,6 +81,13 @@ enum {
                                        no context change: brax.envs.wrappers.training.AutoResetWrapper as the
                                        reference reaches it through carl/envs/brax/wrappers.py:54-78,121-145
                                        (needs carl_batch_t::first_state).  Default: re-draw. */
+  ,
+  CARL_FLAG_BRAX_GENERIC = 32         /* Brax families: step planar models (Halfcheetah, Hopper, Walker2d) with the general
+                                       3-D substep too -- the A/B and test switch for the planar substep, which the
+                                       library otherwise picks for models whose joints and geometry lie in the y = 0
+                                       plane (same records, same results to rounding, a third of the instructions).  A
+                                       planar model's state must BE planar (what reset produces); a caller that sets
+                                       an out-of-plane state itself passes this flag. */
 };
 
 enum { CARL_ACTION_I32 = 0, CARL_ACTION_I64 = 1, CARL_ACTION_F32 = 2 };

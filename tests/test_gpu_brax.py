@@ -927,3 +927,53 @@ def test_committed_brax_transitions(fam, device, golden_dir):
     np.testing.assert_array_equal(term.cpu().numpy()[same], g["terminated"][same])
     e = np.maximum(rel_err(obs.cpu().numpy(), g["obs"]).max(1), rel_err(rew.cpu().numpy(), g["reward"]))
     assert e[same].max() <= 1e-5, e[same].max()
+
+
+@pytest.mark.parametrize("model", ["halfcheetah", "hopper", "walker2d"])
+def test_planar_substep_agrees_with_the_general_substep(device, model):
+    """Planar models (root on two world slides + hinges about y, geometry in the y = 0 plane) are stepped by
+    brax_kernels.hip.h's substep_planar -- the same records, phases and formulas without the zero components -- unless the
+    batch carries CARL_FLAG_BRAX_GENERIC.  From the same state one env step of the two paths must agree to rounding on every
+    lane that took the same contact decisions (compared through the branch record), with identical flags; and the state
+    stays in the plane (up to the rounding residue of reset's float32 kinematics, which the planar substep leaves alone)."""
+    from carl_amd import envs as E
+    from carl_amd.brax_engine import BraxVecEngine
+    from carl_amd.envs.brax.models import SYSTEMS
+
+    cls = {"halfcheetah": E.CARLBraxHalfcheetahStiffness, "hopper": E.CARLBraxHopper, "walker2d": E.CARLBraxWalker2d}[model]
+    feats = cls.get_context_features()
+    names = list(feats)
+    n = 4096
+    rng = np.random.default_rng(21)
+    rows = np.tile([float(f.default_value) for f in feats.values()], (n, 1))
+    rows[:, names.index("gravity")] = rng.uniform(-15, -5, n)
+    rows[:, names.index("friction")] = rng.uniform(0.3, 1.5, n)
+    rows = rows.astype(np.float32).astype(np.float64)
+    kw = dict(selector=O.SEL_STATIC, seed=9, ctx_idx0=np.arange(n), branch_record=True)
+    s = SYSTEMS[cls.env_name](names)
+    fast = BraxVecEngine(s, len(names), rows, n, device, **kw)
+    slow = BraxVecEngine(SYSTEMS[cls.env_name](names), len(names), rows, n, device, generic_substep=True, **kw)
+    fast.reset()
+    slow.reset()
+    assert torch.equal(fast.state, slow.state)
+    amp = float(max(s.act_hi[: s.n_act]))
+    worst, agree_share = 0.0, []
+    for t in range(25):
+        slow.set_state64(fast.state64())
+        for name in ("elapsed", "episode", "ep_return", "ctx_idx", "n_calls", "episodes_done"):
+            getattr(slow, name).copy_(getattr(fast, name))
+        a = torch.as_tensor(rng.uniform(-amp, amp, (n, s.n_act)).astype(np.float32), device=device)
+        o1, r1, te1, tr1 = fast.step(a)
+        o2, r2, te2, tr2 = slow.step(a)
+        assert torch.equal(tr1, tr2)
+        same = (fast.branch_sig[:, 0] == slow.branch_sig[:, 0]) & (te1 == te2)
+        agree_share.append(float(same.float().mean()))
+        d = (o1.double() - o2.double()).abs() / (1 + o2.double().abs())
+        dr = (r1.double() - r2.double()).abs() / (1 + r2.double().abs())
+        worst = max(worst, float(d[same.bool()].max()), float(dr[same.bool()].max()))
+        st = fast.state64()  # [N, L, 13]: p, r (w x y z), v, w
+        # y position, r.x, r.z, v.y, w.x, w.z: what the float32 forward kinematics of reset left there (<= 1e-5: velocities of a reset draw), never more
+        assert float(st[:, :, [1, 4, 6, 8, 10, 12]].abs().max()) <= 2e-5
+    print(f"{model}: planar vs general substep, 25 steps x {n} envs: max |d| / (1 + |x|) {worst:.2e} on agreeing lanes "
+          f"(share {min(agree_share):.5f})")
+    assert worst <= 2e-6 and min(agree_share) >= 0.999
