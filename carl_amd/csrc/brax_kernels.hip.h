@@ -584,12 +584,19 @@ static __device__ __forceinline__ JointGeom joint_geometry(const carl_brax_sys_t
   // kinds, so two separate calls under complementary lane masks cost it two evaluations (~30 float64 instructions each).
   [[maybe_unused]] double R00 = 0.0, R01 = 0.0, R02 = 0.0;
   double a_y = rel.x, a_x = rel.w;
-  if (MULTI && nr != 1) {  // rel = Rx(al) Ry(be) Rz(ga): decompose, ga = sign * theta_3 (nr = 0: all locked)
+  // STRAIGHT-LINE for the multi-hinge kernels: the Euler-angle path is evaluated on every lane and the single-hinge
+  // lanes just do not use it.  A wavefront of such a model always holds both kinds of joint, so `if (nr != 1)` never
+  // skipped anything -- it only cost the exec-mask bookkeeping and the register copies at the joins (31 saveexec, 30
+  // branches, ~90 moves in the substep loop's ISA).
+  const bool eul = MULTI && nr != 1;
+  if (MULTI) {  // rel = Rx(al) Ry(be) Rz(ga): decompose, ga = sign * theta_3 (nr = 0: all locked)
     R00 = 1.0 - 2.0 * (rel.y * rel.y + rel.z * rel.z);
     R01 = 2.0 * (rel.x * rel.y - rel.w * rel.z);
     R02 = fmin(fmax(2.0 * (rel.x * rel.z + rel.w * rel.y), -1.0), 1.0);
-    a_y = -(2.0 * (rel.y * rel.z - rel.w * rel.x));  // -R12
-    a_x = 1.0 - 2.0 * (rel.x * rel.x + rel.y * rel.y);  // R22
+    const double m12 = -(2.0 * (rel.y * rel.z - rel.w * rel.x));  // -R12
+    const double r22 = 1.0 - 2.0 * (rel.x * rel.x + rel.y * rel.y);  // R22
+    a_y = eul ? m12 : a_y;
+    a_x = eul ? r22 : a_x;
   }
 #ifdef CARL_EXP_BRAX_FAST_ATAN
   const double a1 = (double)atan2_fast((float)a_y, (float)a_x);
@@ -599,13 +606,14 @@ static __device__ __forceinline__ JointGeom joint_geometry(const carl_brax_sys_t
   g.theta = (float)(2.0 * a1);  // (meaningful on single-hinge lanes)
   g.wrel = bc.w - bp.w;
   g.thetadot = dot(g.x_c, g.wrel);
-  if (MULTI && nr != 1) {
+  if (MULTI) {
 #ifdef CARL_EXP_BRAX_EULER_F32
     const float al = (float)a1, be = asinf((float)R02), ga = atan2_fast((float)-R01, (float)R00);
 #else
     const float al = (float)a1, be = (float)asin_f64(R02), ga = (float)atan2_f64(-R01, R00);
 #endif
-    const float sg = (nr == 3) ? s.dof_sign3[i] : 1.0f;
+    const float sg3 = s.dof_sign3[i];
+    const float sg = (nr == 3) ? sg3 : 1.0f;
     g.ang[0] = al; g.ang[1] = be; g.ang[2] = sg * ga;
     g.axis[0] = g.x_p;
     // The second and third hinge axes, rp (x) Rx(al) e_y and rp (x) Rx(al) Ry(be) e_z = rp (x) (0, cos al, sin al) and
@@ -625,13 +633,12 @@ static __device__ __forceinline__ JointGeom joint_geometry(const carl_brax_sys_t
     }
     const float w0 = dot(g.wrel, g.axis[0]), w1 = dot(g.wrel, g.axis[1]), w2 = dot(g.wrel, g.axis[2]);
     g.rate[1] = w1;
-    if (nr == 3) {  // axis0 and axis2 are not orthogonal: axis0 . axis2 = sign * sin(be)
+    {  // three hinges: axis0 and axis2 are not orthogonal (axis0 . axis2 = sign * sin(be)); else the plain projections
+       // (a locked direction is damped by k_ang_damp)
       const float cc = dot(g.axis[0], g.axis[2]), den = 1.0f - cc * cc;
-      g.rate[0] = (w0 - cc * w2) / den;
-      g.rate[2] = (w2 - cc * w0) / den;
-    } else {
-      g.rate[0] = w0;
-      g.rate[2] = w2;  // locked direction: damped by k_ang_damp
+      const float r0 = (w0 - cc * w2) / den, r2 = (w2 - cc * w0) / den;
+      g.rate[0] = (nr == 3) ? r0 : w0;
+      g.rate[2] = (nr == 3) ? r2 : w2;
     }
   }
   return g;
@@ -752,7 +759,7 @@ static __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const T
     const Body bc = m.body(i);
     const Body bp = (P < 0) ? world_body() : m.body(P);
     const vf4 q4 = ld4(&rec.k_vel), q5 = ld4(&rec.stiffness);  // k_vel k_limit k_ang_damp damping | stiffness lo hi
-    const float tau1 = (!MULTI || nr == 1) ? m.at(m.lay.tau + d) : 0.0f;
+    const float tau1 = m.at(m.lay.tau + d);
     const uint32_t sig_lim = m.atu(m.lay.sig + 2 * i + 1);
     const JointRec la{V(q0.x, q0.y, q0.z), V(q1.x, q1.y, q1.z), qt{q2.x, q2.y, q2.z, q2.w}, qt{q3.x, q3.y, q3.z, q3.w}, wa};
     const JointGeom g = joint_geometry<MULTI>(s, la, i, bc, bp);
@@ -776,28 +783,35 @@ static __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const T
     }
     f = f + tof(ed) * kp + ev * q4.x;
     v3 t;
-    if (!MULTI || nr == 1) {
-      t = g.axx * kp;  // keep the hinge axes aligned
+    {  // single hinge: keep the hinge axes aligned + the hinge torque about the child-side axis
+      uint32_t lim1 = 0u;
       float ta = tau1 - q4.w * g.thetadot - q5.x * g.theta;
-      if (g.theta < q5.y) { ta += k_limit * (q5.y - g.theta); lim |= 16u; }
-      if (g.theta > q5.z) { ta -= k_limit * (g.theta - q5.z); lim |= 32u; }
-      t = t + g.x_c * ta;
-    } else {  // 2 or 3 stacked hinges: per-dof torques about the current axes; a missing third
-              // dof is locked by the constraint spring on its Euler angle
-      t = V(0, 0, 0);
+      if (g.theta < q5.y) { ta += k_limit * (q5.y - g.theta); lim1 |= 16u; }
+      if (g.theta > q5.z) { ta -= k_limit * (g.theta - q5.z); lim1 |= 32u; }
+      t = g.axx * kp + g.x_c * ta;
+      if constexpr (MULTI) {  // 2 or 3 stacked hinges (or none): per-dof torques about the current axes; a missing dof is
+                              // locked by the constraint spring on its Euler angle.  Straight-line like joint_geometry:
+                              // evaluated on every lane, selected by the lane's number of hinges.
+        v3 t2 = V(0, 0, 0);
+        uint32_t lim2 = 0u;
 #pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        float ta;
-        if (k < nr) {
-          const int dk = d + k;
-          ta = m.at(m.lay.tau + dk) - s.dof_damping[dk] * g.rate[k] - s.dof_stiffness[dk] * g.ang[k];
-          if (g.ang[k] < s.dof_lo[dk]) { ta += k_limit * (s.dof_lo[dk] - g.ang[k]); lim |= 16u << (2 * k); }
-          if (g.ang[k] > s.dof_hi[dk]) { ta -= k_limit * (g.ang[k] - s.dof_hi[dk]); lim |= 32u << (2 * k); }
-        } else {
-          ta = -kp * g.ang[k];
+        for (int k = 0; k < 3; ++k) {
+          const int dk = min(d + k, CARL_BRAX_MAX_DOF - 1);
+          const bool act = k < nr;
+          const float lo = s.dof_lo[dk], hi = s.dof_hi[dk];
+          float tk = m.at(m.lay.tau + dk) - s.dof_damping[dk] * g.rate[k] - s.dof_stiffness[dk] * g.ang[k];
+          const bool below = g.ang[k] < lo, above = g.ang[k] > hi;
+          tk = below ? tk + k_limit * (lo - g.ang[k]) : tk;
+          tk = above ? tk - k_limit * (g.ang[k] - hi) : tk;
+          lim2 |= (act && below) ? (16u << (2 * k)) : 0u;
+          lim2 |= (act && above) ? (32u << (2 * k)) : 0u;
+          t2 = t2 + g.axis[k] * (act ? tk : -kp * g.ang[k]);
         }
-        t = t + g.axis[k] * ta;
+        const bool single = nr == 1;
+        t = V(single ? t.x : t2.x, single ? t.y : t2.y, single ? t.z : t2.z);
+        lim1 = single ? lim1 : lim2;
       }
+      lim |= lim1;
     }
     t = t - g.wrel * q4.z;
     m.atu(m.lay.sig + 2 * i + 1) = sig_lim * 33u + lim;
