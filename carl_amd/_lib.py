@@ -206,6 +206,7 @@ EXPORTS.update({
     "carl_brax_step": (C.c_int, [C.POINTER(Batch), _vp, C.POINTER(BraxSys), C.POINTER(StepIO), _vp]),
     "carl_brax_rollout": (C.c_int, [C.POINTER(Batch), _vp, C.POINTER(BraxSys), C.POINTER(StepIO), C.c_int32, _vp]),
     "carl_brax_lane_widths": (C.c_int, [C.POINTER(BraxSys), _vp, C.c_int32]),
+    "carl_brax_model_is_planar": (C.c_int, [C.POINTER(BraxSys)]),
     "carl_brax_fragment_plan": (C.c_int, [C.c_int32] * 6 + [_vp, C.c_int32]),
 })
 

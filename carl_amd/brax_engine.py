@@ -102,13 +102,42 @@ class BraxVecEngine(VecEngine):
 
     def set_state64(self, state) -> None:
         """Inverse of ``state64``: ``[N, L, 13]`` (or ``[N, 13 L]``) float64 -> the HBM record (pose split into a
-        float32 head and tail; velocities rounded to float32)."""
+        float32 head and tail; velocities rounded to float32).  Planar models (Halfcheetah, Hopper, Walker2d) are
+        stepped by a substep that assumes the state lies in the y = 0 plane -- what ``reset`` produces; a state
+        that does not switches the engine to the general substep (``_check_planar_state``).  Direct writes to
+        ``eng.state`` bypass that check: pass ``generic_substep=True`` if you write out-of-plane states yourself."""
         L = self.sys.n_links
         st = torch.as_tensor(state, dtype=torch.float64, device=self.device).reshape(self.n, L, 13)
+        self._check_planar_state(st)
         pose = st[:, :, :7].reshape(self.n, 7 * L)
         head = pose.to(torch.float32)
         tail = (pose - head.to(torch.float64)).to(torch.float32)
         self._state_storage.copy_(torch.cat([head, tail, st[:, :, 7:].reshape(self.n, 6 * L).to(torch.float32)], dim=1))
+
+    def is_planar_model(self) -> bool:
+        """True when the library steps this model with the planar substep (Halfcheetah, Hopper, Walker2d: every joint
+        axis is +-y and all geometry lies in the y = 0 plane) -- unless ``generic_substep=True`` was passed."""
+        return bool(self.lib.carl_brax_model_is_planar(C.byref(self.sys))) and not (self.b.flags & _lib.FLAG_BRAX_GENERIC)
+
+    def _check_planar_state(self, st: torch.Tensor) -> None:
+        """The planar substep neither reads nor updates the out-of-plane components of a state (y positions, the x / z
+        quaternion components, v_y, w_x, w_z): a caller-provided state that is not planar would silently get wrong
+        physics.  Such a state switches this engine to the general 3-D substep, with one warning."""
+        if not self.is_planar_model():
+            return
+        off = torch.stack([st[:, :, 1].abs().amax(), st[:, :, 4].abs().amax(), st[:, :, 6].abs().amax(),
+                           st[:, :, 8].abs().amax(), st[:, :, 10].abs().amax(), st[:, :, 12].abs().amax()]).amax()
+        if float(off) > 1e-4:  # (reset's float32 kinematics leaves <= 1e-5 out of plane)
+            import warnings
+
+            self.b.flags |= _lib.FLAG_BRAX_GENERIC
+            warnings.warn(f"set_state64: the state leaves the y = 0 plane of a planar model (largest out-of-plane "
+                          f"component {float(off):.3g}); this engine now steps it with the general 3-D substep "
+                          "(CARL_FLAG_BRAX_GENERIC)", RuntimeWarning, stacklevel=3)
+
+    def rollout_variant(self) -> int:
+        """Brax families have ONE rollout kernel (no staged / direct-store pair): nothing to warn about."""
+        return _lib.ROLLOUT_STAGED
 
     def alloc_rollout(self, n_steps: int, final_obs: bool = False, branch_record: bool = False) -> dict:
         out = super().alloc_rollout(n_steps, final_obs)

@@ -331,6 +331,10 @@ int carl_rollout_variant(const carl_batch_t* batch) {
     fail(CARL_ERR_INVALID_ARGUMENT, "carl_rollout_variant: batch is NULL");
     return CARL_ERR_INVALID_ARGUMENT;
   }
+  if (batch->family < 0 || batch->family >= CARL_N_FAMILIES) {  // the Brax families have one rollout kernel: not a question
+    fail(CARL_ERR_INVALID_ARGUMENT, "carl_rollout_variant: family %d is not a classic-control family", batch->family);
+    return CARL_ERR_INVALID_ARGUMENT;
+  }
   return rollout_variant(batch);
 }
 

@@ -107,7 +107,7 @@ int validate_brax(const carl_batch_t* b, const carl_brax_sys_t* sd, const carl_b
 // profiles/r01g), so a joint or body round with one busy lane per env costs as much as a full one:
 // the width is the number of links (every phase = one round), rounded up to an instantiated
 // (width, MULTI) pair, and widened for small batches so that the launch has at least two
-// wavefronts per SIMD.  CARL_AMD_BRAX_SUB=<width> overrides (tests, experiments).
+// wavefronts per SIMD.  carl_brax_sys_t::lanes_per_env pins it (autotune, tests).
 constexpr int kBraxWidths[] = {2, 4, 7, 8, 9, 11, 16};
 constexpr bool brax_instantiated(int k, bool multi, bool task) {
   if (task) return k == 4 || k == 8 || k == 16;  // reacher: 3 links, pusher: 8
@@ -158,13 +158,6 @@ int brax_lanes_per_env(int n_links, bool multi, bool task, int n_lanes, int hint
     want = hint;
     pinned = true;
   }
-  if (const char* env = getenv("CARL_AMD_BRAX_SUB")) {  // read per call: tests switch it
-    const int k = atoi(env);
-    if (k >= 1 && k <= 16) {
-      want = k;
-      pinned = true;
-    }
-  }
   int k = 16;
   for (int w : kBraxWidths)
     if (w >= want && brax_instantiated(w, multi, task)) {
@@ -195,7 +188,8 @@ int launch_brax(const carl_batch_t* b, const carl_brax_sys_t* sd, const carl_bra
   const int envs = carl::brax::kLanes / K;  // one wavefront = envs x K lanes; LDS rows are `envs` floats wide
   const carl::brax::Layout lay = carl::brax::Layout::make(sh->n_links, sh->n_dof, carl::brax::io_rows_of(*sh));
   // independent wavefronts per workgroup, sharing the LDS copy of the static tables: as many (<= kMaxWavesPerWg) as fit
-  const size_t static_lds = sizeof(carl_brax_sys_t) + sizeof(carl::brax::Prepared);
+  // (the kernel's static LDS: model table, prepared topology / records, the fragment hand-over flags)
+  const size_t static_lds = sizeof(carl_brax_sys_t) + sizeof(carl::brax::Prepared) + sizeof(int) * carl::brax::kMaxWavesPerWg3;
 #ifdef CARL_EXP_BRAX_LDS_PAD  // measurement only (needs -DCARL_ABLATION): fewer resident wavefronts per SIMD through LDS
   const size_t wave_bytes = lay.bytes(envs) > (size_t)CARL_EXP_BRAX_LDS_PAD ? lay.bytes(envs) : (size_t)CARL_EXP_BRAX_LDS_PAD;
 #else
@@ -348,6 +342,14 @@ int carl_brax_fragment_plan(int32_t n_groups, int32_t n_workgroups, int32_t wave
     o[0] = sh.g_lo + f.grp; o[1] = f.t_lo; o[2] = f.t_hi; o[3] = f.wait_head ? 1 : 0; o[4] = f.signal_head ? 1 : 0;
   }
   return p.n_frag;
+}
+
+int carl_brax_model_is_planar(const carl_brax_sys_t* sys_host) {
+  if (sys_host == nullptr) {
+    fail(CARL_ERR_INVALID_ARGUMENT, "carl_brax_model_is_planar: NULL argument");
+    return 0;
+  }
+  return brax_is_planar(sys_host) ? 1 : 0;
 }
 
 int carl_brax_lane_widths(const carl_brax_sys_t* sys_host, int32_t* widths_out, int32_t cap) {

@@ -79,7 +79,8 @@ class CARLBraxEnv(CARLEnv):
         ``mass_check``: what happens to ``mass_<link>`` contexts below the model's stability floor
         (``feature_tables.MASS_RATIO_FLOOR``) -- every value inside the reference's bounds (0.1, inf) constructs:
         "warn" (default): the EFFECTIVE mass is clamped at the floor per env inside the kernel (the context
-        observation keeps the sampled value) and one warning names the features; "error": raise ``ValueError``
+        observation keeps the sampled value; ``effective_mass_context()`` returns the clamped one) and one warning
+        names the features; "error": raise ``ValueError``
         (round 2's behaviour); "off": no clamp, no warning (such envs go non-finite within a few steps)."""
         if mass_check not in ("warn", "error", "off"):
             raise ValueError("mass_check must be 'warn', 'error' or 'off'")
@@ -173,6 +174,32 @@ class CARLBraxEnv(CARLEnv):
                              "to ignore physics contexts as the reference effectively does")
         warnings.warn(msg + " -- the physics runs these envs at the floor (the context observation keeps the sampled "
                       "value); mass_check='error' refuses instead", RuntimeWarning, stacklevel=3)
+
+    def effective_mass_context(self) -> dict[str, torch.Tensor]:
+        """The ``mass_<link>`` context values the PHYSICS runs each env at: ``{feature: [N] float32}`` in the
+        feature's own unit (kg).  Equal to the sampled context -- what ``obs["context"]`` reports -- except where
+        ``mass_check="warn"`` clamps the effective mass ratio at the model's stability floor
+        (``carl_brax_ctx_map_t::mass_ratio_floor`` / ``_multi``): a context-conditioned policy that wants the mass
+        the dynamics actually use reads it here.  Same rule as ``load_ctx`` in
+        carl_amd/csrc/brax_kernels.hip.h: ratio = value / CARL default; the higher ``_multi`` floor applies to an
+        env in which two or more links are lighter than nominal (ratio < 0.999)."""
+        eng = self.env
+        cm = eng.sys.ctx
+        table = eng.ctx_table  # [F][C] float32 on the device
+        idx = eng.ctx_idx.long()
+        names = list(self.get_context_features().keys())
+        out: dict[str, torch.Tensor] = {}
+        if cm.n_mass == 0:
+            return out
+        ratios = [table[cm.mass_row[k]][idx] / float(cm.mass_nominal[k]) for k in range(cm.n_mass)]
+        n_light = sum((r < 0.999).to(torch.int32) for r in ratios)
+        compat = getattr(self, "_reference_compat", False)
+        for k, r in enumerate(ratios):
+            floor = torch.where(n_light >= 2, torch.full_like(r, float(cm.mass_ratio_floor_multi[k])),
+                                torch.full_like(r, float(cm.mass_ratio_floor[k])))
+            eff = r if compat else torch.maximum(r, floor)
+            out[names[cm.mass_row[k]]] = eff * float(cm.mass_nominal[k])
+        return out
 
     def _base_observation_space(self) -> spaces.Space:
         obs = np.inf * np.ones(self.env.D, dtype=np.float32)

@@ -67,6 +67,8 @@ class MixedVecEngine:
         self._streams = [torch.cuda.Stream(device=dev, priority=(-1 if k % 2 else 0)) for k in range(len(self.parts))]
         self._fork = torch.cuda.Event()
         self._joins = [torch.cuda.Event() for _ in self.parts]
+        self._pending = []      # outputs allocated by free-running launches that were not joined yet (see rollout / join)
+        self._in_flight = False  # a free-running launch was enqueued since the last join()
 
     # ------------------------------------------------------------------ fork / join
     def _each(self, fn):
@@ -84,6 +86,12 @@ class MixedVecEngine:
             cur.wait_event(j)
         return out
 
+    def _auto_join(self) -> None:
+        """A call that touches engine state on the caller's stream while free-running launches are still in flight
+        on the parts' streams would race with them: order the caller's stream after them first."""
+        if self._in_flight:
+            self.join()
+
     def part_slice(self, k: int) -> slice:
         return slice(self.offsets[k], self.offsets[k] + self.sizes[k])
 
@@ -95,12 +103,14 @@ class MixedVecEngine:
     def reset(self, mask: torch.Tensor | None = None) -> list[torch.Tensor]:
         if mask is not None and mask.numel() != self.n:
             raise ValueError("mask must have one entry per lane of the mixed batch")
+        self._auto_join()
         return self._each(lambda k, p: p.reset(None if mask is None else mask[self.part_slice(k)]))
 
     def step(self, actions: Sequence):
         """One step of every lane of every family -> (obs per part, reward[N], terminated[N], truncated[N])."""
         if len(actions) != len(self.parts):
             raise ValueError(f"expected {len(self.parts)} action arrays (one per family)")
+        self._auto_join()
         res = self._each(lambda k, p: p.step(actions[k]))
         return [r[0] for r in res], self.reward, self.terminated, self.truncated
 
@@ -124,9 +134,29 @@ class MixedVecEngine:
             res = []
             for k, (p, s) in enumerate(zip(self.parts, self._streams)):
                 s.wait_event(self._fork)
+                a = actions[k]
+                given = None if outs is None else outs[k]
                 with torch.cuda.stream(s):
-                    res.append(p.rollout(actions[k], None if outs is None else outs[k]))
+                    out_k = p.rollout(a, given)
+                # The caching allocator hands a freed block back to the stream it was ALLOCATED on.  The actions (and
+                # caller-provided output buffers) were made on the caller's stream and are used on the part's stream;
+                # outputs allocated inside the call (``outs=None``) were made on the part's stream and are read by the
+                # caller after ``join()``: each is recorded on the other stream, so dropping the tensor cannot hand its
+                # block to a kernel that starts before the other stream's work on it has finished.  A
+                # converted copy of the actions (dtype / device / layout) is made inside ``p.rollout`` on the part's
+                # stream and consumed there.
+                if torch.is_tensor(a) and a.is_cuda:
+                    a.record_stream(s)
+                if given is None:
+                    self._pending.append(out_k)
+                else:
+                    for t in given.values():
+                        if torch.is_tensor(t) and t.is_cuda:
+                            t.record_stream(s)
+                self._in_flight = True
+                res.append(out_k)
             return res
+        self._auto_join()
         return [p.rollout(actions[k], None if outs is None else outs[k]) for k, p in enumerate(self.parts)]
 
     def join(self) -> None:
@@ -135,6 +165,12 @@ class MixedVecEngine:
         for j, s in zip(self._joins, self._streams):
             j.record(s)
             cur.wait_event(j)
+        for out in self._pending:  # the caller reads these on ITS stream from here on
+            for t in out.values():
+                if torch.is_tensor(t) and t.is_cuda:
+                    t.record_stream(cur)
+        self._pending.clear()
+        self._in_flight = False
 
     def autotune(self, n_steps: int = 2) -> None:
         for p in self.parts:

@@ -224,7 +224,7 @@ int carl_rollout(const carl_batch_t* batch, const carl_step_io_t* io, int32_t n_
  * lane count silently took the ~50 % slower direct-store kernel in ABI <= 4 -- now a caller can ask (and the
  * Python engine warns once). */
 enum { CARL_ROLLOUT_STAGED = 0, CARL_ROLLOUT_DIRECT_SHAPE = 1, CARL_ROLLOUT_DIRECT_FLAG = 2 };
-int carl_rollout_variant(const carl_batch_t* batch);
+int carl_rollout_variant(const carl_batch_t* batch); /* CARL_ERR_INVALID_ARGUMENT for a non-classic family */
 
 /* done-mask compaction: ascending lane ids with terminated|truncated set.
  * idx_out [n], count_out [1], scratch >= carl_done_compact_scratch_elems(n) int32.
@@ -409,6 +409,13 @@ int carl_brax_rollout(const carl_batch_t* batch, const carl_brax_sys_t* sys_dev,
  * ascending; returns their number (<= cap).  Results do not depend on the width: it is a pure
  * scheduling choice (carl_amd.brax_engine.BraxVecEngine.autotune times them on the real batch). */
 int carl_brax_lane_widths(const carl_brax_sys_t* sys_host, int32_t* widths_out, int32_t cap);
+/* 1 when step / rollout launches of this model take the planar substep (root on two world slides x, z and a hinge
+ * about y, every other link on a hinge about +-y, all geometry in the y = 0 plane: Halfcheetah, Hopper, Walker2d as
+ * carl_amd.envs.brax.models builds them) unless the batch carries CARL_FLAG_BRAX_GENERIC; 0 otherwise.  The planar
+ * substep neither reads nor updates out-of-plane state components, so a caller that writes states itself asks here
+ * (carl_amd.brax_engine.BraxVecEngine.set_state64 does, and falls back to the general substep).  No reference
+ * counterpart: brax's spring pipeline has one code path (carl/envs/brax/carl_brax_env.py:163-176). */
+int carl_brax_model_is_planar(const carl_brax_sys_t* sys_host);
 /* How a step / rollout launch of a batch larger than the chip holds at once is divided (no reference counterpart: the
  * reference steps its envs in vmapped lock-step, carl/envs/brax/carl_brax_env.py:163-190).  A "group" is one
  * wavefront's worth of envs; workgroup w of n_workgroups owns a contiguous share of the n_groups groups and cuts its

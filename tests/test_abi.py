@@ -182,6 +182,25 @@ def test_rollout_variant_is_answered_on_the_host():
     b.flags = _lib.FLAG_ROLLOUT_DIRECT
     assert lib.carl_rollout_variant(C.byref(b)) == _lib.ROLLOUT_DIRECT_FLAG
     assert lib.carl_rollout_variant(None) == -1 and b"NULL" in lib.carl_last_error()
+    b.family = -1  # a Brax batch: one rollout kernel, the question does not apply
+    assert lib.carl_rollout_variant(C.byref(b)) == -1 and b"classic-control" in lib.carl_last_error()
+
+
+def test_planar_model_query_is_answered_on_the_host():
+    """carl_brax_model_is_planar: which models step / rollout launches advance with the planar substep"""
+    from carl_amd import _lib
+    from carl_amd.envs import brax as BX
+    from carl_amd.envs.brax import models
+
+    lib = _lib.load()
+    want = {"halfcheetah": 1, "hopper": 1, "walker2d": 1, "ant": 0, "humanoid": 0, "humanoidstandup": 0,
+            "inverted_pendulum": 0, "inverted_double_pendulum": 0, "reacher": 0, "pusher": 0}
+    classes = {c.env_name: c for c in (getattr(BX, n) for n in dir(BX)) if isinstance(c, type) and hasattr(c, "env_name")}
+    for name, flag in want.items():
+        names = list(classes[name].get_context_features().keys())
+        s = models.SYSTEMS[name](names)
+        assert lib.carl_brax_model_is_planar(C.byref(s)) == flag, name
+    assert lib.carl_brax_model_is_planar(None) == 0 and b"NULL" in lib.carl_last_error()
 
 
 def _plan(lib, n_groups, n_wg, n_waves, T, wg, wave):

@@ -1,0 +1,88 @@
+"""carl_amd/dropin.py::Mi355xVecEnv on the HIP engine: the reference's call sequence
+(tests/dropin_util.py::RefSequenceEnv) over the shim == the mirror class ``carl_amd.envs.CARL<Family>`` bit for bit,
+== the oracle within 1e-5; batched shim == a ``VecEngine`` driven directly."""
+import numpy as np
+import pytest
+import torch
+
+from carl_amd import _lib
+from carl_amd import envs as E
+from carl_amd.context.selection import RoundRobinSelector
+from carl_amd.dropin import Mi355xVecEnv
+from carl_amd.engine import VecEngine
+from dropin_util import RefSequenceEnv
+from oracle import oracle as O
+from test_dropin import _contexts
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("family,cls", [(O.CARTPOLE, E.CARLCartPole), (O.PENDULUM, E.CARLPendulum)])
+def test_reference_sequence_over_the_shim_equals_the_mirror_class_bit_for_bit(device, family, cls):
+    contexts = _contexts(family)
+    name = O.FAMILY_NAMES[family]
+    shim = Mi355xVecEnv(name, 1, device, seed=11)
+    assert shim.eng.b.selector == _lib.SEL_HOST  # the reference's selector object decides, not the device
+    ref = RefSequenceEnv(shim, contexts, RoundRobinSelector, name)
+    mirror = cls(contexts=contexts, device=device, seed=11)  # default selector: round robin, like the reference
+    rng = np.random.default_rng(5)
+    n_steps = 0
+    for episode in range(9):
+        obs, info = ref.reset(seed=100 + episode)
+        m_obs, m_info = mirror.reset(seed=100 + episode)
+        assert info["context_id"] == m_info["context_id"] == episode % 3
+        assert list(obs["context"]) == list(m_obs["context"])
+        # the reference draws the init state on the HOST (np_random) and writes it through unwrapped.state; the
+        # mirror draws on the device -- give the mirror the same state, through the same protocol
+        mirror.unwrapped.state = np.asarray(shim.state)
+        np.testing.assert_array_equal(shim.eng.state.cpu().numpy(), mirror.env.state.cpu().numpy())
+        ctx = contexts[episode % 3]
+        row = np.array([[ctx[k] for k in O.feature_names(family)]])
+        for t in range(80):
+            a = int(rng.integers(0, 2)) if family == O.CARTPOLE else np.float32([rng.uniform(-2, 2)])
+            state = np.asarray(shim.state, dtype=np.float64)[None]
+            o, r, term, trunc, info = ref.step(a)
+            mo, mr, mterm, mtrunc, minfo = mirror.step(a)
+            np.testing.assert_array_equal(o["obs"], mo["obs"])  # bit for bit
+            assert (r, term, trunc) == (mr, mterm, mtrunc) and info["context_id"] == minfo["context_id"]
+            assert type(r) is float and type(term) is bool and o["obs"].dtype == np.float32
+            _, o_want, r_want, t_want = O.transitions(family, row, state, np.asarray(a).reshape(1))
+            assert np.abs(o["obs"] - o_want[0]).max() <= 1e-5 * (1 + np.abs(o_want[0]).max())
+            assert abs(r - float(r_want[0])) <= 1e-5 * (1 + abs(r)) and term == bool(t_want[0])
+            n_steps += 1
+            if term or trunc:
+                break
+    assert n_steps > 100  # nine episodes of a random policy
+
+
+def test_timelimit_of_the_registry_is_the_engines(device):
+    """gymnasium.make wraps TimeLimit(max_episode_steps) around the env (carl_gymnasium_env.py:64)"""
+    shim = Mi355xVecEnv("Pendulum-v1", 1, device)
+    shim.reset(seed=0)
+    flags = [shim.step(np.float32([0.0]))[2:4] for _ in range(200)]
+    assert flags[-1] == (False, True) and all(f == (False, False) for f in flags[:-1])
+
+
+def test_batched_shim_equals_the_engine_driven_directly(device):
+    n, C_ = 4096, 512
+    rng = np.random.default_rng(0)
+    table = np.tile(O.default_row(O.CARTPOLE), (C_, 1))
+    table[:, 0] = rng.uniform(5, 15, C_)
+    table[:, 3] = rng.uniform(0.3, 1.0, C_)
+    idx = rng.integers(0, C_, n).astype(np.int32)
+    shim = Mi355xVecEnv("cartpole", n, device, seed=3)
+    shim.set_contexts(table, idx)
+    eng = VecEngine("cartpole", table, n, device, selector=_lib.SEL_HOST, seed=3, ctx_idx0=idx)
+    o1, _ = shim.reset(seed=3)
+    eng.seed(3)
+    o2 = eng.reset()
+    assert torch.equal(o1, o2) and shim.observation_space.shape == (n, 4)
+    for t in range(40):
+        a = torch.randint(0, 2, (n,), device=device, dtype=torch.int32)
+        o, r, te, tr, info = shim.step(a)
+        o2, r2, te2, tr2 = eng.step(a)
+        assert torch.equal(o, o2) and torch.equal(r, r2) and torch.equal(te, te2) and torch.equal(tr, tr2)
+        assert torch.equal(info["final_observation"], eng.final_obs)
+    assert int(shim.eng.episodes_done.sum()) > 0  # auto-reset ran inside step
+    shim.unwrapped.gravity = 3.0  # the reference's scalar setattr: broadcast into the whole column
+    assert bool((shim.eng.ctx_table[0] == 3.0).all())

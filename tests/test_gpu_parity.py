@@ -71,6 +71,53 @@ def flag_margin(fam, ctx_rows, next_state):
     return np.full(s.shape[0], np.inf)
 
 
+def state_from_obs(fam, obs):
+    """the state a family's observation determines (angles modulo 2 pi, which the dynamics do not see)"""
+    o = np.asarray(obs, dtype=np.float64)
+    if fam == O.PENDULUM:
+        return np.stack([np.arctan2(o[:, 1], o[:, 0]), o[:, 2]], axis=1)
+    if fam == O.ACROBOT:
+        return np.stack([np.arctan2(o[:, 1], o[:, 0]), np.arctan2(o[:, 3], o[:, 2]), o[:, 4], o[:, 5]], axis=1)
+    return o  # CartPole, MountainCar(Continuous): the observation IS the state
+
+
+def restep_rollout_with_oracle(fam, table, s0, acts, out, t_max=None, max_edge_flags=8):
+    """Tie a fused rollout's OUTPUT to the oracle directly: every (t, lane) of the rollout is
+    re-stepped by `O.transitions` from the state the PREVIOUS row of the same output determines (on a done step the
+    returned observation is the reset observation = the next episode's first state, so the chain never breaks) and
+    the kernel's transition must match within 1e-5: observation (the terminal one where `final_obs` was written,
+    else done rows are skipped for the observation only), reward, `terminated`.  Flags may differ only on rows whose
+    float64 next state sits within 1e-5 of a threshold (counted, bounded).  Returns the number of rows checked."""
+    T = int(acts.shape[0]) if t_max is None else min(int(t_max), int(acts.shape[0]))
+    prev = np.asarray(s0, dtype=np.float64)
+    have_final = "final_obs" in out
+    rows, edge = 0, 0
+    worst = 0.0
+    for t in range(T):
+        a = acts[t].cpu().numpy()
+        w_s, w_obs, w_rew, w_term = O.transitions(fam, table, prev, a)
+        obs_t = out["obs"][t].cpu().numpy()
+        term = out["terminated"][t].cpu().numpy()
+        done = (term | out["truncated"][t].cpu().numpy()) != 0
+        got = np.where(done[:, None], out["final_obs"][t].cpu().numpy(), obs_t) if have_final else obs_t
+        bad_flag = term != w_term
+        if bad_flag.any():
+            assert (flag_margin(fam, table[bad_flag], w_s[bad_flag]) < 1e-5).all(), (t, int(bad_flag.sum()))
+            edge += int(bad_flag.sum())
+        use = ~bad_flag if have_final else (~bad_flag & ~done)
+        e = rel_err(got[use], w_obs[use]).max(initial=0.0)
+        # (CartPole's reward on a step AFTER termination is 0 in gymnasium; with auto-reset that step does not exist)
+        er = rel_err(out["reward"][t].cpu().numpy()[~bad_flag], w_rew[~bad_flag]).max(initial=0.0)
+        worst = max(worst, float(e), float(er))
+        assert e <= TOL and er <= TOL, (O.FAMILY_NAMES[fam], t, float(e), float(er))
+        rows += int(use.sum())
+        prev = state_from_obs(fam, obs_t)  # what the kernel continues from (reset state on done rows)
+    assert edge <= max_edge_flags, edge
+    print(f"restep {O.FAMILY_NAMES[fam]}: {rows} rows re-stepped by the oracle, worst {worst:.2e}, {edge} threshold-edge flags",
+          flush=True)
+    return rows
+
+
 def run_transitions(fam, ctx_rows, state, action, device, **kw):
     """one engine step from prescribed (context, state, action) rows, lane i <-> row i"""
     n = state.shape[0]
@@ -480,6 +527,8 @@ def test_full_size_config2_pendulum_properties(device):
     trunc = out["truncated"].cpu().numpy()
     assert (trunc[199] == 1).all() and (trunc[399] == 1).all() and trunc.sum() == 2 * n  # TimeLimit 200
     assert (eng.episodes_done == 2).all() and (eng.elapsed == 0).all()
+    # the bench's exact kernel (rollout_staged_kernel<Pendulum, PLAIN>) against the oracle, row by row: 16.4 M rows
+    assert restep_rollout_with_oracle(fam, table, s0, acts, out, t_max=250) >= 250 * n - n
 
 
 def test_full_size_config3_mixed_batch_properties(device):
@@ -491,8 +540,11 @@ def test_full_size_config3_mixed_batch_properties(device):
         table = random_table(fam, rng, n)
         eng = _engine(fam, table, n, device, selector=O.SEL_STATIC, seed=4, fin_capacity=1 << 22)
         eng.reset()
+        s0 = eng.state.t().cpu().numpy()
         acts = torch.as_tensor(random_actions(fam, rng, (T, n)), device=device)
-        out = eng.rollout(acts)
+        out = eng.rollout(acts, eng.alloc_rollout(T, final_obs=True))
+        # every transition of the first 250 steps re-stepped by the oracle (16.4 M rows per family)
+        assert restep_rollout_with_oracle(fam, table, s0, acts, out, t_max=250) >= 250 * n - 8
         done = (out["terminated"] | out["truncated"]).bool()
         # sum over time of done flags == episodes finished == entries in the compact log
         assert torch.equal(done.sum(0).to(torch.int32), eng.episodes_done)
@@ -584,6 +636,7 @@ def test_full_size_cartpole_65536_dense_done_path_properties(device):
     e2.reset()
     e3 = _engine(fam, table, n, device, fin_capacity=1 << 22, **kw)
     e3.reset()
+    s0 = e1.state.t().cpu().numpy()
     o1 = e1.rollout(acts)                                      # dense, lean
     o2 = e2.rollout(acts, e2.alloc_rollout(T, final_obs=True))  # dense, terminal observations
     o3 = e3.rollout(acts, e3.alloc_rollout(T, final_obs=True))  # generic done path (finished-episode log on)
@@ -611,6 +664,10 @@ def test_full_size_cartpole_65536_dense_done_path_properties(device):
     t_idx, l_idx = done.nonzero(as_tuple=True)
     ro = o1["obs"][t_idx, l_idx]
     assert bool(((ro >= lo[l_idx, None]) & (ro <= hi[l_idx, None])).all())
+    # (iii) the headline's exact kernel -- rollout_staged_kernel<CartPole, PLAIN, AR>, whose outputs equal o2's bit for
+    # bit (above) -- against the oracle DIRECTLY: all 65 536 x 250 = 16.4 M transitions re-stepped by `O.transitions`
+    # (terminal observations from o2's `final_obs`)
+    assert restep_rollout_with_oracle(fam, table, s0, acts, o2) >= T * n - 8
 
 
 @pytest.mark.parametrize("selector", [O.SEL_ROUND_ROBIN, O.SEL_RANDOM], ids=["round_robin", "random"])
