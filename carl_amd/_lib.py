@@ -15,11 +15,13 @@ import torch  # noqa: F401  (must precede the CDLL load, see module docstring)
 
 from carl_amd import build as _build
 
-CARL_ABI_VERSION = 5
+CARL_ABI_VERSION = 6
 CARL_MAX_CTX_OBS = 32
 
 # carl_family_t
 CARTPOLE, PENDULUM, ACROBOT, MOUNTAINCAR, MOUNTAINCAR_CONT = range(5)
+CARL_N_FAMILIES = 5
+ERR_INVALID_ARGUMENT, ERR_UNSUPPORTED = -1, -2  # CARL_ERR_* (include/carl_amd.h)
 # carl_selector_t
 SEL_STATIC, SEL_ROUND_ROBIN, SEL_RANDOM, SEL_HOST = range(4)
 FLAG_AUTORESET = 1
@@ -76,6 +78,7 @@ EXPORTS = {
     "carl_reset_indexed": (C.c_int, [C.POINTER(Batch), _vp, _vp, _vp, _vp]),
     "carl_step": (C.c_int, [C.POINTER(Batch), C.POINTER(StepIO), _vp]),
     "carl_rollout": (C.c_int, [C.POINTER(Batch), C.POINTER(StepIO), C.c_int32, _vp]),
+    "carl_rollout_pair": (C.c_int, [C.POINTER(Batch), C.POINTER(StepIO), C.POINTER(Batch), C.POINTER(StepIO), C.c_int32, _vp]),
     "carl_rollout_variant": (C.c_int, [C.POINTER(Batch)]),
     "carl_done_compact": (C.c_int, [_vp, _vp, C.c_int32, _vp, _vp, _vp, _vp]),
     "carl_done_compact_scratch_elems": (C.c_int32, [C.c_int32]),

@@ -237,6 +237,34 @@ int launch_step(const carl_batch_t* b, const carl_step_io_t* io, int n_steps, hi
   return check_launch("carl_rollout");
 }
 
+// One launch for a mixed batch of two classic families (engine_kernels.hip.h: rollout_staged_pair_kernel).  A is the
+// float64 Acrobot -- the family whose single wavefront per SIMD leaves issue slots for another family's wavefronts;
+// pairing two memory-bound float32 families would gain nothing.
+template <class FamB>
+int launch_pair(const carl_batch_t* a, const carl_step_io_t* ioa, const carl_batch_t* b, const carl_step_io_t* iob,
+                int n_steps, hipStream_t s) {
+  using FamA = carl::Acrobot;
+  using kern_t = void (*)(carl_batch_t, carl_step_io_t, carl_batch_t, carl_step_io_t, int, int);
+  kern_t kern = static_cast<kern_t>(carl::rollout_staged_pair_kernel<FamA, FamB, false, false>);
+  if constexpr (carl::dense_done_of<FamB>::value) {
+    if (b->flags & CARL_FLAG_AUTORESET) kern = static_cast<kern_t>(carl::rollout_staged_pair_kernel<FamA, FamB, false, true>);
+  }
+  const size_t sh = carl::rollout_pair_lds_bytes<FamA, FamB>();
+  if (int e = carl_host::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), sh, "carl_rollout_pair")) return e;
+  const int grid_a = (a->n_lanes + carl::kRolloutLanes - 1) / carl::kRolloutLanes;
+  const int grid_b = (b->n_lanes + carl::kRolloutLanes - 1) / carl::kRolloutLanes;
+  hipLaunchKernelGGL(kern, dim3(grid_a + grid_b), dim3(carl::kStagedThreads), sh, s, *a, *ioa, *b, *iob, n_steps, grid_a);
+  return check_launch("carl_rollout_pair");
+}
+
+// the lean staged configuration of one part of a pair launch (what launch_step would run as
+// rollout_staged_kernel<Fam, false, PLAIN = true>)
+bool pair_part_ok(const carl_batch_t* b, const carl_step_io_t* io) {
+  const bool keeps_context = b->selector == CARL_SEL_STATIC || b->selector == CARL_SEL_HOST;
+  return b->n_lanes > 0 && rollout_variant(b) == CARL_ROLLOUT_STAGED && keeps_context && b->fin_count == nullptr &&
+         io->final_obs == nullptr && io->action_dtype != CARL_ACTION_I64;
+}
+
 #define CARL_DISPATCH(family, CALL)                                   \
   switch (family) {                                                   \
     case CARL_CARTPOLE: return CALL(carl::CartPole);                  \
@@ -324,6 +352,38 @@ int carl_rollout(const carl_batch_t* batch, const carl_step_io_t* io, int32_t n_
 #define CALL(F) launch_step<F>(batch, io, n_steps, (hipStream_t)stream)
   CARL_DISPATCH(batch->family, CALL)
 #undef CALL
+}
+
+int carl_rollout_pair(const carl_batch_t* batch_a, const carl_step_io_t* io_a, const carl_batch_t* batch_b,
+                      const carl_step_io_t* io_b, int32_t n_steps, void* stream) {
+  if (int e = validate_batch(batch_a, "carl_rollout_pair")) return e;
+  if (int e = validate_batch(batch_b, "carl_rollout_pair")) return e;
+  if (int e = validate_io(batch_a, io_a, "carl_rollout_pair")) return e;
+  if (int e = validate_io(batch_b, io_b, "carl_rollout_pair")) return e;
+  if (n_steps < 0) return fail(CARL_ERR_INVALID_ARGUMENT, "carl_rollout_pair: n_steps %d < 0", n_steps);
+  if (n_steps == 0) return 0;
+  // exactly one part is the float64 Acrobot (A); the other is any float32 family
+  const bool a_acro = batch_a->family == CARL_ACROBOT && !(batch_a->flags & CARL_FLAG_ACROBOT_FP32);
+  const bool b_acro = batch_b->family == CARL_ACROBOT && !(batch_b->flags & CARL_FLAG_ACROBOT_FP32);
+  if (a_acro == b_acro || batch_a->family == batch_b->family)
+    return fail(CARL_ERR_UNSUPPORTED, "carl_rollout_pair: a pair launch is Acrobot (float64) + one other family");
+  if (!a_acro) {
+    const carl_batch_t* tb = batch_a; batch_a = batch_b; batch_b = tb;
+    const carl_step_io_t* ti = io_a; io_a = io_b; io_b = ti;
+  }
+  if (batch_b->family == CARL_ACROBOT)
+    return fail(CARL_ERR_UNSUPPORTED, "carl_rollout_pair: the second family cannot be Acrobot");
+  if (!pair_part_ok(batch_a, io_a) || !pair_part_ok(batch_b, io_b))
+    return fail(CARL_ERR_UNSUPPORTED, "carl_rollout_pair: both parts must be lean staged rollouts (n_lanes %% 16 == 0, static / host "
+                "selector, no finished-episode log, no terminal observations, int32 / float32 actions)");
+  hipStream_t s = (hipStream_t)stream;
+  switch (batch_b->family) {
+    case CARL_CARTPOLE: return launch_pair<carl::CartPole>(batch_a, io_a, batch_b, io_b, n_steps, s);
+    case CARL_PENDULUM: return launch_pair<carl::Pendulum>(batch_a, io_a, batch_b, io_b, n_steps, s);
+    case CARL_MOUNTAINCAR: return launch_pair<carl::MountainCar>(batch_a, io_a, batch_b, io_b, n_steps, s);
+    case CARL_MOUNTAINCAR_CONT: return launch_pair<carl::MountainCarCont>(batch_a, io_a, batch_b, io_b, n_steps, s);
+    default: return fail(CARL_ERR_UNSUPPORTED, "carl_rollout_pair: family %d", batch_b->family);
+  }
 }
 
 int carl_rollout_variant(const carl_batch_t* batch) {

@@ -776,9 +776,9 @@ constexpr int kStageChunk = 8;
 constexpr int kStorers = CARL_STORERS;                                   // storer waves per workgroup
 constexpr int kStagedThreads = kRolloutLanes + (1 + kStorers) * kWave;  // + loader wave + storer waves
 
-template <class Fam>
+template <class Fam, int CHUNK = kStageChunk>
 __host__ __device__ constexpr size_t rollout_staged_lds_bytes() {
-  return (size_t)2 * kStageChunk * (LdsSink<Fam>::kStepBytes + kRolloutLanes * sizeof(float));
+  return (size_t)2 * CHUNK * (LdsSink<Fam>::kStepBytes + kRolloutLanes * sizeof(float));
 }
 
 // A chunk of actions in flight: issue() starts the HBM loads into registers, commit() writes
@@ -786,7 +786,7 @@ __host__ __device__ constexpr size_t rollout_staged_lds_bytes() {
 // travel as two 16-byte vectors per lane-row and are narrowed at commit time.
 template <class AStore, class Action, int CHUNK>
 struct ActionPipe {
-  static_assert(CHUNK == 8, "the in-flight chunk is held in eight named register groups");
+  static_assert(CHUNK == 8 || CHUNK == 4, "the in-flight chunk is held in eight (four) named register groups");
   static constexpr bool kSame = std::is_same_v<AStore, Action>;
   // native 16-byte vectors in named members: first-class register values.  (A float4 array
   // member that is live across the chunk loop stayed a private-memory object -> scratch.)
@@ -844,14 +844,16 @@ struct ActionPipe {
     a2 = load_row(row + lane4);
     row += n;
     a3 = load_row(row + lane4);
-    row += n;
-    a4 = load_row(row + lane4);
-    row += n;
-    a5 = load_row(row + lane4);
-    row += n;
-    a6 = load_row(row + lane4);
-    row += n;
-    a7 = load_row(row + lane4);
+    if constexpr (CHUNK == 8) {
+      row += n;
+      a4 = load_row(row + lane4);
+      row += n;
+      a5 = load_row(row + lane4);
+      row += n;
+      a6 = load_row(row + lane4);
+      row += n;
+      a7 = load_row(row + lane4);
+    }
   }
   __device__ __forceinline__ void commit(Action* buf, const AStore* __restrict__ act, size_t n, int lane_base, int l,
                                          int n_steps) const {
@@ -865,10 +867,12 @@ struct ActionPipe {
       dst[row] = narrow(a1);
       dst[2 * row] = narrow(a2);
       dst[3 * row] = narrow(a3);
-      dst[4 * row] = narrow(a4);
-      dst[5 * row] = narrow(a5);
-      dst[6 * row] = narrow(a6);
-      dst[7 * row] = narrow(a7);
+      if constexpr (CHUNK == 8) {
+        dst[4 * row] = narrow(a4);
+        dst[5 * row] = narrow(a5);
+        dst[6 * row] = narrow(a6);
+        dst[7 * row] = narrow(a7);
+      }
       return;
     }
     // last, ragged chunk of the rollout (once per launch): a plain row loop
@@ -925,12 +929,12 @@ __device__ __forceinline__ void drain_records(char* buf, const carl_step_io_t& i
 }
 
 // before the first step: all flag rows of both record buffers to zero (LdsSink::kLazyFlags)
-template <class Fam>
+template <class Fam, int CHUNK>
 __device__ __forceinline__ void zero_flag_rows(char* out_buf, int l, int which) {
   using SK = LdsSink<Fam>;
   typedef float vf4 __attribute__((ext_vector_type(4)));
   if (l < 32)
-    for (int u = which; u < 2 * kStageChunk; u += kStorers)
+    for (int u = which; u < 2 * CHUNK; u += kStorers)
       *reinterpret_cast<vf4*>(out_buf + (size_t)u * SK::kStepBytes + SK::kFlagOff + 16 * l) = vf4{0.0f, 0.0f, 0.0f, 0.0f};
 }
 
@@ -943,11 +947,13 @@ __device__ __forceinline__ void zero_flag_rows(char* out_buf, int l, int which) 
 // MOVES (with PLAIN, kDenseDone families): the dense done handling with context changes on reset (see dense_draw).
 // FINAL (with PLAIN, kDenseDone families): ... and with terminal observations written (see step_dense).
 // AR (with PLAIN, kDenseDone families): compiled for launches with CARL_FLAG_AUTORESET set (see step_dense).
-template <class Fam, bool A64, bool PLAIN = false, bool LDSCTX = false, bool MOVES = false, bool FINAL = false,
-          bool AR = false>
-__global__ void __launch_bounds__(kStagedThreads) rollout_staged_kernel(const carl_batch_t b, const carl_step_io_t io,
-                                                                        const int n_steps) {
-  extern __shared__ float lds_dyn[];
+// CHUNK: steps per LDS buffer (8; the heterogeneous pair launch below runs its families at 4 so that two workgroups
+// fit on a compute unit).  `wg`: the workgroup's index among the batch's workgroups (blockIdx.x, or the index inside
+// this family's share of a pair launch).
+template <class Fam, bool A64, bool PLAIN, bool LDSCTX, bool MOVES, bool FINAL, bool AR, int CHUNK>
+__device__ __forceinline__ void rollout_staged_body(const carl_batch_t& b, const carl_step_io_t& io, const int n_steps,
+                                                    const int wg, float* lds_dyn) {
+  constexpr int kStageChunk = CHUNK;  // (shadows the namespace-scope default inside this body)
   stage_family_tables<Fam>();
   using AStore = action_store_t<Fam, A64>;
   using Action = typename Fam::Action;
@@ -971,10 +977,10 @@ __global__ void __launch_bounds__(kStagedThreads) rollout_staged_kernel(const ca
   const bool loader = wave == kRolloutLanes / kWave;
   const int hl = threadIdx.x % kWave;    // lane within a helper wave
 #ifdef CARL_EXP_XCD_SWIZZLE  // measurement only: workgroup i runs on XCD i % 8 -- give every XCD one contiguous lane range
-  const int wg = (gridDim.x % 8 == 0) ? (int)((blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8) : (int)blockIdx.x;
-  const int lane_base = wg * kRolloutLanes;
+  const int wgx = (gridDim.x % 8 == 0) ? (int)((blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8) : (int)blockIdx.x;
+  const int lane_base = wgx * kRolloutLanes;
 #else
-  const int lane_base = blockIdx.x * kRolloutLanes;
+  const int lane_base = wg * kRolloutLanes;
 #endif
   const int lane = lane_base + (compute ? (int)threadIdx.x : 0);
   const bool active = compute && lane < b.n_lanes;
@@ -986,7 +992,7 @@ __global__ void __launch_bounds__(kStagedThreads) rollout_staged_kernel(const ca
   LaneRegs<Fam> r{};
   ActionPipe<AStore, Action, kStageChunk> pipe;
   float* const final_base = (io.final_obs != nullptr && active) ? io.final_obs + (size_t)lane * Fam::D : nullptr;
-  if (!compute && !loader) zero_flag_rows<Fam>(out_buf, hl, storer);
+  if (!compute && !loader) zero_flag_rows<Fam, CHUNK>(out_buf, hl, storer);
   if (loader) {
     pipe.issue(act, n, lane_base, hl, 0, n_steps);
     pipe.commit(act_buf, act, n, lane_base, hl, n_steps);
@@ -1114,6 +1120,55 @@ __global__ void __launch_bounds__(kStagedThreads) rollout_staged_kernel(const ca
     drain_records<Fam>(out_buf + (size_t)(buf ^ 1) * kStageChunk * SK::kStepBytes, io, n, lane_base, hl, storer,
                        last_t0, n_steps - last_t0);
   }
+}
+
+template <class Fam, bool A64, bool PLAIN = false, bool LDSCTX = false, bool MOVES = false, bool FINAL = false,
+          bool AR = false>
+__global__ void __launch_bounds__(kStagedThreads) rollout_staged_kernel(const carl_batch_t b, const carl_step_io_t io,
+                                                                        const int n_steps) {
+  extern __shared__ float lds_dyn[];
+  rollout_staged_body<Fam, A64, PLAIN, LDSCTX, MOVES, FINAL, AR, kStageChunk>(b, io, n_steps, (int)blockIdx.x, lds_dyn);
+}
+
+// -------------------------------- two families in ONE launch ------------------------
+// BASELINE config 3 is a mixed batch (Acrobot + MountainCar).  As two launches the families run back to back: an
+// Acrobot workgroup's 139 KB of LDS (8-step chunks) leaves no room for a MountainCar workgroup on the same compute
+// unit, and at 65 536 lanes each launch is ONE compute wavefront per SIMD -- Acrobot's float64 RK4 then issues an
+// instruction every ~5.3 cycles and the SIMD idles in between, while MountainCar waits for the next launch (350 us
+// per 250-step mixed launch: 246 + 59 + two launch boundaries).  Stream-level co-residence was tried in round 3 (a
+// fork / join per call costs more than the overlap returns).  Here ONE launch carries both families: workgroups
+// [0, grid_a) run family A's staged rollout, [grid_a, grid_a + grid_b) family B's, both at 4-step chunks so that one
+// workgroup of each fits a compute unit (2 x (69.6 KB + the 8 KB sin/cos table) < 160 KB) -- B's wavefronts issue
+// beside A's.  The blocked order matters: consecutive workgroups go to consecutive XCDs and, inside an XCD, to the
+// compute unit with the most free resources, so the first grid_a workgroups take one slot on every compute unit and
+// B's take the second (measured with tools/wg_placement: of 512 such workgroups, i and i + 256 share a compute unit,
+// always; an interleaved order would put all of A on four XCDs).  What it buys is bounded by the vector ALU: Acrobot's
+// float64 stream keeps the SIMD's pipe ~85 % busy by itself, so B's instructions still cost their own pipe time
+// (MountainCar: ~25 us of its 58 us) -- 65 536 + 65 536 lanes: 314 us against 277 + 58 + a launch boundary = 340 us
+// on the same box; 8 192 + 8 192: 211 against 252 us.  Raising Acrobot's issue priority (s_setprio 3) changes
+// nothing (measured).  Same bodies, same arithmetic,
+// same per-lane order of operations as the single-family kernel: results are bit-identical to separate launches
+// (tests/test_gpu_mixed_and_multiproc.py).  Lean configuration only (PLAIN; AR for a dense-done family), int32 /
+// float32 actions: with int64 actions the Acrobot body needs 134 VGPRs and two workgroups no longer share a SIMD.
+constexpr int kPairChunk = 4;
+
+template <class FamA, class FamB>
+__host__ __device__ constexpr size_t rollout_pair_lds_bytes() {
+  constexpr size_t a = rollout_staged_lds_bytes<FamA, kPairChunk>(), b = rollout_staged_lds_bytes<FamB, kPairChunk>();
+  return a > b ? a : b;
+}
+
+template <class FamA, class FamB, bool ARA, bool ARB>
+__global__ void __launch_bounds__(kStagedThreads) __attribute__((amdgpu_waves_per_eu(4)))
+rollout_staged_pair_kernel(const carl_batch_t ba, const carl_step_io_t ioa, const carl_batch_t bb, const carl_step_io_t iob,
+                           const int n_steps, const int grid_a) {
+  extern __shared__ float lds_dyn[];
+  if ((int)blockIdx.x < grid_a)  // (workgroup-uniform)
+    rollout_staged_body<FamA, false, true, false, false, false, ARA && dense_done_of<FamA>::value, kPairChunk>(
+        ba, ioa, n_steps, (int)blockIdx.x, lds_dyn);
+  else
+    rollout_staged_body<FamB, false, true, false, false, false, ARB && dense_done_of<FamB>::value, kPairChunk>(
+        bb, iob, n_steps, (int)blockIdx.x - grid_a, lds_dyn);
 }
 
 // -------------------------------- done-mask compaction ------------------------------

@@ -429,6 +429,13 @@ class VecEngine:
                           "lanes for the fast path.", RuntimeWarning, stacklevel=2)
         if out is None:
             out = self.alloc_rollout(T)
+        io = self._rollout_io(a, dt, out, T)
+        with torch.cuda.device(self.device):
+            _lib.check(self._c_rollout(io, T))
+        return out
+
+    def _rollout_io(self, a: torch.Tensor, dt: int, out: dict, T: int) -> "_lib.StepIO":
+        """``carl_step_io_t`` of a fused rollout: validated actions + the caller's ``[T, ...]`` output buffers"""
         if out["reward"].shape[0] < T:
             raise ValueError("rollout output buffers are shorter than the action sequence")
         io = _lib.StepIO()
@@ -437,9 +444,7 @@ class VecEngine:
         io.terminated, io.truncated = _ptr(out["terminated"]), _ptr(out["truncated"])
         io.final_obs = _ptr(out.get("final_obs"))
         io.branch_sig = _ptr(out.get("branch_sig"))
-        with torch.cuda.device(self.device):
-            _lib.check(self._c_rollout(io, T))
-        return out
+        return io
 
     def rollout_variant(self) -> int:
         """Which kernel ``rollout`` launches for this batch: ``_lib.ROLLOUT_STAGED`` (fast path, needs

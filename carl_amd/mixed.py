@@ -69,6 +69,8 @@ class MixedVecEngine:
         self._joins = [torch.cuda.Event() for _ in self.parts]
         self._pending = []      # outputs allocated by free-running launches that were not joined yet (see rollout / join)
         self._in_flight = False  # a free-running launch was enqueued since the last join()
+        self.pair_launches = 0   # fused rollouts that went out as ONE heterogeneous launch (carl_rollout_pair)
+        self._pair_ok = None     # False: this batch can never take the one-launch pair kernel (see _rollout_pair)
 
     # ------------------------------------------------------------------ fork / join
     def _each(self, fn):
@@ -117,8 +119,24 @@ class MixedVecEngine:
     def alloc_rollout(self, n_steps: int, final_obs: bool = False) -> list[dict]:
         return [p.alloc_rollout(n_steps, final_obs) for p in self.parts]
 
-    def rollout(self, actions: Sequence, outs: Sequence[dict] | None = None, *, free_running: bool = False) -> list[dict]:
+    # a Brax part of at most this many envs leaves more than half of the chip's wavefront slots empty (4 096 envs at 16
+    # lanes per env = 1 024 wavefronts = one per SIMD): two such launches side by side finish sooner than back to back
+    SMALL_BRAX_PART = 8192
+
+    def _small_brax_parts(self) -> bool:
+        return len(self.parts) > 1 and all(hasattr(p, "sys") and p.n <= self.SMALL_BRAX_PART for p in self.parts)
+
+    def rollout(self, actions: Sequence, outs: Sequence[dict] | None = None, *, free_running: bool = False,
+                overlap: bool | None = None) -> list[dict]:
         """T fused steps of every family; ``actions[k]`` is part k's ``[T, n_k(, A_k)]``.
+
+        ``overlap`` (default: decided per batch): run the parts' launches side by side on the parts' streams, forked
+        from and joined back into the caller's stream inside this call -- still ONE stream-ordered operation for the
+        caller.  It pays when every part under-fills the chip: the 8-GPU shard of BASELINE config 5 (Halfcheetah x 4 096
+        + Humanoid x 4 096 per GPU) is two launches of ~1 000 wavefronts each on 1 024 SIMDs -- latency-bound at one
+        wavefront per SIMD -- and takes max(a, b) x 1.2 side by side instead of a + b (measured: 1.60 -> 0.9 ms per
+        20-step launch).  Full-size parts each fill the chip by themselves and go back to back (the fork / join costs
+        more than it returns there: DESIGN.md section 4).
 
         ``free_running=True``: part k's launch goes on part k's own stream, ordered after the caller's stream NOW, and
         is NOT joined back -- consecutive ``rollout`` calls of different parts then overlap on the device (part A's
@@ -157,7 +175,47 @@ class MixedVecEngine:
                 res.append(out_k)
             return res
         self._auto_join()
+        if self._pair_ok is not False and overlap is None:
+            res = self._rollout_pair(actions, outs)
+            if res is not None:
+                return res
+        if overlap is None:
+            overlap = self._small_brax_parts()
+        if overlap:
+            return self._each(lambda k, p: p.rollout(actions[k], None if outs is None else outs[k]))
         return [p.rollout(actions[k], None if outs is None else outs[k]) for k, p in enumerate(self.parts)]
+
+    def _rollout_pair(self, actions, outs):
+        """Two classic-control families, one of them the float64 Acrobot, in the lean staged configuration: ONE launch
+        for both (``carl_rollout_pair``: BASELINE config 3's Acrobot + MountainCar as a heterogeneous launch, the second
+        family's wavefronts issuing in the gaps of Acrobot's RK4).  Returns ``None`` when the library declines
+        (``CARL_ERR_UNSUPPORTED``: other families, int64 actions, terminal observations, moving selectors ...) -- the
+        caller then launches the parts one after the other; results are bit-identical either way."""
+        import ctypes as C
+
+        from carl_amd import _lib
+
+        if len(self.parts) != 2 or any(hasattr(p, "sys") for p in self.parts):
+            self._pair_ok = False
+            return None
+        pa, pb = self.parts
+        T = int(actions[0].shape[0])
+        if int(actions[1].shape[0]) != T:
+            return None
+        aa, dta = pa._action_tensor(actions[0], (T,))
+        ab, dtb = pb._action_tensor(actions[1], (T,))
+        if outs is None:
+            outs = [pa.alloc_rollout(T), pb.alloc_rollout(T)]
+        ioa, iob = pa._rollout_io(aa, dta, outs[0], T), pb._rollout_io(ab, dtb, outs[1], T)
+        with torch.cuda.device(self.device):
+            code = pa.lib.carl_rollout_pair(C.byref(pa.b), C.byref(ioa), C.byref(pb.b), C.byref(iob), T, pa._stream())
+        if code == _lib.ERR_UNSUPPORTED:
+            if {pa.family, pb.family} - set(range(_lib.CARL_N_FAMILIES)) or _lib.ACROBOT not in (pa.family, pb.family):
+                self._pair_ok = False  # never eligible: stop asking
+            return None
+        _lib.check(code)
+        self.pair_launches += 1
+        return list(outs)
 
     def join(self) -> None:
         """Order the caller's stream after everything the parts' streams hold (after ``rollout(free_running=True)``)."""

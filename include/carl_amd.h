@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define CARL_ABI_VERSION 5
+#define CARL_ABI_VERSION 6
 #define CARL_MAX_CTX_OBS 32
 
 #define CARL_ERR_INVALID_ARGUMENT (-1)
@@ -218,6 +218,19 @@ int carl_step(const carl_batch_t* batch, const carl_step_io_t* io, void* stream)
  * steps one env object per Python call); exists because a single step of 65 536
  * lanes is shorter than a kernel launch. */
 int carl_rollout(const carl_batch_t* batch, const carl_step_io_t* io, int32_t n_steps, void* stream);
+
+/* T consecutive steps of TWO batches of different classic-control families in ONE launch: BASELINE config 3's mixed
+ * batch ("CARLAcrobot + CARLMountainCar", carl/envs/gymnasium/classic_control/carl_acrobot.py:11-115 +
+ * carl_mountaincar.py:11-85 -- in the reference two unrelated env objects, carl/envs/carl_env.py:245-342 holds no
+ * cross-env state).  One part must be the float64 Acrobot, the other any other family; both in the lean staged
+ * configuration (n_lanes % 16 == 0, static / host selector, no finished-episode log, io.final_obs NULL, int32 /
+ * float32 actions).  Each family's workgroups run the same staged rollout as carl_rollout at 4-step chunks, so one
+ * workgroup of each fits a compute unit and the second family's wavefronts issue in the gaps of Acrobot's RK4:
+ * results are bit-identical to two carl_rollout calls, the launch takes ~max instead of the sum.
+ * Returns CARL_ERR_UNSUPPORTED (nothing enqueued) for any other combination: the caller then makes the two
+ * carl_rollout calls itself (carl_amd.mixed.MixedVecEngine.rollout does). */
+int carl_rollout_pair(const carl_batch_t* batch_a, const carl_step_io_t* io_a, const carl_batch_t* batch_b,
+                      const carl_step_io_t* io_b, int32_t n_steps, void* stream);
 
 /* Which kernel carl_rollout launches for this batch (classic-control families).  The staged kernel (transition
  * records assembled in LDS, written with 16-byte stores by dedicated waves) needs n_lanes % 16 == 0; any other

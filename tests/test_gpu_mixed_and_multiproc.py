@@ -60,6 +60,84 @@ def test_mixed_batch_equals_separate_engines(n, T, device):
     assert int(mixed.episodes_done[mixed.part_slice(1)].min()) >= 1
 
 
+@pytest.mark.parametrize("other", [O.MOUNTAINCAR, O.CARTPOLE, O.PENDULUM, O.MOUNTAINCAR_CONT], ids=lambda f: O.FAMILY_NAMES[f])
+@pytest.mark.parametrize("n_a,n_b,T,max_steps", [(4112, 1040, 37, 5), (1024, 4096, 64, 0)])
+def test_pair_launch_equals_two_launches_bit_for_bit(other, n_a, n_b, T, max_steps, device):
+    """`carl_rollout_pair`: Acrobot + one other family as ONE heterogeneous launch at 4-step chunks ==
+    the two families' own `carl_rollout` launches (8-step chunks), in every output and counter: unequal part sizes,
+    ragged last workgroups (4112 = 16 x 256 + 16), a ragged last chunk (37 = 9 x 4 + 1), resets of every lane inside
+    the window (TimeLimit 5), either order of the parts.  Combinations the library declines (int64 actions, terminal
+    observations) fall back to two launches with the same results."""
+    from carl_amd.mixed import MixedVecEngine
+
+    rng = np.random.default_rng(T + other)
+    fams, sizes = (O.ACROBOT, other), (n_a, n_b)
+    tables = [random_table(f, rng, n) for f, n in zip(fams, sizes)]
+    kw = dict(selector=O.SEL_STATIC, seed=5)
+    if max_steps:
+        kw["max_episode_steps"] = max_steps
+    mk = lambda order: [_engine(fams[k], tables[k], sizes[k], device, ctx_idx0=np.arange(sizes[k]), lane_offset=k * 8192,  # noqa: E731
+                                **kw) for k in order]
+    acts = [torch.as_tensor(random_actions(f, rng, (T, n)), device=device) for f, n in zip(fams, sizes)]
+    for order in ((0, 1), (1, 0)):
+        sep, parts = mk(order), mk(order)
+        mixed = MixedVecEngine(parts)
+        for e in sep:
+            e.reset()
+        mixed.reset()
+        a = [acts[k] for k in order]
+        outs = mixed.rollout(a)
+        assert mixed.pair_launches == 1  # one launch for both families
+        ref = [e.rollout(x) for e, x in zip(sep, a)]
+        for k in range(2):
+            for name in ("obs", "reward", "terminated", "truncated"):
+                assert torch.equal(outs[k][name], ref[k][name]), (order, k, name)
+            for name in _BOOKKEEPING:
+                assert torch.equal(getattr(parts[k], name), getattr(sep[k], name)), (order, k, name)
+        if max_steps:
+            assert int(mixed.episodes_done.min()) >= T // max_steps
+        # declined combinations: terminal observations requested; int64 actions (discrete families)
+        outs2 = mixed.rollout(a, [p.alloc_rollout(T, final_obs=True) for p in parts])
+        ref2 = [e.rollout(x, e.alloc_rollout(T, final_obs=True)) for e, x in zip(sep, a)]
+        a64 = [x.long() if x.dtype == torch.int32 else x for x in a]
+        outs3 = mixed.rollout(a64)
+        ref3 = [e.rollout(x) for e, x in zip(sep, a64)]
+        assert mixed.pair_launches == 1
+        for k in range(2):
+            for name in ("obs", "reward", "terminated", "truncated"):
+                assert torch.equal(outs2[k][name], ref2[k][name]) and torch.equal(outs3[k][name], ref3[k][name]), (k, name)
+            assert torch.equal(parts[k].state, sep[k].state)
+
+
+def test_pair_launch_is_refused_for_other_combinations(device):
+    """ABI: CARL_ERR_UNSUPPORTED, nothing enqueued, for two float32 families / two Acrobots / a moving selector"""
+    import ctypes as C
+
+    from carl_amd import _lib
+
+    n, T = 1024, 8
+    rng = np.random.default_rng(0)
+
+    def call(ea, eb):
+        acts = [torch.as_tensor(random_actions(e.family, rng, (T, n)), device=device) for e in (ea, eb)]
+        ios = []
+        for e, a in zip((ea, eb), acts):
+            aa, dt = e._action_tensor(a, (T,))
+            ios.append(e._rollout_io(aa, dt, e.alloc_rollout(T), T))
+        return ea.lib.carl_rollout_pair(C.byref(ea.b), C.byref(ios[0]), C.byref(eb.b), C.byref(ios[1]), T, ea._stream())
+
+    mk = lambda f, **kw: _engine(f, random_table(f, rng, n), n, device, **{"selector": O.SEL_STATIC, **kw})  # noqa: E731
+    assert call(mk(O.PENDULUM), mk(O.MOUNTAINCAR)) == _lib.ERR_UNSUPPORTED
+    assert call(mk(O.ACROBOT), mk(O.ACROBOT)) == _lib.ERR_UNSUPPORTED
+    assert call(mk(O.ACROBOT, selector=O.SEL_ROUND_ROBIN), mk(O.MOUNTAINCAR)) == _lib.ERR_UNSUPPORTED
+    assert call(mk(O.ACROBOT, acrobot_fp32=True), mk(O.MOUNTAINCAR)) == _lib.ERR_UNSUPPORTED
+    ea, eb = mk(O.ACROBOT), mk(O.MOUNTAINCAR)
+    ea.reset()
+    eb.reset()
+    assert call(ea, eb) == 0 and call(eb, ea) == 0  # either order
+    torch.cuda.synchronize()
+
+
 def test_mixed_batch_per_call_step(device):
     """the per-call path of a mixed batch: reward / flags arrive as one [2n] vector"""
     from carl_amd.mixed import MixedVecEngine

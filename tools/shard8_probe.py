@@ -42,7 +42,14 @@ def main():
         ("pendulum_8192_T250", ("pendulum",), 8192, 250, 20, "train"),
         ("pendulum_8192_T1000", ("pendulum",), 8192, 1000, 8, "train"),
         ("config3_16384_T250", ("acrobot", "mountaincar"), 8192, 250, 20, "train"),
+        ("config3_65536_T250", ("acrobot", "mountaincar"), 65536, 250, 20, "train"),
+        ("acrobot_65536_T250", ("acrobot",), 65536, 250, 20, "train"),
+        ("mountaincar_65536_T250", ("mountaincar",), 65536, 250, 20, "train"),
+        ("ant_256_T20", ("ant",), 256, 20, 20, "train"),
+        ("ant_1024_T20", ("ant",), 1024, 20, 20, "train"),
+        ("ant_2048_T20", ("ant",), 2048, 20, 20, "train"),
         ("ant_4096_T20", ("ant",), 4096, 20, 20, "train"),
+        ("ant_8192_T20", ("ant",), 8192, 20, 20, "train"),
         ("ant_32768_T20", ("ant",), 32768, 20, 10, "train"),
         ("cheetah_humanoid_4096_T20", ("halfcheetah", "humanoid"), 4096, 20, 20, "train"),
         ("halfcheetah_4096_T20", ("halfcheetah",), 4096, 20, 20, "train"),
