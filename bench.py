@@ -32,7 +32,15 @@ Also in the same JSON line:
 
   sustained     the same launch train for >= 0.3 s (the K-launch region of the driver's command is ~1.5 ms: burst
                 clocks; sustained runs clock ~8 % lower)
-  strong        (N > 1) 65 536 contexts over the WHOLE node (65 536 / N per GPU), same launch train
+  weak          (N > 1) 65 536 contexts PER GPU, same launch train -- `value` itself is the strong-scaling run
+                (BASELINE's "at 65k parallel contexts (whole node)": 65 536 / N contexts per GPU); `--weak` swaps them
+  repetitions   the K-launch timed region is run `--reps` (5) times; `value` / `ms_per_step` are the MEDIAN region
+                (each region is exactly K launches between barrier + synchronize), all regions are listed
+  clocks        sclk / mclk of this GPU sampled from sysfs while the sustained train runs (a 12 % swing between two
+                runs of one binary can then be told from a regression)
+  shard8        (N = 1) the 8-GPU operating point of BASELINE's configs measured on this ONE GPU: CARLCartPole /
+                CARLPendulum x 8 192, CARLBraxAnt x 4 096, CARLBraxHalfcheetah x 4 096 + CARLBraxHumanoid x 4 096,
+                each with predicted_node_value = 8 x and the implied strong-scaling efficiency
 
 Multi-GPU: lanes sharded by contiguous global-id ranges, no data-path collective; one RCCL all-gather of the
 per-lane episodic returns after the timed region (the reporting collective of SURVEY.md 8e), timed separately
@@ -51,6 +59,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); ~6300 GB/s achievable
+BENCH_VERSION = 4       # r04: headline CartPole x 65 536 (as r03); value = median of --reps regions; strong scaling is
+                        # `value` for N > 1; shard8 / kernel-time / VALU records added.  r03 = 3, r02 = 2 (Pendulum headline)
 
 # algorithmic bytes per env-step
 # (a) SURVEY.md 8(d), per-call model (state/ctx/elapsed re-read every step)
@@ -74,12 +84,24 @@ BRAX_ENVS = ("ant", "halfcheetah", "humanoid")
 DEFAULT_CHUNK = {e: (20 if e in BRAX_ENVS else 250) for e in BYTES_8D}
 # the other BASELINE workloads, run after the headline one (same launch train, fewer words):
 #   name -> (families, total lanes per family, "weak" = per GPU / "strong" = split over the GPUs)
+#   mode "follow": like the headline (strong by default: the total is split over the GPUs; --weak: per GPU);
+#   "strong": always split (BASELINE defines configs 4 / 5 over the node).  Fourth entry: env steps per launch (None = default)
 ALSO = {
-    "cartpole": (("cartpole",), 65536, "weak"),                      # north_star's target env (the default headline)
-    "pendulum": (("pendulum",), 65536, "weak"),                      # BASELINE config 2
-    "config3": (("acrobot", "mountaincar"), 65536, "weak"),          # 131 072-context mixed batch per GPU
-    "config4": (("ant",), 32768, "strong"),                          # 32 768 contexts over the node
-    "config5": (("halfcheetah", "humanoid"), 32768, "strong"),       # 65 536 contexts over the node
+    "cartpole": (("cartpole",), 65536, "follow", None),                # north_star's target env (the default headline)
+    "cartpole_T1000": (("cartpole",), 65536, "follow", 1000),         # the same with 1 000-step launches: 4 x fewer launch boundaries
+    "pendulum": (("pendulum",), 65536, "follow", None),                # BASELINE config 2
+    "config3": (("acrobot", "mountaincar"), 65536, "follow", None),    # 131 072-context mixed batch
+    "config4": (("ant",), 32768, "strong", None),                      # 32 768 contexts over the node
+    "config5": (("halfcheetah", "humanoid"), 32768, "strong", None),   # 65 536 contexts over the node
+}
+# the 8-GPU operating point of the BASELINE configs, measured on ONE GPU (N = 1 runs only): what each GPU of a node
+# holds when BASELINE's totals are split eight ways.  name -> (families, lanes per family per GPU, full-size record)
+SHARD8 = {
+    "cartpole_8192": (("cartpole",), 8192, "cartpole"),
+    "pendulum_8192": (("pendulum",), 8192, "pendulum"),
+    "config3_8192+8192": (("acrobot", "mountaincar"), 8192, "config3"),
+    "config4_ant_4096": (("ant",), 4096, "config4"),
+    "config5_halfcheetah_4096+humanoid_4096": (("halfcheetah", "humanoid"), 4096, "config5"),
 }
 
 
@@ -93,20 +115,28 @@ def parse():
     p.add_argument("--lanes", type=int, default=65536, help="lanes (= contexts) per family per GPU")
     p.add_argument("--chunk", type=int, default=0, help="env steps per fused launch (default 250; Brax 20)")
     p.add_argument("--buffer-sets", type=int, default=2, help="action/output buffer sets the launches rotate through")
-    p.add_argument("--strong", action="store_true",
-                   help="headline value = strong scaling (--lanes is the TOTAL number of contexts, split over the GPUs). "
-                        "Default: weak -- --lanes contexts PER GPU; for N > 1 the other one is reported in the same line "
-                        "(under 'strong' / 'weak') either way")
+    p.add_argument("--strong", action="store_true", help="(default since r04; kept for older command lines)")
+    p.add_argument("--weak", action="store_true",
+                   help="headline value = weak scaling (--lanes contexts PER GPU).  Default: strong -- --lanes is the TOTAL "
+                        "number of contexts (BASELINE: 65 536 over the whole node), split over the GPUs; for N > 1 the other "
+                        "mode is reported in the same line (under 'weak' / 'strong') either way")
+    p.add_argument("--reps", type=int, default=5, help="repetitions of the K-launch timed region (value = the median region)")
+    p.add_argument("--no-shard8", action="store_true")
+    p.add_argument("--lanes-per-env", default="",
+                   help="Brax launch shape pinned instead of autotuned, e.g. 'ant=9,halfcheetah=7,humanoid=11' (counter passes: "
+                        "the autotune probes would otherwise be averaged into the per-kernel counters)")
     p.add_argument("--rccl", action="store_true",
                    help="single GPU: build a one-rank RCCL process group and run the reporting all-gather through it")
     p.add_argument("--sustained-seconds", type=float, default=0.3)
-    p.add_argument("--also", default="pendulum,config3,config4,config5",
+    p.add_argument("--also", default="cartpole_T1000,pendulum,config3,config4,config5",
                    help="comma list of extra workloads reported under 'also' (" + ", ".join(ALSO) + "), or 'none'")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-per-call", action="store_true")
     p.add_argument("--cpu-envs-per-core", type=int, default=256)
     p.add_argument("--cpu-steps-per-env", type=int, default=1000)
     a = p.parse_args()
+    a.strong = not a.weak
+    Workload.pinned_lanes_per_env = {k: int(v) for k, v in (kv.split("=") for kv in a.lanes_per_env.split(",") if kv)}
     a.families = tuple(a.env.split("+"))
     for f in a.families:
         if f not in BYTES_8D:
@@ -170,6 +200,8 @@ def make_actions(eng, T, device, seed):
 class Workload:
     """One or several families on this rank, their rotating action/output buffer sets, and the launch train."""
 
+    pinned_lanes_per_env: dict = {}  # --lanes-per-env
+
     def __init__(self, families, lanes_per_gpu, T, sets, rank, world, device):
         import torch
 
@@ -191,7 +223,12 @@ class Workload:
         for e in self.envs:
             e.reset(seed=0)
         if any(f in BRAX_ENVS for f in self.families):  # launch shape chosen by timing on this batch
-            self.eng.autotune(n_steps=T)                 # (results do not depend on it; probed at the launch length:
+            if all(f in self.pinned_lanes_per_env for f in self.families if f in BRAX_ENVS):
+                for f, p in zip(self.families, parts):
+                    if f in BRAX_ENVS:
+                        p.sys.lanes_per_env = self.pinned_lanes_per_env[f]
+            else:
+                self.eng.autotune(n_steps=T)             # (results do not depend on it; probed at the launch length:
                                                          #  the best width for 20-step launches is not the 2-step one)
         torch.cuda.synchronize()
         self._i = 0
@@ -306,6 +343,114 @@ def traffic_record(key):
         return None
 
 
+
+def profile_record(name, key):
+    """A committed measurement a bench run cannot take itself (counters / kernel timestamps need rocprofv3 around the
+    process): profiles/<name>.json, keyed by workload (env:lanes:chunk)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", name + ".json")) as f:
+            return json.load(f).get(key)
+    except OSError:
+        return None
+
+
+class ClockSampler:
+    """sclk / mclk of THIS GPU from sysfs (pp_dpm_sclk / pp_dpm_mclk: the level marked '*'), polled by a thread while a
+    launch train runs.  The card is found through the device's PCI bus id; if that fails the record says so."""
+
+    def __init__(self, device):
+        import glob
+
+        import torch
+
+        self.dir = None
+        try:
+            bus = "%02x:00.0" % torch.cuda.get_device_properties(device).pci_bus_id
+            for d in glob.glob("/sys/class/drm/card*/device"):
+                if os.path.realpath(d).endswith(bus) and os.path.exists(os.path.join(d, "pp_dpm_sclk")):
+                    self.dir = d
+                    break
+        except Exception:
+            pass
+        self.samples = {"sclk": [], "mclk": []}
+        self._stop = False
+        self._thread = None
+
+    def _read(self, which):
+        try:
+            with open(os.path.join(self.dir, "pp_dpm_" + which)) as f:
+                for line in f:
+                    if "*" in line:
+                        return int("".join(c for c in line.split(":")[1] if c.isdigit()))
+        except (OSError, ValueError, IndexError):
+            pass
+        return None
+
+    def __enter__(self):
+        if self.dir is not None:
+            import threading
+
+            def poll():
+                while not self._stop:
+                    for k in self.samples:
+                        v = self._read(k)
+                        if v is not None:
+                            self.samples[k].append(v)
+                    time.sleep(0.01)
+
+            self._thread = threading.Thread(target=poll, daemon=True)
+            self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop = True
+        if self._thread is not None:
+            self._thread.join()
+
+    def record(self):
+        if self.dir is None:
+            return {"source": None, "note": "sysfs clock files of this GPU not found"}
+        out = {"source": "sysfs pp_dpm_sclk / pp_dpm_mclk, polled every 10 ms during the sustained launch train"}
+        for k, v in self.samples.items():
+            if v:
+                v = sorted(v)
+                out[k + "_mhz"] = {"min": v[0], "median": v[len(v) // 2], "max": v[-1], "samples": len(v)}
+        return out
+
+
+def timed_regions(wl, K, W, reps, barrier, max_over_ranks):
+    """`reps` repetitions of the contract's timed region (W warm-up launches before the first; each region = exactly K
+    launches between barrier + synchronize).  Returns the per-region (wall max-over-ranks, HIP-event launch period) and
+    the index of the median region by wall clock."""
+    regions = []
+    for r in range(max(1, reps)):
+        wall, period = wl.train(K, W if r == 0 else 0, barrier)
+        regions.append((max_over_ranks(wall), period))
+    order = sorted(range(len(regions)), key=lambda i: regions[i][0])
+    return regions, order[(len(order) - 1) // 2]
+
+
+# SQ_INSTS_VALU x cycles per wavefront-instruction / (SIMDs x clock): the time the vector ALUs of the chip need to ISSUE
+# the launch's instruction stream -- the compute roofline of the Brax kernels (VERDICT r03 #4a).  2.98 cycles per fp32
+# wavefront-instruction at >= 2 wavefronts per SIMD: profiles/r03_fp64_rate.txt (the float64 / packed share issues at
+# 4.7: the floor below is therefore a LOWER bound of the issue time, the fraction an upper bound of the distance left).
+VALU_CYCLES_PER_INST = 2.98
+N_SIMDS = 1024
+SCLK_HZ = 2.4e9
+
+
+def roofline_valu_of(key, avg_launch_s):
+    rec = profile_record("brax_valu", key)
+    if not rec:
+        return None
+    floor_s = rec["insts_valu_per_launch"] * VALU_CYCLES_PER_INST / N_SIMDS / SCLK_HZ
+    return {"bound": "valu-issue", "insts_valu_per_launch": rec["insts_valu_per_launch"],
+            "cycles_per_inst": VALU_CYCLES_PER_INST, "simds": N_SIMDS, "sclk_hz": SCLK_HZ,
+            "issue_floor_ms": floor_s * 1e3, "kernel_ms": avg_launch_s * 1e3, "frac": floor_s / avg_launch_s,
+            "source": rec.get("source"), "insts_salu_per_launch": rec.get("insts_salu_per_launch"),
+            "insts_lds_per_launch": rec.get("insts_lds_per_launch")}
+
+
 def roofline_of(wl, avg_launch_s):
     achieved = wl.bytes_per_launch / avg_launch_s / 1e9
     r = {
@@ -318,10 +463,23 @@ def roofline_of(wl, avg_launch_s):
         "algorithmic_bytes_per_launch": wl.bytes_per_launch,
     }
     part_n = wl.n // len(wl.families)
-    rec = traffic_record(f"{'+'.join(wl.families)}:{part_n}:{wl.T}")
+    key = f"{'+'.join(wl.families)}:{part_n}:{wl.T}"
+    rec = traffic_record(key)
     if rec:
         r["traffic"] = rec["hbm_bytes_per_launch"]
         r["traffic_source"] = rec["source"]
+    # `frac` = frac_period: bytes / the launch-to-launch PERIOD measured live (HIP events on the launch stream; what a
+    # caller gets).  frac_kernel: the same bytes / the kernel's own duration as rocprofv3 --kernel-trace --stats reports
+    # it for this workload (committed under profiles/: a bench run cannot trace itself).  The difference is the launch
+    # boundary: end-of-kernel write-back of the L2-resident tail of the output stream + dispatch of the next launch.
+    r["frac_period"] = r["frac"]
+    kt = profile_record("kernel_times", key)
+    if kt:
+        r["kernel_avg_us_rocprofv3"] = kt["kernel_avg_us"]
+        r["frac_kernel"] = wl.bytes_per_launch / (kt["kernel_avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
+        r["kernel_time_source"] = kt["source"]
+    else:
+        r["kernel_avg_us_rocprofv3"] = r["frac_kernel"] = None
     return r
 
 
@@ -571,20 +729,27 @@ def main():
     n = wl.n
     shape = wl.launch_shape()
 
-    # ---- timed region: exactly K fused launches (K x T env steps of every lane) --------
-    wall, avg_launch_s = wl.train(K, W, barrier)
-    elapsed = max_over_ranks(wall)
+    # ---- timed region: exactly K fused launches (K x T env steps of every lane), repeated --reps times ----
+    regions, med = timed_regions(wl, K, W, args.reps, barrier, max_over_ranks)
+    elapsed, avg_launch_s = regions[med]
     roofline = roofline_of(wl, avg_launch_s)
     per_rank_launch_ms = gather_over_ranks(avg_launch_s * 1e3)
+    repetitions = {"n": len(regions), "median_index": med, "steps_each": K,
+                   "ms_per_step": [w / K * 1e3 for w, _ in regions], "launch_period_ms": [p_ * 1e3 for _, p_ in regions],
+                   "value": [n * world * T * K / w for w, _ in regions],
+                   "note": "each region = exactly K launches between barrier + synchronize; value / ms_per_step / roofline "
+                           "are the median region's"}
 
     # ---- the same launch train, sustained: the K-launch region above is ~1-2 ms (burst clocks) ----
     import math
 
     Ks = max(K, int(math.ceil(args.sustained_seconds / max(avg_launch_s, 1e-6))))
-    wall_s, avg_s = wl.train(Ks, 0, barrier)
+    with ClockSampler(device) as clk:
+        wall_s, avg_s = wl.train(Ks, 0, barrier)
     el_s = max_over_ranks(wall_s)
     sustained = {"steps": Ks, "seconds": el_s, "value": n * world * T * Ks / el_s, "unit": "env-steps/s",
                  "ms_per_step": el_s / Ks * 1e3, "avg_launch_ms": avg_s * 1e3, "frac": roofline_of(wl, avg_s)["frac"]}
+    clocks = clk.record()
 
     # ---- reporting collective: episodic returns all-gathered over RCCL ------------
     gather_ms, rccl_ranks = None, None
@@ -636,6 +801,19 @@ def main():
                 dt = time.perf_counter() - t0
                 per_call["captured_value"] = n * Kc / dt
                 per_call["captured_ms_per_step"] = dt / Kc * 1e3
+                # ... and as a 100-step graph (the form to hold on to when the policy that refills the action buffer is
+                # captured too): a ONE-step graph pays a whole graph launch (~11 us) per env step -- slower than the eager
+                # `step` (4 us) -- so the eager call is the per-step path and `capture_step(n_steps >= 16)` the replay path
+                g100 = eng.capture_step(a1, n_steps=100)
+                g100.replay()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(Kc // 100):
+                    g100.replay()
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                per_call["captured_100_value"] = n * (Kc // 100) * 100 / dt
+                per_call["captured_100_ms_per_step"] = dt / ((Kc // 100) * 100) * 1e3
         gc.enable()
 
     cpu = None
@@ -648,14 +826,16 @@ def main():
     del wl
     torch.cuda.empty_cache()
     for name in names:
-        fams, total, mode = ALSO[name]
-        if fams == args.families:
+        fams, total, mode, chunk = ALSO[name]
+        if fams == args.families and chunk in (None, T):
             continue
-        lanes = total // world if mode == "strong" else total
-        Ta = DEFAULT_CHUNK[fams[0]]
+        split = mode == "strong" or (mode == "follow" and args.strong)
+        lanes = total // world if split else total
+        mode = "strong" if split else "weak"
+        Ta = chunk or DEFAULT_CHUNK[fams[0]]
         w2 = Workload(fams, lanes, Ta, args.buffer_sets, rank, world, device)
-        wall2, avg2 = w2.train(K, W, barrier)
-        el2 = max_over_ranks(wall2)
+        regs2, m2 = timed_regions(w2, K, W, args.reps, barrier, max_over_ranks)
+        el2, avg2 = regs2[m2]
         r2 = roofline_of(w2, avg2)
         also[name] = {
             "workload": " + ".join(f"CARL{f} x {lanes}" for f in fams) + f" contexts/GPU, {Ta} env steps per launch",
@@ -663,14 +843,18 @@ def main():
             "lanes_per_gpu": w2.n, "chunk": Ta, "ms_per_step": el2 / K * 1e3,
             "avg_launch_ms": avg2 * 1e3, "frac": r2["frac"], "achieved_GBs": r2["achieved"],
             "bytes_per_unit": r2["bytes_per_unit"], "traffic": r2["traffic"],
+            "frac_kernel": r2["frac_kernel"], "kernel_avg_us_rocprofv3": r2["kernel_avg_us_rocprofv3"],
+            "repetitions_ms_per_step": [w / K * 1e3 for w, _ in regs2],
             "mean_last_episode_return": w2.mean_last_return(), "lanes_per_env": w2.launch_shape(),
             "classes": [type(e).__name__ for e in w2.envs],
+            "one_launch_pair": (w2.eng.pair_launches > 0) if w2.mixed else None,
         }
         if all(f in BRAX_ENVS for f in fams):
             # the Brax path moves ~1 % of what HBM could: its bound is the vector ALU (committed counters, not measured here)
-            also[name]["bound"] = ("vector ALU: SQ_ACTIVE_INST_VALU per resident wavefront x wavefronts per SIMD = 1.1 (Ant, three per "
-                                   "SIMD) / 0.9 (Humanoid, two) of a SIMD's issue capacity -- profiles/r03_brax_sq_counters.txt; `frac` "
-                                   "above is the HBM fraction of the same launch")
+            also[name]["bound"] = ("vector-ALU issue (roofline_valu: SQ_INSTS_VALU of the full-size launch x cycles per wavefront-"
+                                   "instruction / (1 024 SIMDs x 2.4 GHz) against the launch time); `frac` above is the HBM fraction "
+                                   "of the same launch, which the metric asks for")
+            also[name]["roofline_valu"] = roofline_valu_of(f"{'+'.join(fams)}:{lanes}:{Ta}", avg2)
             # double-buffered use: the same contexts as two free-running half-batches (one family: two engines of half
             # the lanes; two families: one engine each), launches overlapping across streams
             w4 = SplitWorkload(fams[0], lanes // 2, Ta, args.buffer_sets, rank, world, device) if len(fams) == 1 else w2
@@ -696,13 +880,42 @@ def main():
         del w2
         torch.cuda.empty_cache()
 
+    # ---- the 8-GPU shard regime on this ONE GPU ----
+    shard8 = None
+    if world == 1 and not args.no_shard8:
+        shard8 = {}
+        full = {k: v["value"] for k, v in also.items()}
+        full["+".join(args.families)] = n * T * K / elapsed
+        for name, (fams, lanes, full_key) in SHARD8.items():
+            Ta = DEFAULT_CHUNK[fams[0]]
+            w5 = Workload(fams, lanes, Ta, args.buffer_sets, rank, world, device)
+            regs5, m5 = timed_regions(w5, K, W, args.reps, barrier, max_over_ranks)
+            el5, avg5 = regs5[m5]
+            v5 = w5.n * Ta * K / el5
+            v_full = full.get(full_key)
+            shard8[name] = {
+                "workload": " + ".join(f"CARL{f} x {lanes}" for f in fams) + f" contexts on this GPU (1/8 of the node's), {Ta} env steps per launch",
+                "value_per_gpu": v5, "unit": "env-steps/s", "ms_per_step": el5 / K * 1e3, "avg_launch_ms": avg5 * 1e3,
+                "lanes_per_gpu": w5.n, "frac": roofline_of(w5, avg5)["frac"], "lanes_per_env": w5.launch_shape(),
+                "predicted_node_value": 8 * v5,
+                "full_size_1gpu_value": v_full,
+                "predicted_speedup_8gpu": (8 * v5 / v_full) if v_full else None,
+                "implied_strong_scaling_efficiency": (v5 / v_full) if v_full else None,
+                "one_launch_pair": (w5.eng.pair_launches > 0) if w5.mixed else None,
+                "repetitions_ms_per_step": [w / K * 1e3 for w, _ in regs5],
+            }
+            del w5
+            torch.cuda.empty_cache()
+        shard8["note"] = ("prediction = 8 x this GPU's rate (lanes are independent, no data-path collective: SURVEY 8e); a shard "
+                          "this small is bound by ONE wavefront's dependent-issue latency per env step, not by HBM: DESIGN.md 6")
+
     # ---- N > 1: the OTHER scaling mode of the headline workload, same launch train ----
     other = None
     if world > 1:
         lanes3 = args.lanes if args.strong else args.lanes // world  # headline strong -> weak run; headline weak -> strong run
         w3 = Workload(args.families, lanes3, T, args.buffer_sets, rank, world, device)
-        wall3, avg3 = w3.train(K, W, barrier)
-        el3 = max_over_ranks(wall3)
+        regs3, m3 = timed_regions(w3, K, W, args.reps, barrier, max_over_ranks)
+        el3, avg3 = regs3[m3]
         other = {"scaling": "weak" if args.strong else "strong", "lanes_per_gpu": w3.n, "total_lanes": w3.n * world,
                  "value": w3.n * world * T * K / el3, "unit": "env-steps/s", "ms_per_step": el3 / K * 1e3,
                  "avg_launch_ms": avg3 * 1e3, "frac_per_gpu": roofline_of(w3, avg3)["frac"]}
@@ -725,6 +938,8 @@ def main():
                        "lanes_per_gpu": n, "total_lanes": n * world, "chunk": T,
                        "env_steps_per_step": n * world * T, "buffer_sets": args.buffer_sets,
                        "parallelism": f"lane-shard x{world}", "lanes_per_env": shape},
+            "bench_version": BENCH_VERSION, "workload_id": f"{'+'.join(args.families)}:{n}:{T}:v{BENCH_VERSION}",
+            "repetitions": repetitions, "clocks": clocks, "shard8": shard8,
             "roofline": roofline, "cpu_baseline": cpu, "sustained": sustained,
             ("weak" if args.strong else "strong"): other, "per_call": per_call, "also": also,
             "mean_last_episode_return": mean_return, "return_allgather_ms": gather_ms, "rccl_ranks": rccl_ranks,

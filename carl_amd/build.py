@@ -63,12 +63,11 @@ def needs_build(extra_flags: list[str] | None = None) -> bool:
 
 
 def _refuse_ablation(extra_flags: list[str] | None) -> None:
-    """The product library is never built with profiling-only switches (CARL_EXP_*: kernels that skip
-    stores / the done path).  Ablation libraries are made by tools/build_ablations.sh under gpurun_in/."""
+    """The profiling-only switches of rounds 1-3 (CARL_EXP_*: kernels that skip stores / the done path) no longer
+    exist in the sources (removed in round 4; commit 3a3c7b2 still builds them): a flag that names one is a mistake."""
     bad = [f for f in (extra_flags or []) if "CARL_EXP_" in f or "CARL_ABLATION" in f or "CARL_STORERS" in f]
     if bad:
-        raise ValueError(f"refusing to build carl_amd/lib/libcarl_amd.so with ablation switches {bad}; "
-                         "use tools/build_ablations.sh (writes gpurun_in/libcarl_<variant>.so)")
+        raise ValueError(f"{bad}: the CARL_EXP_* / CARL_STORERS ablation switches were removed from the sources in round 4")
 
 
 def build(force: bool = False, verbose: bool = False, extra_flags: list[str] | None = None) -> str:

@@ -35,14 +35,9 @@
 #include "carl_device.hip.h"
 #include "fast_math.hip.h"
 
-// CARL_EXP_BRAX_* switches compile MEASUREMENT-ONLY kernels (a cost attribution: what a piece of the substep costs
-// by leaving it out or replacing it with the float32 form -- results differ); refused without -DCARL_ABLATION, which
-// carl_amd/build.py never passes (tools/build_variant.sh writes such libraries to gpurun_in/).
-#if (defined(CARL_EXP_BRAX_FAST_ATAN) || defined(CARL_EXP_BRAX_NO_CONTACTS) || defined(CARL_EXP_BRAX_NO_PHASE_A) || \
-     defined(CARL_EXP_BRAX_NO_PHASE_B) || defined(CARL_EXP_BRAX_EULER_F32) || defined(CARL_EXP_BRAX_LDS_PAD) || defined(CARL_EXP_BRAX_NO_CHILDREN) || defined(CARL_EXP_BRAX_F32_INTEGRATE)) &&              \
-    !defined(CARL_ABLATION)
-#error "CARL_EXP_BRAX_* build measurement-only kernels; pass -DCARL_ABLATION to confirm (never for the product library)"
-#endif
+// (The CARL_EXP_BRAX_* measurement-only switches of round 3 -- cost attribution by leaving a piece of the substep out or
+// replacing it with its float32 form -- were removed in round 4; results in profiles/r03_brax_occupancy.txt, the tree
+// that builds them is commit 3a3c7b2.)
 
 namespace carl {
 namespace brax {
@@ -598,20 +593,12 @@ static __device__ __forceinline__ JointGeom joint_geometry(const carl_brax_sys_t
     a_y = eul ? m12 : a_y;
     a_x = eul ? r22 : a_x;
   }
-#ifdef CARL_EXP_BRAX_FAST_ATAN
-  const double a1 = (double)atan2_fast((float)a_y, (float)a_x);
-#else
   const double a1 = atan2_f64(a_y, a_x);
-#endif
   g.theta = (float)(2.0 * a1);  // (meaningful on single-hinge lanes)
   g.wrel = bc.w - bp.w;
   g.thetadot = dot(g.x_c, g.wrel);
   if (MULTI) {
-#ifdef CARL_EXP_BRAX_EULER_F32
-    const float al = (float)a1, be = asinf((float)R02), ga = atan2_fast((float)-R01, (float)R00);
-#else
     const float al = (float)a1, be = (float)asin_f64(R02), ga = (float)atan2_f64(-R01, R00);
-#endif
     const float sg3 = s.dof_sign3[i];
     const float sg = (nr == 3) ? sg3 : 1.0f;
     g.ang[0] = al; g.ang[1] = be; g.ang[2] = sg * ga;
@@ -744,11 +731,7 @@ static __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const T
   const int L = K.L;
   // phase A -- spring.joints.resolve, one joint per lane
   uint32_t wa = W.wa;
-#ifdef CARL_EXP_BRAX_NO_PHASE_A
-  for (int i = L; i < L; i += kSub) {
-#else
   for (int i = K.first_joint + m.sub; i < L; i += kSub, wa = (i < L) ? pk.a[min(i, L - 1)].word : wa) {
-#endif
     if (wa & kWaFree) continue;
     const LinkA& rec = pk.a[i];
     const int P = wa_parent(wa);
@@ -832,12 +815,8 @@ static __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const T
   // phase B -- per body: wrench sum, semi-implicit Euler, its contacts, integrate
   const float dl = K.dl, da = c.da, inv_dt = K.inv_dt, dt = K.dt;
   uint32_t wb = W.wb, wch = W.wch;
-#ifdef CARL_EXP_BRAX_NO_PHASE_B
-  for (int i = L; i < L; i += kSub) {
-#else
   for (int i = m.sub; i < L; i += kSub, wb = (i < L) ? pk.b[min(i, L - 1)].word : wb,
            wch = (i < L) ? pk.b[min(i, L - 1)].children : wch) {
-#endif
     const vf4 qb = ld4(&pk.b[i]);  // .z inv_inertia[0], .w reach (the index words are in registers)
     const bool iso = (wb & kWbIso) != 0u;
     Body b = m.body(i);
@@ -847,7 +826,6 @@ static __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const T
     // own joint's wrench (a free root has none: it reads the zero rows)
     const int own = (wb & kWbFree) ? m.lay.zero : m.lay.wrench + 12 * i;
     v3 F = m.get3(own), T = m.get3(own + 3);
-#ifndef CARL_EXP_BRAX_NO_CHILDREN
     {  // children's reactions, ascending: a wavefront-uniform trip count and loads whose addresses come from a
        // register (a link with fewer children reads the zero rows), so a pass is one batch of independent LDS reads
       const int nch = wb_children(wb);
@@ -875,7 +853,6 @@ static __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const T
           T = T + m.get3(wr + 9);
         }
     }
-#endif
     const float inv_m = __builtin_amdgcn_rcpf(mass_i);  // v_rcp_f32 (1 ulp): the phase is issue-bound
     b.v = b.v + (F * inv_m + V(0, 0, c.gravity_z)) * dt;
     b.w = b.w + apply_inv_inertia(s, i, rf, T, iso, qb.z) * dt;
@@ -884,11 +861,7 @@ static __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const T
     float cnt = 0.0f;
     uint32_t hit = 0u;
     // no sphere of this link can reach the plane while its COM is higher than the farthest sphere surface
-#ifdef CARL_EXP_BRAX_NO_CONTACTS
-    const int n_sph = 0;
-#else
     const int n_sph = ((float)b.p.z < qb.w) ? wb_spheres(wb) : 0;
-#endif
     // third row of the rotation matrix in float64: a sphere's height -- hence its depth, which the Baumgarte
     // term multiplies by erp / dt -- is a pose difference
     const double R20 = 2.0 * (b.r.x * b.r.z - b.r.w * b.r.y), R21 = 2.0 * (b.r.y * b.r.z + b.r.w * b.r.x),
@@ -937,17 +910,6 @@ static __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const T
       b.v = b.v + cdv * ic;
       b.w = b.w + cdw * ic;
     }
-#ifdef CARL_EXP_BRAX_F32_INTEGRATE
-    {
-      const v3 pf = tof(b.p) + b.v * dt;
-      const qt dqf = qmul(qt{0.0f, b.w.x, b.w.y, b.w.z}, rf);
-      const float hf = 0.5f * dt;
-      b.p = tod(pf);
-      b.r = tod(qnormalize(qt{rf.w + hf * dqf.w, rf.x + hf * dqf.x, rf.y + hf * dqf.y, rf.z + hf * dqf.z}));
-      m.put(i, b);
-      continue;
-    }
-#endif
     const double dtd = (double)dt;
     b.p = D(fma((double)b.v.x, dtd, b.p.x), fma((double)b.v.y, dtd, b.p.y), fma((double)b.v.z, dtd, b.p.z));
     const qtd dq = qmul_vec(D((double)b.w.x, (double)b.w.y, (double)b.w.z), b.r);

@@ -190,11 +190,7 @@ int launch_brax(const carl_batch_t* b, const carl_brax_sys_t* sd, const carl_bra
   // independent wavefronts per workgroup, sharing the LDS copy of the static tables: as many (<= kMaxWavesPerWg) as fit
   // (the kernel's static LDS: model table, prepared topology / records, the fragment hand-over flags)
   const size_t static_lds = sizeof(carl_brax_sys_t) + sizeof(carl::brax::Prepared) + sizeof(int) * carl::brax::kMaxWavesPerWg3;
-#ifdef CARL_EXP_BRAX_LDS_PAD  // measurement only (needs -DCARL_ABLATION): fewer resident wavefronts per SIMD through LDS
-  const size_t wave_bytes = lay.bytes(envs) > (size_t)CARL_EXP_BRAX_LDS_PAD ? lay.bytes(envs) : (size_t)CARL_EXP_BRAX_LDS_PAD;
-#else
   const size_t wave_bytes = lay.bytes(envs);
-#endif
   if (wave_bytes + static_lds > 160 * 1024)
     return fail(CARL_ERR_UNSUPPORTED, "%s: model needs %zu B of LDS per wavefront", who, wave_bytes);
   // Registers allow 2 (multi-hinge / task models) or 3 wavefronts per SIMD = 8 / 12 per CU (brax_kernels.hip.h:

@@ -12,18 +12,10 @@
 
 #include "carl_device.hip.h"
 
-// CARL_EXP_* switches compile PROFILING-ONLY kernels that skip stores, loads or the done path
-// (tools/build_ablations.sh).  A product build must never carry one by accident: they are refused
-// unless the build also says -DCARL_ABLATION (carl_amd/build.py adds it only for `--ablation`, and
-// writes such libraries under gpurun_in/, never to carl_amd/lib/).
-#if (defined(CARL_EXP_NO_REWARD_STORE) || defined(CARL_EXP_NO_FLAG_STORES) || defined(CARL_EXP_NO_DONE) ||      \
-     defined(CARL_EXP_NO_OBS_STORE) || defined(CARL_EXP_NO_ACTIONS) || defined(CARL_EXP_NO_LOADER) ||            \
-     defined(CARL_EXP_NO_DRAIN) || defined(CARL_EXP_TEMPORAL) || defined(CARL_STORERS) ||                        \
-     defined(CARL_EXP_DENSE_ROLLED) || defined(CARL_EXP_NO_FLAG_DRAIN) || defined(CARL_EXP_NO_DRAW) ||             \
-     defined(CARL_EXP_XCD_SWIZZLE)) &&          \
-    !defined(CARL_ABLATION)
-#error "CARL_EXP_* / CARL_STORERS build profiling-only kernels; pass -DCARL_ABLATION to confirm (never for the product library)"
-#endif
+// (Rounds 1-3 carried ~30 CARL_EXP_* / CARL_TRY_* profiling switches in these loops -- kernels that skip stores, loads
+// or the done path, for cost attribution.  Their measurements are recorded under profiles/ and in DESIGN.md's
+// appendix; the switches themselves were removed in round 4 so that the product loops read straight.  The tree that
+// builds them is commit 3a3c7b2 (tools/build_ablations.sh there).)
 
 namespace carl {
 
@@ -202,20 +194,14 @@ struct LdsSink {
   int t;              // global step index of this record
   int tid;
   __device__ __forceinline__ void put_reward(float r) const {
-#ifndef CARL_EXP_NO_REWARD_STORE
     reinterpret_cast<float*>(step_base + kObsBytes)[tid] = r;
-#endif
   }
   __device__ __forceinline__ void put_flags(bool te, bool tr) const {
-#ifndef CARL_EXP_NO_FLAG_STORES
     reinterpret_cast<uint8_t*>(step_base + kFlagOff)[tid] = (uint8_t)te;
     reinterpret_cast<uint8_t*>(step_base + kFlagOff + 256)[tid] = (uint8_t)tr;
-#endif
   }
   __device__ __forceinline__ void put_obs(const float (&o)[Fam::D]) const {
-#ifndef CARL_EXP_NO_OBS_STORE
     store_obs<Fam::D>(reinterpret_cast<float*>(step_base), (size_t)tid, o);
-#endif
   }
   // only evaluated on the done path (the terminal observation is stored to HBM directly)
   __device__ __forceinline__ float* final_obs_ptr() const {
@@ -395,11 +381,7 @@ __device__ __forceinline__ void dense_draw(const carl_batch_t& b, const Ctx& ctx
       pn = select_words(cn != r.cidx, q, r.p);
     }
   }
-#ifndef CARL_EXP_NO_DRAW
   const u32x4 w = lane_words(b.seed, glane, r.episode, kSubInit);
-#else  // profiling only: the chunk's init-state draw without its Philox block
-  const u32x4 w{(uint32_t)glane * 2654435761u, r.episode * 40503u, (uint32_t)glane, r.episode};
-#endif
   float fresh[Fam::S];
   typename Fam::Aux fa;
   Fam::reset(pn, w, fresh);
@@ -490,39 +472,23 @@ __device__ __forceinline__ void step_lane(const carl_batch_t& b, const Ctx& ctx,
     const bool truncated = (max_steps > 0) && (r.elapsed >= max_steps);
     r.ep_return += reward;
     Fam::observe(r.s, r.aux, o);
-#ifndef CARL_EXP_NO_REWARD_STORE  // CARL_EXP_*: ablation builds for profiling only
     cur.put_reward(reward);
-#else
-    asm volatile("" ::"v"(reward));
-#endif
-#ifndef CARL_EXP_NO_FLAG_STORES
     if constexpr (!Sink::kLazyFlags) cur.put_flags(terminated, truncated);
-#endif
     te = terminated;
     tr = truncated;
     done = terminated | truncated;
-#ifdef CARL_EXP_NO_DONE  // profiling only: the floor of a family's step without the done path
-    done = false;
-#endif
   }
   if (__builtin_expect(ballot(done) != 0ull, 0)) {
-#ifndef CARL_EXP_NO_FLAG_STORES
     if constexpr (Sink::kLazyFlags) {  // the flag rows are pre-zeroed: only waves with a finished lane write
       if (active) cur.put_flags(te, tr);
     }
-#endif
     if constexpr (PLAIN)
       finish_plain<Fam>(b, glane, done, o, r);
     else
       finish_episodes<Fam, Ctx, Sink::kLazyFlags && predraw_of<Fam>::value>(b, ctx, done, lane, glane,
                                                                             cur.final_obs_ptr(), o, r);
   }
-#ifndef CARL_EXP_NO_OBS_STORE
   if (active) cur.put_obs(o);
-#else
-#pragma unroll
-  for (int d = 0; d < Fam::D; ++d) asm volatile("" ::"v"(o[d]));
-#endif
 }
 
 template <class Fam, class Ctx>
@@ -718,7 +684,6 @@ __global__ void __launch_bounds__(kRolloutThreads) rollout_kernel(const carl_bat
     } else {
       const Action* my = act_buf + buf * kActChunk * kRolloutLanes + threadIdx.x;
       const int steps = min(kActChunk, n_steps - t0);
-#ifndef CARL_EXP_NO_ACTIONS
       Action a_next = my[0];
       settle(a_next);  // see rollout_staged_kernel
       if (lane_base + kRolloutLanes <= b.n_lanes) {  // full workgroup: no per-step predicate
@@ -736,17 +701,8 @@ __global__ void __launch_bounds__(kRolloutThreads) rollout_kernel(const carl_bat
           cur.advance(n);
         }
       }
-#else  // ablation: no LDS action reads
-      (void)my;
-      for (int u = 0; u < steps; ++u) {
-        step_lane<Fam>(b, ctx, cur, max_steps, active, lane, glane, (Action)1, r);
-        cur.advance(n);
-      }
-#endif
     }
-#ifndef CARL_EXP_NO_ACTIONS
     __syncthreads();
-#endif
   }
   if (active) store_lane<Fam>(b, ctx, lane, r);
 }
@@ -770,10 +726,7 @@ __global__ void __launch_bounds__(kRolloutThreads) rollout_kernel(const carl_bat
 // commits chunk c+1 (loaded during iteration c-1) to LDS and issues the loads of chunk c+2, so
 // the HBM latency overlaps a whole chunk of compute.  The storer never waits on vmcnt.
 constexpr int kStageChunk = 8;
-#ifndef CARL_STORERS
-#define CARL_STORERS 3
-#endif
-constexpr int kStorers = CARL_STORERS;                                   // storer waves per workgroup
+constexpr int kStorers = 3;                                              // storer waves per workgroup (2, 4, 5, 8: +-1 %)
 constexpr int kStagedThreads = kRolloutLanes + (1 + kStorers) * kWave;  // + loader wave + storer waves
 
 template <class Fam, int CHUNK = kStageChunk>
@@ -801,11 +754,7 @@ struct ActionPipe {
   int t0;
 
   __device__ static __forceinline__ R load_row(const AStore* __restrict__ p) {
-#ifndef CARL_EXP_TEMPORAL
 #define CARL_LD(q) __builtin_nontemporal_load(q)  // read once
-#else
-#define CARL_LD(q) (*(q))
-#endif
     if constexpr (kSame) {
       return CARL_LD(reinterpret_cast<const V*>(p));
     } else {
@@ -892,14 +841,10 @@ __device__ __forceinline__ void drain_records(char* buf, const carl_step_io_t& i
   // (n % 16 == 0), so every 16-byte piece below is entirely inside or entirely outside
   const int valid = min(kRolloutLanes, (int)n - lane_base);
   typedef float vf4 __attribute__((ext_vector_type(4)));
-  // streamed once, never re-read by this kernel: non-temporal stores (CARL_EXP_TEMPORAL: ablation)
+  // streamed once, never re-read by this kernel: non-temporal stores (temporal ones: +6 %, measured)
   auto put = [](char* dst, const char* src) {
     const vf4 v = *reinterpret_cast<const vf4*>(src);
-#ifndef CARL_EXP_TEMPORAL
     __builtin_nontemporal_store(v, reinterpret_cast<vf4*>(dst));
-#else
-    *reinterpret_cast<vf4*>(dst) = v;
-#endif
   };
   for (int u = which; u < steps; u += kStorers) {
     char* rec = buf + (size_t)u * SK::kStepBytes;
@@ -913,9 +858,7 @@ __device__ __forceinline__ void drain_records(char* buf, const carl_step_io_t& i
 #pragma unroll
       for (int off = 0; off < SK::kObsBytes; off += 1024) put(g_obs + off + 16 * l, rec + off + 16 * l);
       put(reinterpret_cast<char*>(io.reward + row) + 16 * l, rec + SK::kObsBytes + 16 * l);
-#ifndef CARL_EXP_NO_FLAG_DRAIN  // measurement only: the terminated / truncated rows never reach HBM
       if (l < 32) put(reinterpret_cast<char*>(fl_dst), fl);
-#endif
     } else {  // ragged last workgroup: per-piece guards (each guard is its own block with its own LDS wait:
               // slower, but only this one workgroup pays it)
 #pragma unroll
@@ -965,23 +908,14 @@ __device__ __forceinline__ void rollout_staged_body(const carl_batch_t& b, const
   // 0..3 compute, 4 loader, 5.. storers (wave-uniform).  Eight waves = two per SIMD: every
   // compute wave shares its SIMD with exactly one light helper wave, so no compute wave is
   // slowed more than the others before the chunk barrier.
-#ifdef CARL_TRY_VECTOR_WAVE_ID
-  const int wave = threadIdx.x / kWave;
-#else
   // (readfirstlane: the compiler then KNOWS the role tests below are wavefront-uniform -- scalar branches and scalar
   // loop control / address arithmetic in the helper waves instead of exec-mask loops over per-lane counters)
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
-#endif
   const int storer = wave - (kRolloutLanes / kWave + 1);  // 0..kStorers-1 on storer waves
   const bool compute = wave < kRolloutLanes / kWave;
   const bool loader = wave == kRolloutLanes / kWave;
   const int hl = threadIdx.x % kWave;    // lane within a helper wave
-#ifdef CARL_EXP_XCD_SWIZZLE  // measurement only: workgroup i runs on XCD i % 8 -- give every XCD one contiguous lane range
-  const int wgx = (gridDim.x % 8 == 0) ? (int)((blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8) : (int)blockIdx.x;
-  const int lane_base = wgx * kRolloutLanes;
-#else
   const int lane_base = wg * kRolloutLanes;
-#endif
   const int lane = lane_base + (compute ? (int)threadIdx.x : 0);
   const bool active = compute && lane < b.n_lanes;
   const uint64_t glane = (uint64_t)(b.lane_offset + lane);
@@ -1037,11 +971,7 @@ __device__ __forceinline__ void rollout_staged_body(const carl_batch_t& b, const
         Action acts[kStageChunk];
 #pragma unroll
         for (int u = 0; u < kStageChunk; ++u) acts[u] = my[u * kRolloutLanes];
-#ifdef CARL_EXP_DENSE_ROLLED
-        if (false) {
-#else
         if (steps == kStageChunk) {  // fully unrolled: record addresses are immediates, no loop control
-#endif
           // (AR: the chunk's first step is the launch's first step when t0 == 0; two copies of the unrolled chunk
           // would double the kernel for one step's worth of instructions, so that step always takes ENTRY)
 #pragma unroll
@@ -1096,16 +1026,12 @@ __device__ __forceinline__ void rollout_staged_body(const carl_batch_t& b, const
       }
       }
     } else if constexpr (ROLE == 1) {
-#ifndef CARL_EXP_NO_LOADER
       // chunk c+1 (loads issued one iteration ago) -> LDS; then start chunk c+2
       pipe.commit(act_buf + (buf ^ 1) * kBufActs, act, n, lane_base, hl, n_steps);
       pipe.issue(act, n, lane_base, hl, t0 + 2 * kStageChunk, n_steps);
-#endif
     } else if (t0 > 0) {  // storer: the previous chunk's records (always a full chunk)
-#ifndef CARL_EXP_NO_DRAIN
       drain_records<Fam>(out_buf + (size_t)(buf ^ 1) * kStageChunk * SK::kStepBytes, io, n, lane_base, hl, storer,
                          t0 - kStageChunk, kStageChunk);
-#endif
     }
     __syncthreads();
   }

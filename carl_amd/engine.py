@@ -399,8 +399,12 @@ class VecEngine:
     def capture_step(self, action_buffer: torch.Tensor, n_steps: int = 1) -> "CapturedStep":
         """Capture ``n_steps`` per-call step launches that read ``action_buffer`` (a device tensor whose
         ADDRESS stays fixed: the policy writes the next action into it) into a hipGraph.  ``replay()`` then
-        costs one graph launch instead of the Python + ctypes + launch path of ``step`` -- the form a
-        policy-in-the-loop caller should hold on to.  Engine state is untouched by the capture."""
+        costs ONE graph launch for ``n_steps`` env steps.  Measured (65 536 CartPole lanes): a graph launch costs
+        ~11 us, so a ONE-step graph (10.9 us per env step) is SLOWER than the eager ``step`` (4.3 us: prepared ctypes
+        call, raw stream handle) -- a policy-in-the-loop caller that acts on every observation calls ``step``; the
+        captured form pays off from ~4 steps per replay (``n_steps=100``: 3.7 us per env step, the same as a
+        ``torch.cuda.graph`` around 100 ``step`` calls) and is meant for a policy that is captured into the same graph
+        region or for open-loop replays.  Engine state is untouched by the capture."""
         return CapturedStep(self, action_buffer, n_steps)
 
     def alloc_rollout(self, n_steps: int, final_obs: bool = False) -> dict:
