@@ -299,7 +299,11 @@ def humanoid_sys(feature_names: list[str] | None = None, reference_compat: bool 
     (spring backend: dt 0.0015 x 10 frames; forward weight 1.25 on the whole-body COM velocity,
     healthy reward 5 while z in [1, 2], ctrl cost 0.1, reset noise U(+-0.01) on q AND qd).
     Multi-dof joints stack intrinsically in MJCF joint order about the joint frame's x, y, +-z
-    (``dof_sign3``); the spring-constraint constants are this build's choice.  PARITY UNPINNED."""
+    (``dof_sign3``); the spring-constraint constants are this build's choice.  PARITY UNPINNED against brax itself;
+    the GEOMETRY is pinned: the capsule / sphere volumes of every link reproduce the masses the reference holds as
+    context defaults (tests/test_brax_model_tables.py, via an independent MJCF reader in the test infrastructure, which
+    also compares every field of this table -- round 4: that comparison moved the knees' joint stiffness 1 -> 0
+    (the asset gives none) and the left hip's y range -110 -> -120 degrees)."""
     s = _lib.BraxSys()
     s.env_kind = _lib.BRAX_HUMANOID
     s.healthy_q_index = -1
@@ -334,13 +338,13 @@ def humanoid_sys(feature_names: list[str] | None = None, reference_compat: bool 
          [("right_hip_x", X, (-25, 5), 10, 5), ("right_hip_z", Z, (-60, 35), 10, 5),
           ("right_hip_y", Y, (-110, 20), 20, 5)],
          [(cap, (0, 0, 0), (0, 0.01, -0.34), 0.06)]),
-        ("right_shin", 3, (0, 0.01, -0.403), ident, (0, 0, 0.02), [("right_knee", (0, -1, 0), (-160, -2), 1, 1)],
+        ("right_shin", 3, (0, 0.01, -0.403), ident, (0, 0, 0.02), [("right_knee", (0, -1, 0), (-160, -2), 0, 1)],
          [(cap, (0, 0, 0), (0, 0, -0.3), 0.049), (sph, (0, 0, -0.35), None, 0.075)]),
         ("left_thigh", 2, (0, 0.1, -0.04), ident, (0, 0, 0),
          [("left_hip_x", (-1, 0, 0), (-25, 5), 10, 5), ("left_hip_z", (0, 0, -1), (-60, 35), 10, 5),
-          ("left_hip_y", Y, (-110, 20), 20, 5)],
+          ("left_hip_y", Y, (-120, 20), 20, 5)],  # (the asset's asymmetry: right -110, left -120)
          [(cap, (0, 0, 0), (0, -0.01, -0.34), 0.06)]),
-        ("left_shin", 5, (0, -0.01, -0.403), ident, (0, 0, 0.02), [("left_knee", (0, -1, 0), (-160, -2), 1, 1)],
+        ("left_shin", 5, (0, -0.01, -0.403), ident, (0, 0, 0.02), [("left_knee", (0, -1, 0), (-160, -2), 0, 1)],
          [(cap, (0, 0, 0), (0, 0, -0.3), 0.049), (sph, (0, 0, -0.35), None, 0.075)]),
         ("right_upper_arm", 0, (0, -0.17, 0.06), ident, (0, 0, 0),
          [("right_shoulder1", (2, 1, 1), (-85, 60), 1, 1), ("right_shoulder2", (0, -1, 1), (-85, 60), 1, 1)],

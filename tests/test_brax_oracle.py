@@ -262,15 +262,16 @@ def test_humanoid_consistent_state_has_no_constraint_force(humanoid):
     so with those angles at zero the state is a fixed point of the substep."""
     s = humanoid
     q = np.array(s.init_q[:24], dtype=np.float64)
-    q[13] = q[17] = -0.5  # knees inside their (-160, -2) deg range; their dof stiffness is the only spring
+    q[13] = q[17] = -0.5  # knees inside their (-160, -2) deg range (no dof spring of their own: the asset gives none)
+    q[12] = q[16] = -0.3  # hip y: dof stiffness 20 -- the only spring that acts
     st = B.forward_kinematics(s, q, np.zeros(23))
     row = HU_DEFAULT.copy()
     row[0] = -1e-6
     st2 = B.substeps(s, row, np.zeros(23), 1, st.copy())
     dv = np.abs(st2.reshape(11, 13)[:, 7:] - st.reshape(11, 13)[:, 7:])
-    others = [i for i in range(11) if i not in (3, 4, 5, 6)]  # thigh/shin pairs feel the knee spring
+    others = [i for i in range(11) if i not in (2, 3, 4, 5, 6)]  # pelvis / thighs (and the shins hanging on them) feel the hip springs
     assert dv[others].max() < 1e-6
-    assert dv[[4, 6]].max() > 1e-5
+    assert dv[[3, 5]].max() > 1e-5
 
 
 def test_humanoid_stands_then_random_actions_stay_finite(humanoid):
