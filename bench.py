@@ -244,22 +244,25 @@ class Workload:
         else:
             self.eng.rollout(self.acts[s][0], self.outs[s][0])
 
-    def train(self, K, W, barrier):
+    def train(self, K, W, barrier, collect=True):
         """W untimed launches, then exactly K timed ones -> (wall seconds incl. the syncs, average launch
         seconds from one HIP-event pair on the launch stream)."""
         import torch
 
         import gc
 
+        # The timed region is ~1.5 ms of host time: a generation-2 garbage collection landing inside it (the context
+        # sets of the workloads are 65 536-row Python-side objects) stalls the launch loop for tens of milliseconds --
+        # seen as a wall-clock value 10 x below the HIP-event figure of the same launches.  Collect BEFORE the warm-up
+        # launches and keep the collector off while the clock runs.  (Round 3 collected between the warm-up and the timed
+        # launches: the first timed launch then took 135-145 us instead of 85 -- cold host caches after the collection --
+        # 3 % of a 20-launch region: tools/diag_region.py.)
+        if collect:
+            gc.collect()
+        gc.disable()
         for _ in range(W):
             self.launch()
         torch.cuda.synchronize()
-        # The timed region is ~1.5 ms of host time: a generation-2 garbage collection landing inside it (the context
-        # sets of the workloads are 65 536-row Python-side objects) stalls the launch loop for tens of milliseconds --
-        # seen as a wall-clock value 10 x below the HIP-event figure of the same launches.  Collect now, and keep the
-        # collector off while the clock runs.
-        gc.collect()
-        gc.disable()
         # one HIP-event pair around the whole launch train, on the stream the kernels run on (torch's
         # current stream): launches are back-to-back, so elapsed / K is the kernel's average duration
         # plus the ~1-2 us kernel boundary
@@ -424,7 +427,7 @@ def timed_regions(wl, K, W, reps, barrier, max_over_ranks):
     the index of the median region by wall clock."""
     regions = []
     for r in range(max(1, reps)):
-        wall, period = wl.train(K, W if r == 0 else 0, barrier)
+        wall, period = wl.train(K, W if r == 0 else 0, barrier, collect=(r == 0))
         regions.append((max_over_ranks(wall), period))
     order = sorted(range(len(regions)), key=lambda i: regions[i][0])
     return regions, order[(len(order) - 1) // 2]
