@@ -452,3 +452,78 @@ def test_free_running_half_batches_equal_the_one_stream_rollouts(device):
     for k in range(2):
         assert torch.equal(ma.parts[k].state, mb.parts[k].state)
     assert torch.equal(ma.ep_return, mb.ep_return) and torch.equal(ma.episodes_done, mb.episodes_done)
+
+
+def test_free_running_with_temporaries_and_auto_join(device):
+    """a collector that builds a NEW action tensor each iteration and lets the engine allocate the
+    outputs (``outs=None``) used to race with the caching allocator -- actions were allocated on the caller's stream and
+    read on the parts' streams, outputs the other way round, neither recorded on the other stream.  Now both are
+    (`record_stream`), and a `step` / `reset` / plain `rollout` issued while free-running launches are in flight joins
+    first.  Many iterations with dropped temporaries + allocator churn in between == the one-stream engine."""
+    from carl_amd.mixed import MixedVecEngine
+
+    n, T, R = 4096, 16, 12
+    fams, rng, mk = _pair(device, n, max_episode_steps=9)
+    sep, parts = mk(), mk()
+    mixed = MixedVecEngine(parts)
+    for e in sep:
+        e.reset()
+    mixed.reset()
+    g = torch.Generator(device=device).manual_seed(3)
+    kept = []
+    for r in range(R):
+        acts = [torch.randint(0, 3, (T, n), generator=g, device=device, dtype=torch.int32) for _ in fams]  # temporaries
+        outs = mixed.rollout(acts, None, free_running=True)
+        ref = [e.rollout(a) for e, a in zip(sep, acts)]
+        kept.append((outs, ref))
+        del acts
+        junk = [torch.empty(T * n, device=device, dtype=torch.int32).fill_(7) for _ in range(4)]  # allocator churn on the caller's stream
+        del junk
+    assert mixed._in_flight
+    # a per-call step while launches are in flight: joins by itself, then equals the separate engines
+    a1 = [torch.randint(0, 3, (n,), generator=g, device=device, dtype=torch.int32) for _ in fams]
+    obs, rew, term, trunc = mixed.step(a1)
+    assert not mixed._in_flight
+    for k, e in enumerate(sep):
+        o, r_, te, tr = e.step(a1[k])
+        assert torch.equal(obs[k], o) and torch.equal(rew[mixed.part_slice(k)], r_)
+    torch.cuda.synchronize()
+    for outs, ref in kept:
+        for k in range(2):
+            for name in ("obs", "reward", "terminated", "truncated"):
+                assert torch.equal(outs[k][name], ref[k][name]), (k, name)
+    for k in range(2):
+        for name in _BOOKKEEPING:
+            assert torch.equal(getattr(parts[k], name), getattr(sep[k], name)), (k, name)
+
+
+def test_small_brax_parts_side_by_side_equal_back_to_back(device):
+    """The 8-GPU shard of BASELINE config 5 (Halfcheetah x 4 096 + Humanoid x 4 096 per GPU): `MixedVecEngine.rollout`
+    launches such small Brax parts side by side on the parts' streams (fork / join inside the call) -- same bytes as
+    back to back (`overlap=False`), and one stream-ordered operation for the caller."""
+    from carl_amd.context.selection import StaticSelector
+    from carl_amd.envs import CARLBraxHalfcheetah, CARLBraxHumanoid
+    from carl_amd.mixed import MixedVecEngine
+
+    n, T = 1024, 5
+
+    def mk():
+        return [cls(batch_size=n, device=device, context_selector=StaticSelector, seed=2, lane_offset=k * n, autotune=False)
+                for k, cls in enumerate((CARLBraxHalfcheetah, CARLBraxHumanoid))]
+    a, b = mk(), mk()
+    ma, mb = MixedVecEngine([p.env for p in a]), MixedVecEngine([p.env for p in b])
+    assert ma._small_brax_parts()
+    for m_ in (ma, mb):
+        m_.seed(2)
+        m_.reset()
+    g = torch.Generator(device=device).manual_seed(5)
+    acts = [torch.rand((T, n, p.env.sys.n_act), generator=g, device=device) * 0.8 - 0.4 for p in a]
+    o1 = ma.rollout(acts)                  # side by side (automatic)
+    o2 = mb.rollout(acts, overlap=False)   # back to back
+    after = o1[0]["reward"].sum() + o1[1]["reward"].sum()  # consumed on the caller's stream right away: must be ordered after both
+    torch.cuda.synchronize()
+    for k in range(2):
+        for name in ("obs", "reward", "terminated", "truncated"):
+            assert torch.equal(o1[k][name], o2[k][name]), (k, name)
+        assert torch.equal(ma.parts[k].state, mb.parts[k].state)
+    assert float(after) == float(o2[0]["reward"].sum() + o2[1]["reward"].sum())
