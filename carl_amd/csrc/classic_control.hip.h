@@ -222,10 +222,12 @@ struct Pendulum {
 // instructions (46 each: 3-term reduction, two degree-6 polynomials in z, and the quadrant swap / sign logic on
 // 64-bit values).  Here x = i * (pi / 256) + r with |r| <= pi / 512: (sin, cos) of the grid point come from a
 // 512-entry table of correctly rounded doubles (8 KiB of LDS, staged once per workgroup from a constant array;
-// generated by tools/gen_sincos_table.py), sin r and cos r need three and two terms, and
+// generated by tools/gen_sincos_table.py), sin r and cos r need two terms each, and
 //   sin x = S cos r + C sin r,   cos x = C cos r - S sin r
-// -- ~19 instructions and no quadrant logic; max error < 3e-16 (tests/test_sincos_table.py: table entries against
-// mpmath, the formula against long-double libm over +-40 rad).
+// -- 13 vector instructions + the table read, no quadrant logic; max error < 1e-13 (tests/test_sincos_table.py: table
+// entries against mpmath, the formula against long-double libm over +-40 rad).  Round 4 traded 3e-16 for 1e-13 -- eight
+// orders below the 1e-5 parity bar -- to take 4 of the 19 instructions out of each of the step's eight evaluations
+// (magic-number rounding, one-term reduction, sin r without its r^5 term): Acrobot is vector-ALU-bound.
 #include "sincos_table.inc"
 __device__ const double kSinCosTab[2 * CARL_SINCOS_TAB_N] = {CARL_SINCOS_TAB_VALUES};
 
@@ -245,16 +247,19 @@ struct SinCosTab {
   __device__ static __forceinline__ void sincos2(double xa, double xb, double& sna, double& csa, double& snb,
                                                  double& csb) {
     const vd2* t = lds();
-    const double inv = CARL_SINCOS_TAB_INV_STEP, hi = CARL_SINCOS_TAB_STEP_HI, lo = CARL_SINCOS_TAB_STEP_LO;
-    const double ka = rint(xa * inv), kb = rint(xb * inv);
-    const vd2 ea = t[(int)ka & (CARL_SINCOS_TAB_N - 1)], eb = t[(int)kb & (CARL_SINCOS_TAB_N - 1)];
-    double ra = fma(ka, -hi, xa), rb = fma(kb, -hi, xb);
-    ra = fma(ka, -lo, ra);
-    rb = fma(kb, -lo, rb);
+    const double inv = CARL_SINCOS_TAB_INV_STEP, hi = CARL_SINCOS_TAB_STEP_HI;
+    // k = rint(x / step) by the 1.5 * 2^52 trick: the sum's low mantissa bits ARE the integer (two's complement), so
+    // the table index is the low dword of `ta` -- no v_rndne_f64 + v_cvt_i32_f64 (|x / step| < 2^31: |x| < 2.6e7 rad)
+    const double magic = 0x1.8p52;
+    const double ta = fma(xa, inv, magic), tb = fma(xb, inv, magic);
+    const double ka = ta - magic, kb = tb - magic;
+    const vd2 ea = t[__double2loint(ta) & (CARL_SINCOS_TAB_N - 1)], eb = t[__double2loint(tb) & (CARL_SINCOS_TAB_N - 1)];
+    // r = x - k * step with step = hi alone: the dropped k * lo is < 2e-15 for |x| <= 40 rad (lo = 4.8e-19)
+    const double ra = fma(ka, -hi, xa), rb = fma(kb, -hi, xb);
     const double za = ra * ra, zb = rb * rb;
-    // sin r = r + r z (-1/6 + z / 120), cos r = 1 + z (-1/2 + z / 24):  |r| <= pi / 512 -> truncation < 1e-16
-    const double sra = fma(ra * za, fma(za, 1.0 / 120.0, -1.0 / 6.0), ra);
-    const double srb = fma(rb * zb, fma(zb, 1.0 / 120.0, -1.0 / 6.0), rb);
+    // sin r = r - r z / 6 (dropped r^5 / 120 <= 7.3e-14 at |r| <= pi / 512), cos r = 1 + z (-1/2 + z / 24) (< 1e-16)
+    const double sra = fma(ra * za, -1.0 / 6.0, ra);
+    const double srb = fma(rb * zb, -1.0 / 6.0, rb);
     const double cra = fma(za, fma(za, 1.0 / 24.0, -0.5), 1.0);
     const double crb = fma(zb, fma(zb, 1.0 / 24.0, -0.5), 1.0);
     sna = fma(ea.x, cra, ea.y * sra);
