@@ -164,6 +164,15 @@ __device__ __forceinline__ void sincos2_fast(double xa, double xb, double& sna, 
   csb = ((qb + 1) & 2) ? -c2b : c2b;
 }
 
+// ... and with ONE Newton step: v_rcp_f64 is good to 2^29 ulp (2^-24 relative), one step squares that (~4e-15) -- what
+// Acrobot's `_dsdt` uses for 1 / det: its result feeds float32 state at a 1e-5 parity bar (131 072 random transitions
+// against the float64 oracle: tests/test_gpu_parity.py::test_random_transitions_100k), two dependent float64 fmas
+// fewer per RK4 stage
+__device__ __forceinline__ double rcp_fast1(double d) {
+  const double r = __builtin_amdgcn_rcp(d);
+  return fma(r, fma(-d, r, 1.0), r);
+}
+
 __device__ __forceinline__ float cos_fast(float x) {
   float s, c;
   sincos_fast(x, s, c);
