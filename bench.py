@@ -158,7 +158,7 @@ def context_dists(env):
         "ant": [U("mass_torso", 5, 15), U("gravity", -15, -5), U("friction", 0.3, 1.5)],
         # BASELINE config 5
         # (not mass_torso: below ~0.75 x its default the torso's effective mass makes the explicit spring
-        #  integration of this model unstable -- CARLBraxEnv refuses such contexts)
+        #  integration of this model unstable -- CARLBraxEnv clamps or refuses such contexts)
         "halfcheetah": [U("joint_stiffness", 0.5, 2.0), U("gravity", -15, -5)],
         "humanoid": [U("joint_stiffness", 0.5, 2.0), U("gravity", -15, -5)],
     }[env]

@@ -3,7 +3,7 @@
 take and their spoken names.  The wrapper itself -- goal position from (direction, distance), position
 integrated from the observed planar velocity, progress reward, success inside the radius (:69-140) -- is
 not a Python wrapper here: it is an epilogue of the Brax step kernel (``carl_brax_sys_t::goal_mode``,
-DESIGN.md section 7), switched on by ``CARLBraxEnv`` when the goal features vary across the contexts.
+DESIGN.md section 5), switched on by ``CARLBraxEnv`` when the goal features vary across the contexts.
 The language goal of ``BraxLanguageWrapper`` (:143-181) is a host-side sentence:
 ``CARLBraxEnv.describe_goal`` / ``use_language_goals=True``."""
 from __future__ import annotations

@@ -5,7 +5,7 @@ wheel (``envs/assets/ant.xml`` ...; carl/envs/brax/carl_ant.py:16) -- neither br
 assets are in the reference tree or installable here, so geometry, joint ranges, gears and
 the spring-backend constants below are restated from upstream memory [upstream-memory] of
 brax 0.12.1's ``ant.xml`` (a Gym-Ant derivative with brax ``<custom>`` numerics) and
-``brax/envs/ant.py``.  PARITY UNPINNED.
+``brax/envs/ant.py``.  PARITY UNPINNED against brax itself.
 
 Spring backend conventions restated here: ``spring_mass_scale = spring_inertia_scale = 1``
 in the asset, i.e. the pipeline runs every link with effective mass ``m**(1-1) = 1`` and

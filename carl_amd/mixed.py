@@ -136,7 +136,7 @@ class MixedVecEngine:
         + Humanoid x 4 096 per GPU) is two launches of ~1 000 wavefronts each on 1 024 SIMDs -- latency-bound at one
         wavefront per SIMD -- and takes max(a, b) x 1.2 side by side instead of a + b (measured: 1.60 -> 0.9 ms per
         20-step launch).  Full-size parts each fill the chip by themselves and go back to back (the fork / join costs
-        more than it returns there: DESIGN.md section 4).  ``overlap=False`` forces one launch per part, back to back
+        more than it returns there: DESIGN.md appendix A).  ``overlap=False`` forces one launch per part, back to back
         (also for the Acrobot + x pair, which otherwise goes out as ONE heterogeneous launch -- ``_rollout_pair``).
 
         ``free_running=True``: part k's launch goes on part k's own stream, ordered after the caller's stream NOW, and

@@ -134,7 +134,7 @@ def test_model_table_equals_the_independent_restatement_field_by_field(name):
 
 
 def test_which_colliders_each_model_carries():
-    """spheres vs the plane z = 0 only; a capsule collides as its two end spheres (documented in DESIGN.md 7)"""
+    """spheres vs the plane z = 0 only; a capsule collides as its two end spheres (documented in DESIGN.md 5.1)"""
     want = {"ant": 21, "halfcheetah": 16, "humanoid": 29}
     for name, n in want.items():
         s, _ = _table(name)

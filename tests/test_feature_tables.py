@@ -17,7 +17,7 @@ GOAL_WRAPPER = GOLDEN.pop("_goal_wrapper")
 
 
 # the default tables hold the reference's features and nothing else; joint_stiffness (BASELINE config 5) lives in
-# the opt-in classes CARLBraxHalfcheetahStiffness / CARLBraxHumanoidStiffness only (DESIGN.md section 7)
+# the opt-in classes CARLBraxHalfcheetahStiffness / CARLBraxHumanoidStiffness only (DESIGN.md section 5.1)
 EXTENSIONS: dict = {}
 # carl_inverted_double_pendulum.py:32-34: key "mass_pole2" constructed with name "mass_pole"
 KNOWN_NAME_SLIPS = {("CARLBraxInvertedDoublePendulum", "mass_pole2")}

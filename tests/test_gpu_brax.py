@@ -1,6 +1,6 @@
 """HIP Brax lane engine (through the C ABI) against the fp64 oracle of the same specification
 (oracle/brax_spring.c).  PARITY WITH BRAX ITSELF IS UNPINNED (brax 0.12.1 is neither in the reference tree nor
-installable; DESIGN.md section 5) -- these tests pin the LDS-resident kernel against an independent fp64
+installable; DESIGN.md section 7) -- these tests pin the LDS-resident kernel against an independent fp64
 implementation, per transition.
 
 Tolerance: north_star's "within 1e-5 fp32 (bit-exact for discrete done flags ...)", asserted as a MAXIMUM of

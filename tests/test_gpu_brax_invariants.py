@@ -1,6 +1,6 @@
 """Physics invariants of the HIP Brax kernel at full size (BASELINE config 4 / 5 batch sizes) -- needs an MI355X.
 
-brax 0.12.1 is not installable here, so the Brax rows cannot be pinned against brax itself (DESIGN.md section 5:
+brax 0.12.1 is not installable here, so the Brax rows cannot be pinned against brax itself (DESIGN.md section 7:
 PARITY UNPINNED).  What CAN be pinned on the GPU path is what any correct maximal-coordinate spring pipeline --
 brax's included -- satisfies, independent of its constants: momentum conservation in free flight (internal joint
 wrenches are equal and opposite), dissipation under damping with a zero action, the penetration the impulse +
