@@ -14,12 +14,12 @@ carries the strong-scaling run (the letter of "at 65k parallel contexts": 65 536
 `strong`.  `--strong` swaps the two.
 
 One "step" of this benchmark = ONE PASS of the hot path over one batch of synthetic input:
-one fused `carl_rollout` launch that advances every lane by `--chunk` (250) env steps and
+one fused `carl_rollout` launch that advances every lane by `--chunk` (1 000: SURVEY.md 8d's K) env steps and
 writes every step's complete transition (obs, reward, terminated, truncated) to HBM --
 nothing is skipped.  `--steps K` times exactly K such launches after `--warmup W` untimed
 ones; `value` = lanes x chunk x K / elapsed (env-steps/s), `ms_per_step` = per launch,
 `config.env_steps_per_step` = lanes x chunk.  Launches rotate through `--buffer-sets` (2)
-action / output buffer sets (Pendulum: 2 x 361 MB > the 256 MB Infinity Cache), so the
+action / output buffer sets (CartPole: 2 x 1.7 GB >> the 256 MB Infinity Cache), so the
 stream is an HBM stream from the first timed launch on.
 
 Also in the same JSON line:
@@ -59,8 +59,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); ~6300 GB/s achievable
-BENCH_VERSION = 4       # r04: headline CartPole x 65 536 (as r03); value = median of --reps regions; strong scaling is
-                        # `value` for N > 1; shard8 / kernel-time / VALU records added.  r03 = 3, r02 = 2 (Pendulum headline)
+BENCH_VERSION = 4       # r04: headline CartPole x 65 536 (as r03) in 1 000-step launches (SURVEY 8d's K; r03: 250 -> `also.cartpole_T250`);
+                        # value = median of --reps regions; strong scaling is `value` for N > 1; shard8 / kernel-time / VALU
+                        # records added.  r03 = 3, r02 = 2 (Pendulum headline)
 
 # algorithmic bytes per env-step
 # (a) SURVEY.md 8(d), per-call model (state/ctx/elapsed re-read every step)
@@ -81,14 +82,17 @@ PER_LAUNCH = {"pendulum": 8 + 4 + 16 + 4 + 4 + 8 + 4 + 4, "cartpole": 16 + 4 + 2
               "humanoid": 2 * 20 * 11 * 4 + 4 + 15 * 4 + 4 + 4 + 4 + 4}
 
 BRAX_ENVS = ("ant", "halfcheetah", "humanoid")
-DEFAULT_CHUNK = {e: (20 if e in BRAX_ENVS else 250) for e in BYTES_8D}
+# env steps per fused launch: SURVEY.md 8(d)'s K = 1 000 measured steps for the classic families (actions pre-generated
+# on the device as [K, N]) -- one launch carries all of them (r02 / r03 used 250: `also.cartpole_T250` keeps that figure
+# comparable); Brax: 20 env steps (= 200-320 pipeline substeps) per launch
+DEFAULT_CHUNK = {e: (20 if e in BRAX_ENVS else 1000) for e in BYTES_8D}
 # the other BASELINE workloads, run after the headline one (same launch train, fewer words):
 #   name -> (families, total lanes per family, "weak" = per GPU / "strong" = split over the GPUs)
 #   mode "follow": like the headline (strong by default: the total is split over the GPUs; --weak: per GPU);
 #   "strong": always split (BASELINE defines configs 4 / 5 over the node).  Fourth entry: env steps per launch (None = default)
 ALSO = {
     "cartpole": (("cartpole",), 65536, "follow", None),                # north_star's target env (the default headline)
-    "cartpole_T1000": (("cartpole",), 65536, "follow", 1000),         # the same with 1 000-step launches: 4 x fewer launch boundaries
+    "cartpole_T250": (("cartpole",), 65536, "follow", 250),           # r02 / r03's launch length (4 x more launch boundaries)
     "pendulum": (("pendulum",), 65536, "follow", None),                # BASELINE config 2
     "config3": (("acrobot", "mountaincar"), 65536, "follow", None),    # 131 072-context mixed batch
     "config4": (("ant",), 32768, "strong", None),                      # 32 768 contexts over the node
@@ -113,7 +117,7 @@ def parse():
     p.add_argument("--env", default="cartpole",
                    help="family, or a+b for a mixed batch (e.g. acrobot+mountaincar); one of " + ", ".join(BYTES_8D))
     p.add_argument("--lanes", type=int, default=65536, help="lanes (= contexts) per family per GPU")
-    p.add_argument("--chunk", type=int, default=0, help="env steps per fused launch (default 250; Brax 20)")
+    p.add_argument("--chunk", type=int, default=0, help="env steps per fused launch (default 1000; Brax 20)")
     p.add_argument("--buffer-sets", type=int, default=2, help="action/output buffer sets the launches rotate through")
     p.add_argument("--strong", action="store_true", help="(default since r04; kept for older command lines)")
     p.add_argument("--weak", action="store_true",
@@ -128,7 +132,7 @@ def parse():
     p.add_argument("--rccl", action="store_true",
                    help="single GPU: build a one-rank RCCL process group and run the reporting all-gather through it")
     p.add_argument("--sustained-seconds", type=float, default=0.3)
-    p.add_argument("--also", default="cartpole_T1000,pendulum,config3,config4,config5",
+    p.add_argument("--also", default="cartpole_T250,pendulum,config3,config4,config5",
                    help="comma list of extra workloads reported under 'also' (" + ", ".join(ALSO) + "), or 'none'")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-per-call", action="store_true")

@@ -22,7 +22,8 @@ def test_workload_tables_are_consistent():
     assert bench.BYTES_8D["acrobot"] == 110 and bench.BYTES_8D["mountaincar"] == 74 and bench.BYTES_8D["ant"] == 1110
 
 
-@pytest.mark.parametrize("key", ["cartpole:65536:250", "pendulum:65536:250", "acrobot+mountaincar:65536:250"])
+@pytest.mark.parametrize("key", ["cartpole:65536:1000", "pendulum:65536:1000", "acrobot+mountaincar:65536:1000",
+                                 "cartpole:65536:250"])
 def test_committed_profiler_records_exist_for_the_classic_workloads(key):
     kt = bench.profile_record("kernel_times", key)
     tr = bench.traffic_record(key)
@@ -30,7 +31,8 @@ def test_committed_profiler_records_exist_for_the_classic_workloads(key):
     assert tr and tr["hbm_bytes_per_launch"] > 1e8
     # traffic within 2 % of the fused kernel's algorithmic bytes: no wasted re-reads (the judge's first check)
     fams = key.split(":")[0].split("+")
-    alg = sum((bench.IO_PER_STEP[f] * 250 + bench.PER_LAUNCH[f]) * 65536 for f in fams)
+    T = int(key.split(":")[2])
+    alg = sum((bench.IO_PER_STEP[f] * T + bench.PER_LAUNCH[f]) * 65536 for f in fams)
     assert 0.99 < tr["hbm_bytes_per_launch"] / alg < 1.02, (key, tr["hbm_bytes_per_launch"] / alg)
     # the kernel cannot be faster than the HBM peak allows for its algorithmic bytes
     assert alg / (kt["kernel_avg_us"] * 1e-6) / 1e9 < bench.HBM_PEAK_GBS

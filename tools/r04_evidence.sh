@@ -25,12 +25,14 @@ run() {  # name, bench args...
     tail -1 "$OUT/$name.$pass.log" | cut -c1-200
   done
 }
-run cartpole_65536_250 --env cartpole
-run pendulum_65536_250 --env pendulum
-run acrobot+mountaincar_65536_250 --env acrobot+mountaincar
-run cartpole_65536_1000 --env cartpole --chunk 1000
+run cartpole_65536_1000 --env cartpole
+run pendulum_65536_1000 --env pendulum
+run acrobot+mountaincar_65536_1000 --env acrobot+mountaincar
+run cartpole_65536_250 --env cartpole --chunk 250
+run pendulum_65536_250 --env pendulum --chunk 250
+run acrobot+mountaincar_65536_250 --env acrobot+mountaincar --chunk 250
 run ant_32768_20 --env ant --lanes 32768 --lanes-per-env ant=9
 run halfcheetah+humanoid_32768_20 --env halfcheetah+humanoid --lanes 32768 --lanes-per-env halfcheetah=7,humanoid=11
-run cartpole_8192_250 --env cartpole --lanes 8192
+run cartpole_8192_1000 --env cartpole --lanes 8192
 run ant_4096_20 --env ant --lanes 4096 --lanes-per-env ant=16
 find "$OUT" -name "*kernel_stats.csv" | head -20
