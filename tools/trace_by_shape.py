@@ -25,7 +25,9 @@ print(f"{'kernel':72s} {'workgroups':>10s} {'class':>8s} {'calls':>6s} {'avg us'
 for (short, wgs), lst in sorted(groups.items()):
     durs = sorted((e - s) / 1e3 for s, e, _ in lst)
     med = durs[len(durs) // 2]
-    for label, sel in (("<=2xmed", [x for x in lst if (x[1] - x[0]) / 1e3 <= 2 * med]), (">2xmed", [x for x in lst if (x[1] - x[0]) / 1e3 > 2 * med])):
+    dur = lambda x: (x[1] - x[0]) / 1e3  # noqa: E731
+    for label, sel in (("<med/2", [x for x in lst if dur(x) < 0.5 * med]), ("~median", [x for x in lst if 0.5 * med <= dur(x) <= 2 * med]),
+                       (">2xmed", [x for x in lst if dur(x) > 2 * med])):
         if not sel:
             continue
         d = [(e - s) / 1e3 for s, e, _ in sel]
