@@ -768,3 +768,25 @@ def test_rollout_variant_is_visible_and_odd_lane_counts_warn(device):
             got = d.rollout(acts)
             for k in ("obs", "reward", "terminated", "truncated"):
                 assert torch.equal(ref[k], got[k]), k
+
+
+@pytest.mark.parametrize("fam", [O.CARTPOLE, O.PENDULUM], ids=["cartpole", "pendulum"])
+def test_one_1000_step_launch_equals_four_250_step_launches_at_full_size(fam, device):
+    """bench.py's headline launch length (SURVEY 8d's K = 1 000 steps in ONE launch, 65 536 lanes) against the 250-step
+    launches the full-size oracle re-step test covers: same bytes in every output row and every counter."""
+    n, T = 65536, 1000
+    rng = np.random.default_rng(9)
+    table = random_table(fam, rng, n)
+    acts = torch.as_tensor(random_actions(fam, rng, (T, n)), device=device)
+    kw = dict(selector=O.SEL_STATIC, seed=31, ctx_idx0=np.arange(n))
+    e1, e2 = _engine(fam, table, n, device, **kw), _engine(fam, table, n, device, **kw)
+    e1.reset()
+    e2.reset()
+    o1 = e1.rollout(acts)
+    for q in range(4):
+        o2 = e2.rollout(acts[250 * q: 250 * (q + 1)])
+        for k in ("obs", "reward", "terminated", "truncated"):
+            assert torch.equal(o1[k][250 * q: 250 * (q + 1)], o2[k]), (q, k)
+    for k in ("state", "elapsed", "episode", "n_calls", "ep_return", "last_return", "last_length", "episodes_done"):
+        assert torch.equal(getattr(e1, k), getattr(e2, k)), k
+    assert int(e1.episodes_done.sum()) >= 4 * n  # TimeLimit 200 / 500: every lane finished episodes inside the launch
