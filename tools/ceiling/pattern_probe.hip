@@ -36,7 +36,7 @@ extern "C" __global__ void __launch_bounds__(512) probe_kernel(const int* __rest
     return;
   }
   const bool reader_on = mode == 0 || mode == 2 || mode == 4 || mode == 5 || mode >= 7;
-  const bool obs_on = mode < 7 || mode >= 9, rew_on = mode == 0 || mode == 1 || mode == 2 || mode == 5 || mode >= 9;
+  const bool obs_on = mode < 7 || mode >= 9, rew_on = mode == 0 || mode == 1 || mode == 2 || mode == 5 || mode >= 9;  // (17, 18: all five)
   const bool flags_on = mode == 0 || mode == 1 || mode == 5 || mode >= 9;
   __shared__ int progress;  // steps the writers have issued (storer 0 publishes per chunk)
   if (threadIdx.x == 0) progress = 0;
@@ -44,6 +44,36 @@ extern "C" __global__ void __launch_bounds__(512) probe_kernel(const int* __rest
   if (wave == 4) {  // reader (the loader wave): 8 rows in flight
     if (!reader_on) return;
     int acc = 0;
+    if (mode == 19 || mode == 20) {  // 19: each workgroup re-reads ITS OWN first 8 rows (8 KiB, cacheable loads: L2 hits, spread over the channels); 20: the same with nt loads
+      typedef int vi4 __attribute__((ext_vector_type(4)));
+      for (int t0 = 0; t0 < T; t0 += 8) {
+        vi4 r[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const vi4* p = reinterpret_cast<const vi4*>(act + (size_t)u * n + lane_base) + l;
+          r[u] = mode == 19 ? *p : __builtin_nontemporal_load(p);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += r[u].x + r[u].w;
+        asm volatile("" ::: "memory");
+      }
+      if (acc == 123456789) sink[0] = (float)acc;
+      return;
+    }
+    if (mode == 17 || mode == 18) {  // where do the reads cost?  17: every workgroup reads workgroup 0's piece of each row (L2 hits
+                                     // after the first); 18: the same 8 rows over and over (L1 / L2 hits): no HBM reads at all
+      typedef int vi4 __attribute__((ext_vector_type(4)));
+      for (int t0 = 0; t0 < T; t0 += 8) {
+        vi4 r[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          r[u] = __builtin_nontemporal_load(reinterpret_cast<const vi4*>(act + (size_t)(mode == 18 ? u : min(t0 + u, T - 1)) * n) + l);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += r[u].x + r[u].w;
+      }
+      if (acc == 123456789) sink[0] = (float)acc;
+      return;
+    }
     if (mode >= 13) {
       typedef int vi4 __attribute__((ext_vector_type(4)));
       for (int t0 = 0; t0 < T; t0 += 8) {

@@ -26,10 +26,12 @@ NAMES = {0: "all five streams (read 4 + write 16 + 4 + 1 + 1 B)", 1: "no reader 
          3: "obs only (write 16 B)", 4: "reader + obs (read 4 + write 16 B)", 5: "all five, temporal stores", 6: "plain fill of the obs buffer (16 B x lanes x T)", 7: "reader alone, 8 rows in flight",
          8: "reader alone, pipelined (8 + 8 in flight)", 9: "all five streams, pipelined reader", 10: "all five, reads in bursts of 32 rows",
          11: "all five, reads in bursts of 64 rows", 12: "all five, reads in bursts of 128 rows", 13: "all five, loads without cache bits",
-         14: "all five, loads sc0", 15: "all five, loads sc1", 16: "all five, loads sc0 sc1"}
-BYTES = {0: 26, 1: 22, 2: 24, 3: 16, 4: 20, 5: 26, 6: 16, 7: 4, 8: 4, 9: 26, 10: 26, 11: 26, 12: 26, 13: 26, 14: 26, 15: 26, 16: 26}
+         14: "all five, loads sc0", 15: "all five, loads sc1", 16: "all five, loads sc0 sc1", 17: "all five, every workgroup reads workgroup 0's piece (L2 hits)",
+         18: "all five, the same 8 rows again and again (no HBM reads)",
+         19: "all five, each workgroup re-reads its own 8 KiB (cacheable)", 20: "all five, each workgroup re-reads its own 8 KiB (nt)"}
+BYTES = {0: 26, 1: 22, 2: 24, 3: 16, 4: 20, 5: 26, 6: 16, 7: 4, 8: 4, 9: 26, 10: 26, 11: 26, 12: 26, 13: 26, 14: 26, 15: 26, 16: 26, 17: 26, 18: 26, 19: 26, 20: 26}
 for rep in range(2):
-    for mode in (0, 1, 13, 14, 15, 16):
+    for mode in (0, 1, 19, 20):
         k = [0]
 
         def go():
