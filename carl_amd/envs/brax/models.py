@@ -156,6 +156,19 @@ def _wire_context(s, feature_names, reference_compat, link_ids, mass_defaults):
             m.n_mass = k + 1
 
 
+def apply_viscosity_rule(s, feature_names, rule: str) -> None:
+    """What the ``viscosity`` context does to the physics.  ``"observed"`` (default): nothing -- it only appears in
+    ``obs["context"]`` (Quirk B2: its intended semantics are unclear; fluid forces are not modelled).  ``"reference"``:
+    the LITERAL rule of the reference's ``_update_context`` -- ``sys.replace(ang_damping=context["viscosity"])`` AFTER
+    the ``ang_damping`` line (carl/envs/brax/carl_brax_env.py:276-279), i.e. the viscosity column is what the angular
+    damping reads and the ``ang_damping`` column is overwritten.  (In the reference itself neither reaches the jitted
+    step: Quirk B1.)"""
+    if rule not in ("observed", "reference"):
+        raise ValueError("viscosity rule must be 'observed' or 'reference'")
+    if rule == "reference" and feature_names and "viscosity" in feature_names and s.ctx.ang_damping >= 0:
+        s.ctx.ang_damping = list(feature_names).index("viscosity")
+
+
 def _capsule_ends(pos, theta_y, half):
     """ends of a capsule given MJCF `pos`, `axisangle="0 1 0 theta"` and half-length (local z axis)"""
     d = np.array([math.sin(theta_y), 0.0, math.cos(theta_y)])

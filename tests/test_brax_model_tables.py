@@ -171,3 +171,20 @@ def test_planar_models_capsules_reproduce_the_reference_masses(name, cls):
         assert abs(1000.0 * vol[i] - want[link]) < 2e-6 * want[link], (name, link, 1000.0 * vol[i], want[link])
         n += 1
     assert n == (3 if name == "hopper" else 6)
+
+
+def test_viscosity_rule_of_the_reference_is_available():
+    """Quirk B2: the reference writes `viscosity` into `ang_damping` after the `ang_damping` line
+    (carl/envs/brax/carl_brax_env.py:276-279).  Default here: observed only; "reference": the literal rule."""
+    s, names = _table("ant")
+    row_ad, row_vi = names.index("ang_damping"), names.index("viscosity")
+    assert s.ctx.ang_damping == row_ad
+    models.apply_viscosity_rule(s, names, "observed")
+    assert s.ctx.ang_damping == row_ad
+    models.apply_viscosity_rule(s, names, "reference")
+    assert s.ctx.ang_damping == row_vi
+    compat = models.SYSTEMS["ant"](names, reference_compat=True)  # physics contexts ignored: nothing to overwrite
+    models.apply_viscosity_rule(compat, names, "reference")
+    assert compat.ctx.ang_damping == -1
+    with pytest.raises(ValueError):
+        models.apply_viscosity_rule(s, names, "fluid")

@@ -977,3 +977,31 @@ def test_planar_substep_agrees_with_the_general_substep(device, model):
     print(f"{model}: planar vs general substep, 25 steps x {n} envs: max |d| / (1 + |x|) {worst:.2e} on agreeing lanes "
           f"(share {min(agree_share):.5f})")
     assert worst <= 2e-6 and min(agree_share) >= 0.999
+
+
+def test_reference_viscosity_rule_moves_the_angular_damping(device):
+    """`CARLBraxEnv(viscosity="reference")` (Quirk B2, carl_brax_env.py:276-279: the viscosity context overwrites
+    ang_damping): an env whose viscosity column holds x steps exactly like a default-rule env whose ang_damping column
+    holds x -- whatever its own ang_damping column says; under the default rule viscosity is observed only."""
+    from carl_amd.context.selection import StaticSelector
+    from carl_amd.envs import CARLBraxAnt
+
+    n = 64
+    base = CARLBraxAnt.get_default_context()
+    mk = lambda **kv: {i: {**base, **kv} for i in range(n)}  # noqa: E731
+    a = CARLBraxAnt(contexts=mk(ang_damping=-0.8), batch_size=n, device=device, context_selector=StaticSelector, seed=1, autotune=False)
+    b = CARLBraxAnt(contexts=mk(ang_damping=-0.05, viscosity=-0.8), batch_size=n, device=device, context_selector=StaticSelector,
+                    seed=1, autotune=False, viscosity="reference")
+    c = CARLBraxAnt(contexts=mk(ang_damping=-0.05, viscosity=-0.8), batch_size=n, device=device, context_selector=StaticSelector,
+                    seed=1, autotune=False)  # default rule: viscosity does nothing
+    for e in (a, b, c):
+        e.reset(seed=1)
+    g = torch.Generator(device=device).manual_seed(0)
+    differs = False
+    for t in range(12):
+        act = torch.rand((n, 8), generator=g, device=device) * 2 - 1
+        oa, ob, oc = a.step(act)[0]["obs"], b.step(act)[0]["obs"], c.step(act)[0]["obs"]
+        assert torch.equal(oa, ob), t
+        differs |= not torch.equal(oa, oc)
+    assert differs
+    assert float(b.step(act)[0]["context"]["viscosity"][0]) == pytest.approx(-0.8)  # still observed as sampled
