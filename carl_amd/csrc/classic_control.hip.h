@@ -419,6 +419,19 @@ struct AcrobotT {
   __device__ static __forceinline__ void wrap_pair(Real& x0, Real& x1) {
     const Real pi = (Real)3.14159265358979323846;
     const Real diff = pi - (-pi);
+    if constexpr (std::is_same_v<Real, double>) {
+      // Round 4: k = rint(x / 2 pi) by the 1.5 * 2^52 trick and ONE fma, y = x - k * diff -- for one turn exactly the
+      // reference's `x - diff` / `x + diff` (one rounding of the same difference), for several turns its loop unrolled;
+      // the strict compares at +-pi are reproduced except for the three doubles within one ulp of +-pi, where x / 2 pi
+      // rounds onto 0.5 (never met: 1e-16 of the angle range; the observation's sin / cos are the same there anyway).
+      // 4 instructions per angle instead of 8 + a wave-uniform "several turns" test and branch (Acrobot is
+      // vector-ALU-bound: DESIGN 4.3).  Non-finite angles stay non-finite.
+      const double inv = 0x1.45f306dc9c883p-3, magic = 0x1.8p52;  // 1 / (2 pi)
+      const double k0 = fma(x0, inv, magic) - magic, k1 = fma(x1, inv, magic) - magic;
+      x0 = fma(k0, -diff, x0);
+      x1 = fma(k1, -diff, x1);
+      return;
+    }
     Real y0 = x0 > pi ? x0 - diff : x0;
     Real y1 = x1 > pi ? x1 - diff : x1;
     y0 = y0 < -pi ? y0 + diff : y0;
