@@ -218,3 +218,128 @@ class Mi355xVecEnv:
     @property
     def feature_names(self) -> list[str]:
         return list(self._names)
+
+
+# ======================================================================================================================
+# Brax families: the object the REFERENCE's ``CARLBraxEnv`` wraps
+# ======================================================================================================================
+class Mi355xBraxVecEnv:
+    """What ``CARLBraxEnv(env=...)`` (carl/envs/brax/carl_brax_env.py:121,163-190) needs from ``env`` -- the surface of
+    the reference's ``GymWrapper`` / ``VectorGymWrapper`` around ``brax.envs.create(env_name, backend="spring",
+    batch_size)`` (carl/envs/brax/wrappers.py:32-158) -- answered by the lane engine:
+
+    * ``observation_space`` / ``action_space``: ``Box(-inf, inf, [obs])`` and the actuators' control ranges
+      (wrappers.py:46-51), batched for ``batch_size > 1`` (:111-118);
+    * ``reset(*, seed=None, options=None) -> (obs, {})`` and ``step(action) -> (obs, reward, terminated, False, info)``
+      with ``terminated = done`` (brax's EpisodeWrapper folds its 1 000-step truncation into ``done``) and
+      ``truncated = False`` (wrappers.py:69-78, 136-145);
+    * done envs return to the state of their last explicit ``reset()`` -- brax's ``AutoResetWrapper``, which
+      ``brax.envs.create`` puts under both wrappers (``autoreset_mode="first_state"``);
+    * ``env.unwrapped.sys = sys`` (carl_brax_env.py:292): the reference rebuilds a brax ``System`` from the context
+      (``sys.replace(gravity=..., ang_damping=...)``, ``set_masses``, ``geom_friction.at[:, 0].set``,
+      ``elasticity.at[:].set``: :272-290) and assigns it.  The setter reads exactly those fields back -- duck-typed:
+      ``sys.gravity[2]``, ``sys.ang_damping``, ``sys.geom_friction[0][0]``, ``sys.elasticity[0]``,
+      ``sys.link.inertia.mass[sys.link_names.index(link)]`` -- and writes them into the engine's context columns.
+      In the reference that assignment lands on the gym shim and never reaches the jitted step (SURVEY Quirk B1); here it
+      DOES move the physics, which is what ``_update_context`` intends;
+    * ``env.context = ctx`` (:236, :302): a plain attribute.
+
+    The engine runs with ``CARL_SEL_HOST``: the reference's selector decides.  Goal-directed variants
+    (``BraxWalkerGoalWrapper``) are part of the mirror classes (``carl_amd.envs.CARLBrax<Family>``), whose kernels fuse
+    the wrapper's arithmetic; this shim is the plain env.  ``brax`` itself is not needed by the shim, but the
+    reference's ``_update_context`` imports it to build the ``System`` (``mjcf.load``)."""
+
+    metadata: dict = {"render_modes": []}
+    render_mode = None
+
+    def __init__(self, env_name: str, batch_size: int = 1, device="cuda", *, seed: int = 0, engine=None):
+        from carl_amd.envs import brax as BX
+        from carl_amd.envs.brax import models
+
+        classes = {c.env_name: c for name, c in vars(BX).items()
+                   if isinstance(c, type) and getattr(c, "env_name", None) and not name.endswith("Stiffness")}
+        if env_name not in classes:
+            raise ValueError(f"unknown brax env {env_name!r}; one of {sorted(classes)}")
+        feats = classes[env_name].get_context_features()
+        self._names = list(feats.keys())
+        self._defaults = [float(f.default_value) for f in feats.values()]
+        self.env_name, self.num_envs = env_name, int(batch_size)
+        if engine is None:
+            from carl_amd.brax_engine import BraxVecEngine
+
+            engine = BraxVecEngine(models.SYSTEMS[env_name](self._names), len(self._names), [self._defaults], self.num_envs,
+                                   device, selector=_lib.SEL_HOST, auto_reset=True, autoreset_mode="first_state", seed=seed)
+        self.eng = engine
+        s = engine.sys
+        obs = np.inf * np.ones(int(s.obs_dim), dtype=np.float32)
+        self.single_observation_space = spaces.Box(-obs, obs, dtype=np.float32)
+        self.single_action_space = spaces.Box(np.array(s.act_lo[: s.n_act], dtype=np.float32),
+                                              np.array(s.act_hi[: s.n_act], dtype=np.float32), dtype=np.float32)
+        batched = self.num_envs > 1
+        self.observation_space = spaces.batch_space(self.single_observation_space, self.num_envs) if batched else self.single_observation_space
+        self.action_space = spaces.batch_space(self.single_action_space, self.num_envs) if batched else self.single_action_space
+        self.context = None
+        self._sys = None
+
+    @property
+    def unwrapped(self):
+        return self
+
+    # ------------------------------------------------------------------ the reference's context push
+    @property
+    def sys(self):
+        return self._sys
+
+    @sys.setter
+    def sys(self, system) -> None:
+        """``self.env.unwrapped.sys = sys`` (carl_brax_env.py:292): read the fields ``_update_context`` wrote"""
+        self._sys = system
+        col = {n: i for i, n in enumerate(self._names)}
+        table = self.eng.ctx_table
+
+        def put(name, value):
+            if name in col:
+                table[col[name]][...] = float(value)
+
+        if hasattr(system, "gravity"):
+            put("gravity", np.asarray(system.gravity).reshape(-1)[2])
+        if hasattr(system, "ang_damping"):
+            put("ang_damping", np.asarray(system.ang_damping).reshape(-1)[0])
+        if hasattr(system, "geom_friction"):
+            put("friction", np.asarray(system.geom_friction).reshape(-1)[0])  # [:, 0] of every geom was set to the context's value
+        if hasattr(system, "elasticity"):
+            put("elasticity", np.asarray(system.elasticity).reshape(-1)[0])
+        link = getattr(system, "link", None)
+        names = list(getattr(system, "link_names", []))
+        if link is not None and names:
+            mass = np.asarray(link.inertia.mass).reshape(-1)
+            for n in self._names:
+                if n.startswith("mass_") and n.split("_", 1)[-1] in names:
+                    put(n, mass[names.index(n.split("_", 1)[-1])])
+        if self.num_envs > 1 and hasattr(self.eng, "refresh_ctx_obs"):
+            self.eng.refresh_ctx_obs()
+
+    # ------------------------------------------------------------------ GymWrapper / VectorGymWrapper surface
+    def reset(self, *, seed: int | None = None, options: dict[str, Any] | None = None):
+        if seed is not None:
+            self.eng.seed(seed)
+        obs = self.eng.reset()
+        if self.num_envs == 1:
+            return Mi355xVecEnv._host(obs)[0].astype(np.float32), {}
+        return obs, {}
+
+    def step(self, action):
+        h = Mi355xVecEnv._host
+        if self.num_envs == 1:
+            a = np.asarray(action, dtype=np.float32).reshape(1, -1)
+            obs, reward, term, trunc = self.eng.step(a)
+            done = bool(h(term)[0]) or bool(h(trunc)[0])
+            return h(obs)[0].astype(np.float32), float(h(reward)[0]), done, False, {}
+        obs, reward, term, trunc = self.eng.step(action)
+        return obs, reward, (term | trunc), (trunc & 0), {}  # terminated = done, truncated = False (wrappers.py:142-143)
+
+    def close(self) -> None:
+        pass
+
+    def render(self):
+        return None

@@ -111,3 +111,66 @@ class OracleBackedEngine:
 
     def refresh_ctx_obs(self):
         pass
+
+
+# ---- Brax: the reference's call sequence on the wrapped env (carl/envs/brax/carl_brax_env.py) ----------------------
+class FakeBraxSystem:
+    """What the reference's ``_update_context`` leaves in the brax ``System`` it assigns (duck-typed: brax is not
+    installable here): gravity vector, ang_damping (overwritten by viscosity: :276-279), per-geom friction /
+    elasticity arrays, link masses by name (``set_masses``: :81-101)."""
+
+    def __init__(self, context: dict, link_names: list[str], n_geoms: int = 21):
+        from types import SimpleNamespace
+
+        self.gravity = np.array([0.0, 0.0, context.get("gravity", -9.81)])                      # :272-273
+        self.ang_damping = context.get("ang_damping", -0.05)                                     # :274-275
+        if "viscosity" in context:
+            self.ang_damping = context["viscosity"]                                              # :276-277 (Quirk B2)
+        mass = np.ones(len(link_names))
+        for k, v in context.items():                                                             # set_masses, :57-73
+            if k.startswith("mass"):
+                name = k.split("_", 1)[-1]
+                if name not in link_names:
+                    raise RuntimeError(f"Link {name} not in available link names {link_names}.")
+                mass[link_names.index(name)] = v
+        self.link = SimpleNamespace(inertia=SimpleNamespace(mass=mass))
+        self.link_names = link_names
+        self.geom_friction = np.ones((n_geoms, 3))
+        if "friction" in context:
+            self.geom_friction[:, 0] = context["friction"]                                       # :281-284
+        self.elasticity = np.zeros(n_geoms)
+        if "elasticity" in context:
+            self.elasticity[:] = context["elasticity"]                                           # :285-288
+
+
+class RefBraxSequenceEnv(Wrapper):
+    """The calls ``CARLBraxEnv`` makes on ``env``, in the reference's order."""
+
+    def __init__(self, env, contexts, selector_cls, link_names):
+        super().__init__(env)                                    # carl_env.py:75
+        self._brax_env = env.unwrapped                           # carl_brax_env.py:193
+        self.base_observation_space = env.observation_space     # carl_env.py:77
+        self.contexts, self.context, self.link_names = contexts, None, link_names
+        self.context_selector = selector_cls(contexts=contexts)
+
+    @property
+    def context_id(self):
+        return self.context_selector.context_id
+
+    def _update_context(self):                                   # carl_brax_env.py:255-292
+        self.env.unwrapped.sys = FakeBraxSystem(self.context, self.link_names)
+
+    def reset(self, *, seed=None, options=None):                 # carl_brax_env.py:294-306
+        last = self.context_id
+        self.context = self.context_selector.select()
+        if self.context_id != last:
+            self._update_context()
+        self.env.context = self.context
+        state, info = self.env.reset(seed=seed, options=options)
+        info["context_id"] = self.context_id
+        return {"obs": state, "context": dict(self.context)}, info
+
+    def step(self, action):
+        state, reward, terminated, truncated, info = super().step(action)  # carl_env.py:339
+        info["context_id"] = self.context_id
+        return {"obs": state, "context": dict(self.context)}, reward, terminated, truncated, info

@@ -112,3 +112,35 @@ def test_batched_path_has_the_vector_env_shape():
     assert o.shape == (n, 4) and r.shape == (n,) and te.shape == (n,) and "final_observation" in info
     env.unwrapped.gravity = 3.0  # scalar broadcast: every row of the column
     assert (env.eng.ctx_table[0] == 3.0).all()
+
+
+def test_brax_shim_reads_the_system_the_reference_assigns():
+    """carl_brax_env.py:292 (`self.env.unwrapped.sys = sys`): the fields `_update_context` wrote (:272-290) land in the
+    engine's context columns -- including the reference's literal viscosity -> ang_damping overwrite (Quirk B2)"""
+    from types import SimpleNamespace
+
+    from carl_amd.dropin import Mi355xBraxVecEnv
+    from carl_amd.envs import CARLBraxAnt
+    from carl_amd.envs.brax import models
+    from dropin_util import FakeBraxSystem
+
+    names = list(CARLBraxAnt.get_context_features().keys())
+    default = np.array([[float(f.default_value)] for f in CARLBraxAnt.get_context_features().values()], dtype=np.float32)
+    eng = SimpleNamespace(sys=models.SYSTEMS["ant"](names), ctx_table=default.copy(), ctx_idx=np.zeros(1, np.int32), n=1)
+    env = Mi355xBraxVecEnv("ant", 1, engine=eng)
+    assert env.unwrapped is env and env.observation_space.shape == (27,) and env.action_space.shape == (8,)
+    assert float(env.action_space.low[0]) == -1.0 and float(env.action_space.high[0]) == 1.0
+    links = ["torso"] + [f"l{i}" for i in range(8)]
+    ctx = {"gravity": -12.5, "friction": 0.7, "elasticity": 0.2, "ang_damping": -0.3, "mass_torso": 14.0, "viscosity": 0.0}
+    env.unwrapped.sys = FakeBraxSystem(ctx, links)
+    t = {n: float(eng.ctx_table[names.index(n), 0]) for n in names}
+    assert t["gravity"] == pytest.approx(-12.5) and t["friction"] == pytest.approx(0.7) and t["elasticity"] == pytest.approx(0.2)
+    assert t["mass_torso"] == pytest.approx(14.0)
+    assert t["ang_damping"] == 0.0  # viscosity (0) was written into ang_damping AFTER the ang_damping line (:276-279)
+    assert t["target_distance"] == 100.0  # untouched columns keep their defaults
+    env.context = ctx  # carl_brax_env.py:302: a plain attribute
+    assert env.context is ctx and env.sys.link_names == links
+    with pytest.raises(RuntimeError):  # the reference's own error for an unknown link (set_masses)
+        FakeBraxSystem({"mass_wing": 1.0}, links)
+    with pytest.raises(ValueError):
+        Mi355xBraxVecEnv("quadruped", engine=eng)

@@ -86,3 +86,38 @@ def test_batched_shim_equals_the_engine_driven_directly(device):
     assert int(shim.eng.episodes_done.sum()) > 0  # auto-reset ran inside step
     shim.unwrapped.gravity = 3.0  # the reference's scalar setattr: broadcast into the whole column
     assert bool((shim.eng.ctx_table[0] == 3.0).all())
+
+
+def test_reference_brax_sequence_over_the_shim_equals_the_mirror_class_bit_for_bit(device):
+    """`CARLBraxEnv`'s call sequence (tests/dropin_util.py::RefBraxSequenceEnv: selector -> `_update_context` builds a
+    System and assigns `env.unwrapped.sys` -> `env.context = ctx` -> `env.reset` / `env.step`) over `Mi355xBraxVecEnv`
+    == this repo's mirror class with the reference's own rules switched on (`autoreset="first_state"` = brax's
+    AutoResetWrapper, `viscosity="reference"` = the literal :276-279 overwrite), bit for bit -- and the contexts DO move
+    the physics (they do not in the reference: Quirk B1)."""
+    from carl_amd.dropin import Mi355xBraxVecEnv
+    from dropin_util import RefBraxSequenceEnv
+
+    base = E.CARLBraxAnt.get_default_context()
+    contexts = {0: dict(base), 1: {**base, "gravity": -14.0, "friction": 0.6, "mass_torso": 13.0, "viscosity": 0.0},
+                2: {**base, "gravity": -6.0, "elasticity": 0.3, "ang_damping": -0.5, "viscosity": 0.2}}
+    links = ["torso", "aux_1", "ankle_1_body", "aux_2", "ankle_2_body", "aux_3", "ankle_3_body", "aux_4", "ankle_4_body"]
+    shim = Mi355xBraxVecEnv("ant", 1, device, seed=5)
+    ref = RefBraxSequenceEnv(shim, contexts, RoundRobinSelector, links)
+    mirror = E.CARLBraxAnt(contexts=contexts, batch_size=1, device=device, seed=5, autoreset="first_state",
+                           viscosity="reference", mass_check="off")
+    rng = np.random.default_rng(2)
+    finals = []
+    for episode in range(4):
+        obs, info = ref.reset(seed=40 + episode)
+        m_obs, m_info = mirror.reset(seed=40 + episode)
+        assert info["context_id"] == m_info["context_id"] == episode % 3
+        np.testing.assert_array_equal(obs["obs"], m_obs["obs"])
+        for t in range(25):
+            a = rng.uniform(-1, 1, 8).astype(np.float32)
+            o, r, term, trunc, _ = ref.step(a)
+            mo, mr, mterm, mtrunc, _ = mirror.step(a)
+            np.testing.assert_array_equal(o["obs"], mo["obs"])
+            assert (r, term, trunc) == (mr, mterm, mtrunc) and trunc is False and type(term) is bool
+        finals.append(o["obs"].copy())
+    assert shim.context is contexts[0]  # episode 3 -> context 0 again (carl_brax_env.py:302)
+    assert not np.array_equal(finals[0], finals[1])  # another context -> other dynamics (gravity -14 vs -9.8)
