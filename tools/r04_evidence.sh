@@ -21,7 +21,7 @@ run() {  # name, bench args...
       write) flags="--pmc WRITE_SIZE" ;;
       sq) case $name in ant*|halfcheetah*) flags="--pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" ;; *) continue ;; esac ;;
     esac
-    rocprofv3 $flags -d "$OUT/$name/$pass" -o bench --output-format csv -- python bench.py $COMMON "$@" > "$OUT/$name.$pass.log" 2>&1
+    timeout 240 rocprofv3 $flags -d "$OUT/$name/$pass" -o bench --output-format csv -- python bench.py $COMMON "$@" > "$OUT/$name.$pass.log" 2>&1
     tail -1 "$OUT/$name.$pass.log" | cut -c1-200
   done
 }
