@@ -533,9 +533,9 @@ def cpu_baseline_brax(env, table):
             for c in range(cores)]
     ctx = mp.get_context("spawn")
     with ctx.Pool(cores) as pool:
-        pool.map(_cpu_worker_brax, [(env, names, j[2][:2], 2) for j in jobs])  # warm the workers
+        pool.map_async(_cpu_worker_brax, [(env, names, j[2][:2], 2) for j in jobs]).get(timeout=300)  # warm the workers
         t0 = time.perf_counter()
-        res = pool.map(_cpu_worker_brax, jobs)
+        res = pool.map_async(_cpu_worker_brax, jobs).get(timeout=600)  # (bounded: a stuck worker must not hang the bench)
         wall = time.perf_counter() - t0
     return {
         "value": sum(r[0] for r in res) / wall, "unit": "env-steps/s", "cores": cores, "kind": "port",
@@ -568,9 +568,9 @@ def cpu_baseline(args, env, table, lanes):
             for c in range(cores)]
     ctx = mp.get_context("spawn")
     with ctx.Pool(cores) as pool:
-        pool.map(_cpu_worker, [(fam, j[1][:2], names, 10) for j in jobs])  # warm the workers (imports)
+        pool.map_async(_cpu_worker, [(fam, j[1][:2], names, 10) for j in jobs]).get(timeout=300)  # warm the workers (imports)
         t0 = time.perf_counter()
-        res = pool.map(_cpu_worker, jobs)
+        res = pool.map_async(_cpu_worker, jobs).get(timeout=600)  # (bounded: a stuck worker must not hang the bench)
         wall = time.perf_counter() - t0
     total = sum(r[0] for r in res)
     single = res[0][0] / res[0][1]
@@ -825,7 +825,10 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args, args.families[0], wl.tables[0], n_fam)
+        try:
+            cpu = cpu_baseline(args, args.families[0], wl.tables[0], n_fam)
+        except Exception as e:  # the CPU line is a reported baseline: its failure must not take the GPU measurement with it
+            cpu = {"value": None, "unit": "env-steps/s", "cores": os.cpu_count(), "kind": "port", "error": repr(e)[:200]}
 
     # ---- the other BASELINE workloads, same launch train ---------------------------
     also = {}
