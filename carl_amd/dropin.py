@@ -67,6 +67,15 @@ def _family_class(env_id: str):
             "MountainCar-v0": cc.CARLMountainCar, "MountainCarContinuous-v0": cc.CARLMountainCarContinuous}[env_id]
 
 
+try:  # where gymnasium IS installed (the reference's own environment) the shims are gymnasium.Env subclasses, so that
+    # `gymnasium.Wrapper.__init__` -- which newer gymnasium releases guard with `isinstance(env, Env)` -- accepts them
+    import gymnasium as _gymnasium
+
+    _EnvBase = _gymnasium.Env
+except Exception:  # this image: no gymnasium; the protocol is duck-typed
+    _EnvBase = object
+
+
 class _Spec:
     """what ``gymnasium.Wrapper.spec`` forwards: the registry id and the TimeLimit"""
 
@@ -74,7 +83,7 @@ class _Spec:
         self.id, self.max_episode_steps = env_id, max_episode_steps
 
 
-class Mi355xVecEnv:
+class Mi355xVecEnv(_EnvBase):
     metadata: dict = {"render_modes": []}
     render_mode = None
     reward_range = (-float("inf"), float("inf"))
@@ -223,7 +232,7 @@ class Mi355xVecEnv:
 # ======================================================================================================================
 # Brax families: the object the REFERENCE's ``CARLBraxEnv`` wraps
 # ======================================================================================================================
-class Mi355xBraxVecEnv:
+class Mi355xBraxVecEnv(_EnvBase):
     """What ``CARLBraxEnv(env=...)`` (carl/envs/brax/carl_brax_env.py:121,163-190) needs from ``env`` -- the surface of
     the reference's ``GymWrapper`` / ``VectorGymWrapper`` around ``brax.envs.create(env_name, backend="spring",
     batch_size)`` (carl/envs/brax/wrappers.py:32-158) -- answered by the lane engine:

@@ -4,6 +4,8 @@ CPU half: the shim's protocol layer driven by the reference's call sequence (tes
 every call cited to carl_env.py / carl_gymnasium_env.py / carl_cartpole.py) on an oracle-backed engine, against an
 independent scalar restatement of the same loop (oracle/ref_style.py).  The GPU half (tests/test_gpu_dropin.py) runs
 the same sequence on the HIP engine and compares with the mirror class bit for bit."""
+import os
+
 import numpy as np
 import pytest
 
@@ -144,3 +146,56 @@ def test_brax_shim_reads_the_system_the_reference_assigns():
         FakeBraxSystem({"mass_wing": 1.0}, links)
     with pytest.raises(ValueError):
         Mi355xBraxVecEnv("quadruped", engine=eng)
+
+
+def test_shims_are_gymnasium_envs_where_gymnasium_exists():
+    """In the reference's own environment gymnasium is installed and `gymnasium.Wrapper.__init__` may insist on
+    `isinstance(env, gymnasium.Env)`: the shims then subclass it.  Simulated with a stand-in module that has
+    gymnasium.Env's property surface (`unwrapped`, `np_random` with a setter) -- in a subprocess, this image has none."""
+    import subprocess
+    import sys
+    import textwrap
+
+    code = textwrap.dedent("""
+        import sys, types
+        import numpy as np
+        g = types.ModuleType("gymnasium")
+        class Env:
+            metadata = {"render_modes": []}
+            render_mode = None
+            spec = None
+            _np_random = None
+            @property
+            def unwrapped(self):
+                return self
+            @property
+            def np_random(self):
+                if self._np_random is None:
+                    self._np_random = np.random.default_rng()
+                return self._np_random
+            @np_random.setter
+            def np_random(self, v):
+                self._np_random = v
+            def reset(self, *, seed=None, options=None):
+                raise NotImplementedError
+        g.Env = Env
+        sys.modules["gymnasium"] = g
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        from carl_amd.dropin import Mi355xVecEnv, Mi355xBraxVecEnv
+        from dropin_util import OracleBackedEngine
+        from oracle import oracle as O
+        env = Mi355xVecEnv("CartPole-v1", 1, engine=OracleBackedEngine(O.CARTPOLE, O.default_row(O.CARTPOLE), 1))
+        assert isinstance(env, Env) and issubclass(Mi355xBraxVecEnv, Env) and env.unwrapped is env
+        env.reset(seed=3)
+        a = env.np_random.uniform(size=2)
+        env.reset(seed=3)
+        assert (a == env.np_random.uniform(size=2)).all()
+        env.unwrapped.gravity = 12.0
+        assert env.unwrapped.gravity == 12.0
+        env.unwrapped.state = np.array([0.01, 0.0, 0.02, 0.0])
+        o, r, te, tr, info = env.step(1)
+        assert o.shape == (4,) and r == 1.0 and te is False
+        print("ok")
+    """) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
