@@ -16,8 +16,11 @@ LIB_DIR = os.path.join(_HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libcarl_amd.so")
 ARCH = "gfx950"
 
-# translation unit -> extra compile flags (see the header comment of carl_brax.hip)
-SOURCES = {"carl_amd.hip": [], "carl_brax.hip": ["-fno-slp-vectorize"]}
+# translation unit -> extra compile flags.  No SLP vectorizer in either unit: carl_brax.hip -- see its header comment;
+# carl_amd.hip (r04, tools/ab_probe.sh, interleaved builds on one box): with it the Acrobot + MountainCar pair launch
+# is 3.5 % slower at 65 536 lanes per family and 2.5 % at 8 192, CartPole at 8 192 lanes 2 % slower, and the one
+# packing that paid (Pendulum's sine / cosine polynomials) is written out by hand in fast_math.hip.h: sincos_fast_pk.
+SOURCES = {"carl_amd.hip": ["-fno-slp-vectorize"], "carl_brax.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc() -> str:

@@ -171,7 +171,7 @@ struct Pendulum {
                   ctx.get(INIT_VEL_MAX, c)};
   }
 
-  __device__ static __forceinline__ void prepare(const float (&s)[S], Aux& a) { sincos_fast(s[0], a.sn, a.cs); }
+  __device__ static __forceinline__ void prepare(const float (&s)[S], Aux& a) { sincos_fast_pk(s[0], a.sn, a.cs); }
 
   // PendulumEnv.step; reward from the OLD (th, thdot); never terminates
   __device__ static __forceinline__ bool step(const Params& p, float (&s)[S], Aux& aux, float action,
@@ -196,7 +196,7 @@ struct Pendulum {
     newthdot = fminf(fmaxf(newthdot, -max_speed), max_speed);
     s[0] = __fmaf_rn(newthdot, p.dt, th);
     s[1] = newthdot;
-    sincos_fast(s[0], aux.sn, aux.cs);
+    sincos_fast_pk(s[0], aux.sn, aux.cs);
     reward = -costs;
     return false;
   }
@@ -544,7 +544,8 @@ struct MountainCar {
 #pragma clang fp contract(off)
     float position = s[0], velocity = s[1];
     // velocity += (action - 1) force + cos(3 position) (-gravity)     (roundings spelled out: see CartPole::step)
-    velocity = __fmaf_rn(cos_fast(3.0f * position), -p.gravity, __fmaf_rn((float)(action - 1), p.force, velocity));
+    // cos(3 position) as cos_twice_fast(1.5 position): fl(1.5 p) is exactly fl(3 p) / 2 (a power-of-two scaling)
+    velocity = __fmaf_rn(cos_twice_fast(1.5f * position), -p.gravity, __fmaf_rn((float)(action - 1), p.force, velocity));
     velocity = fminf(fmaxf(velocity, -p.max_speed), p.max_speed);
     position += velocity;
     position = fminf(fmaxf(position, p.min_position), p.max_position);
@@ -598,7 +599,7 @@ struct MountainCarCont {
     float position = s[0], velocity = s[1];
     const float force = fminf(fmaxf(action, -1.0f), 1.0f);
     // velocity += force power - 0.0025 cos(3 position)                (roundings spelled out: see CartPole::step)
-    velocity = __fmaf_rn(-0.0025f, cos_fast(3.0f * position), __fmaf_rn(force, p.power, velocity));
+    velocity = __fmaf_rn(-0.0025f, cos_twice_fast(1.5f * position), __fmaf_rn(force, p.power, velocity));
     velocity = (velocity > p.max_speed) ? p.max_speed : velocity;
     velocity = (velocity < -p.max_speed) ? -p.max_speed : velocity;
     position += velocity;

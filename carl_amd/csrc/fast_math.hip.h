@@ -47,6 +47,60 @@ __device__ __forceinline__ void sincos_fast(float x, float& sn, float& cs) {
   }
 }
 
+// ---- Pendulum's version: the same reduction constants and polynomials, arranged for the regime where ONE wavefront
+// per SIMD issues the whole step (8 192 lanes per GPU: the 8-GPU split; ~90 instructions per step at one per ~5.5
+// cycles), where every instruction is ~1 % of the step:
+//  * k by the 1.5 * 2^23 trick: after t = fma(x, 2/pi, 1.5 * 2^23) the low mantissa bits of t ARE the integer
+//    (two's complement, |k| < 2^22 since |x| <= 1e5), k = t - 1.5 * 2^23: no multiply + round + float->int
+//    conversion.  (The product is not rounded before the nearest-integer step, so k differs from rint(fl(x 2/pi))
+//    at exact ties only; r then sits a hair outside [-pi/4, pi/4], well inside the polynomials' accuracy.)
+//  * the sine and cosine Horner chains side by side in the halves of v_pk_fma_f32 / v_pk_mul_f32 (the same IEEE
+//    fma per half as the scalar instruction): 5 packed instructions for 10;
+//  * quadrant signs by moving bit 1 of q (of q + 1) onto the sign bit with one shift / add and one v_bitop3_b32
+//    each, instead of and + compare + select;
+//  * the library path for huge arguments is a CALL (sincosf inlined is ~500 instructions that the register
+//    allocator and scheduler of the hot loop otherwise have to work around).
+// pendulum_8192_T1000 (tools/shard8_probe.py, one box, interleaved builds): 205 us with the plain version, 197 us
+// with the compiler's SLP packing of it, 181 us with this one; no change at 65 536 lanes (store-bound there).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __attribute__((noinline)) float2 sincosf_outlined(float x) {
+  float s, c;
+  sincosf(x, &s, &c);
+  return make_float2(s, c);
+}
+
+__device__ __forceinline__ void sincos_fast_pk(float x, float& sn, float& cs) {
+  const float two_over_pi = 0x1.45f306p-1f;
+  const float hi = 0x1.921fb6p+0f, mid = -0x1.777a5cp-25f, lo = -0x1.ee59dap-50f;
+  const float magic = 0x1.8p23f;
+  const float t = __fmaf_rn(x, two_over_pi, magic);
+  const float k = t - magic;
+  float r = __fmaf_rn(k, -hi, x);
+  r = __fmaf_rn(k, -mid, r);
+  r = __fmaf_rn(k, -lo, r);
+  const float z = r * r;
+  const f32x2 zz = {z, z};
+  f32x2 p = __builtin_elementwise_fma(zz, f32x2{2.7557314297e-06f, -2.7557314297e-07f},
+                                      f32x2{-1.9841270114e-04f, 2.4801587642e-05f});
+  p = __builtin_elementwise_fma(zz, p, f32x2{8.3333337680e-03f, -1.3888889225e-03f});
+  p = __builtin_elementwise_fma(zz, p, f32x2{-1.6666667163e-01f, 4.1666667908e-02f});
+  const f32x2 m = f32x2{r, z} * zz;  // {r z, z z}
+  const f32x2 sc = __builtin_elementwise_fma(m, p, f32x2{r, __fmaf_rn(z, -0.5f, 1.0f)});  // {sin r, cos r}
+  const unsigned q = __float_as_uint(t);
+  const float s2 = (q & 1u) ? sc.y : sc.x, c2 = (q & 1u) ? sc.x : sc.y;
+  sn = __uint_as_float(__float_as_uint(s2) ^ ((q << 30) & 0x80000000u));         // quadrants 2, 3
+  cs = __uint_as_float(__float_as_uint(c2) ^ (((q + 1u) << 30) & 0x80000000u));  // quadrants 1, 2
+  const bool big = !(fabsf(x) <= 1.0e5f);  // also catches NaN/inf
+  if (__builtin_expect(ballot(big) != 0ull, 0)) {
+    if (big) {
+      const float2 lib = sincosf_outlined(x);
+      sn = lib.x;
+      cs = lib.y;
+    }
+  }
+}
+
 // For arguments that are small in practice (CartPole's pole angle: an episode ends at 0.21 rad): when EVERY lane
 // of the wave has |x| <= 0.78 the reduction finds k = 0, r = x and quadrant 0, so the polynomials alone give the
 // same bits as sincos_fast -- without the multiply / round / three-fma reduction and the quadrant swap and sign
@@ -177,6 +231,33 @@ __device__ __forceinline__ float cos_fast(float x) {
   float s, c;
   sincos_fast(x, s, c);
   return c;
+}
+
+__device__ __attribute__((noinline)) float cos_fast_outlined(float x) { return cos_fast(x); }
+
+// cos(2h) for the MountainCar families' cos(3 position) (h = 1.5 position; position lives in [-1.2, 0.6] with
+// the default contexts, so |h| <= 1.8): c = cos h by an even degree-10 polynomial fitted on |h| <= 1.86 (least
+// squares on Chebyshev nodes, coefficients rounded to fp32), then the double-angle identity 2 c^2 - 1 -- no
+// reduction, no sine polynomial, no quadrant logic: 9 vector instructions against the 34 of sincos_fast.  Max abs
+// error against libm's double cos over |2h| <= 3.7 (2e6 samples, the fp32 roundings emulated:
+// tests/test_sincos_table.py): 1.7e-7.  A lane outside the fitted range (contexts that move min_position /
+// max_position) takes cos_fast(2h) itself -- selected PER LANE inside the rare wave-uniform branch, so a lane's
+// result never depends on its wave mates -- and as a CALL: inlined, the range-reduced version and its library path
+// sat in the middle of the step loop (of BOTH loops of the Acrobot + MountainCar pair kernel, whose Acrobot half then
+// scheduled 1.4 % slower).
+__device__ __forceinline__ float cos_twice_fast(float h) {
+  const float z = h * h;
+  float p = __fmaf_rn(z, -0x1.1173p-22f, 0x1.9ec0c8p-16f);
+  p = __fmaf_rn(z, p, -0x1.6c0d24p-10f);
+  p = __fmaf_rn(z, p, 0x1.555518p-5f);
+  p = __fmaf_rn(z, p, -0x1.fffffep-2f);
+  const float c = __fmaf_rn(z, p, 1.0f);
+  float r = __fmaf_rn(c + c, c, -1.0f);
+  const bool wide = !(fabsf(h) <= 1.85f);  // also catches NaN
+  if (__builtin_expect(ballot(wide) != 0ull, 0)) {
+    if (wide) r = cos_fast_outlined(h + h);
+  }
+  return r;
 }
 
 // atan2 with one reduction step and a degree-7 odd polynomial (Cephes atanf coefficients):

@@ -146,6 +146,33 @@ def test_golden_fixture_transitions(fam, device, golden_dir):
     assert not trunc.any()
 
 
+@pytest.mark.parametrize("fam", [O.MOUNTAINCAR, O.MOUNTAINCAR_CONT], ids=["mountaincar", "mountaincarcont"])
+def test_mountaincar_wide_track_contexts(fam, device):
+    """min_position / max_position are context features without bounds (carl_mountaincar.py:15-50): positions far
+    outside the default [-1.2, 0.6] -- where the kernel's short double-angle cosine is not fitted and the lane takes
+    the range-reduced one -- mixed lane by lane with ordinary ones, incl. huge arguments (|3 p| > 1e5)."""
+    rng = np.random.default_rng(77 + fam)
+    n = 65536
+    ctx = random_table(fam, rng, n)
+    ctx[:, 0], ctx[:, 1] = -3.0e5, 3.0e5  # MIN_POS, MAX_POS
+    pos = np.where(rng.random(n) < 0.5, rng.uniform(-1.2, 0.6, n), rng.uniform(-40, 40, n))
+    pos[::97] = rng.integers(-200000, 200000, pos[::97].shape)  # whole numbers: 3 p is exact in float32 too
+    pos[1::97] = rng.choice([-1.2334, 1.2334, -1.2333, 1.2333], pos[1::97].shape)  # |1.5 p| either side of 1.85
+    s = np.stack([pos, rng.uniform(-0.07, 0.07, n)], 1).astype(np.float32)
+    a = random_actions(fam, rng, n)
+    s2, obs, rew, term, _ = run_transitions(fam, ctx, s, a, device)
+    w_s2, w_obs, w_rew, w_term = O.transitions(fam, ctx, s.astype(np.float64), a, precision="f64")
+    # the cosine enters the velocity times gravity (<= 3.5e-3); float32 rounding of 3 p at |p| = 40 alone is 1.3e-8
+    assert np.abs(s2[:, 1] - w_s2[:, 1]).max() <= 5e-8
+    assert rel_err(s2, w_s2).max() <= TOL
+    assert rel_err(obs, w_obs).max() <= TOL
+    assert rel_err(rew, w_rew).max() <= TOL
+    # a lane's result does not depend on its wave mates: the same rows in another order give the same bits
+    perm = rng.permutation(n)
+    p_s2, *_ = run_transitions(fam, ctx[perm], s[perm], a[perm], device)
+    assert np.array_equal(p_s2, s2[perm])
+
+
 @pytest.mark.parametrize("fam", range(5), ids=O.FAMILY_NAMES)
 def test_random_transitions_100k(fam, device):
     """>= 1e5 random (context, state, action) triples per family vs the float64 oracle"""

@@ -57,3 +57,74 @@ def test_table_formula_error_bound():
     sn, cs = S * cr + C * sr, C * cr - S * sr
     assert np.abs(sn - np.sin(np.longdouble(x))).max() < 6e-11
     assert np.abs(cs - np.cos(np.longdouble(x))).max() < 6e-11
+
+
+def test_mountaincar_double_angle_cosine_error_bound():
+    """fast_math.hip.h: cos_twice_fast (MountainCar / MountainCarContinuous: cos(3 position) as cos(2 h), h = 1.5
+    position).  The constants are read out of the header; the fp32 Horner steps are emulated with exact products
+    rounded once (what v_fma_f32 does).  Bound over the whole fitted range |2 h| <= 3.7: 2e-7."""
+    src = open(os.path.join(ROOT, "carl_amd", "csrc", "fast_math.hip.h")).read()
+    body = src.split("float cos_twice_fast(float h)")[1].split("return r;")[0]
+    c = [np.float32(float.fromhex(v)) for v in re.findall(r"-?0x[0-9a-f.]+p[+-]\d+(?=f)", body)]
+    assert len(c) == 5, c
+    guard = float(re.search(r"fabsf\(h\) <= ([0-9.]+)f", body).group(1))
+    f32, f64 = np.float32, np.float64
+
+    def fma(a, b, d):
+        return (a.astype(f64) * b.astype(f64) + f64(d)).astype(f32)  # 24 x 24-bit product is exact in double
+
+    x = np.linspace(-2 * guard, 2 * guard, 2_000_001).astype(f32)
+    h = (x * f32(0.5)).astype(f32)
+    z = (h * h).astype(f32)
+    p = fma(z, np.full_like(z, c[0]), c[1])
+    for ck in c[2:]:
+        p = fma(z, p, ck)
+    cs = fma(z, p, 1.0)
+    r = fma((cs + cs).astype(f32), cs, -1.0)
+    assert np.abs(r.astype(f64) - np.cos(x.astype(f64))).max() < 2e-7
+    # 1.5 p and 3 p / 2 are the same float (what lets the kernel form h straight from the position)
+    pos = np.random.default_rng(0).uniform(-1.3, 0.7, 100_000).astype(f32)
+    assert np.array_equal((f32(1.5) * pos).astype(f32), ((f32(3.0) * pos).astype(f32) * f32(0.5)).astype(f32))
+    # default position range [-1.2, 0.6] sits inside the fitted range
+    assert 1.5 * 1.2 <= guard
+
+
+def test_pendulum_packed_sincos_error_bound():
+    """fast_math.hip.h: sincos_fast_pk (Pendulum).  NumPy emulation of its formula -- nearest integer by the
+    1.5 * 2^23 trick with the integer read from the low mantissa bits, three-term reduction, the two polynomials,
+    quadrant signs by XOR -- with every fp32 fma as an exact double product rounded once.  Constants read out of the
+    header.  Bound 1.5e-7 over |x| <= 1e5 (where the kernel leaves the fast path) and 1.2e-7 over +-100 rad."""
+    src = open(os.path.join(ROOT, "carl_amd", "csrc", "fast_math.hip.h")).read()
+    body = src.split("void sincos_fast_pk(float x, float& sn, float& cs)")[1].split("const bool big")[0]
+    hexes = [float.fromhex(v) for v in re.findall(r"-?0x[0-9a-f.]+p[+-]?\d+(?=f)", body)]
+    two_over_pi, hi, mid, lo, magic = hexes[:5]
+    assert magic == 1.5 * 2 ** 23
+    dec = [float(v) for v in re.findall(r"(-?\d\.\d+e-\d+)f", body)]
+    (s3, c3), (s2_, c2_), (s1, c1), (s0, c0) = [(dec[i], dec[i + 1]) for i in range(0, 8, 2)]
+    f32, f64 = np.float32, np.float64
+
+    def fma(a, b, d):
+        return (np.asarray(a, f32).astype(f64) * np.asarray(b, f32).astype(f64) + np.asarray(d, f32).astype(f64)).astype(f32)
+
+    rng = np.random.default_rng(5)
+    for span, bound in ((1.0e5, 1.5e-7), (100.0, 1.2e-7)):
+        x = rng.uniform(-span, span, 2_000_000).astype(f32)
+        t = fma(x, f32(two_over_pi), f32(magic))
+        k = (t - f32(magic)).astype(f32)
+        q = t.view(np.uint32)
+        assert np.array_equal((q & 3).astype(np.int64), k.astype(np.int64) & 3)  # the low mantissa bits are k mod 4
+        assert np.abs(k.astype(f64) - x.astype(f64) * (2 / np.pi)).max() <= 0.5 + 1e-2
+        r = fma(k, f32(-hi), x)
+        r = fma(k, f32(-mid), r)
+        r = fma(k, f32(-lo), r)
+        z = (r * r).astype(f32)
+        ps = fma(z, f32(s3), f32(s2_)); ps = fma(z, ps, f32(s1)); ps = fma(z, ps, f32(s0))
+        pc = fma(z, f32(c3), f32(c2_)); pc = fma(z, pc, f32(c1)); pc = fma(z, pc, f32(c0))
+        S = fma((r * z).astype(f32), ps, r)
+        C = fma((z * z).astype(f32), pc, fma(z, f32(-0.5), f32(1.0)))
+        odd = (q & 1).astype(bool)
+        sn = np.where(odd, C, S).view(np.uint32) ^ ((q << np.uint32(30)) & np.uint32(0x80000000))
+        cs = np.where(odd, S, C).view(np.uint32) ^ (((q + np.uint32(1)) << np.uint32(30)) & np.uint32(0x80000000))
+        sn, cs = sn.view(f32), cs.view(f32)
+        assert np.abs(sn.astype(f64) - np.sin(x.astype(f64))).max() < bound
+        assert np.abs(cs.astype(f64) - np.cos(x.astype(f64))).max() < bound

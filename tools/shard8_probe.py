@@ -36,6 +36,7 @@ def main():
         ("cartpole_2x32768_free_T250", ("cartpole", "cartpole"), 32768, 250, 20, "free"),
         ("cartpole_4x16384_free_T250", ("cartpole",) * 4, 16384, 250, 20, "free"),
         ("pendulum_65536_T250", ("pendulum",), 65536, 250, 20, "train"),
+        ("pendulum_65536_T1000", ("pendulum",), 65536, 1000, 8, "train"),
         ("pendulum_2x32768_free_T250", ("pendulum", "pendulum"), 32768, 250, 20, "free"),
         ("cartpole_8192_T250", ("cartpole",), 8192, 250, 20, "train"),
         ("cartpole_8192_T1000", ("cartpole",), 8192, 1000, 8, "train"),
@@ -43,6 +44,8 @@ def main():
         ("pendulum_8192_T1000", ("pendulum",), 8192, 1000, 8, "train"),
         ("config3_16384_T250", ("acrobot", "mountaincar"), 8192, 250, 20, "train"),
         ("config3_65536_T250", ("acrobot", "mountaincar"), 65536, 250, 20, "train"),
+        ("config3_65536_T1000", ("acrobot", "mountaincar"), 65536, 1000, 8, "train"),
+        ("config3_16384_T1000", ("acrobot", "mountaincar"), 8192, 1000, 8, "train"),
         ("acrobot_65536_T250", ("acrobot",), 65536, 250, 20, "train"),
         ("mountaincar_65536_T250", ("mountaincar",), 65536, 250, 20, "train"),
         ("ant_256_T20", ("ant",), 256, 20, 20, "train"),
