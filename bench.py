@@ -379,9 +379,37 @@ class ClockSampler:
                     break
         except Exception:
             pass
-        self.samples = {"sclk": [], "mclk": []}
+        self.samples = {"sclk": [], "mclk": [], "fclk": [], "socclk": []}
+        # hwmon of the same card: temperatures (edge / junction / mem) and package power.  r04: on ONE box inside ONE
+        # gpurun call the driver's command ran at 274 us per launch first and at 304 us a minute of GPU work later, with
+        # sclk and mclk unchanged -- the "fast / medium / slow boxes" of the pool are at least partly the state a box is in
+        self.hwmon = self.discover_hwmon(self.dir)
+        self.hw_samples = {k: [] for k in self.hwmon}
         self._stop = False
         self._thread = None
+
+    @staticmethod
+    def discover_hwmon(card_dir):
+        """{record key: (file, scale)} of the card's hwmon: temp*_input (millidegrees; labelled edge / junction / mem) and
+        package power (microwatts)"""
+        import glob
+
+        found = {}
+        if card_dir is None:
+            return found
+        for h in sorted(glob.glob(os.path.join(card_dir, "hwmon", "hwmon*"))):
+            for f in sorted(glob.glob(os.path.join(h, "temp*_input"))):
+                try:
+                    with open(f.replace("_input", "_label")) as lf:
+                        label = lf.read().strip()
+                except OSError:
+                    label = os.path.basename(f).split("_")[0]
+                found["temp_" + label + "_c"] = (f, 1e-3)
+            for name in ("power1_average", "power1_input"):
+                if os.path.exists(os.path.join(h, name)):
+                    found["power_w"] = (os.path.join(h, name), 1e-6)
+                    break
+        return found
 
     def _read(self, which):
         try:
@@ -403,6 +431,12 @@ class ClockSampler:
                         v = self._read(k)
                         if v is not None:
                             self.samples[k].append(v)
+                    for k, (path, scale) in self.hwmon.items():
+                        try:
+                            with open(path) as f:
+                                self.hw_samples[k].append(int(f.read()) * scale)
+                        except (OSError, ValueError):
+                            pass
                     time.sleep(0.01)
 
             self._thread = threading.Thread(target=poll, daemon=True)
@@ -417,11 +451,16 @@ class ClockSampler:
     def record(self):
         if self.dir is None:
             return {"source": None, "note": "sysfs clock files of this GPU not found"}
-        out = {"source": "sysfs pp_dpm_sclk / pp_dpm_mclk, polled every 10 ms during the sustained launch train"}
+        out = {"source": "sysfs pp_dpm_{sclk,mclk,fclk,socclk} and hwmon temperatures / power of this card, polled every "
+                         "10 ms during the sustained launch train"}
         for k, v in self.samples.items():
             if v:
                 v = sorted(v)
                 out[k + "_mhz"] = {"min": v[0], "median": v[len(v) // 2], "max": v[-1], "samples": len(v)}
+        for k, v in self.hw_samples.items():
+            if v:
+                v = sorted(v)
+                out[k] = {"min": round(v[0], 1), "median": round(v[len(v) // 2], 1), "max": round(v[-1], 1)}
         return out
 
 

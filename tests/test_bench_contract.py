@@ -61,3 +61,19 @@ def test_clock_sampler_degrades_without_sysfs(tmp_path):
     (d / "pp_dpm_mclk").write_text("0: 2000Mhz *\n")
     c.dir = str(d)
     assert c._read("sclk") == 2352 and c._read("mclk") == 2000
+    # temperatures / power of the card's hwmon (what tells a warm box from a cool one when the clocks read the same)
+    h = d / "hwmon" / "hwmon3"
+    h.mkdir(parents=True)
+    (h / "temp1_input").write_text("45000\n"); (h / "temp1_label").write_text("edge\n")
+    (h / "temp3_input").write_text("61000\n"); (h / "temp3_label").write_text("mem\n")
+    (h / "power1_average").write_text("512000000\n")
+    hw = bench.ClockSampler.discover_hwmon(str(d))
+    assert set(hw) == {"temp_edge_c", "temp_mem_c", "power_w"}
+    c.hwmon, c.hw_samples, c._stop = hw, {k: [] for k in hw}, False
+    import time as _t
+
+    with c:
+        _t.sleep(0.05)
+    rec = c.record()
+    assert rec["temp_mem_c"]["median"] == 61.0 and rec["power_w"]["max"] == 512.0 and rec["sclk_mhz"]["median"] == 2352
+    assert bench.ClockSampler.discover_hwmon(None) == {}
