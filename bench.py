@@ -93,6 +93,8 @@ DEFAULT_CHUNK = {e: (20 if e in BRAX_ENVS else 1000) for e in BYTES_8D}
 ALSO = {
     "cartpole": (("cartpole",), 65536, "follow", None),                # north_star's target env (the default headline)
     "cartpole_T250": (("cartpole",), 65536, "follow", 250),           # r02 / r03's launch length (4 x more launch boundaries)
+    "cartpole_u8": (("cartpole",), 65536, "follow", None),             # the same workload fed uint8 actions (ABI 7: one byte
+                                                                       # per lane-step on the only per-step read stream)
     "pendulum": (("pendulum",), 65536, "follow", None),                # BASELINE config 2
     "config3": (("acrobot", "mountaincar"), 65536, "follow", None),    # 131 072-context mixed batch
     "config4": (("ant",), 32768, "strong", None),                      # 32 768 contexts over the node
@@ -132,7 +134,7 @@ def parse():
     p.add_argument("--rccl", action="store_true",
                    help="single GPU: build a one-rank RCCL process group and run the reporting all-gather through it")
     p.add_argument("--sustained-seconds", type=float, default=0.3)
-    p.add_argument("--also", default="cartpole_T250,pendulum,config3,config4,config5",
+    p.add_argument("--also", default="cartpole_T250,cartpole_u8,pendulum,config3,config4,config5",
                    help="comma list of extra workloads reported under 'also' (" + ", ".join(ALSO) + "), or 'none'")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-per-call", action="store_true")
@@ -188,14 +190,15 @@ def make_env(env, n, rank, world, device, lane_base=0):
     return carl_env, table
 
 
-def make_actions(eng, T, device, seed):
+def make_actions(eng, T, device, seed, u8=False):
     import torch
 
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     info = eng.info
     if info.action_is_discrete:
-        return torch.randint(0, info.n_actions, (T, eng.n), generator=g, device=device, dtype=torch.int32)
+        a = torch.randint(0, info.n_actions, (T, eng.n), generator=g, device=device, dtype=torch.int32)
+        return a.to(torch.uint8) if u8 else a  # (the same action values either way)
     lo, hi = float(info.action_low), float(info.action_high)
     shape = (T, eng.n) if info.action_dim == 1 else (T, eng.n, int(info.action_dim))
     return torch.rand(shape, generator=g, device=device, dtype=torch.float32) * (hi - lo) + lo
@@ -206,12 +209,12 @@ class Workload:
 
     pinned_lanes_per_env: dict = {}  # --lanes-per-env
 
-    def __init__(self, families, lanes_per_gpu, T, sets, rank, world, device):
+    def __init__(self, families, lanes_per_gpu, T, sets, rank, world, device, action_u8=False):
         import torch
 
         from carl_amd.mixed import MixedVecEngine
 
-        self.families, self.T, self.device = tuple(families), T, device
+        self.families, self.T, self.device, self.action_u8 = tuple(families), T, device, action_u8
         self.envs, self.tables = [], []
         for k, f in enumerate(self.families):
             e, t = make_env(f, lanes_per_gpu, rank, world, device, lane_base=k * lanes_per_gpu * world)
@@ -221,7 +224,7 @@ class Workload:
         self.eng = MixedVecEngine([e.env for e in self.envs], self.families) if self.mixed else self.envs[0].env
         parts = self.eng.parts if self.mixed else [self.eng]
         self.n = sum(p.n for p in parts)
-        self.acts = [[make_actions(p, T, device, 1 + rank + 1000 * s + 100 * k) for k, p in enumerate(parts)]
+        self.acts = [[make_actions(p, T, device, 1 + rank + 1000 * s + 100 * k, u8=action_u8) for k, p in enumerate(parts)]
                      for s in range(sets)]
         self.outs = [[p.alloc_rollout(T) for p in parts] for _ in range(sets)]
         for e in self.envs:
@@ -237,7 +240,9 @@ class Workload:
         torch.cuda.synchronize()
         self._i = 0
         self.units_per_launch = self.n * T
-        self.bytes_per_launch = sum((IO_PER_STEP[f] * T + PER_LAUNCH[f]) * p.n for f, p in zip(self.families, parts))
+        act_saved = {f: (3 if action_u8 and p.info.action_is_discrete else 0) for f, p in zip(self.families, parts)}
+        self.bytes_per_launch = sum(((IO_PER_STEP[f] - act_saved[f]) * T + PER_LAUNCH[f]) * p.n
+                                    for f, p in zip(self.families, parts))
         self.bytes_per_launch_8d = sum(BYTES_8D[f] * T * p.n for f, p in zip(self.families, parts))
 
     def launch(self):
@@ -509,7 +514,7 @@ def roofline_of(wl, avg_launch_s):
         "algorithmic_bytes_per_launch": wl.bytes_per_launch,
     }
     part_n = wl.n // len(wl.families)
-    key = f"{'+'.join(wl.families)}:{part_n}:{wl.T}"
+    key = f"{'+'.join(wl.families)}{'_u8' if getattr(wl, 'action_u8', False) else ''}:{part_n}:{wl.T}"
     rec = traffic_record(key)
     if rec:
         r["traffic"] = rec["hbm_bytes_per_launch"]
@@ -876,18 +881,20 @@ def main():
     torch.cuda.empty_cache()
     for name in names:
         fams, total, mode, chunk = ALSO[name]
-        if fams == args.families and chunk in (None, T):
+        u8 = name.endswith("_u8")
+        if fams == args.families and chunk in (None, T) and not u8:
             continue
         split = mode == "strong" or (mode == "follow" and args.strong)
         lanes = total // world if split else total
         mode = "strong" if split else "weak"
         Ta = chunk or DEFAULT_CHUNK[fams[0]]
-        w2 = Workload(fams, lanes, Ta, args.buffer_sets, rank, world, device)
+        w2 = Workload(fams, lanes, Ta, args.buffer_sets, rank, world, device, action_u8=u8)
         regs2, m2 = timed_regions(w2, K, W, args.reps, barrier, max_over_ranks)
         el2, avg2 = regs2[m2]
         r2 = roofline_of(w2, avg2)
         also[name] = {
-            "workload": " + ".join(f"CARL{f} x {lanes}" for f in fams) + f" contexts/GPU, {Ta} env steps per launch",
+            "workload": " + ".join(f"CARL{f} x {lanes}" for f in fams) + f" contexts/GPU, {Ta} env steps per launch"
+                        + (", uint8 actions" if u8 else ""),
             "value": w2.n * world * Ta * K / el2, "unit": "env-steps/s", "scaling": mode,
             "lanes_per_gpu": w2.n, "chunk": Ta, "ms_per_step": el2 / K * 1e3,
             "avg_launch_ms": avg2 * 1e3, "frac": r2["frac"], "achieved_GBs": r2["achieved"],

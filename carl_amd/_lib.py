@@ -15,7 +15,7 @@ import torch  # noqa: F401  (must precede the CDLL load, see module docstring)
 
 from carl_amd import build as _build
 
-CARL_ABI_VERSION = 6
+CARL_ABI_VERSION = 7
 CARL_MAX_CTX_OBS = 32
 
 # carl_family_t
@@ -31,7 +31,7 @@ FLAG_AUTORESET_FIRST_STATE = 8
 FLAG_ROLLOUT_DIRECT = 16
 FLAG_BRAX_GENERIC = 32
 ROLLOUT_STAGED, ROLLOUT_DIRECT_SHAPE, ROLLOUT_DIRECT_FLAG = range(3)
-ACTION_I32, ACTION_I64, ACTION_F32 = range(3)
+ACTION_I32, ACTION_I64, ACTION_F32, ACTION_U8 = range(4)
 
 _vp = C.c_void_p
 

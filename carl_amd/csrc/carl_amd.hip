@@ -100,8 +100,11 @@ int validate_io(const carl_batch_t* b, const carl_step_io_t* io, const char* who
   if (!io->action || !io->obs || !io->reward || !io->terminated || !io->truncated)
     return fail(CARL_ERR_INVALID_ARGUMENT, "%s: a required io pointer is NULL", who);
   const bool discrete = kInfo[b->family].action_is_discrete != 0;
-  if (discrete && io->action_dtype != CARL_ACTION_I32 && io->action_dtype != CARL_ACTION_I64)
-    return fail(CARL_ERR_INVALID_ARGUMENT, "%s: discrete family needs int32/int64 actions", who);
+  if (discrete && io->action_dtype != CARL_ACTION_I32 && io->action_dtype != CARL_ACTION_I64 &&
+      io->action_dtype != CARL_ACTION_U8)
+    return fail(CARL_ERR_INVALID_ARGUMENT, "%s: discrete family needs int32/int64 (carl_rollout: or uint8) actions", who);
+  if (io->action_dtype == CARL_ACTION_U8 && (reinterpret_cast<uintptr_t>(io->action) & 3) != 0)
+    return fail(CARL_ERR_INVALID_ARGUMENT, "%s: uint8 actions must be 4-byte aligned", who);
   if (!discrete && io->action_dtype != CARL_ACTION_F32)
     return fail(CARL_ERR_INVALID_ARGUMENT, "%s: continuous family needs float32 actions", who);
   return 0;
@@ -154,6 +157,16 @@ int launch_step(const carl_batch_t* b, const carl_step_io_t* io, int n_steps, hi
   const size_t sh = (lds ? (size_t)Fam::F * b->n_contexts * sizeof(float) : 0) +
                     (rollout ? carl::rollout_action_lds_bytes() : 0);
   const bool a64 = io->action_dtype == CARL_ACTION_I64;
+  // uint8 actions: the lean staged rollout only (include/carl_amd.h: CARL_ACTION_U8)
+  const bool a8 = io->action_dtype == CARL_ACTION_U8;
+  if (a8) {
+    const bool keeps_context = b->selector == CARL_SEL_STATIC || b->selector == CARL_SEL_HOST;
+    const bool lean = b->fin_count == nullptr && io->final_obs == nullptr;
+    if (!rollout || rollout_variant(b) != CARL_ROLLOUT_STAGED || !keeps_context || !lean || !carl::predraw_of<Fam>::value)
+      return fail(CARL_ERR_UNSUPPORTED,
+                  "uint8 actions: carl_rollout in its lean staged configuration only (n_lanes %% 16 == 0, static / host "
+                  "selector, no finished-episode log, no final_obs); pass int32 / int64 actions");
+  }
   const dim3 g(grid), t(block);
 #define CARL_LAUNCH(KERNEL, ...)                                                                    \
   do {                                                                                              \
@@ -195,6 +208,15 @@ int launch_step(const carl_batch_t* b, const carl_step_io_t* io, int n_steps, hi
           if (b->flags & CARL_FLAG_AUTORESET)
             kern = a64 ? static_cast<kern_t>(carl::rollout_staged_kernel<Fam, true, true, false, false, false, true>)
                        : static_cast<kern_t>(carl::rollout_staged_kernel<Fam, false, true, false, false, false, true>);
+        }
+        if constexpr (std::is_same_v<typename Fam::Action, int>) {
+          if (a8) {  // the same two kernels reading one byte per action
+            kern = static_cast<kern_t>(carl::rollout_staged_kernel<Fam, carl::kActU8, true>);
+            if constexpr (carl::dense_done_of<Fam>::value) {
+              if (b->flags & CARL_FLAG_AUTORESET)
+                kern = static_cast<kern_t>(carl::rollout_staged_kernel<Fam, carl::kActU8, true, false, false, false, true>);
+            }
+          }
         }
         picked = true;
       }
@@ -262,7 +284,7 @@ int launch_pair(const carl_batch_t* a, const carl_step_io_t* ioa, const carl_bat
 bool pair_part_ok(const carl_batch_t* b, const carl_step_io_t* io) {
   const bool keeps_context = b->selector == CARL_SEL_STATIC || b->selector == CARL_SEL_HOST;
   return b->n_lanes > 0 && rollout_variant(b) == CARL_ROLLOUT_STAGED && keeps_context && b->fin_count == nullptr &&
-         io->final_obs == nullptr && io->action_dtype != CARL_ACTION_I64;
+         io->final_obs == nullptr && (io->action_dtype == CARL_ACTION_I32 || io->action_dtype == CARL_ACTION_F32);
 }
 
 #define CARL_DISPATCH(family, CALL)                                   \

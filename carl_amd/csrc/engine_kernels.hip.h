@@ -555,10 +555,13 @@ __device__ __forceinline__ Cursors<Fam> make_cursors(const carl_step_io_t& io, i
   return c;
 }
 
-// action element type as stored by the caller: discrete families accept int32 or int64
-template <class Fam, bool A64>
+// action element type as stored by the caller: discrete families accept int32 (AK 0) or int64 (AK 1 -- the `A64 = true`
+// of the kernels' template lists converts to it); the lean staged rollout also uint8 (AK 2 = kActU8: one byte per
+// lane-step instead of four -- the action stream is the fused rollout's only per-step READ)
+constexpr int kActU8 = 2;
+template <class Fam, int AK>
 using action_store_t = std::conditional_t<std::is_same_v<typename Fam::Action, float>, float,
-                                          std::conditional_t<A64, long long, int>>;
+                                          std::conditional_t<AK == 1, long long, std::conditional_t<AK == kActU8, unsigned char, int>>>;
 
 // -------------------------------- step (per call) -----------------------------------
 template <class Fam, bool LDS, bool A64>
@@ -749,7 +752,8 @@ struct ActionPipe {
   struct Wide {  // four int64 actions: little-endian, values fit 32 bits
     vi4 lo, hi;
   };
-  using R = std::conditional_t<kSame, V, Wide>;
+  static constexpr bool kU8 = std::is_same_v<AStore, unsigned char>;  // four uint8 actions: one dword per lane-row
+  using R = std::conditional_t<kSame, V, std::conditional_t<kU8, unsigned int, Wide>>;
   R a0, a1, a2, a3, a4, a5, a6, a7;
   int t0;
 
@@ -757,6 +761,8 @@ struct ActionPipe {
 #define CARL_LD(q) __builtin_nontemporal_load(q)  // read once
     if constexpr (kSame) {
       return CARL_LD(reinterpret_cast<const V*>(p));
+    } else if constexpr (kU8) {
+      return CARL_LD(reinterpret_cast<const unsigned int*>(p));  // (4-byte aligned: n % 16 == 0, base checked by the host)
     } else {
       const vi4* q = reinterpret_cast<const vi4*>(p);
       return Wide{CARL_LD(q), CARL_LD(q + 1)};
@@ -766,6 +772,8 @@ struct ActionPipe {
   __device__ static __forceinline__ V narrow(const R& r) {
     if constexpr (kSame) {
       return r;
+    } else if constexpr (kU8) {
+      return V{(int)(r & 255u), (int)((r >> 8) & 255u), (int)((r >> 16) & 255u), (int)(r >> 24)};
     } else {
       return V{r.lo.x, r.lo.z, r.hi.x, r.hi.z};
     }
@@ -893,7 +901,7 @@ __device__ __forceinline__ void zero_flag_rows(char* out_buf, int l, int which) 
 // CHUNK: steps per LDS buffer (8; the heterogeneous pair launch below runs its families at 4 so that two workgroups
 // fit on a compute unit).  `wg`: the workgroup's index among the batch's workgroups (blockIdx.x, or the index inside
 // this family's share of a pair launch).
-template <class Fam, bool A64, bool PLAIN, bool LDSCTX, bool MOVES, bool FINAL, bool AR, int CHUNK>
+template <class Fam, int A64, bool PLAIN, bool LDSCTX, bool MOVES, bool FINAL, bool AR, int CHUNK>
 __device__ __forceinline__ void rollout_staged_body(const carl_batch_t& b, const carl_step_io_t& io, const int n_steps,
                                                     const int wg, float* lds_dyn) {
   constexpr int kStageChunk = CHUNK;  // (shadows the namespace-scope default inside this body)
@@ -1048,8 +1056,8 @@ __device__ __forceinline__ void rollout_staged_body(const carl_batch_t& b, const
   }
 }
 
-template <class Fam, bool A64, bool PLAIN = false, bool LDSCTX = false, bool MOVES = false, bool FINAL = false,
-          bool AR = false>
+template <class Fam, int A64, bool PLAIN = false, bool LDSCTX = false, bool MOVES = false, bool FINAL = false,
+          bool AR = false>  // A64: the action storage kind (0 int32 / float32, 1 int64, kActU8)
 __global__ void __launch_bounds__(kStagedThreads) rollout_staged_kernel(const carl_batch_t b, const carl_step_io_t io,
                                                                         const int n_steps) {
   extern __shared__ float lds_dyn[];

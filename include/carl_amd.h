@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define CARL_ABI_VERSION 6
+#define CARL_ABI_VERSION 7
 #define CARL_MAX_CTX_OBS 32
 
 #define CARL_ERR_INVALID_ARGUMENT (-1)
@@ -90,7 +90,14 @@ enum {
                                        an out-of-plane state itself passes this flag. */
 };
 
-enum { CARL_ACTION_I32 = 0, CARL_ACTION_I64 = 1, CARL_ACTION_F32 = 2 };
+/* Storage type of carl_step_io.action.  The reference's discrete action is whatever integer the caller's policy
+ * produced (gymnasium Discrete: np.int64; carl/envs/carl_env.py:321 passes it through): I32 / I64 everywhere.
+ * U8 (ABI 7) is a ROLLOUT-ONLY input format for discrete families: one byte per lane-step -- the action stream is the
+ * fused rollout's only per-step read, and at 4 bytes it costs a fifth of a CartPole launch.  Accepted by carl_rollout
+ * in its lean staged configuration (n_lanes % 16 == 0, STATIC / HOST selector, no finished-episode log, no final_obs;
+ * action pointer 4-byte aligned); anything else returns CARL_ERR_UNSUPPORTED and the caller widens the actions.
+ * Same values in, same transitions out: bit-identical to the I32 launch (tests/test_gpu_parity.py). */
+enum { CARL_ACTION_I32 = 0, CARL_ACTION_I64 = 1, CARL_ACTION_F32 = 2, CARL_ACTION_U8 = 3 };
 
 typedef struct carl_family_info {
   int32_t state_dim;          /* S: columns of `state` */
@@ -166,7 +173,7 @@ typedef struct carl_batch {
  * (carl/envs/carl_env.py:321-342) minus the context half (see carl_batch.ctx_obs). */
 typedef struct carl_step_io {
   const void* action;   /* [n_lanes * action_dim], dtype per action_dtype */
-  int32_t action_dtype; /* CARL_ACTION_* ; discrete families take I32/I64, Box F32 */
+  int32_t action_dtype; /* CARL_ACTION_* ; discrete families take I32/I64 (carl_rollout also U8), Box F32 */
   int32_t reserved;
   float* obs;           /* [n_lanes][D]; with AUTORESET the post-reset observation
                            for done lanes (gymnasium vector-env convention) */

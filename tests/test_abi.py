@@ -31,6 +31,18 @@ def test_library_exports_every_declared_symbol():
     assert lib.carl_abi_version() == _lib.CARL_ABI_VERSION
 
 
+def test_action_dtype_codes_match_the_header():
+    """CARL_ACTION_* of include/carl_amd.h == the binding's constants (ABI 7 added U8, a rollout-only input format)"""
+    from carl_amd import _lib
+
+    src = open(HEADER).read()
+    m = re.search(r"enum \{ (CARL_ACTION_I32[^}]*)\};", src)
+    codes = {k.strip(): int(v) for k, v in (item.split("=") for item in m.group(1).split(","))}
+    assert codes == {"CARL_ACTION_I32": _lib.ACTION_I32, "CARL_ACTION_I64": _lib.ACTION_I64,
+                     "CARL_ACTION_F32": _lib.ACTION_F32, "CARL_ACTION_U8": _lib.ACTION_U8}
+    assert int(re.search(r"#define CARL_ABI_VERSION (\d+)", src).group(1)) == _lib.CARL_ABI_VERSION == 7
+
+
 def test_family_info_is_host_side():
     from carl_amd import _lib
 

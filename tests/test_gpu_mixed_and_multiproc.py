@@ -527,3 +527,32 @@ def test_small_brax_parts_side_by_side_equal_back_to_back(device):
             assert torch.equal(o1[k][name], o2[k][name]), (k, name)
         assert torch.equal(ma.parts[k].state, mb.parts[k].state)
     assert float(after) == float(o2[0]["reward"].sum() + o2[1]["reward"].sum())
+
+
+def test_mixed_batch_with_uint8_actions_takes_separate_launches_same_results(device):
+    """uint8 actions (ABI 7) are read by the single-family lean rollout; the heterogeneous pair kernel reads int32 --
+    a mixed batch fed uint8 launches its parts one after the other, with the transitions of the int32 pair launch."""
+    from carl_amd.engine import VecEngine
+    from carl_amd.mixed import MixedVecEngine
+
+    dev = device
+    rng = np.random.default_rng(8)
+    n, T = 1024, 19
+
+    def build():
+        parts = []
+        for fam in (O.ACROBOT, O.MOUNTAINCAR):
+            t = np.tile(O.default_row(fam), (n, 1))
+            parts.append(VecEngine(fam, t, n, dev, selector=O.SEL_STATIC, seed=2, ctx_idx0=np.arange(n)))
+        m = MixedVecEngine(parts)
+        m.reset()
+        return m
+
+    m8, m32 = build(), build()
+    a32 = [torch.as_tensor(rng.integers(0, 3, (T, n)).astype(np.int32), device=dev) for _ in range(2)]
+    o8 = m8.rollout([a.to(torch.uint8) for a in a32])
+    o32 = m32.rollout(a32)
+    assert m8.pair_launches == 0 and m32.pair_launches == 1
+    for p8, p32 in zip(o8, o32):
+        for k in ("obs", "reward", "terminated", "truncated"):
+            assert torch.equal(p8[k], p32[k]), k

@@ -817,3 +817,90 @@ def test_one_1000_step_launch_equals_four_250_step_launches_at_full_size(fam, de
     for k in ("state", "elapsed", "episode", "n_calls", "ep_return", "last_return", "last_length", "episodes_done"):
         assert torch.equal(getattr(e1, k), getattr(e2, k)), k
     assert int(e1.episodes_done.sum()) >= 4 * n  # TimeLimit 200 / 500: every lane finished episodes inside the launch
+
+
+# ------------------------------------------------------------------ uint8 actions (ABI 7: rollout-only input format)
+@pytest.mark.parametrize("fam", [O.CARTPOLE, O.ACROBOT, O.MOUNTAINCAR], ids=["cartpole", "acrobot", "mountaincar"])
+@pytest.mark.parametrize("T,n,auto_reset,max_steps", [(37, 1024, True, 5), (8, 1008, True, 0), (200, 4096, False, 0),
+                                                      (5, 16, True, 3), (1000, 512, True, 0)])
+def test_uint8_actions_equal_int32_actions_bit_for_bit(fam, T, n, auto_reset, max_steps, device):
+    """One byte per lane-step on the launch's only per-step read stream (include/carl_amd.h: CARL_ACTION_U8): the same
+    action VALUES as uint8 give the same transitions and the same engine state as int32 -- full and ragged chunks, a
+    ragged last workgroup, with and without auto-reset (CartPole: both specialisations of its dense done path), and a
+    sentinel row behind the last step stays untouched."""
+    rng = np.random.default_rng(fam * 100 + T)
+    table = random_table(fam, rng, n)
+    a_np = random_actions(fam, rng, (T, n))
+    a32 = torch.as_tensor(a_np, device=device)
+    a8 = a32.to(torch.uint8)
+    kw = dict(selector=O.SEL_STATIC, seed=11, max_episode_steps=max_steps, ctx_idx0=np.arange(n), auto_reset=auto_reset)
+    e1, e2 = _engine(fam, table, n, device, **kw), _engine(fam, table, n, device, **kw)
+    e1.reset()
+    e2.reset()
+    buf = e1.alloc_rollout(T + 1)
+    for k, v in (("obs", -7.0), ("reward", -7.0), ("terminated", 9), ("truncated", 9)):
+        buf[k][T].fill_(v)
+    o8 = e1.rollout(a8, buf)
+    o32 = e2.rollout(a32)
+    for k in ("obs", "reward", "terminated", "truncated"):
+        assert torch.equal(o8[k][:T], o32[k]), k
+    assert bool((buf["obs"][T] == -7.0).all()) and bool((buf["terminated"][T] == 9).all())
+    for name in ("state", "elapsed", "ctx_idx", "episode", "n_calls", "ep_return", "episodes_done"):
+        assert torch.equal(getattr(e1, name), getattr(e2, name)), name
+
+
+def test_uint8_actions_outside_the_lean_staged_rollout(device):
+    """The library reads uint8 actions in ONE configuration; everywhere else it says CARL_ERR_UNSUPPORTED through the C
+    ABI (no silent reinterpretation) and the Python engine widens the actions once -- same results: a moving selector,
+    terminal observations, a lane count that is not a multiple of 16, and the per-call step."""
+    import ctypes as C
+
+    from carl_amd import _lib
+
+    fam, T = O.CARTPOLE, 21
+    rng = np.random.default_rng(5)
+    for n, kw, final in ((1024, dict(selector=O.SEL_ROUND_ROBIN), False), (1024, dict(selector=O.SEL_STATIC), True),
+                         (1000, dict(selector=O.SEL_STATIC), False)):
+        table = random_table(fam, rng, 37)
+        a32 = torch.as_tensor(random_actions(fam, rng, (T, n)), device=device)
+        a8 = a32.to(torch.uint8)
+        kw = dict(seed=4, max_episode_steps=6, **kw)
+        e1, e2 = _engine(fam, table, n, device, **kw), _engine(fam, table, n, device, **kw)
+        e1.reset()
+        e2.reset()
+        # straight through the C ABI: declined, nothing launched
+        out = e1.alloc_rollout(T, final_obs=final)
+        io = e1._rollout_io(a8.contiguous(), _lib.ACTION_U8, out, T)
+        with torch.cuda.device(device):
+            assert e1._c_rollout(io, T) == _lib.ERR_UNSUPPORTED
+        assert b"uint8" in e1.lib.carl_last_error()
+        # through the engine: widened, same transitions as int32
+        import warnings
+
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)  # (the odd lane count's direct-store warning)
+            o8, o32 = e1.rollout(a8, out), e2.rollout(a32, e2.alloc_rollout(T, final_obs=final))
+        for k in o32:
+            assert torch.equal(o8[k], o32[k]), k
+        assert torch.equal(e1.state, e2.state)
+    # per-call step: uint8 is widened by the engine (the C entry point declines it)
+    obs8, *_ = e1.step(a8[0])
+    obs32, *_ = e2.step(a32[0])
+    assert torch.equal(obs8, obs32)
+    io = _lib.StepIO()
+    io.action, io.action_dtype = a8[0].contiguous().data_ptr(), _lib.ACTION_U8
+    io.obs, io.reward = e1.obs.data_ptr(), e1.reward.data_ptr()
+    io.terminated, io.truncated = e1.terminated.data_ptr(), e1.truncated.data_ptr()
+    with torch.cuda.device(device):
+        assert e1.lib.carl_step(C.byref(e1.b), C.byref(io), e1._stream()) == _lib.ERR_UNSUPPORTED
+    # a misaligned uint8 pointer is an invalid argument, not a fault
+    n = 1024
+    e3 = _engine(fam, random_table(fam, rng, n), n, device, selector=O.SEL_STATIC, ctx_idx0=np.arange(n))
+    e3.reset()
+    big = torch.zeros(T * n + 8, dtype=torch.uint8, device=device)
+    out = e3.alloc_rollout(T)
+    io = e3._rollout_io(big[1:1 + T * n].view(T, n), _lib.ACTION_U8, out, T)
+    with torch.cuda.device(device):
+        assert e3._c_rollout(io, T) == _lib.ERR_INVALID_ARGUMENT
+    e3.rollout(big[1:1 + T * n].view(T, n), out)  # the engine re-homes such a view
+    torch.cuda.synchronize()

@@ -30,9 +30,11 @@ def avg(pattern, wgs, cls="~median"):
 SRC = ("rocprofv3 --kernel-trace of the driver's command, dispatches told apart by launch shape (tools/r04_final.sh, "
        "tools/kernel_times_from_driver_trace.py; same gpurun call as profiles/r04_bench_driver_cmd.json)")
 spec = {
-    "cartpole:65536:1000": [("rollout_staged_kernel<carl::CartPole", 256, "~median")],
-    "cartpole:65536:250": [("rollout_staged_kernel<carl::CartPole", 256, "<med/2")],
-    "cartpole:8192:1000": [("rollout_staged_kernel<carl::CartPole", 32, "~median")],
+    # (second template argument = the action storage kind: 0 int32, 2 uint8)
+    "cartpole:65536:1000": [("rollout_staged_kernel<carl::CartPole, 0,", 256, "~median")],
+    "cartpole:65536:250": [("rollout_staged_kernel<carl::CartPole, 0,", 256, "<med/2")],
+    "cartpole:8192:1000": [("rollout_staged_kernel<carl::CartPole, 0,", 32, "~median")],
+    "cartpole_u8:65536:1000": [("rollout_staged_kernel<carl::CartPole, 2,", 256, "~median")],
     "pendulum:65536:1000": [("rollout_staged_kernel<carl::Pendulum", 256, "~median")],
     "pendulum:8192:1000": [("rollout_staged_kernel<carl::Pendulum", 32, "~median")],
     "acrobot+mountaincar:65536:1000": [("rollout_staged_pair_kernel<carl::AcrobotT<double>, carl::MountainCar", 512, "~median")],

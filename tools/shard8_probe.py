@@ -33,6 +33,10 @@ def main():
         # name, families, lanes per family, T, K, mode
         ("cartpole_65536_T250", ("cartpole",), 65536, 250, 20, "train"),
         ("cartpole_65536_T1000", ("cartpole",), 65536, 1000, 8, "train"),
+        ("cartpole_u8_65536_T1000", ("cartpole",), 65536, 1000, 8, "train-u8"),
+        ("cartpole_u8_65536_T250", ("cartpole",), 65536, 250, 20, "train-u8"),
+        ("cartpole_u8_8192_T1000", ("cartpole",), 8192, 1000, 8, "train-u8"),
+        ("mountaincar_u8_65536_T250", ("mountaincar",), 65536, 250, 20, "train-u8"),
         ("cartpole_2x32768_free_T250", ("cartpole", "cartpole"), 32768, 250, 20, "free"),
         ("cartpole_4x16384_free_T250", ("cartpole",) * 4, 16384, 250, 20, "free"),
         ("pendulum_65536_T250", ("pendulum",), 65536, 250, 20, "train"),
@@ -54,6 +58,8 @@ def main():
         ("ant_4096_T20", ("ant",), 4096, 20, 20, "train"),
         ("ant_8192_T20", ("ant",), 8192, 20, 20, "train"),
         ("ant_32768_T20", ("ant",), 32768, 20, 10, "train"),
+        ("humanoid_32768_T20", ("humanoid",), 32768, 20, 10, "train"),
+        ("halfcheetah_32768_T20", ("halfcheetah",), 32768, 20, 10, "train"),
         ("cheetah_humanoid_4096_T20", ("halfcheetah", "humanoid"), 4096, 20, 20, "train"),
         ("halfcheetah_4096_T20", ("halfcheetah",), 4096, 20, 20, "train"),
         ("humanoid_4096_T20", ("humanoid",), 4096, 20, 20, "train"),
@@ -62,7 +68,8 @@ def main():
     for name, fams, lanes, T, K, mode in cases:
         if only and name not in only:
             continue
-        wl = bench.Workload(fams, lanes, T, 2, 0, 1, dev)
+        wl = bench.Workload(fams, lanes, T, 2, 0, 1, dev, action_u8=mode.endswith("-u8"))
+        mode = mode.replace("-u8", "")
         per, walls = [], []
         for r in range(a.reps + 1):
             if mode == "free":
