@@ -96,6 +96,7 @@ ALSO = {
     "cartpole_u8": (("cartpole",), 65536, "follow", None),             # the same workload fed uint8 actions (ABI 7: one byte
                                                                        # per lane-step on the only per-step read stream)
     "pendulum": (("pendulum",), 65536, "follow", None),                # BASELINE config 2
+    "pendulum_f16": (("pendulum",), 65536, "follow", None),            # ... fed float16 torques (ABI 7: two bytes per lane-step)
     "config3": (("acrobot", "mountaincar"), 65536, "follow", None),    # 131 072-context mixed batch
     "config4": (("ant",), 32768, "strong", None),                      # 32 768 contexts over the node
     "config5": (("halfcheetah", "humanoid"), 32768, "strong", None),   # 65 536 contexts over the node
@@ -134,7 +135,7 @@ def parse():
     p.add_argument("--rccl", action="store_true",
                    help="single GPU: build a one-rank RCCL process group and run the reporting all-gather through it")
     p.add_argument("--sustained-seconds", type=float, default=0.3)
-    p.add_argument("--also", default="cartpole_T250,cartpole_u8,pendulum,config3,config4,config5",
+    p.add_argument("--also", default="cartpole_T250,cartpole_u8,pendulum,pendulum_f16,config3,config4,config5",
                    help="comma list of extra workloads reported under 'also' (" + ", ".join(ALSO) + "), or 'none'")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-per-call", action="store_true")
@@ -201,7 +202,8 @@ def make_actions(eng, T, device, seed, u8=False):
         return a.to(torch.uint8) if u8 else a  # (the same action values either way)
     lo, hi = float(info.action_low), float(info.action_high)
     shape = (T, eng.n) if info.action_dim == 1 else (T, eng.n, int(info.action_dim))
-    return torch.rand(shape, generator=g, device=device, dtype=torch.float32) * (hi - lo) + lo
+    a = torch.rand(shape, generator=g, device=device, dtype=torch.float32) * (hi - lo) + lo
+    return a.to(torch.float16) if u8 and info.action_dim == 1 else a  # (narrow format: classic Box families only)
 
 
 class Workload:
@@ -240,7 +242,8 @@ class Workload:
         torch.cuda.synchronize()
         self._i = 0
         self.units_per_launch = self.n * T
-        act_saved = {f: (3 if action_u8 and p.info.action_is_discrete else 0) for f, p in zip(self.families, parts)}
+        act_saved = {f: ((3 if p.info.action_is_discrete else 2 if p.info.action_dim == 1 else 0) if action_u8 else 0)
+                     for f, p in zip(self.families, parts)}
         self.bytes_per_launch = sum(((IO_PER_STEP[f] - act_saved[f]) * T + PER_LAUNCH[f]) * p.n
                                     for f, p in zip(self.families, parts))
         self.bytes_per_launch_8d = sum(BYTES_8D[f] * T * p.n for f, p in zip(self.families, parts))
@@ -514,7 +517,7 @@ def roofline_of(wl, avg_launch_s):
         "algorithmic_bytes_per_launch": wl.bytes_per_launch,
     }
     part_n = wl.n // len(wl.families)
-    key = f"{'+'.join(wl.families)}{'_u8' if getattr(wl, 'action_u8', False) else ''}:{part_n}:{wl.T}"
+    key = f"{'+'.join(wl.families)}{'_narrow' if getattr(wl, 'action_u8', False) else ''}:{part_n}:{wl.T}"
     rec = traffic_record(key)
     if rec:
         r["traffic"] = rec["hbm_bytes_per_launch"]
@@ -881,7 +884,7 @@ def main():
     torch.cuda.empty_cache()
     for name in names:
         fams, total, mode, chunk = ALSO[name]
-        u8 = name.endswith("_u8")
+        u8 = name.endswith("_u8") or name.endswith("_f16")  # the narrow action formats of the lean staged rollout
         if fams == args.families and chunk in (None, T) and not u8:
             continue
         split = mode == "strong" or (mode == "follow" and args.strong)
@@ -894,7 +897,7 @@ def main():
         r2 = roofline_of(w2, avg2)
         also[name] = {
             "workload": " + ".join(f"CARL{f} x {lanes}" for f in fams) + f" contexts/GPU, {Ta} env steps per launch"
-                        + (", uint8 actions" if u8 else ""),
+                        + (", uint8 actions" if name.endswith("_u8") else ", float16 actions" if u8 else ""),
             "value": w2.n * world * Ta * K / el2, "unit": "env-steps/s", "scaling": mode,
             "lanes_per_gpu": w2.n, "chunk": Ta, "ms_per_step": el2 / K * 1e3,
             "avg_launch_ms": avg2 * 1e3, "frac": r2["frac"], "achieved_GBs": r2["achieved"],

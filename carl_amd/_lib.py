@@ -31,7 +31,7 @@ FLAG_AUTORESET_FIRST_STATE = 8
 FLAG_ROLLOUT_DIRECT = 16
 FLAG_BRAX_GENERIC = 32
 ROLLOUT_STAGED, ROLLOUT_DIRECT_SHAPE, ROLLOUT_DIRECT_FLAG = range(3)
-ACTION_I32, ACTION_I64, ACTION_F32, ACTION_U8 = range(4)
+ACTION_I32, ACTION_I64, ACTION_F32, ACTION_U8, ACTION_F16, ACTION_BF16 = range(6)
 
 _vp = C.c_void_p
 

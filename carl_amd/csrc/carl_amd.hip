@@ -105,8 +105,11 @@ int validate_io(const carl_batch_t* b, const carl_step_io_t* io, const char* who
     return fail(CARL_ERR_INVALID_ARGUMENT, "%s: discrete family needs int32/int64 (carl_rollout: or uint8) actions", who);
   if (io->action_dtype == CARL_ACTION_U8 && (reinterpret_cast<uintptr_t>(io->action) & 3) != 0)
     return fail(CARL_ERR_INVALID_ARGUMENT, "%s: uint8 actions must be 4-byte aligned", who);
-  if (!discrete && io->action_dtype != CARL_ACTION_F32)
-    return fail(CARL_ERR_INVALID_ARGUMENT, "%s: continuous family needs float32 actions", who);
+  const bool half = io->action_dtype == CARL_ACTION_F16 || io->action_dtype == CARL_ACTION_BF16;
+  if (!discrete && io->action_dtype != CARL_ACTION_F32 && !half)
+    return fail(CARL_ERR_INVALID_ARGUMENT, "%s: continuous family needs float32 (carl_rollout: or float16 / bfloat16) actions", who);
+  if (half && (reinterpret_cast<uintptr_t>(io->action) & 7) != 0)
+    return fail(CARL_ERR_INVALID_ARGUMENT, "%s: float16 / bfloat16 actions must be 8-byte aligned", who);
   return 0;
 }
 
@@ -158,14 +161,15 @@ int launch_step(const carl_batch_t* b, const carl_step_io_t* io, int n_steps, hi
                     (rollout ? carl::rollout_action_lds_bytes() : 0);
   const bool a64 = io->action_dtype == CARL_ACTION_I64;
   // uint8 actions: the lean staged rollout only (include/carl_amd.h: CARL_ACTION_U8)
-  const bool a8 = io->action_dtype == CARL_ACTION_U8;
+  const bool af16 = io->action_dtype == CARL_ACTION_F16, abf16 = io->action_dtype == CARL_ACTION_BF16;
+  const bool a8 = io->action_dtype == CARL_ACTION_U8 || af16 || abf16;  // (any of the narrow rollout-only formats)
   if (a8) {
     const bool keeps_context = b->selector == CARL_SEL_STATIC || b->selector == CARL_SEL_HOST;
     const bool lean = b->fin_count == nullptr && io->final_obs == nullptr;
     if (!rollout || rollout_variant(b) != CARL_ROLLOUT_STAGED || !keeps_context || !lean || !carl::predraw_of<Fam>::value)
       return fail(CARL_ERR_UNSUPPORTED,
-                  "uint8 actions: carl_rollout in its lean staged configuration only (n_lanes %% 16 == 0, static / host "
-                  "selector, no finished-episode log, no final_obs); pass int32 / int64 actions");
+                  "uint8 / float16 / bfloat16 actions: carl_rollout in its lean staged configuration only (n_lanes %% 16 == 0, "
+                  "static / host selector, no finished-episode log, no final_obs); pass int32 / int64 / float32 actions");
   }
   const dim3 g(grid), t(block);
 #define CARL_LAUNCH(KERNEL, ...)                                                                    \
@@ -208,6 +212,10 @@ int launch_step(const carl_batch_t* b, const carl_step_io_t* io, int n_steps, hi
           if (b->flags & CARL_FLAG_AUTORESET)
             kern = a64 ? static_cast<kern_t>(carl::rollout_staged_kernel<Fam, true, true, false, false, false, true>)
                        : static_cast<kern_t>(carl::rollout_staged_kernel<Fam, false, true, false, false, false, true>);
+        }
+        if constexpr (std::is_same_v<typename Fam::Action, float>) {
+          if (af16) kern = static_cast<kern_t>(carl::rollout_staged_kernel<Fam, carl::kActF16, true>);
+          if (abf16) kern = static_cast<kern_t>(carl::rollout_staged_kernel<Fam, carl::kActBF16, true>);
         }
         if constexpr (std::is_same_v<typename Fam::Action, int>) {
           if (a8) {  // the same two kernels reading one byte per action

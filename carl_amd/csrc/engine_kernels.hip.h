@@ -558,10 +558,19 @@ __device__ __forceinline__ Cursors<Fam> make_cursors(const carl_step_io_t& io, i
 // action element type as stored by the caller: discrete families accept int32 (AK 0) or int64 (AK 1 -- the `A64 = true`
 // of the kernels' template lists converts to it); the lean staged rollout also uint8 (AK 2 = kActU8: one byte per
 // lane-step instead of four -- the action stream is the fused rollout's only per-step READ)
-constexpr int kActU8 = 2;
+// ... and the Box families float16 / bfloat16 (kActF16 / kActBF16: two bytes per lane-step, widened exactly).
+constexpr int kActU8 = 2, kActF16 = 3, kActBF16 = 4;
+struct f16_bits {
+  unsigned short v;
+};
+struct bf16_bits {
+  unsigned short v;
+};
 template <class Fam, int AK>
-using action_store_t = std::conditional_t<std::is_same_v<typename Fam::Action, float>, float,
-                                          std::conditional_t<AK == 1, long long, std::conditional_t<AK == kActU8, unsigned char, int>>>;
+using action_store_t =
+    std::conditional_t<std::is_same_v<typename Fam::Action, float>,
+                       std::conditional_t<AK == kActF16, f16_bits, std::conditional_t<AK == kActBF16, bf16_bits, float>>,
+                       std::conditional_t<AK == 1, long long, std::conditional_t<AK == kActU8, unsigned char, int>>>;
 
 // -------------------------------- step (per call) -----------------------------------
 template <class Fam, bool LDS, bool A64>
@@ -753,7 +762,9 @@ struct ActionPipe {
     vi4 lo, hi;
   };
   static constexpr bool kU8 = std::is_same_v<AStore, unsigned char>;  // four uint8 actions: one dword per lane-row
-  using R = std::conditional_t<kSame, V, std::conditional_t<kU8, unsigned int, Wide>>;
+  static constexpr bool kF16 = std::is_same_v<AStore, f16_bits>, kBF16 = std::is_same_v<AStore, bf16_bits>;
+  typedef unsigned int vu2 __attribute__((ext_vector_type(2)));  // four 16-bit floats
+  using R = std::conditional_t<kSame, V, std::conditional_t<kU8, unsigned int, std::conditional_t<kF16 || kBF16, vu2, Wide>>>;
   R a0, a1, a2, a3, a4, a5, a6, a7;
   int t0;
 
@@ -763,6 +774,8 @@ struct ActionPipe {
       return CARL_LD(reinterpret_cast<const V*>(p));
     } else if constexpr (kU8) {
       return CARL_LD(reinterpret_cast<const unsigned int*>(p));  // (4-byte aligned: n % 16 == 0, base checked by the host)
+    } else if constexpr (kF16 || kBF16) {
+      return CARL_LD(reinterpret_cast<const vu2*>(p));  // (8-byte aligned likewise)
     } else {
       const vi4* q = reinterpret_cast<const vi4*>(p);
       return Wide{CARL_LD(q), CARL_LD(q + 1)};
@@ -774,6 +787,12 @@ struct ActionPipe {
       return r;
     } else if constexpr (kU8) {
       return V{(int)(r & 255u), (int)((r >> 8) & 255u), (int)((r >> 16) & 255u), (int)(r >> 24)};
+    } else if constexpr (kF16) {  // every float16 is a float32: exact
+      auto h = [](unsigned int bits) { return (float)__builtin_bit_cast(_Float16, (unsigned short)bits); };
+      return V{h(r.x & 0xffffu), h(r.x >> 16), h(r.y & 0xffffu), h(r.y >> 16)};
+    } else if constexpr (kBF16) {  // bfloat16 = the high half of the float32
+      return V{__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16),
+               __uint_as_float(r.y & 0xffff0000u)};
     } else {
       return V{r.lo.x, r.lo.z, r.hi.x, r.hi.z};
     }

@@ -203,8 +203,8 @@ class MixedVecEngine:
         T = int(actions[0].shape[0])
         if int(actions[1].shape[0]) != T:
             return None
-        if any(torch.is_tensor(a) and a.dtype == torch.uint8 for a in actions[:2]):
-            return None  # the pair kernel reads int32 / float32 actions; uint8 parts take their own launches
+        if any(torch.is_tensor(a) and a.dtype in (torch.uint8, torch.float16, torch.bfloat16) for a in actions[:2]):
+            return None  # the pair kernel reads int32 / float32 actions; narrow-format parts take their own launches
         aa, dta = pa._action_tensor(actions[0], (T,))
         ab, dtb = pb._action_tensor(actions[1], (T,))
         if outs is None:

@@ -97,7 +97,11 @@ enum {
  * in its lean staged configuration (n_lanes % 16 == 0, STATIC / HOST selector, no finished-episode log, no final_obs;
  * action pointer 4-byte aligned); anything else returns CARL_ERR_UNSUPPORTED and the caller widens the actions.
  * Same values in, same transitions out: bit-identical to the I32 launch (tests/test_gpu_parity.py). */
-enum { CARL_ACTION_I32 = 0, CARL_ACTION_I64 = 1, CARL_ACTION_F32 = 2, CARL_ACTION_U8 = 3 };
+enum { CARL_ACTION_I32 = 0, CARL_ACTION_I64 = 1, CARL_ACTION_F32 = 2, CARL_ACTION_U8 = 3,
+       /* Box families, carl_rollout's lean staged configuration only (pointer 8-byte aligned): IEEE float16 / bfloat16 as
+        * a policy network under autocast emits them; widened exactly, so the transitions are those of the float32
+        * launch fed the widened values */
+       CARL_ACTION_F16 = 4, CARL_ACTION_BF16 = 5 };
 
 typedef struct carl_family_info {
   int32_t state_dim;          /* S: columns of `state` */
@@ -173,7 +177,8 @@ typedef struct carl_batch {
  * (carl/envs/carl_env.py:321-342) minus the context half (see carl_batch.ctx_obs). */
 typedef struct carl_step_io {
   const void* action;   /* [n_lanes * action_dim], dtype per action_dtype */
-  int32_t action_dtype; /* CARL_ACTION_* ; discrete families take I32/I64 (carl_rollout also U8), Box F32 */
+  int32_t action_dtype; /* CARL_ACTION_* ; discrete families take I32/I64 (carl_rollout also U8), Box F32 (carl_rollout
+                           also F16 / BF16) */
   int32_t reserved;
   float* obs;           /* [n_lanes][D]; with AUTORESET the post-reset observation
                            for done lanes (gymnasium vector-env convention) */

@@ -904,3 +904,39 @@ def test_uint8_actions_outside_the_lean_staged_rollout(device):
         assert e3._c_rollout(io, T) == _lib.ERR_INVALID_ARGUMENT
     e3.rollout(big[1:1 + T * n].view(T, n), out)  # the engine re-homes such a view
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["float16", "bfloat16"])
+@pytest.mark.parametrize("fam", [O.PENDULUM, O.MOUNTAINCAR_CONT], ids=["pendulum", "mountaincarcont"])
+@pytest.mark.parametrize("T,n", [(37, 1024), (8, 1008), (5, 16), (1000, 512)])
+def test_half_precision_actions_equal_their_float32_widening_bit_for_bit(fam, dtype, T, n, device):
+    """CARL_ACTION_F16 / BF16 (Box families, rollout-only): two bytes per lane-step, widened exactly in the loader wave --
+    the transitions are those of the float32 launch fed ``actions.float()``; incl. values outside the action bounds,
+    zeros of both signs, subnormal halves, and (configurations the lean kernel does not cover) the engine's widening."""
+    rng = np.random.default_rng(fam * 100 + T)
+    table = random_table(fam, rng, n)
+    a = torch.as_tensor(random_actions(fam, rng, (T, n)), device=device).to(dtype)
+    a[0, :8] = torch.tensor([0.0, -0.0, 6.0e-8, -6.0e-8, 3.0, -3.0, 1.0, -1.0], device=device).to(dtype)
+    kw = dict(selector=O.SEL_STATIC, seed=11, max_episode_steps=7, ctx_idx0=np.arange(n))
+    e1, e2 = _engine(fam, table, n, device, **kw), _engine(fam, table, n, device, **kw)
+    e1.reset()
+    e2.reset()
+    buf = e1.alloc_rollout(T + 1)
+    buf["obs"][T].fill_(-7.0)
+    oh = e1.rollout(a, buf)
+    of = e2.rollout(a.float())
+    for k in ("obs", "reward", "terminated", "truncated"):
+        assert torch.equal(oh[k][:T], of[k]), k
+    assert bool((buf["obs"][T] == -7.0).all())
+    for name in ("state", "elapsed", "episode", "ep_return", "episodes_done"):
+        assert torch.equal(getattr(e1, name), getattr(e2, name)), name
+    if T == 37:  # declined by the library (terminal observations), widened by the engine
+        from carl_amd import _lib
+
+        out = e1.alloc_rollout(T, final_obs=True)
+        io = e1._rollout_io(a.contiguous(), _lib.ACTION_F16 if dtype == torch.float16 else _lib.ACTION_BF16, out, T)
+        with torch.cuda.device(device):
+            assert e1._c_rollout(io, T) == _lib.ERR_UNSUPPORTED
+        o1, o2 = e1.rollout(a, out), e2.rollout(a.float(), e2.alloc_rollout(T, final_obs=True))
+        for k in o2:
+            assert torch.equal(o1[k], o2[k]), k

@@ -34,9 +34,10 @@ spec = {
     "cartpole:65536:1000": [("rollout_staged_kernel<carl::CartPole, 0,", 256, "~median")],
     "cartpole:65536:250": [("rollout_staged_kernel<carl::CartPole, 0,", 256, "<med/2")],
     "cartpole:8192:1000": [("rollout_staged_kernel<carl::CartPole, 0,", 32, "~median")],
-    "cartpole_u8:65536:1000": [("rollout_staged_kernel<carl::CartPole, 2,", 256, "~median")],
-    "pendulum:65536:1000": [("rollout_staged_kernel<carl::Pendulum", 256, "~median")],
-    "pendulum:8192:1000": [("rollout_staged_kernel<carl::Pendulum", 32, "~median")],
+    "cartpole_narrow:65536:1000": [("rollout_staged_kernel<carl::CartPole, 2,", 256, "~median")],
+    "pendulum:65536:1000": [("rollout_staged_kernel<carl::Pendulum, 0,", 256, "~median")],
+    "pendulum_narrow:65536:1000": [("rollout_staged_kernel<carl::Pendulum, 3,", 256, "~median")],
+    "pendulum:8192:1000": [("rollout_staged_kernel<carl::Pendulum, 0,", 32, "~median")],
     "acrobot+mountaincar:65536:1000": [("rollout_staged_pair_kernel<carl::AcrobotT<double>, carl::MountainCar", 512, "~median")],
     "acrobot+mountaincar:8192:1000": [("rollout_staged_pair_kernel<carl::AcrobotT<double>, carl::MountainCar", 64, "~median")],
     "ant:32768:20": [("brax_kernel<1, false, 9, false, false>", 256, "~median")],

@@ -22,6 +22,7 @@ def main():
     p.add_argument("--builds", type=int, default=6)
     p.add_argument("--skew", default="", help="comma-separated byte skews for the slab experiment")
     p.add_argument("--slabs", action="store_true")
+    p.add_argument("--act-skew", default="", help="comma-separated byte offsets of the action arrays past a 2 MiB boundary")
     a = p.parse_args()
     import torch
 
@@ -64,6 +65,24 @@ def main():
                     off += slot[name]
                 wl.outs[si][0] = carved
             measure(wl, f"slab-skew-{skew}", 0)
+        return
+
+    if a.act_skew:
+        # (e) the ACTION arrays (the launch's only per-step read stream) moved relative to fixed output arrays: each
+        # set's [T][N] int32 actions copied into a slab at `skew` bytes past a 2 MiB boundary
+        wl = bench.Workload(("cartpole",), 65536, 1000, 2, 0, 1, dev)
+        measure(wl, "actions-as-allocated", 0)
+        MiB = 1 << 20
+        src = [wl.acts[si][0] for si in range(len(wl.acts))]
+        nbytes = src[0].numel() * src[0].element_size()
+        slabs = [torch.empty(nbytes + 64 * MiB, dtype=torch.uint8, device=dev) for _ in src]
+        for skew in [int(x) for x in a.act_skew.split(",")]:
+            for si, slab in enumerate(slabs):
+                off = (-slab.data_ptr()) % (2 * MiB) + skew
+                view = slab[off:off + nbytes].view(src[si].dtype).view(src[si].shape)
+                view.copy_(src[si])
+                wl.acts[si][0] = view
+            measure(wl, f"action-skew-{skew}", 0)
         return
 
     if a.slabs:
