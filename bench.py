@@ -191,7 +191,7 @@ def make_env(env, n, rank, world, device, lane_base=0):
     return carl_env, table
 
 
-def make_actions(eng, T, device, seed, u8=False):
+def make_actions(eng, T, device, seed, narrow=False):
     import torch
 
     g = torch.Generator(device=device)
@@ -199,11 +199,11 @@ def make_actions(eng, T, device, seed, u8=False):
     info = eng.info
     if info.action_is_discrete:
         a = torch.randint(0, info.n_actions, (T, eng.n), generator=g, device=device, dtype=torch.int32)
-        return a.to(torch.uint8) if u8 else a  # (the same action values either way)
+        return a.to(torch.uint8) if narrow else a  # (the same action values either way)
     lo, hi = float(info.action_low), float(info.action_high)
     shape = (T, eng.n) if info.action_dim == 1 else (T, eng.n, int(info.action_dim))
     a = torch.rand(shape, generator=g, device=device, dtype=torch.float32) * (hi - lo) + lo
-    return a.to(torch.float16) if u8 and info.action_dim == 1 else a  # (narrow format: classic Box families only)
+    return a.to(torch.float16) if narrow and info.action_dim == 1 else a  # (narrow format: classic Box families only)
 
 
 class Workload:
@@ -211,12 +211,12 @@ class Workload:
 
     pinned_lanes_per_env: dict = {}  # --lanes-per-env
 
-    def __init__(self, families, lanes_per_gpu, T, sets, rank, world, device, action_u8=False):
+    def __init__(self, families, lanes_per_gpu, T, sets, rank, world, device, narrow_actions=False):
         import torch
 
         from carl_amd.mixed import MixedVecEngine
 
-        self.families, self.T, self.device, self.action_u8 = tuple(families), T, device, action_u8
+        self.families, self.T, self.device, self.narrow_actions = tuple(families), T, device, narrow_actions
         self.envs, self.tables = [], []
         for k, f in enumerate(self.families):
             e, t = make_env(f, lanes_per_gpu, rank, world, device, lane_base=k * lanes_per_gpu * world)
@@ -226,7 +226,7 @@ class Workload:
         self.eng = MixedVecEngine([e.env for e in self.envs], self.families) if self.mixed else self.envs[0].env
         parts = self.eng.parts if self.mixed else [self.eng]
         self.n = sum(p.n for p in parts)
-        self.acts = [[make_actions(p, T, device, 1 + rank + 1000 * s + 100 * k, u8=action_u8) for k, p in enumerate(parts)]
+        self.acts = [[make_actions(p, T, device, 1 + rank + 1000 * s + 100 * k, narrow=narrow_actions) for k, p in enumerate(parts)]
                      for s in range(sets)]
         self.outs = [[p.alloc_rollout(T) for p in parts] for _ in range(sets)]
         for e in self.envs:
@@ -242,7 +242,7 @@ class Workload:
         torch.cuda.synchronize()
         self._i = 0
         self.units_per_launch = self.n * T
-        act_saved = {f: ((3 if p.info.action_is_discrete else 2 if p.info.action_dim == 1 else 0) if action_u8 else 0)
+        act_saved = {f: ((3 if p.info.action_is_discrete else 2 if p.info.action_dim == 1 else 0) if narrow_actions else 0)
                      for f, p in zip(self.families, parts)}
         self.bytes_per_launch = sum(((IO_PER_STEP[f] - act_saved[f]) * T + PER_LAUNCH[f]) * p.n
                                     for f, p in zip(self.families, parts))
@@ -517,7 +517,7 @@ def roofline_of(wl, avg_launch_s):
         "algorithmic_bytes_per_launch": wl.bytes_per_launch,
     }
     part_n = wl.n // len(wl.families)
-    key = f"{'+'.join(wl.families)}{'_narrow' if getattr(wl, 'action_u8', False) else ''}:{part_n}:{wl.T}"
+    key = f"{'+'.join(wl.families)}{'_narrow' if getattr(wl, 'narrow_actions', False) else ''}:{part_n}:{wl.T}"
     rec = traffic_record(key)
     if rec:
         r["traffic"] = rec["hbm_bytes_per_launch"]
@@ -884,20 +884,20 @@ def main():
     torch.cuda.empty_cache()
     for name in names:
         fams, total, mode, chunk = ALSO[name]
-        u8 = name.endswith("_u8") or name.endswith("_f16")  # the narrow action formats of the lean staged rollout
-        if fams == args.families and chunk in (None, T) and not u8:
+        narrow = name.endswith("_u8") or name.endswith("_f16")  # the narrow action formats of the lean staged rollout
+        if fams == args.families and chunk in (None, T) and not narrow:
             continue
         split = mode == "strong" or (mode == "follow" and args.strong)
         lanes = total // world if split else total
         mode = "strong" if split else "weak"
         Ta = chunk or DEFAULT_CHUNK[fams[0]]
-        w2 = Workload(fams, lanes, Ta, args.buffer_sets, rank, world, device, action_u8=u8)
+        w2 = Workload(fams, lanes, Ta, args.buffer_sets, rank, world, device, narrow_actions=narrow)
         regs2, m2 = timed_regions(w2, K, W, args.reps, barrier, max_over_ranks)
         el2, avg2 = regs2[m2]
         r2 = roofline_of(w2, avg2)
         also[name] = {
             "workload": " + ".join(f"CARL{f} x {lanes}" for f in fams) + f" contexts/GPU, {Ta} env steps per launch"
-                        + (", uint8 actions" if name.endswith("_u8") else ", float16 actions" if u8 else ""),
+                        + (", uint8 actions" if name.endswith("_u8") else ", float16 actions" if narrow else ""),
             "value": w2.n * world * Ta * K / el2, "unit": "env-steps/s", "scaling": mode,
             "lanes_per_gpu": w2.n, "chunk": Ta, "ms_per_step": el2 / K * 1e3,
             "avg_launch_ms": avg2 * 1e3, "frac": r2["frac"], "achieved_GBs": r2["achieved"],

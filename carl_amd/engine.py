@@ -301,10 +301,10 @@ class VecEngine:
     def n_contexts(self) -> int:
         return int(self.b.n_contexts)
 
-    def _action_tensor(self, action, lead: tuple[int, ...], allow_u8: bool = False) -> tuple[torch.Tensor, int]:
+    def _action_tensor(self, action, lead: tuple[int, ...], allow_narrow: bool = False) -> tuple[torch.Tensor, int]:
         a = action if torch.is_tensor(action) else torch.as_tensor(np.asarray(action))
         if self.info.action_is_discrete:
-            if allow_u8 and a.dtype == torch.uint8:  # rollout-only input format (include/carl_amd.h: CARL_ACTION_U8)
+            if allow_narrow and a.dtype == torch.uint8:  # rollout-only input format (include/carl_amd.h: CARL_ACTION_U8)
                 dt = _lib.ACTION_U8
                 if a.is_contiguous() and a.data_ptr() % 4:  # (a view into a larger buffer: the kernel reads dwords)
                     a = a.clone()
@@ -312,7 +312,7 @@ class VecEngine:
                 if a.dtype not in (torch.int32, torch.int64):
                     a = a.to(torch.int64)
                 dt = _lib.ACTION_I32 if a.dtype == torch.int32 else _lib.ACTION_I64
-        elif allow_u8 and a.dtype in (torch.float16, torch.bfloat16):  # (likewise: CARL_ACTION_F16 / BF16)
+        elif allow_narrow and a.dtype in (torch.float16, torch.bfloat16):  # (likewise: CARL_ACTION_F16 / BF16)
             dt = _lib.ACTION_F16 if a.dtype == torch.float16 else _lib.ACTION_BF16
             if a.is_contiguous() and a.data_ptr() % 8:
                 a = a.clone()
@@ -435,7 +435,7 @@ class VecEngine:
         env-steps/s); Box families: float32, or ``torch.float16`` / ``torch.bfloat16`` (widened exactly).  Same transitions
         bit for bit as the wide launch fed the same values."""
         T = int(actions.shape[0])
-        a, dt = self._action_tensor(actions, (T,), allow_u8=True)
+        a, dt = self._action_tensor(actions, (T,), allow_narrow=True)
         if not self._warned_direct and self.rollout_variant() == _lib.ROLLOUT_DIRECT_SHAPE:
             import warnings
 

@@ -70,7 +70,7 @@ def main():
     for name, fams, lanes, T, K, mode in cases:
         if only and name not in only:
             continue
-        wl = bench.Workload(fams, lanes, T, 2, 0, 1, dev, action_u8=mode.endswith("-u8"))
+        wl = bench.Workload(fams, lanes, T, 2, 0, 1, dev, narrow_actions=mode.endswith("-u8"))
         mode = mode.replace("-u8", "")
         per, walls = [], []
         for r in range(a.reps + 1):
