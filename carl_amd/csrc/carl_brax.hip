@@ -2,8 +2,8 @@
 // their kernel dispatch.  A translation unit of its own because it is compiled with
 // -fno-slp-vectorize: the SLP vectoriser packs the per-lane 3-vector algebra into v_pk_*_f32
 // pairs and then spends as many v_mov as it saved to build the register pairs; the kernel is
-// bound by instruction issue, and without packing it is 9-22 % faster (profiles/r01g), whereas
-// the classic-control rollout loop (packed sincos polynomials) is 1.5 % faster with it.
+// bound by instruction issue, and without packing it is 9-22 % faster (profiles/r01g).  (Round 4: the classic-control
+// unit is built with the same flag -- carl_amd/build.py; its one useful packing is written by hand.)
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
