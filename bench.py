@@ -137,6 +137,9 @@ def parse():
     p.add_argument("--sustained-seconds", type=float, default=0.3)
     p.add_argument("--also", default="cartpole_T250,cartpole_u8,pendulum,pendulum_f16,config3,config4,config5",
                    help="comma list of extra workloads reported under 'also' (" + ", ".join(ALSO) + "), or 'none'")
+    p.add_argument("--narrow-actions", action="store_true",
+                   help="feed the MAIN workload uint8 (discrete) / float16 (Box) actions (ABI 7); profiling runs of "
+                        "also.cartpole_u8 / pendulum_f16 -- the default headline reads int32")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-per-call", action="store_true")
     p.add_argument("--cpu-envs-per-core", type=int, default=256)
@@ -779,7 +782,7 @@ def main():
     K, W = args.steps, args.warmup
     T = args.chunk or DEFAULT_CHUNK[args.families[0]]
     n_fam = args.lanes // world if args.strong else args.lanes
-    wl = Workload(args.families, n_fam, T, args.buffer_sets, rank, world, device)
+    wl = Workload(args.families, n_fam, T, args.buffer_sets, rank, world, device, narrow_actions=args.narrow_actions)
     n = wl.n
     shape = wl.launch_shape()
 
@@ -972,7 +975,7 @@ def main():
     other = None
     if world > 1:
         lanes3 = args.lanes if args.strong else args.lanes // world  # headline strong -> weak run; headline weak -> strong run
-        w3 = Workload(args.families, lanes3, T, args.buffer_sets, rank, world, device)
+        w3 = Workload(args.families, lanes3, T, args.buffer_sets, rank, world, device, narrow_actions=args.narrow_actions)
         regs3, m3 = timed_regions(w3, K, W, args.reps, barrier, max_over_ranks)
         el3, avg3 = regs3[m3]
         other = {"scaling": "weak" if args.strong else "strong", "lanes_per_gpu": w3.n, "total_lanes": w3.n * world,
@@ -997,7 +1000,7 @@ def main():
                        "lanes_per_gpu": n, "total_lanes": n * world, "chunk": T,
                        "env_steps_per_step": n * world * T, "buffer_sets": args.buffer_sets,
                        "parallelism": f"lane-shard x{world}", "lanes_per_env": shape},
-            "bench_version": BENCH_VERSION, "workload_id": f"{'+'.join(args.families)}:{n}:{T}:v{BENCH_VERSION}",
+            "bench_version": BENCH_VERSION, "workload_id": f"{'+'.join(args.families)}{'_narrow' if args.narrow_actions else ''}:{n}:{T}:v{BENCH_VERSION}",
             "repetitions": repetitions, "clocks": clocks, "shard8": shard8,
             "roofline": roofline, "cpu_baseline": cpu, "sustained": sustained,
             ("weak" if args.strong else "strong"): other, "per_call": per_call, "also": also,

@@ -8,12 +8,14 @@
 #   tools/r04_evidence.sh [tag]      then   python tools/make_r04_profiles.py gpurun_out/prof_<tag> "<source label>"
 set -u
 TAG=${1:-r04}
+ONLY=${2:-}   # optional: a grep pattern over the workload names (e.g. narrow)
 export TMPDIR=/tmp CARL_AMD_NO_BUILD=1
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 COMMON="--steps 20 --warmup 5 --reps 3 --also none --no-shard8 --no-cpu-baseline --no-per-call --sustained-seconds 0.1"
 run() {  # name, bench args...
   local name=$1; shift
+  if [ -n "$ONLY" ] && ! echo "$name" | grep -q "$ONLY"; then return; fi
   for pass in kt fetch write sq; do
     case $pass in
       kt) flags="--kernel-trace --stats" ;;
@@ -34,5 +36,7 @@ run acrobot+mountaincar_65536_250 --env acrobot+mountaincar --chunk 250
 run ant_32768_20 --env ant --lanes 32768 --lanes-per-env ant=9
 run halfcheetah+humanoid_32768_20 --env halfcheetah+humanoid --lanes 32768 --lanes-per-env halfcheetah=7,humanoid=11
 run cartpole_8192_1000 --env cartpole --lanes 8192
+run cartpole_narrow_65536_1000 --env cartpole --narrow-actions
+run pendulum_narrow_65536_1000 --env pendulum --narrow-actions
 run ant_4096_20 --env ant --lanes 4096 --lanes-per-env ant=16
 find "$OUT" -name "*kernel_stats.csv" | head -20
