@@ -765,6 +765,25 @@ struct ActionPipe {
   static constexpr bool kF16 = std::is_same_v<AStore, f16_bits>, kBF16 = std::is_same_v<AStore, bf16_bits>;
   typedef unsigned int vu2 __attribute__((ext_vector_type(2)));  // four 16-bit floats
   using R = std::conditional_t<kSame, V, std::conditional_t<kU8, unsigned int, std::conditional_t<kF16 || kBF16, vu2, Wide>>>;
+  // The narrow formats stay narrow in LDS: the loader wave copies each row's dword(s) as loaded and the COMPUTE waves
+  // widen their own element when they read it (ds_read_u8 / ds_read_u16 + at most one conversion): the loader wave's
+  // per-chunk work is then eight loads and eight 4- / 8-byte LDS writes whatever the format.  (Pendulum with float16
+  // torques at 250-step launches: 66.7 -> 64.2 us against 66.4 with float32; it is NOT what makes MountainCar slower
+  // with uint8 actions than with int32 -- 214 -> 225 us per 1 000 steps either way)
+  static constexpr bool kNarrow = kU8 || kF16 || kBF16;
+  using LdsElem = std::conditional_t<kU8, unsigned char, std::conditional_t<kF16 || kBF16, unsigned short, Action>>;
+  using LdsRow = std::conditional_t<kNarrow, R, V>;  // four lanes' worth of one step
+  __device__ static __forceinline__ Action widen(LdsElem e) {
+    if constexpr (kU8) {
+      return (Action)e;
+    } else if constexpr (kF16) {
+      return (Action)__builtin_bit_cast(_Float16, e);  // every float16 is a float32: exact
+    } else if constexpr (kBF16) {
+      return __uint_as_float((unsigned int)e << 16);  // bfloat16 = the high half of the float32
+    } else {
+      return e;
+    }
+  }
   R a0, a1, a2, a3, a4, a5, a6, a7;
   int t0;
 
@@ -782,17 +801,9 @@ struct ActionPipe {
     }
 #undef CARL_LD
   }
-  __device__ static __forceinline__ V narrow(const R& r) {
-    if constexpr (kSame) {
+  __device__ static __forceinline__ LdsRow narrow(const R& r) {
+    if constexpr (kSame || kNarrow) {
       return r;
-    } else if constexpr (kU8) {
-      return V{(int)(r & 255u), (int)((r >> 8) & 255u), (int)((r >> 16) & 255u), (int)(r >> 24)};
-    } else if constexpr (kF16) {  // every float16 is a float32: exact
-      auto h = [](unsigned int bits) { return (float)__builtin_bit_cast(_Float16, (unsigned short)bits); };
-      return V{h(r.x & 0xffffu), h(r.x >> 16), h(r.y & 0xffffu), h(r.y >> 16)};
-    } else if constexpr (kBF16) {  // bfloat16 = the high half of the float32
-      return V{__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16),
-               __uint_as_float(r.y & 0xffff0000u)};
     } else {
       return V{r.lo.x, r.lo.z, r.hi.x, r.hi.z};
     }
@@ -831,12 +842,12 @@ struct ActionPipe {
       a7 = load_row(row + lane4);
     }
   }
-  __device__ __forceinline__ void commit(Action* buf, const AStore* __restrict__ act, size_t n, int lane_base, int l,
+  __device__ __forceinline__ void commit(LdsElem* buf, const AStore* __restrict__ act, size_t n, int lane_base, int l,
                                          int n_steps) const {
     // padding lanes of a ragged last workgroup must see VALID actions too (they run as clones of the
     // last lane; a garbage torque sent the Acrobot's angle to 1e7 rad and its wrap loop with it):
     // they get the batch's last four actions (fast path: what issue() loaded) or zeros (tail chunk)
-    V* dst = reinterpret_cast<V*>(buf + 4 * l);
+    LdsRow* dst = reinterpret_cast<LdsRow*>(buf + 4 * l);
     constexpr int row = kRolloutLanes / 4;
     if (fast) {
       dst[0] = narrow(a0);
@@ -928,7 +939,9 @@ __device__ __forceinline__ void rollout_staged_body(const carl_batch_t& b, const
   using AStore = action_store_t<Fam, A64>;
   using Action = typename Fam::Action;
   using SK = LdsSink<Fam>;
-  Action* act_buf = reinterpret_cast<Action*>(lds_dyn);  // [2][kStageChunk][256]
+  using Pipe = ActionPipe<AStore, Action, kStageChunk>;
+  using LdsAct = typename Pipe::LdsElem;  // = Action, or the narrow storage type (widened by the reader)
+  LdsAct* act_buf = reinterpret_cast<LdsAct*>(lds_dyn);  // [2][kStageChunk][256]
   char* out_buf = reinterpret_cast<char*>(lds_dyn) + (size_t)2 * kStageChunk * kRolloutLanes * sizeof(float);
   float* ctx_lds = reinterpret_cast<float*>(out_buf + (size_t)2 * kStageChunk * SK::kStepBytes);
   const ctx_t<LDSCTX> ctx = make_ctx<LDSCTX, Fam::F>(b, ctx_lds);  // LDSCTX: stages the table, then a barrier
@@ -951,7 +964,7 @@ __device__ __forceinline__ void rollout_staged_body(const carl_batch_t& b, const
   const AStore* act = static_cast<const AStore*>(io.action);
   constexpr int kBufActs = kStageChunk * kRolloutLanes;
   LaneRegs<Fam> r{};
-  ActionPipe<AStore, Action, kStageChunk> pipe;
+  Pipe pipe;
   float* const final_base = (io.final_obs != nullptr && active) ? io.final_obs + (size_t)lane * Fam::D : nullptr;
   if (!compute && !loader) zero_flag_rows<Fam, CHUNK>(out_buf, hl, storer);
   if (loader) {
@@ -986,7 +999,7 @@ __device__ __forceinline__ void rollout_staged_body(const carl_batch_t& b, const
   for (int t0 = 0; t0 < n_steps; t0 += kStageChunk, buf ^= 1) {
     const int steps = min(kStageChunk, n_steps - t0);
     if constexpr (ROLE == 0) {
-      const Action* my = act_buf + buf * kBufActs + threadIdx.x;
+      const LdsAct* my = act_buf + buf * kBufActs + threadIdx.x;
       char* rec = out_buf + (size_t)buf * kStageChunk * SK::kStepBytes;
       if constexpr (PLAIN && dense_done_of<Fam>::value) {
         // every lane's next init state in registers before the chunk's first step
@@ -997,7 +1010,7 @@ __device__ __forceinline__ void rollout_staged_body(const carl_batch_t& b, const
         // the chunk's actions in registers: one LDS wait per chunk instead of one per step
         Action acts[kStageChunk];
 #pragma unroll
-        for (int u = 0; u < kStageChunk; ++u) acts[u] = my[u * kRolloutLanes];
+        for (int u = 0; u < kStageChunk; ++u) acts[u] = Pipe::widen(my[u * kRolloutLanes]);
         if (steps == kStageChunk) {  // fully unrolled: record addresses are immediates, no loop control
           // (AR: the chunk's first step is the launch's first step when t0 == 0; two copies of the unrolled chunk
           // would double the kernel for one step's worth of instructions, so that step always takes ENTRY)
@@ -1034,19 +1047,19 @@ __device__ __forceinline__ void rollout_staged_body(const carl_batch_t& b, const
         // one box Pendulum 271 -> 264, MountainCar 254 -> 230, Acrobot 941 -> 910 ns/step, same bits
         Action acts[kStageChunk];
 #pragma unroll
-        for (int u = 0; u < kStageChunk; ++u) acts[u] = my[u * kRolloutLanes];
+        for (int u = 0; u < kStageChunk; ++u) acts[u] = Pipe::widen(my[u * kRolloutLanes]);
 #pragma unroll
         for (int u = 0; u < kStageChunk; ++u) {
           const SK sink{rec + (size_t)u * SK::kStepBytes, final_base, n * Fam::D, t0 + u, (int)threadIdx.x};
           step_lane<Fam, ctx_t<LDSCTX>, true, SK, PLAIN>(b, ctx, sink, max_steps, true, lane, glane, acts[u], r);
         }
       } else {
-      Action a_next = my[0];
+      Action a_next = Pipe::widen(my[0]);
       settle(a_next);  // arrive before the loop: its head then only waits for the read issued one
                        // step earlier (lgkmcnt(#record writes)), not for the record writes
       for (int u = 0; u < steps; ++u) {
         const Action a = a_next;
-        a_next = my[min(u + 1, kStageChunk - 1) * kRolloutLanes];
+        a_next = Pipe::widen(my[min(u + 1, kStageChunk - 1) * kRolloutLanes]);
         const SK sink{rec + (size_t)u * SK::kStepBytes, final_base, n * Fam::D, t0 + u, (int)threadIdx.x};
         step_lane<Fam, ctx_t<LDSCTX>, true, SK, PLAIN>(b, ctx, sink, max_steps, true, lane, glane, a, r);
       }

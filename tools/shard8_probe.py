@@ -37,6 +37,10 @@ def main():
         ("cartpole_u8_65536_T250", ("cartpole",), 65536, 250, 20, "train-u8"),
         ("cartpole_u8_8192_T1000", ("cartpole",), 8192, 1000, 8, "train-u8"),
         ("mountaincar_u8_65536_T250", ("mountaincar",), 65536, 250, 20, "train-u8"),
+        ("mountaincar_65536_T1000", ("mountaincar",), 65536, 1000, 8, "train"),
+        ("mountaincar_u8_65536_T1000", ("mountaincar",), 65536, 1000, 8, "train-u8"),
+        ("acrobot_65536_T1000", ("acrobot",), 65536, 1000, 8, "train"),
+        ("acrobot_u8_65536_T1000", ("acrobot",), 65536, 1000, 8, "train-u8"),
         ("pendulum_f16_65536_T1000", ("pendulum",), 65536, 1000, 8, "train-u8"),
         ("pendulum_f16_65536_T250", ("pendulum",), 65536, 250, 20, "train-u8"),
         ("cartpole_2x32768_free_T250", ("cartpole", "cartpole"), 32768, 250, 20, "free"),
