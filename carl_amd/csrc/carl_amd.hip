@@ -160,10 +160,10 @@ int launch_step(const carl_batch_t* b, const carl_step_io_t* io, int n_steps, hi
   const size_t sh = (lds ? (size_t)Fam::F * b->n_contexts * sizeof(float) : 0) +
                     (rollout ? carl::rollout_action_lds_bytes() : 0);
   const bool a64 = io->action_dtype == CARL_ACTION_I64;
-  // uint8 actions: the lean staged rollout only (include/carl_amd.h: CARL_ACTION_U8)
+  // the narrow formats (uint8 / float16 / bfloat16): the lean staged rollout only (include/carl_amd.h: CARL_ACTION_U8)
+  const bool au8 = io->action_dtype == CARL_ACTION_U8;
   const bool af16 = io->action_dtype == CARL_ACTION_F16, abf16 = io->action_dtype == CARL_ACTION_BF16;
-  const bool a8 = io->action_dtype == CARL_ACTION_U8 || af16 || abf16;  // (any of the narrow rollout-only formats)
-  if (a8) {
+  if (au8 || af16 || abf16) {
     const bool keeps_context = b->selector == CARL_SEL_STATIC || b->selector == CARL_SEL_HOST;
     const bool lean = b->fin_count == nullptr && io->final_obs == nullptr;
     if (!rollout || rollout_variant(b) != CARL_ROLLOUT_STAGED || !keeps_context || !lean || !carl::predraw_of<Fam>::value)
@@ -218,7 +218,7 @@ int launch_step(const carl_batch_t* b, const carl_step_io_t* io, int n_steps, hi
           if (abf16) kern = static_cast<kern_t>(carl::rollout_staged_kernel<Fam, carl::kActBF16, true>);
         }
         if constexpr (std::is_same_v<typename Fam::Action, int>) {
-          if (a8) {  // the same two kernels reading one byte per action
+          if (au8) {  // the same two kernels reading one byte per action
             kern = static_cast<kern_t>(carl::rollout_staged_kernel<Fam, carl::kActU8, true>);
             if constexpr (carl::dense_done_of<Fam>::value) {
               if (b->flags & CARL_FLAG_AUTORESET)
