@@ -22,6 +22,7 @@ def main():
     p.add_argument("--builds", type=int, default=6)
     p.add_argument("--skew", default="", help="comma-separated byte skews for the slab experiment")
     p.add_argument("--slabs", action="store_true")
+    p.add_argument("--uniform-skew", action="store_true", help="--skew moves ALL arrays of a set by the same offset")
     p.add_argument("--act-skew", default="", help="comma-separated byte offsets of the action arrays past a 2 MiB boundary")
     a = p.parse_args()
     import torch
@@ -60,7 +61,7 @@ def main():
                 off, carved = base, {}
                 for k, name in enumerate(shapes):
                     shp, dt = shapes[name]
-                    o = off + k * skew
+                    o = off + (skew if a.uniform_skew else k * skew)  # (uniform: every array, obs included, moves)
                     carved[name] = slab[o:o + sizes[name]].view(dt).view(shp)
                     off += slot[name]
                 wl.outs[si][0] = carved
