@@ -523,6 +523,7 @@ struct MountainCar {
   enum { MIN_POS, MAX_POS, MAX_SPEED, GOAL_POS, GOAL_VEL, FORCE, GRAVITY, MINP_START, MAXP_START, MINV_START, MAXV_START };
   static constexpr bool kNeedsStepNoise = false;
   static constexpr bool kPredraw = true;
+  static constexpr bool kDeepActionPrefetch = true;  // (48-instruction step: engine_kernels.hip.h, rollout_staged_body)
 
   struct Params {
     float min_position, max_position, max_speed, goal_position, goal_velocity, force, gravity;
@@ -577,6 +578,7 @@ struct MountainCarCont {
   enum { MIN_POS, MAX_POS, MAX_SPEED, GOAL_POS, GOAL_VEL, POWER, MINP_START, MAXP_START, MINV_START, MAXV_START };
   static constexpr bool kNeedsStepNoise = false;
   static constexpr bool kPredraw = true;
+  static constexpr bool kDeepActionPrefetch = true;
 
   struct Params {
     float min_position, max_position, max_speed, goal_position, goal_velocity, power;

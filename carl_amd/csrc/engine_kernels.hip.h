@@ -348,6 +348,11 @@ __device__ __forceinline__ void finish_plain(const carl_batch_t& b, uint64_t gla
 //     ballot; the only branch left is the never-taken one for a lane that finishes a second time before the
 //     next chunk's draw (drawn inline: same words, same order -> bit-identical to the per-call kernel).
 template <class Fam, class = void>
+struct deep_action_prefetch_of : std::false_type {};
+template <class Fam>
+struct deep_action_prefetch_of<Fam, std::void_t<decltype(Fam::kDeepActionPrefetch)>> : std::bool_constant<Fam::kDeepActionPrefetch> {};
+
+template <class Fam, class = void>
 struct dense_done_of : std::false_type {};
 template <class Fam>
 struct dense_done_of<Fam, std::void_t<decltype(Fam::kDenseDone)>> : std::bool_constant<Fam::kDenseDone> {};
@@ -749,7 +754,9 @@ __host__ __device__ constexpr size_t rollout_staged_lds_bytes() {
 // A chunk of actions in flight: issue() starts the HBM loads into registers, commit() writes
 // them to the LDS buffer the compute waves will read.  int64 actions (torch's default integer type)
 // travel as two 16-byte vectors per lane-row and are narrowed at commit time.
-template <class AStore, class Action, int CHUNK>
+// DEEP (narrow formats of the families with the shortest step): issue() always loads all CHUNK rows and commit() always
+// writes them, so that a second chunk can stay in flight across a commit (see rollout_staged_body).
+template <class AStore, class Action, int CHUNK, bool DEEP = false>
 struct ActionPipe {
   static_assert(CHUNK == 8 || CHUNK == 4, "the in-flight chunk is held in eight (four) named register groups");
   static constexpr bool kSame = std::is_same_v<AStore, Action>;
@@ -820,6 +827,25 @@ struct ActionPipe {
                                         int n_steps) {
     t0 = t0_;
     fast = t0 + CHUNK <= n_steps;
+    if constexpr (DEEP) {
+      // two chunks of narrow rows are in flight at a time (rollout_staged_body), and the wait-count pass can only
+      // let the YOUNGER set stay in flight across the older set's commit if the number of loads issued here is a
+      // compile-time fact: always eight, rows past the end of the rollout re-read its last row (valid memory; `fast`
+      // still tells commit() whether the registers hold the chunk)
+      const int lane4 = min(lane_base + 4 * l, (int)n - 4);
+      const int last = n_steps - 1;
+      a0 = load_row(act + (size_t)min(t0, last) * n + lane4);
+      a1 = load_row(act + (size_t)min(t0 + 1, last) * n + lane4);
+      a2 = load_row(act + (size_t)min(t0 + 2, last) * n + lane4);
+      a3 = load_row(act + (size_t)min(t0 + 3, last) * n + lane4);
+      if constexpr (CHUNK == 8) {
+        a4 = load_row(act + (size_t)min(t0 + 4, last) * n + lane4);
+        a5 = load_row(act + (size_t)min(t0 + 5, last) * n + lane4);
+        a6 = load_row(act + (size_t)min(t0 + 6, last) * n + lane4);
+        a7 = load_row(act + (size_t)min(t0 + 7, last) * n + lane4);
+      }
+      return;
+    }
     if (!fast) return;
     // uniform row base + 32-bit lane offset: the loads take the scalar-base addressing form
     const int lane4 = min(lane_base + 4 * l, (int)n - 4);
@@ -849,7 +875,7 @@ struct ActionPipe {
     // they get the batch's last four actions (fast path: what issue() loaded) or zeros (tail chunk)
     LdsRow* dst = reinterpret_cast<LdsRow*>(buf + 4 * l);
     constexpr int row = kRolloutLanes / 4;
-    if (fast) {
+    if (fast || DEEP) {  // (DEEP: issue() always loads all rows -- past the end, the rollout's last row)
       dst[0] = narrow(a0);
       dst[row] = narrow(a1);
       dst[2 * row] = narrow(a2);
@@ -939,7 +965,12 @@ __device__ __forceinline__ void rollout_staged_body(const carl_batch_t& b, const
   using AStore = action_store_t<Fam, A64>;
   using Action = typename Fam::Action;
   using SK = LdsSink<Fam>;
-  using Pipe = ActionPipe<AStore, Action, kStageChunk>;
+  // A second chunk of actions in flight: for the narrow formats (a row is one or two dwords per lane: 8 - 16 registers of
+  // the loader wave) of the families whose step is so short that a chunk (1.6 us for MountainCar) does not cover the
+  // loader's HBM latency.  MountainCar x 65 536 with uint8 actions: 225 -> 183 us per 1 000 steps (int32: 216).  Not for
+  // the others: Pendulum with float16 torques 248 -> 260 us with it (A/B, one box).
+  constexpr bool kDeep = deep_action_prefetch_of<Fam>::value && !std::is_same_v<AStore, Action> && !std::is_same_v<AStore, long long>;
+  using Pipe = ActionPipe<AStore, Action, kStageChunk, kDeep>;
   using LdsAct = typename Pipe::LdsElem;  // = Action, or the narrow storage type (widened by the reader)
   LdsAct* act_buf = reinterpret_cast<LdsAct*>(lds_dyn);  // [2][kStageChunk][256]
   char* out_buf = reinterpret_cast<char*>(lds_dyn) + (size_t)2 * kStageChunk * kRolloutLanes * sizeof(float);
@@ -965,12 +996,14 @@ __device__ __forceinline__ void rollout_staged_body(const carl_batch_t& b, const
   constexpr int kBufActs = kStageChunk * kRolloutLanes;
   LaneRegs<Fam> r{};
   Pipe pipe;
+  [[maybe_unused]] Pipe pipe_b;  // kDeep: the second chunk in flight
   float* const final_base = (io.final_obs != nullptr && active) ? io.final_obs + (size_t)lane * Fam::D : nullptr;
   if (!compute && !loader) zero_flag_rows<Fam, CHUNK>(out_buf, hl, storer);
   if (loader) {
     pipe.issue(act, n, lane_base, hl, 0, n_steps);
     pipe.commit(act_buf, act, n, lane_base, hl, n_steps);
     pipe.issue(act, n, lane_base, hl, kStageChunk, n_steps);  // in flight across the barrier
+    if constexpr (kDeep) pipe_b.issue(act, n, lane_base, hl, 2 * kStageChunk, n_steps);
   } else if (compute) {
     // padding lanes of a ragged last workgroup run as register-only clones of the batch's last lane
     // (valid numbers, so the step loop needs no per-lane predicate and takes no slow math path)
@@ -992,6 +1025,29 @@ __device__ __forceinline__ void rollout_staged_body(const carl_batch_t& b, const
   // allocation.
   auto run_role = [&](auto role_tag) -> int {
   constexpr int ROLE = decltype(role_tag)::value;  // 0 compute, 1 loader, 2 storer
+  if constexpr (ROLE == 1 && kDeep) {
+    // The loader's loop with two chunks in flight, two chunks per trip (one barrier each, as every role executes): chunk
+    // c+1 (loads issued TWO chunks ago) -> LDS, then chunk c+3 starts in the registers it leaves; likewise c+2 / c+4 in
+    // the other set.  Written out per set: with one loop body choosing the set by chunk parity the compiler's
+    // wait-count pass cannot tell which set's loads are the older ones and waits for the loads it has just issued.
+    // (the only way back to the loop's head is through BOTH halves: on every path into a commit the other set's loads
+    // are the younger ones, so its wait is vmcnt(8 + ...), not vmcnt(0))
+    int lbuf = 0;
+    for (int t0 = 0;;) {  // n_steps >= 1
+      pipe.commit(act_buf + (lbuf ^ 1) * kBufActs, act, n, lane_base, hl, n_steps);
+      pipe.issue(act, n, lane_base, hl, t0 + 3 * kStageChunk, n_steps);
+      __syncthreads();
+      lbuf ^= 1;
+      if (t0 + kStageChunk >= n_steps) break;
+      pipe_b.commit(act_buf + (lbuf ^ 1) * kBufActs, act, n, lane_base, hl, n_steps);
+      pipe_b.issue(act, n, lane_base, hl, t0 + 4 * kStageChunk, n_steps);
+      __syncthreads();
+      lbuf ^= 1;
+      t0 += 2 * kStageChunk;
+      if (t0 >= n_steps) break;
+    }
+    return lbuf;
+  }
   int buf = 0;
   [[maybe_unused]] DenseNext<Fam> nx{};  // dense done handling (PLAIN, kDenseDone families): nothing drawn yet
   [[maybe_unused]] const bool autoreset = (b.flags & CARL_FLAG_AUTORESET) != 0;
