@@ -213,6 +213,16 @@ int launch_step(const carl_batch_t* b, const carl_step_io_t* io, int n_steps, hi
             kern = a64 ? static_cast<kern_t>(carl::rollout_staged_kernel<Fam, true, true, false, false, false, true>)
                        : static_cast<kern_t>(carl::rollout_staged_kernel<Fam, false, true, false, false, false, true>);
         }
+        if constexpr (carl::deep_below_lanes_of<Fam>::value > 0) {
+          // a batch that leaves compute units empty: two chunks of actions in flight (same results)
+          if (!a64 && !au8 && !af16 && !abf16 && b->n_lanes < carl::deep_below_lanes_of<Fam>::value) {
+            kern = static_cast<kern_t>(carl::rollout_staged_kernel<Fam, 0, true, false, false, false, false, true>);
+            if constexpr (carl::dense_done_of<Fam>::value) {
+              if (b->flags & CARL_FLAG_AUTORESET)
+                kern = static_cast<kern_t>(carl::rollout_staged_kernel<Fam, 0, true, false, false, false, true, true>);
+            }
+          }
+        }
         if constexpr (std::is_same_v<typename Fam::Action, float>) {
           if (af16) kern = static_cast<kern_t>(carl::rollout_staged_kernel<Fam, carl::kActF16, true>);
           if (abf16) kern = static_cast<kern_t>(carl::rollout_staged_kernel<Fam, carl::kActBF16, true>);

@@ -47,6 +47,7 @@ struct CartPole {
   // family because the smaller done path also frees the step loop's registers: Pendulum 279 -> 266,
   // MountainCar 292 -> 273, MountainCarContinuous 313 -> 276, Acrobot 2330 -> 2205 ns/step (A/B, one box)
   static constexpr bool kPredraw = true;
+  static constexpr int kDeepBelowLanes = 65536;  // (engine_kernels.hip.h: deep_below_lanes_of)
   // short episodes under any policy: the done handling of the PLAIN staged rollout is straight-line selects on
   // every step instead of a wave-uniform branch that is taken ~95 % of the time (engine_kernels.hip.h: step_dense)
   static constexpr bool kDenseDone = true;
@@ -149,6 +150,7 @@ struct Pendulum {
   enum { GRAVITY_DEAD, DT, G, M, L, INIT_ANGLE_MAX, INIT_VEL_MAX };
   static constexpr bool kNeedsStepNoise = false;
   static constexpr bool kPredraw = true;
+  static constexpr int kDeepBelowLanes = 32768;
 
   // `3*g/(2*l)*sin(th)` and `3.0/(m*l**2)*u` evaluate left to right, so the two
   // quotients are per-context constants with the reference's own rounding order

@@ -352,6 +352,12 @@ struct deep_action_prefetch_of : std::false_type {};
 template <class Fam>
 struct deep_action_prefetch_of<Fam, std::void_t<decltype(Fam::kDeepActionPrefetch)>> : std::bool_constant<Fam::kDeepActionPrefetch> {};
 
+// lean int32 / float32 launches of fewer lanes than this keep two chunks of actions in flight (rollout_staged_body)
+template <class Fam, class = void>
+struct deep_below_lanes_of : std::integral_constant<int, 0> {};
+template <class Fam>
+struct deep_below_lanes_of<Fam, std::void_t<decltype(Fam::kDeepBelowLanes)>> : std::integral_constant<int, Fam::kDeepBelowLanes> {};
+
 template <class Fam, class = void>
 struct dense_done_of : std::false_type {};
 template <class Fam>
@@ -957,7 +963,7 @@ __device__ __forceinline__ void zero_flag_rows(char* out_buf, int l, int which) 
 // CHUNK: steps per LDS buffer (8; the heterogeneous pair launch below runs its families at 4 so that two workgroups
 // fit on a compute unit).  `wg`: the workgroup's index among the batch's workgroups (blockIdx.x, or the index inside
 // this family's share of a pair launch).
-template <class Fam, int A64, bool PLAIN, bool LDSCTX, bool MOVES, bool FINAL, bool AR, int CHUNK>
+template <class Fam, int A64, bool PLAIN, bool LDSCTX, bool MOVES, bool FINAL, bool AR, int CHUNK, bool DEEPALL = false>
 __device__ __forceinline__ void rollout_staged_body(const carl_batch_t& b, const carl_step_io_t& io, const int n_steps,
                                                     const int wg, float* lds_dyn) {
   constexpr int kStageChunk = CHUNK;  // (shadows the namespace-scope default inside this body)
@@ -969,7 +975,13 @@ __device__ __forceinline__ void rollout_staged_body(const carl_batch_t& b, const
   // the loader wave) of the families whose step is so short that a chunk (1.6 us for MountainCar) does not cover the
   // loader's HBM latency.  MountainCar x 65 536 with uint8 actions: 225 -> 183 us per 1 000 steps (int32: 216).  Not for
   // the others: Pendulum with float16 torques 248 -> 260 us with it (A/B, one box).
-  constexpr bool kDeep = deep_action_prefetch_of<Fam>::value && !std::is_same_v<AStore, Action> && !std::is_same_v<AStore, long long>;
+  // DEEPALL: the same for int32 / float32 rows (32 more registers in the loader wave), chosen by the host for batches
+  // that leave compute units empty (carl_amd.hip: deep_below_lanes): there the launch lasts as long as one workgroup
+  // needs, and a loader that waits on HBM is on that path -- CartPole x 8 192 / 16 384 / 32 768: 225 -> 214, 228 -> 217,
+  // 237 -> 227 us per 1 000 steps; Pendulum x 8 192 / 16 384: 181 -> 177, 184 -> 180; at 65 536 lanes (store-bound) it
+  // costs 0 - 3 % and is not used (A/B on two boxes, tools/ab_probe.sh).
+  constexpr bool kDeep = !std::is_same_v<AStore, long long> &&
+                         (DEEPALL || (deep_action_prefetch_of<Fam>::value && !std::is_same_v<AStore, Action>));
   using Pipe = ActionPipe<AStore, Action, kStageChunk, kDeep>;
   using LdsAct = typename Pipe::LdsElem;  // = Action, or the narrow storage type (widened by the reader)
   LdsAct* act_buf = reinterpret_cast<LdsAct*>(lds_dyn);  // [2][kStageChunk][256]
@@ -1145,11 +1157,12 @@ __device__ __forceinline__ void rollout_staged_body(const carl_batch_t& b, const
 }
 
 template <class Fam, int A64, bool PLAIN = false, bool LDSCTX = false, bool MOVES = false, bool FINAL = false,
-          bool AR = false>  // A64: the action storage kind (0 int32 / float32, 1 int64, kActU8)
+          bool AR = false, bool DEEPALL = false>  // A64: the action storage kind (0 int32 / float32, 1 int64, kActU8 ...)
 __global__ void __launch_bounds__(kStagedThreads) rollout_staged_kernel(const carl_batch_t b, const carl_step_io_t io,
                                                                         const int n_steps) {
   extern __shared__ float lds_dyn[];
-  rollout_staged_body<Fam, A64, PLAIN, LDSCTX, MOVES, FINAL, AR, kStageChunk>(b, io, n_steps, (int)blockIdx.x, lds_dyn);
+  rollout_staged_body<Fam, A64, PLAIN, LDSCTX, MOVES, FINAL, AR, kStageChunk, DEEPALL>(b, io, n_steps, (int)blockIdx.x,
+                                                                                        lds_dyn);
 }
 
 // -------------------------------- two families in ONE launch ------------------------

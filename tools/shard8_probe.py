@@ -48,6 +48,10 @@ def main():
         ("pendulum_65536_T250", ("pendulum",), 65536, 250, 20, "train"),
         ("pendulum_65536_T1000", ("pendulum",), 65536, 1000, 8, "train"),
         ("pendulum_2x32768_free_T250", ("pendulum", "pendulum"), 32768, 250, 20, "free"),
+        ("cartpole_16384_T1000", ("cartpole",), 16384, 1000, 8, "train"),
+        ("cartpole_32768_T1000", ("cartpole",), 32768, 1000, 8, "train"),
+        ("pendulum_16384_T1000", ("pendulum",), 16384, 1000, 8, "train"),
+        ("pendulum_32768_T1000", ("pendulum",), 32768, 1000, 8, "train"),
         ("cartpole_8192_T250", ("cartpole",), 8192, 250, 20, "train"),
         ("cartpole_8192_T1000", ("cartpole",), 8192, 1000, 8, "train"),
         ("pendulum_8192_T250", ("pendulum",), 8192, 250, 20, "train"),
