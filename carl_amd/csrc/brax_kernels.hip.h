@@ -210,12 +210,21 @@ struct LaneCtx {
 // ds_read_b128 group land on 16 different bank quads at 256 B/clk.)  Then the float rows: each row = kEnvs
 // consecutive floats, one per env.
 constexpr int kBodyBytes = 80;
+// Behind a wavefront's body records: the WORLD as a body record (what a world-jointed link reads as its parent: origin,
+// identity rotation, at rest) and a 32-byte ZERO reaction record (what a link without a k-th child sums in the body phase),
+// so that neither needs a select in the substep.  Written once per launch.
+constexpr int kWorldRecBytes = kBodyBytes, kZeroRecBytes = 32, kFixedBytes = kWorldRecBytes + kZeroRecBytes;
+// A joint's reaction on its parent, handed from the joint phase to the body phase: (force 3, torque 3) as two 16-byte
+// pieces of a 48-byte record per (env, link) -- 48 = 3 x 4 banks, 3 coprime to 16: the lanes of a ds_read_b128 group land
+// on different bank quads.  The records OVERLAY the 12 L wrench rows (same size), which forward kinematics and observe
+// use as scratch between substep loops.
+constexpr int kReactBytes = 48;
+constexpr int kJointXBytes = 192;  // sizeof(Group<>::JointX): the joint phase's float64 constants per link, static LDS
 struct Layout {
   int L;       // links: body records per env
-  int wrench;  // 12 * L rows: per joint (f, t) on the child, (-f, -t') on the parent; reused by FK
+  int wrench;  // 12 * L rows: the substep's reaction records (48 bytes per (env, link)); scratch rows of FK / observe
   int mass;    // L rows (effective mass per link, context-scaled)
   int sig;     // 2 * L rows (uint32): per-link hash of the step's contact / limit branch decisions
-  int zero;    // 6 rows kept at zero: what a link without a k-th child reads in the body phase's child loop
   int goal;    // 3 rows: push task, the env's goal position (context or model default)
   int tau;     // n_dof rows
   int io;      // staging of the env's action / observation record, and of (q, qd) in reset
@@ -226,8 +235,7 @@ struct Layout {
     l.wrench = 0;
     l.mass = l.wrench + 12 * L;
     l.sig = l.mass + L;
-    l.zero = l.sig + 2 * L;
-    l.goal = l.zero + 6;
+    l.goal = l.sig + 2 * L;
     l.tau = l.goal + 3;
     l.io = l.tau + n_dof;
     l.total = l.io + io_rows;
@@ -235,8 +243,9 @@ struct Layout {
   }
   // bytes of dynamic LDS for `envs` envs per workgroup
   __host__ __device__ size_t body_bytes(int envs) const { return (size_t)kBodyBytes * L * envs; }
+  __host__ __device__ size_t rows_offset(int envs) const { return body_bytes(envs) + kFixedBytes; }  // multiple of 16
   __host__ __device__ size_t bytes(int envs) const {  // per wavefront, rounded up to 16 (the next wavefront's records)
-    return (body_bytes(envs) + (size_t)total * 4 * envs + 15) & ~(size_t)15;
+    return (rows_offset(envs) + (size_t)total * 4 * envs + 15) & ~(size_t)15;
   }
 };
 
@@ -463,9 +472,11 @@ struct Lds {
   __device__ __forceinline__ float& velk(int k) const { return vel(k / 6, k % 6); }
   __device__ __forceinline__ v3d pos(int i) const { return D(pd(i, 0), pd(i, 1), pd(i, 2)); }
   __device__ __forceinline__ qtd rot(int i) const { return qtd{pd(i, 3), pd(i, 4), pd(i, 5), pd(i, 6)}; }
-  __device__ __forceinline__ Body body(int i) const {
+  __device__ __forceinline__ int body_off(int i) const { return (env * lay.L + i) * kBodyBytes; }
+  __device__ __forceinline__ int world_off() const { return kEnvs * lay.L * kBodyBytes; }  // the world record (Layout)
+  __device__ __forceinline__ Body body_at(int off) const {
     typedef double vd2 __attribute__((ext_vector_type(2)));
-    const char* q = body_ptr(i);
+    const char* q = rec + off;
     const vd2 a = *reinterpret_cast<const vd2*>(q), b2 = *reinterpret_cast<const vd2*>(q + 16),
               c2 = *reinterpret_cast<const vd2*>(q + 32);
     const vf4 d = *reinterpret_cast<const vf4*>(q + 48), e = *reinterpret_cast<const vf4*>(q + 64);
@@ -477,16 +488,39 @@ struct Lds {
     b.w = V(e.y, e.z, e.w);
     return b;
   }
-  __device__ __forceinline__ void put(int i, const Body& b) const {
+  __device__ __forceinline__ Body body(int i) const { return body_at(body_off(i)); }
+  __device__ __forceinline__ void put_at(int off, const Body& b) const {
     typedef double vd2 __attribute__((ext_vector_type(2)));
     typedef float vf2 __attribute__((ext_vector_type(2)));
-    char* q = body_ptr(i);
+    char* q = rec + off;
     *reinterpret_cast<vd2*>(q) = vd2{b.p.x, b.p.y};
     *reinterpret_cast<vd2*>(q + 16) = vd2{b.p.z, b.r.w};
     *reinterpret_cast<vd2*>(q + 32) = vd2{b.r.x, b.r.y};
     const vf2 rz = __builtin_bit_cast(vf2, b.r.z);
     *reinterpret_cast<vf4*>(q + 48) = vf4{rz.x, rz.y, b.v.x, b.v.y};
     *reinterpret_cast<vf4*>(q + 64) = vf4{b.v.z, b.w.x, b.w.y, b.w.z};
+  }
+  __device__ __forceinline__ void put(int i, const Body& b) const { put_at(body_off(i), b); }
+  // reaction records (kReactBytes; byte offsets from the float rows; the zero record sits just below them)
+  __device__ __forceinline__ int react_off(int i) const { return (env * lay.L + i) * kReactBytes; }
+  __device__ __forceinline__ int zero_off() const { return -kZeroRecBytes; }
+  __device__ __forceinline__ void put_react(int off, v3 f, v3 t) const {
+    char* q = reinterpret_cast<char*>(base) + off;
+    *reinterpret_cast<vf4*>(q) = vf4{f.x, f.y, f.z, t.x};
+    *reinterpret_cast<vf4*>(q + 16) = vf4{t.y, t.z, 0.0f, 0.0f};
+  }
+  // planar models: (force x, force z, torque y) in the record's first piece
+  __device__ __forceinline__ void put_react1(int off, float fx, float fz, float ty) const {
+    *reinterpret_cast<vf4*>(reinterpret_cast<char*>(base) + off) = vf4{fx, fz, ty, 0.0f};
+  }
+  __device__ __forceinline__ vf4 get_react1(int off) const {
+    return *reinterpret_cast<const vf4*>(reinterpret_cast<const char*>(base) + off);
+  }
+  __device__ __forceinline__ void get_react(int off, v3& f, v3& t) const {
+    const char* q = reinterpret_cast<const char*>(base) + off;
+    const vf4 a = *reinterpret_cast<const vf4*>(q), b2 = *reinterpret_cast<const vf4*>(q + 16);
+    f = V(a.x, a.y, a.z);
+    t = V(a.w, b2.x, b2.y);
   }
   __device__ __forceinline__ void put3(int row, v3 a) const {
     at(row) = a.x; at(row + 1) = a.y; at(row + 2) = a.z;
@@ -536,39 +570,91 @@ struct JointGeom {
   float ang[3], rate[3];  // ... Euler x-y-z angles (third signed by dof_sign3) and their rates
 };
 
-// MULTI: the model has links with 0, 2 or 3 hinges (Humanoid; a pure slider); false compiles the Euler-angle
-// path out (Ant, Halfcheetah: fewer registers, shorter joint phase).
+// Per-link constants of the joint phase that are float64, or derived: expanded ON THE DEVICE once per workgroup
+// (expand_joint below; the host-built Packed travels as a kernel argument and stays compact).
+//   G: the relative rotation of the two joint frames is LINEAR in q1 = conj(r_parent) (x) r_child:
+//        rel = conj(r_parent (x) rpl) (x) (r_child (x) joint_rot) = conj(rpl) (x) q1 (x) joint_rot = G q1
+//      with G = L(conj(rpl)) R(joint_rot), a constant 4 x 4 matrix: one float64 quaternion product and one matrix-vector
+//      product per joint and substep instead of three quaternion products (48 -> 32 float64 operations); where every
+//      link frame is unrotated (link_rot = identity: every shipped single-hinge model) rpl = joint_rot and G is
+//      block-diagonal, rel = (|j|^2 q1.w, M q1.xyz): 26.  Stored compact block first:
+//        G00 | G11 G12 G13 | G21 G22 G23 | G31 G32 G33 || G01 G02 G03 | G10 G20 G30
+//      built from the float32 table values widened to float64, i.e. the same numbers the float64 restatement multiplies.
+//   axc: the hinge axis R(joint_rot) e_x in the child's frame (x_c = r_child rotating axc: float32 is enough for a direction)
+struct alignas(16) JointX {
+  double ac[3], ap[3];
+  double G[16];
+  float axc[3], k_pos;
+};
+static_assert(sizeof(JointX) == kJointXBytes, "JointX is read as twelve 16-byte pieces");
+
+// MULTI: the model has links with 0, 2 or 3 hinges (Humanoid; a pure slider) or rotated link frames; false compiles the
+// Euler-angle path and the general G out (Ant, Halfcheetah: fewer registers, shorter joint phase).
 // Everything that is a difference of the two poses is formed in float64 and rounded ONCE: the anchor
 // separation `ed`, the relative rotation of the joint frames, the axis-alignment term and the joint angles.
-// `la`: the link's joint record, already in registers (vector LDS reads of the caller).
+// `la` / `X`: the link's joint records, already in registers (vector LDS reads of the caller).
 struct JointRec {
-  v3 ac, ap;
-  qt rpl, jrot;
+  qt rpl;
   uint32_t word;
 };
+struct JointXr {  // JointX in registers
+  v3d ac, ap;
+  double G[16];
+  v3 axc;
+};
 template <bool MULTI>
-static __device__ __forceinline__ JointGeom joint_geometry(const carl_brax_sys_t& s, const JointRec& la, int i, const Body& bc,
-                                                    const Body& bp) {
+static __device__ __forceinline__ JointXr load_jointx(const JointX& X) {
+  typedef double vd2 __attribute__((ext_vector_type(2)));
+  const vd2* p = reinterpret_cast<const vd2*>(&X);
+  JointXr r;
+  const vd2 a0 = p[0], a1 = p[1], a2 = p[2];
+  r.ac = D(a0.x, a0.y, a1.x);
+  r.ap = D(a1.y, a2.x, a2.y);
+  constexpr int kPairs = MULTI ? 8 : 5;
+#pragma unroll
+  for (int k = 0; k < kPairs; ++k) {
+    const vd2 g = p[3 + k];
+    r.G[2 * k] = g.x;
+    r.G[2 * k + 1] = g.y;
+  }
+  const vf4 ax = *reinterpret_cast<const vf4*>(&X.axc[0]);
+  r.axc = V(ax.x, ax.y, ax.z);
+  return r;
+}
+template <bool MULTI>
+static __device__ __forceinline__ JointGeom joint_geometry(const carl_brax_sys_t& s, const JointRec& la, const JointXr& X, int i,
+                                                    const Body& bc, const Body& bp) {
   JointGeom g;
   {
-    const v3d rc_off = qrot(bc.r, tod(la.ac)), rp_off = qrot(bp.r, tod(la.ap));
+    const v3d rc_off = qrot(bc.r, X.ac), rp_off = qrot(bp.r, X.ap);
     g.ed = (bp.p - bc.p) + (rp_off - rc_off);  // A_p - A_c (at zero slide)
     g.rc_off = tof(rc_off);
     g.rp_off = tof(rp_off);
   }
   g.vA_c = bc.v + cross(bc.w, g.rc_off);
   g.vA_p = bp.v + cross(bp.w, g.rp_off);
-  // joint frames rc = bc.r (x) joint_rot, rp = bp.r (x) rpl and their relative rotation conj(rp) (x) rc.
+  // relative rotation of the joint frames rc = bc.r (x) joint_rot, rp = bp.r (x) rpl: rel = G (conj(bp.r) (x) bc.r).
   // cross(x_c, x_p) = rp (x) cross(xaxis(rel), e_x) = rp (x) (0, a2, -a1): the SMALL components of xaxis(rel)
-  // keep their relative accuracy.
+  // keep their relative accuracy.  The directions themselves (hinge axes, the frame that carries (0, a2, -a1) to the
+  // world) are float32 work on the rounded rotations.
   qtd rel;
-  qt rp;
+  const qt rp = qmul(tof(bp.r), la.rpl);
   {
-    const qtd rcd = qmul(bc.r, tod(la.jrot)), rpd = qmul(bp.r, tod(la.rpl));
-    rel = qmul(qconj(rpd), rcd);
-    rp = tof(rpd);
+    const qtd q1 = qmul(qconj(bp.r), bc.r);
+    const double* G = X.G;
+    if constexpr (MULTI) {
+      rel.w = G[0] * q1.w + G[10] * q1.x + G[11] * q1.y + G[12] * q1.z;
+      rel.x = G[13] * q1.w + G[1] * q1.x + G[2] * q1.y + G[3] * q1.z;
+      rel.y = G[14] * q1.w + G[4] * q1.x + G[5] * q1.y + G[6] * q1.z;
+      rel.z = G[15] * q1.w + G[7] * q1.x + G[8] * q1.y + G[9] * q1.z;
+    } else {
+      rel.w = G[0] * q1.w;
+      rel.x = G[1] * q1.x + G[2] * q1.y + G[3] * q1.z;
+      rel.y = G[4] * q1.x + G[5] * q1.y + G[6] * q1.z;
+      rel.z = G[7] * q1.x + G[8] * q1.y + G[9] * q1.z;
+    }
     const double a1 = 2.0 * (rel.x * rel.y + rel.w * rel.z), a2 = 2.0 * (rel.x * rel.z - rel.w * rel.y);
-    g.x_c = xaxis(tof(rcd));
+    g.x_c = qrot(tof(bc.r), X.axc);
     g.x_p = xaxis(rp);
     g.axx = qrot_yz(rp, (float)a2, (float)-a1);
   }
@@ -621,9 +707,10 @@ static __device__ __forceinline__ JointGeom joint_geometry(const carl_brax_sys_t
     const float w0 = dot(g.wrel, g.axis[0]), w1 = dot(g.wrel, g.axis[1]), w2 = dot(g.wrel, g.axis[2]);
     g.rate[1] = w1;
     {  // three hinges: axis0 and axis2 are not orthogonal (axis0 . axis2 = sign * sin(be)); else the plain projections
-       // (a locked direction is damped by k_ang_damp)
-      const float cc = dot(g.axis[0], g.axis[2]), den = 1.0f - cc * cc;
-      const float r0 = (w0 - cc * w2) / den, r2 = (w2 - cc * w0) / den;
+       // (a locked direction is damped by k_ang_damp).  One v_rcp_f32 for the two quotients (1 ulp; an IEEE division is
+       // ~10 instructions each).
+      const float cc = dot(g.axis[0], g.axis[2]), iden = __builtin_amdgcn_rcpf(1.0f - cc * cc);
+      const float r0 = (w0 - cc * w2) * iden, r2 = (w2 - cc * w0) * iden;
       g.rate[0] = (nr == 3) ? r0 : w0;
       g.rate[2] = (nr == 3) ? r2 : w2;
     }
@@ -681,9 +768,9 @@ static __device__ __forceinline__ double rsqrt_f64(double x) {
 
 // ---- one brax.spring.pipeline.step ---------------------------------------------------------
 // Branch record: every DISCRETE decision of the substep that the float64 restatement also takes is hashed per
-// link (h <- 33 h + bits) into the `sig` rows: row 2 i the contacts that delivered an impulse (bit = the
-// sphere's ordinal on its link), row 2 i + 1 the range limits that were active on link i's joint (slides:
-// bits 0-3, hinges: bits 4-9; below / above per dof).  The step's combination of the rows is an optional output
+// link (h <- 33 h + bits): the contacts that delivered an impulse (bit = the sphere's ordinal on its link) and the
+// range limits that were active on the link's joint (slides: bits 0-3, hinges: bits 4-9; below / above per dof).
+// The step's combination of the per-link hashes is an optional output
 // (carl_step_io_t::branch_sig): a parity check can then separate lanes that took the same branches as the
 // reference arithmetic from lanes where a contact switched within rounding -- an impulse is discontinuous there.
 // Launch-invariant scalars of the substep.  The model table sits in LDS and every phase hand-over is a fence, so the
@@ -694,21 +781,6 @@ struct SubK {
   float dt, dl, inv_dt, erp;
   int L, first_joint, max_children;
 };
-// The index words of the lane's FIRST joint / body (link first_joint + sub / sub), read once per launch: with one lane
-// per link -- the shape every large batch runs in -- a phase then starts with every address it needs in registers and
-// issues all its loads at once; a lane that owns a second link (kSub < n_links) reads that link's words at the end
-// of its first round.
-struct LinkWords {
-  uint32_t wa, wb, wch;
-};
-static __device__ __forceinline__ LinkWords load_words(const Packed& pk, const SubK& K, int sub) {
-  LinkWords w;
-  const int ia = K.first_joint + sub;
-  w.wa = ia < K.L ? pk.a[ia].word : kWaFree;
-  w.wb = sub < K.L ? pk.b[sub].word : 0u;
-  w.wch = sub < K.L ? pk.b[sub].children : 0u;
-  return w;
-}
 static __device__ __forceinline__ float uniform(float x) {
   return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x)));
 }
@@ -725,32 +797,106 @@ static __device__ __forceinline__ SubK make_subk(const carl_brax_sys_t& s, const
 }
 static __device__ __forceinline__ vf4 ld4(const void* p) { return *reinterpret_cast<const vf4*>(p); }
 
+// ONE LANE PER LINK: lane `sub` of an env owns link sub -- its joint (the one to its parent) in the joint phase and
+// its body in the body phase (kSub >= n_links; the host never launches a narrower group).  What a lane needs to find
+// its data is fixed for the launch and kept in registers: a phase starts with every address known and issues all its
+// loads at once.
+struct LaneLink {
+  int i;            // the lane's link (idle lanes: clamped to L - 1, `body` false)
+  bool body;        // the lane owns a body (sub < L)
+  bool joint;       // ... and that link hangs on a joint (everything but a free root)
+  uint32_t wa, wb;  // the index words of LinkA / LinkB
+  int own, par;     // byte offsets (from the wavefront's records) of the own body record, the parent's (the world record)
+  int react;        // byte offset (from the float rows) of the own joint's reaction record
+  int child[4];     // ... of the first four children's reaction records, ascending (absent: the zero record)
+};
+
+// What a lane carries in registers through the n_frames substeps of an env step: its body (the LDS record is rewritten
+// at the end of every body phase -- the children read it in the next joint phase -- but the owner never reads it back),
+// the joint's actuator torques, the branch hashes and 1 / mass.
+template <bool MULTI>
+struct StepRegs {
+  Body b;
+  float tau[MULTI ? 3 : 1];
+  uint32_t sig_hit, sig_lim;
+  float inv_m;
+};
+
+static __device__ __forceinline__ LaneLink make_lane_link(const Packed& pk, const SubK& K, const Lds& m) {
+  LaneLink ll;
+  const bool body = m.sub < K.L;
+  const int i = body ? m.sub : K.L - 1;
+  ll.i = i;
+  ll.body = body;
+  ll.wa = body ? pk.a[i].word : kWaFree;
+  ll.wb = body ? pk.b[i].word : 0u;
+  const uint32_t wch = body ? pk.b[i].children : 0u;
+  ll.joint = body && (ll.wa & kWaFree) == 0u;
+  const int P = wa_parent(ll.wa);
+  ll.own = m.body_off(i);
+  ll.par = P < 0 ? m.world_off() : m.body_off(P);
+  ll.react = m.react_off(i);
+  const int nch = wb_children(ll.wb);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) ll.child[k] = (k < nch) ? m.react_off((int)((wch >> (4 * k)) & 15u)) : m.zero_off();
+  return ll;
+}
+
+// JointX of link i from the host-built record (one lane per link, once per workgroup)
+static __device__ __forceinline__ void expand_joint(const carl_brax_sys_t& s, const Packed& pk, int i, JointX& out) {
+  const LinkA& A = pk.a[i];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    out.ac[k] = (double)A.ac[k];
+    out.ap[k] = (double)A.ap[k];
+  }
+  const qtd j = tod(f4(A.jrot)), cr = qconj(tod(f4(A.rpl)));
+  double G[4][4];
+#pragma unroll
+  for (int cidx = 0; cidx < 4; ++cidx) {  // column cidx of G: conj(rpl) (x) e_cidx (x) joint_rot
+    const qtd e{cidx == 0 ? 1.0 : 0.0, cidx == 1 ? 1.0 : 0.0, cidx == 2 ? 1.0 : 0.0, cidx == 3 ? 1.0 : 0.0};
+    const qtd col = qmul(qmul(cr, e), j);
+    G[0][cidx] = col.w; G[1][cidx] = col.x; G[2][cidx] = col.y; G[3][cidx] = col.z;
+  }
+  out.G[0] = G[0][0];
+#pragma unroll
+  for (int r = 1; r < 4; ++r) {
+#pragma unroll
+    for (int cidx = 1; cidx < 4; ++cidx) out.G[1 + 3 * (r - 1) + (cidx - 1)] = G[r][cidx];
+    out.G[9 + r] = G[0][r];
+    out.G[12 + r] = G[r][0];
+  }
+  const v3 ax = xaxis(f4(A.jrot));
+  out.axc[0] = ax.x; out.axc[1] = ax.y; out.axc[2] = ax.z;
+  out.k_pos = A.k_pos;
+}
+
 template <bool MULTI, bool TASK>
-static __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const Topo& tp, const Packed& pk, const SubK& K,
-                                        const LinkWords& W, const LaneCtx& c, const Lds& m) {
-  const int L = K.L;
-  // phase A -- spring.joints.resolve, one joint per lane
-  uint32_t wa = W.wa;
-  for (int i = K.first_joint + m.sub; i < L; i += kSub, wa = (i < L) ? pk.a[min(i, L - 1)].word : wa) {
-    if (wa & kWaFree) continue;
+static __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const Topo& tp, const Packed& pk, const JointX* jx,
+                                        const SubK& K, const LaneLink& ll, const LaneCtx& c, const Lds& m,
+                                        StepRegs<MULTI>& R) {
+  const int i = ll.i;
+  Body& b = R.b;
+  // phase A -- spring.joints.resolve, the lane's own joint.  The wrench on the child stays in registers (the same lane
+  // applies it in the body phase); only the reaction on the parent goes through LDS.
+  v3 f = V(0, 0, 0), tc = V(0, 0, 0);
+  if (ll.joint) {
+    const uint32_t wa = ll.wa;
     const LinkA& rec = pk.a[i];
-    const int P = wa_parent(wa);
     const int ns = wa_slides(wa), d0 = wa_dof(wa);
-    const int d = d0 + ns, nr = MULTI ? wa_hinges(wa) : 1;
-    // every load of the phase whose address is known here, in one batch
-    const vf4 q0 = ld4(&rec.ac[0]), q1 = ld4(&rec.ap[0]), q2 = ld4(&rec.rpl[0]), q3 = ld4(&rec.jrot[0]);
-    const Body bc = m.body(i);
-    const Body bp = (P < 0) ? world_body() : m.body(P);
+    const int nr = MULTI ? wa_hinges(wa) : 1;
+    // every load of the phase, in one batch
+    const JointXr X = load_jointx<MULTI>(jx[i]);
+    const float k_pos = jx[i].k_pos;
+    const vf4 q2 = ld4(&rec.rpl[0]);
+    const Body bp = m.body_at(ll.par);
     const vf4 q4 = ld4(&rec.k_vel), q5 = ld4(&rec.stiffness);  // k_vel k_limit k_ang_damp damping | stiffness lo hi
-    const float tau1 = m.at(m.lay.tau + d);
-    const uint32_t sig_lim = m.atu(m.lay.sig + 2 * i + 1);
-    const JointRec la{V(q0.x, q0.y, q0.z), V(q1.x, q1.y, q1.z), qt{q2.x, q2.y, q2.z, q2.w}, qt{q3.x, q3.y, q3.z, q3.w}, wa};
-    const JointGeom g = joint_geometry<MULTI>(s, la, i, bc, bp);
+    const JointRec la{qt{q2.x, q2.y, q2.z, q2.w}, wa};
+    const JointGeom g = joint_geometry<MULTI>(s, la, X, i, b, bp);
     const float k_limit = q4.y;
-    const float kp = q1.w * c.stiffness_scale;
+    const float kp = k_pos * c.stiffness_scale;
     v3d ed = g.ed;
     v3 ev = g.vA_p - g.vA_c;
-    v3 f = V(0, 0, 0);
     uint32_t lim = 0u;
     for (int k = 0; k < ns; ++k) {  // prismatic dofs: free along the axis, own spring/damper/force
       const v3d axd = qrot(bp.r, tod(f3(s.slide_axis[i][k])));
@@ -768,13 +914,14 @@ static __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const T
     v3 t;
     {  // single hinge: keep the hinge axes aligned + the hinge torque about the child-side axis
       uint32_t lim1 = 0u;
-      float ta = tau1 - q4.w * g.thetadot - q5.x * g.theta;
+      float ta = R.tau[0] - q4.w * g.thetadot - q5.x * g.theta;
       if (g.theta < q5.y) { ta += k_limit * (q5.y - g.theta); lim1 |= 16u; }
       if (g.theta > q5.z) { ta -= k_limit * (g.theta - q5.z); lim1 |= 32u; }
       t = g.axx * kp + g.x_c * ta;
       if constexpr (MULTI) {  // 2 or 3 stacked hinges (or none): per-dof torques about the current axes; a missing dof is
                               // locked by the constraint spring on its Euler angle.  Straight-line like joint_geometry:
                               // evaluated on every lane, selected by the lane's number of hinges.
+        const int d = d0 + ns;
         v3 t2 = V(0, 0, 0);
         uint32_t lim2 = 0u;
 #pragma unroll
@@ -782,7 +929,7 @@ static __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const T
           const int dk = min(d + k, CARL_BRAX_MAX_DOF - 1);
           const bool act = k < nr;
           const float lo = s.dof_lo[dk], hi = s.dof_hi[dk];
-          float tk = m.at(m.lay.tau + dk) - s.dof_damping[dk] * g.rate[k] - s.dof_stiffness[dk] * g.ang[k];
+          float tk = R.tau[k] - s.dof_damping[dk] * g.rate[k] - s.dof_stiffness[dk] * g.ang[k];
           const bool below = g.ang[k] < lo, above = g.ang[k] > hi;
           tk = below ? tk + k_limit * (lo - g.ang[k]) : tk;
           tk = above ? tk - k_limit * (g.ang[k] - hi) : tk;
@@ -797,8 +944,7 @@ static __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const T
       lim |= lim1;
     }
     t = t - g.wrel * q4.z;
-    m.atu(m.lay.sig + 2 * i + 1) = sig_lim * 33u + lim;
-    const int wr = m.lay.wrench + 12 * i;
+    R.sig_lim = R.sig_lim * 33u + lim;
     v3 pf = f * -1.0f, pt = (cross(g.rp_off, f) + t) * -1.0f;  // on the parent
     if (TASK && s.n_pair > 0 && i == s.push_link) {
       const PairOut po = pair_contact(s, m);
@@ -806,54 +952,42 @@ static __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const T
       pf = po.on_a;
       pt = po.t_a;
     }
-    m.put3(wr, f);
-    m.put3(wr + 3, cross(g.rc_off, f) + t);
-    m.put3(wr + 6, pf);
-    m.put3(wr + 9, pt);
+    tc = cross(g.rc_off, f) + t;
+    m.put_react(ll.react, pf, pt);
   }
   phase_sync();
   // phase B -- per body: wrench sum, semi-implicit Euler, its contacts, integrate
-  const float dl = K.dl, da = c.da, inv_dt = K.inv_dt, dt = K.dt;
-  uint32_t wb = W.wb, wch = W.wch;
-  for (int i = m.sub; i < L; i += kSub, wb = (i < L) ? pk.b[min(i, L - 1)].word : wb,
-           wch = (i < L) ? pk.b[min(i, L - 1)].children : wch) {
+  if (ll.body) {
+    const float dl = K.dl, da = c.da, inv_dt = K.inv_dt, dt = K.dt;
+    const uint32_t wb = ll.wb;
     const vf4 qb = ld4(&pk.b[i]);  // .z inv_inertia[0], .w reach (the index words are in registers)
     const bool iso = (wb & kWbIso) != 0u;
-    Body b = m.body(i);
-    const float mass_i = m.at(m.lay.mass + i);
-    const uint32_t sig_hit = m.atu(m.lay.sig + 2 * i);
     const qt rf = tof(b.r);
-    // own joint's wrench (a free root has none: it reads the zero rows)
-    const int own = (wb & kWbFree) ? m.lay.zero : m.lay.wrench + 12 * i;
-    v3 F = m.get3(own), T = m.get3(own + 3);
-    {  // children's reactions, ascending: a wavefront-uniform trip count and loads whose addresses come from a
-       // register (a link with fewer children reads the zero rows), so a pass is one batch of independent LDS reads
-      const int nch = wb_children(wb);
-      if (K.max_children > 2 && K.max_children <= 4) {  // (Ant's torso, Humanoid's pelvis: all four slots in ONE batch of loads)
-        int r[4];
+    v3 F = f, T = tc;  // own joint's wrench (a free root has none)
+    {  // children's reactions, ascending: a wavefront-uniform trip count and loads whose addresses sit in registers
+       // (a link with fewer children reads the zero record), so the pass is one batch of independent LDS reads
+      if (K.max_children > 2) {  // (Ant's torso, Humanoid's torso: all four slots in ONE batch of loads)
+        v3 fk[4], tk[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) r[k] = (k < nch) ? m.lay.wrench + 12 * (int)((wch >> (4 * k)) & 15u) + 6 : m.lay.zero;
-        v3 f[4], t[4];
+        for (int k = 0; k < 4; ++k) m.get_react(ll.child[k], fk[k], tk[k]);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { f[k] = m.get3(r[k]); t[k] = m.get3(r[k] + 3); }
+        for (int k = 0; k < 4; ++k) { F = F + fk[k]; T = T + tk[k]; }
+      } else if (K.max_children > 0) {
+        v3 fk[2], tk[2];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { F = F + f[k]; T = T + t[k]; }
-      } else
-      for (int k0 = 0; k0 < K.max_children && k0 < 8; k0 += 2) {
-        const int r0 = (k0 < nch) ? m.lay.wrench + 12 * (int)((wch >> (4 * k0)) & 15u) + 6 : m.lay.zero;
-        const int r1 = (k0 + 1 < nch) ? m.lay.wrench + 12 * (int)((wch >> (4 * k0 + 4)) & 15u) + 6 : m.lay.zero;
-        const v3 f0 = m.get3(r0), t0 = m.get3(r0 + 3), f1 = m.get3(r1), t1 = m.get3(r1 + 3);
-        F = (F + f0) + f1;
-        T = (T + t0) + t1;
+        for (int k = 0; k < 2; ++k) m.get_react(ll.child[k], fk[k], tk[k]);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) { F = F + fk[k]; T = T + tk[k]; }
       }
-      if (K.max_children > 8)  // (no shipped model; wavefront-uniform)
-        for (int cc = tp.child_begin[i] + 8; cc < tp.child_begin[i + 1]; ++cc) {
-          const int wr = m.lay.wrench + 12 * tp.child_idx[cc];
-          F = F + m.get3(wr + 6);
-          T = T + m.get3(wr + 9);
+      if (K.max_children > 4)  // (no shipped model; wavefront-uniform)
+        for (int cc = tp.child_begin[i] + 4; cc < tp.child_begin[i + 1]; ++cc) {
+          v3 fk, tk;
+          m.get_react(m.react_off(tp.child_idx[cc]), fk, tk);
+          F = F + fk;
+          T = T + tk;
         }
     }
-    const float inv_m = __builtin_amdgcn_rcpf(mass_i);  // v_rcp_f32 (1 ulp): the phase is issue-bound
+    const float inv_m = R.inv_m;
     b.v = b.v + (F * inv_m + V(0, 0, c.gravity_z)) * dt;
     b.w = b.w + apply_inv_inertia(s, i, rf, T, iso, qb.z) * dt;
     // spring.collisions.resolve: this body's spheres vs the plane z = 0
@@ -901,7 +1035,7 @@ static __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const T
       cdw = cdw + apply_inv_inertia(s, i, rf, cross(r, J), iso, qb.z);
       cnt += 1.0f;
     }
-    m.atu(m.lay.sig + 2 * i) = sig_hit * 33u + hit;
+    R.sig_hit = R.sig_hit * 33u + hit;
     // spring.integrator.integrate
     b.v = b.v * dl;
     b.w = b.w * da;
@@ -917,7 +1051,7 @@ static __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const T
     qtd r2 = qtd{fma(h, dq.w, b.r.w), fma(h, dq.x, b.r.x), fma(h, dq.y, b.r.y), fma(h, dq.z, b.r.z)};
     const double inv = rsqrt_f64(r2.w * r2.w + r2.x * r2.x + r2.y * r2.y + r2.z * r2.z);
     b.r = qtd{r2.w * inv, r2.x * inv, r2.y * inv, r2.z * inv};
-    m.put(i, b);
+    m.put_at(ll.own, b);
   }
   phase_sync();
 }
@@ -934,44 +1068,45 @@ static __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const T
 // y += h omega w.  Pose differences stay float64.  Results agree with the general substep to rounding
 // (tests/test_gpu_brax.py: both paths against each other and against the float64 restatement of the 3-D pipeline).
 template <bool TASK>
-static __device__ __forceinline__ void substep_planar(const carl_brax_sys_t& s, const Topo& tp, const Packed& pk, const SubK& K,
-                                               const LinkWords& W, const LaneCtx& c, const Lds& m) {
+static __device__ __forceinline__ void substep_planar(const carl_brax_sys_t& s, const Topo& tp, const Packed& pk, const JointX* jx,
+                                               const SubK& K, const LaneLink& ll, const LaneCtx& c, const Lds& m,
+                                               StepRegs<false>& R) {
   static_assert(!TASK, "planar models are not task models");
-  const int L = K.L;
-  // phase A -- spring.joints.resolve
-  uint32_t wa = W.wa;
-  for (int i = K.first_joint + m.sub; i < L; i += kSub, wa = (i < L) ? pk.a[min(i, L - 1)].word : wa) {
+  const int i = ll.i;
+  Body& b = R.b;
+  // phase A -- spring.joints.resolve (every link of a planar model has a joint: the root hangs on the world)
+  float fx = 0.0f, fz = 0.0f, tcy = 0.0f;  // the wrench on the child: stays in registers
+  if (ll.joint) {
+    const uint32_t wa = ll.wa;
     const LinkA& rec = pk.a[i];
-    const int P = wa_parent(wa);
-    const int ns = wa_slides(wa), d0 = wa_dof(wa), d = d0 + ns;
-    const vf4 q0 = ld4(&rec.ac[0]), q1 = ld4(&rec.ap[0]);
-    const Body bc = m.body(i);
-    const Body bp = (P < 0) ? world_body() : m.body(P);
+    const int ns = wa_slides(wa), d0 = wa_dof(wa);
+    typedef double vd2 __attribute__((ext_vector_type(2)));
+    const vd2* xp = reinterpret_cast<const vd2*>(&jx[i]);
+    const vd2 x0 = xp[0], x1 = xp[1], x2 = xp[2];  // ac.x ac.y | ac.z ap.x | ap.y ap.z
+    const float k_pos = jx[i].k_pos;
+    const Body bp = m.body_at(ll.par);
     const vf4 q4 = ld4(&rec.k_vel), q5 = ld4(&rec.stiffness);  // k_vel k_limit k_ang_damp damping | stiffness lo hi
-    const float tau1 = m.at(m.lay.tau + d);
     const float tau_s0 = ns > 0 ? m.at(m.lay.tau + d0) : 0.0f, tau_s1 = ns > 0 ? m.at(m.lay.tau + d0 + 1) : 0.0f;
-    const uint32_t sig_lim = m.atu(m.lay.sig + 2 * i + 1);
-    const float k_limit = q4.y, kp = q1.w * c.stiffness_scale;
+    const float k_limit = q4.y, kp = k_pos * c.stiffness_scale;
     // rotation of both bodies as (cos, sin) of the full angle, float64
-    const double cc = bc.r.w * bc.r.w - bc.r.y * bc.r.y, sc = 2.0 * (bc.r.w * bc.r.y);
+    const double cc = b.r.w * b.r.w - b.r.y * b.r.y, sc = 2.0 * (b.r.w * b.r.y);
     const double cp = bp.r.w * bp.r.w - bp.r.y * bp.r.y, sp = 2.0 * (bp.r.w * bp.r.y);
-    const double acx = (double)q0.x, acz = (double)q0.z, apx = (double)q1.x, apz = (double)q1.z;
+    const double acx = x0.x, acz = x1.x, apx = x1.y, apz = x2.y;
     const double rcx = cc * acx + sc * acz, rcz = cc * acz - sc * acx;  // anchor - COM, child side, world
     const double rpx = cp * apx + sp * apz, rpz = cp * apz - sp * apx;  // ... parent side
-    double edx = (bp.p.x - bc.p.x) + (rpx - rcx), edz = (bp.p.z - bc.p.z) + (rpz - rcz);  // A_p - A_c
+    double edx = (bp.p.x - b.p.x) + (rpx - rcx), edz = (bp.p.z - b.p.z) + (rpz - rcz);  // A_p - A_c
     const float rcxf = (float)rcx, rczf = (float)rcz, rpxf = (float)rpx, rpzf = (float)rpz;
     // anchor velocities v + omega x r, omega = (0, w.y, 0)
-    const float vcx = bc.v.x + bc.w.y * rczf, vcz = bc.v.z - bc.w.y * rcxf;
+    const float vcx = b.v.x + b.w.y * rczf, vcz = b.v.z - b.w.y * rcxf;
     const float vpx = bp.v.x + bp.w.y * rpzf, vpz = bp.v.z - bp.w.y * rpxf;
     float evx = vpx - vcx, evz = vpz - vcz;
     // relative rotation conj(u_p) u_c: the hinge angle is twice its argument
-    double Wr = bp.r.w * bc.r.w + bp.r.y * bc.r.y, Yr = bp.r.w * bc.r.y - bp.r.y * bc.r.w;
+    double Wr = bp.r.w * b.r.w + bp.r.y * b.r.y, Yr = bp.r.w * b.r.y - bp.r.y * b.r.w;
     if (Wr < 0.0) { Wr = -Wr; Yr = -Yr; }
     const float sg = q5.w;  // +-1: the hinge axis is +-y (joint_rot maps x to +-y)
     const float theta = sg * (float)(2.0 * atan2_f64(Yr, Wr));
-    const float wrel = bc.w.y - bp.w.y, thetadot = sg * wrel;
+    const float wrel = b.w.y - bp.w.y, thetadot = sg * wrel;
     uint32_t lim = 0u;
-    float fx = 0.0f, fz = 0.0f;
     if (ns > 0) {  // the root: slides along world x and z (the parent is the world), unlimited
       const float qx = (float)(-edx), qz = (float)(-edz), qdx = -evx, qdz = -evz;
       edx = 0.0; edz = 0.0; evx = 0.0f; evz = 0.0f;
@@ -984,38 +1119,40 @@ static __device__ __forceinline__ void substep_planar(const carl_brax_sys_t& s, 
     }
     fx = fx + (float)edx * kp + evx * q4.x;
     fz = fz + (float)edz * kp + evz * q4.x;
-    float ta = tau1 - q4.w * thetadot - q5.x * theta;
+    float ta = R.tau[0] - q4.w * thetadot - q5.x * theta;
     if (theta < q5.y) { ta += k_limit * (q5.y - theta); lim |= 16u; }
     if (theta > q5.z) { ta -= k_limit * (theta - q5.z); lim |= 32u; }
     const float ty = sg * ta - wrel * q4.z;  // about y: hinge torque, angular damping (the axes are parallel: no alignment term)
-    m.atu(m.lay.sig + 2 * i + 1) = sig_lim * 33u + lim;
-    const int wr = m.lay.wrench + 12 * i;
+    R.sig_lim = R.sig_lim * 33u + lim;
     // (a x f).y = a.z f.x - a.x f.z
-    m.at(wr) = fx; m.at(wr + 2) = fz; m.at(wr + 4) = (rczf * fx - rcxf * fz) + ty;
-    m.at(wr + 6) = -fx; m.at(wr + 8) = -fz; m.at(wr + 10) = -((rpzf * fx - rpxf * fz) + ty);
+    tcy = (rczf * fx - rcxf * fz) + ty;
+    m.put_react1(ll.react, -fx, -fz, -((rpzf * fx - rpxf * fz) + ty));
   }
   phase_sync();
   // phase B -- per body: wrench sum, semi-implicit Euler, its contacts, integrate
-  const float dl = K.dl, da = c.da, inv_dt = K.inv_dt, dt = K.dt;
-  uint32_t wb = W.wb, wch = W.wch;
-  for (int i = m.sub; i < L; i += kSub, wb = (i < L) ? pk.b[min(i, L - 1)].word : wb,
-           wch = (i < L) ? pk.b[min(i, L - 1)].children : wch) {
+  if (ll.body) {
+    const float dl = K.dl, da = c.da, inv_dt = K.inv_dt, dt = K.dt;
+    const uint32_t wb = ll.wb;
     const vf4 qb = ld4(&pk.b[i]);  // .z inv_inertia[0], .w reach
-    Body b = m.body(i);
-    const float mass_i = m.at(m.lay.mass + i);
-    const uint32_t sig_hit = m.atu(m.lay.sig + 2 * i);
-    const int own = m.lay.wrench + 12 * i;
-    float Fx = m.at(own), Fz = m.at(own + 2), Ty = m.at(own + 4);
+    float Fx = fx, Fz = fz, Ty = tcy;
     {
-      const int nch = wb_children(wb);
-      for (int k0 = 0; k0 < K.max_children && k0 < 8; k0 += 2) {
-        const int r0 = (k0 < nch) ? m.lay.wrench + 12 * (int)((wch >> (4 * k0)) & 15u) + 6 : m.lay.zero;
-        const int r1 = (k0 + 1 < nch) ? m.lay.wrench + 12 * (int)((wch >> (4 * k0 + 4)) & 15u) + 6 : m.lay.zero;
-        const float fx0 = m.at(r0), fz0 = m.at(r0 + 2), t0 = m.at(r0 + 4), fx1 = m.at(r1), fz1 = m.at(r1 + 2), t1 = m.at(r1 + 4);
-        Fx = (Fx + fx0) + fx1; Fz = (Fz + fz0) + fz1; Ty = (Ty + t0) + t1;
+      if (K.max_children > 2) {
+        vf4 r[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r[k] = m.get_react1(ll.child[k]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { Fx += r[k].x; Fz += r[k].y; Ty += r[k].z; }
+      } else if (K.max_children > 0) {
+        const vf4 r0 = m.get_react1(ll.child[0]), r1 = m.get_react1(ll.child[1]);
+        Fx = (Fx + r0.x) + r1.x; Fz = (Fz + r0.y) + r1.y; Ty = (Ty + r0.z) + r1.z;
       }
+      if (K.max_children > 4)  // (no shipped model; wavefront-uniform)
+        for (int cc2 = tp.child_begin[i] + 4; cc2 < tp.child_begin[i + 1]; ++cc2) {
+          const vf4 r = m.get_react1(m.react_off(tp.child_idx[cc2]));
+          Fx += r.x; Fz += r.y; Ty += r.z;
+        }
     }
-    const float inv_m = __builtin_amdgcn_rcpf(mass_i), inv_i = qb.z;
+    const float inv_m = R.inv_m, inv_i = qb.z;
     float vx = b.v.x + (Fx * inv_m) * dt, vz = b.v.z + (Fz * inv_m + c.gravity_z) * dt;
     float om = b.w.y + (Ty * inv_i) * dt;
     // spring.collisions.resolve: this body's spheres vs the plane z = 0
@@ -1048,7 +1185,7 @@ static __device__ __forceinline__ void substep_planar(const carl_brax_sys_t& s, 
       cdw += inv_i * (rz * Jx - rx * imp);  // (r x J).y
       cnt += 1.0f;
     }
-    m.atu(m.lay.sig + 2 * i) = sig_hit * 33u + hit;
+    R.sig_hit = R.sig_hit * 33u + hit;
     vx *= dl; vz *= dl; om *= da;
     if (cnt > 0.0f) {
       const float ic = __builtin_amdgcn_rcpf(cnt);
@@ -1061,7 +1198,7 @@ static __device__ __forceinline__ void substep_planar(const carl_brax_sys_t& s, 
     const double inv = rsqrt_f64(w2 * w2 + y2 * y2);
     b.r.w = w2 * inv; b.r.y = y2 * inv;
     b.v.x = vx; b.v.z = vz; b.w.y = om;
-    m.put(i, b);
+    m.put_at(ll.own, b);
   }
   phase_sync();
 }
@@ -1087,7 +1224,7 @@ static __device__ __forceinline__ v3d system_com(const carl_brax_sys_t& s, const
 template <bool MULTI, bool TASK>
 // `com_in` / `mass_in`: the whole-body centre of mass and total mass when the caller has just formed them at this very
 // state (the step's forward reward of reward_on_com models: one 11-link pass less per Humanoid env step).
-static __device__ __forceinline__ void observe(const carl_brax_sys_t& s, const Packed& pk, const Lds& m, bool go,
+static __device__ __forceinline__ void observe(const carl_brax_sys_t& s, const Packed& pk, const JointX* jx, const Lds& m, bool go,
                                         bool zero_frc, const v3d* com_in = nullptr, float mass_in = 0.0f) {
   const int skip = s.exclude_current_positions;
   // q[from:] as sin ++ cos (inverted double pendulum): the raw angles are written to the sin rows and
@@ -1129,10 +1266,10 @@ static __device__ __forceinline__ void observe(const carl_brax_sys_t& s, const P
     } else {
       const Body bp = (P < 0) ? world_body() : m.body(P);
       const LinkA& rec = pk.a[i];
-      const vf4 q0 = ld4(&rec.ac[0]), q1 = ld4(&rec.ap[0]), q2 = ld4(&rec.rpl[0]), q3 = ld4(&rec.jrot[0]);
-      const JointRec la{V(q0.x, q0.y, q0.z), V(q1.x, q1.y, q1.z), qt{q2.x, q2.y, q2.z, q2.w}, qt{q3.x, q3.y, q3.z, q3.w},
-                        __float_as_uint(q0.w)};
-      const JointGeom g = joint_geometry<MULTI>(s, la, i, b, bp);
+      const JointXr X = load_jointx<MULTI>(jx[i]);
+      const vf4 q2 = ld4(&rec.rpl[0]);
+      const JointRec la{qt{q2.x, q2.y, q2.z, q2.w}, rec.word};
+      const JointGeom g = joint_geometry<MULTI>(s, la, X, i, b, bp);
       const int ns = s.n_slide[i];
       for (int k = 0; k < ns; ++k) {
         const v3d axd = qrot(bp.r, tod(f3(s.slide_axis[i][k])));
@@ -1529,6 +1666,7 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
   __shared__ carl_brax_sys_t s;
   __shared__ Topo tp;
   __shared__ Packed pk;
+  __shared__ JointX jx_lds[CARL_BRAX_MAX_LINKS];
   __shared__ int head_done[kMaxWavesPerWg3];  // fragment hand-over flags (MODE 1, see below)
   if (threadIdx.x < kMaxWavesPerWg3) head_done[threadIdx.x] = 0;
   extern __shared__ vf4 lds_dyn[];  // per wavefront: body records, then the float rows (16-byte aligned slices)
@@ -1563,13 +1701,16 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
     for (int k = (int)threadIdx.x; k < kWordsD; k += (int)blockDim.x) dd[k] = sd[k];
   }
   __syncthreads();
+  if ((int)threadIdx.x < s.n_links) expand_joint(s, pk, (int)threadIdx.x, jx_lds[threadIdx.x]);
+  __syncthreads();
+  const JointX* const jx = jx_lds;
   // kSub need not divide 64 (one lane per link: 7, 9, 11): the wavefront's spare lanes idle -- they
   // point at the last env's column, own no link (sub beyond every loop bound) and are never active
   const int tid = (int)threadIdx.x & (kLanes - 1), wave = (int)threadIdx.x >> 6;
   const bool lane_ok = tid < kEnvs * kSub;
   const Layout lay = Layout::make(s.n_links, s.n_dof, io_rows_of(s));
   char* const my_lds = reinterpret_cast<char*>(lds_dyn) + (size_t)wave * lay.bytes(kEnvs);  // this wavefront's slice
-  const Lds m{my_lds, reinterpret_cast<float*>(my_lds + lay.body_bytes(kEnvs)), lay,
+  const Lds m{my_lds, reinterpret_cast<float*>(my_lds + lay.rows_offset(kEnvs)), lay,
               lane_ok ? tid / kSub : kEnvs - 1, lane_ok ? tid % kSub : kLanes};
   const size_t n = (size_t)b.n_lanes;
   const int S = CARL_BRAX_LINK_RECORD * s.n_links;  // floats of the env's record in HBM
@@ -1614,7 +1755,7 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
       write_ctx_obs(b, m, n, env, r.cidx);
     }
     if (s.obs_extended) load_ctx<TASK>(s, b, m, r.cidx, go);  // com inertia / velocity use the env's masses
-    observe<MULTI, TASK>(s, pk, m, go, true);
+    observe<MULTI, TASK>(s, pk, jx, m, go, true);
     if (reset_obs != nullptr) record_out(reset_obs, (size_t)env, s.obs_dim, m, go);
     return;
   } else {
@@ -1639,9 +1780,12 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
     const int n_frag = piece.n_frag;
     const float dt_env = s.dt * (float)s.n_frames;
     const SubK K = make_subk(s, tp, pk);
-    const LinkWords W = load_words(pk, K, m.sub);
+    const LaneLink ll = make_lane_link(pk, K, m);
     const int n_frames = __builtin_amdgcn_readfirstlane(s.n_frames);
-    for (int k = m.sub; k < 6; k += kSub) m.at(m.lay.zero + k) = 0.0f;  // (the first phase_sync below orders it)
+    if (tid < kFixedBytes / 4) {  // the world record and the zero reaction record (the first phase_sync below orders it)
+      // world: pose (0, 0, 0 | 1, 0, 0, 0) as doubles, velocities 0; double 1.0 = words (0, 0x3ff00000) at double index 3
+      reinterpret_cast<uint32_t*>(m.rec + m.world_off())[tid] = (tid == 7) ? 0x3ff00000u : 0u;
+    }
     for (int fi = 0; fi < n_frag; ++fi) {
     const Fragment frag = fragment_of(piece, T, fi);
     const int grp = frag.grp, t_lo = frag.t_lo, t_hi = frag.t_hi;
@@ -1680,7 +1824,6 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
         ctrl += u * u;
       }
       for (int d = m.sub; d < s.n_dof; d += kSub) m.at(m.lay.tau + d) = 0.0f;
-      for (int k = m.sub; k < 2 * s.n_links; k += kSub) m.atu(m.lay.sig + k) = 0u;  // this step's branch record
       phase_sync();
       for (int k = m.sub; k < s.n_act; k += kSub)  // act_dof entries are distinct (checked by the host)
         m.at(m.lay.tau + s.act_dof[k]) += s.act_gear[k] * fminf(fmaxf(m.at(m.lay.io + k), s.act_lo[k]), s.act_hi[k]);
@@ -1688,10 +1831,27 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
       float msum;
       // forward progress and root height: pose differences, float64
       const double x0 = s.reward_on_com ? system_com(s, m, &msum).x : m.pos(0).x - qrot(m.rot(0), tod(f3(s.com[0]))).x;
-      if constexpr (PLANAR) {
-        for (int f = 0; f < n_frames; ++f) substep_planar<TASK>(s, tp, pk, K, W, r.ctx, m);
-      } else {
-        for (int f = 0; f < n_frames; ++f) substep<MULTI, TASK>(s, tp, pk, K, W, r.ctx, m);
+      {  // the n_frames substeps, the lane's body / torques / branch hashes in registers (StepRegs)
+        StepRegs<MULTI> R;
+        R.b = m.body_at(ll.own);
+        {
+          const int d = wa_dof(ll.wa) + wa_slides(ll.wa);  // the joint's first hinge dof
+#pragma unroll
+          for (int k = 0; k < (MULTI ? 3 : 1); ++k) R.tau[k] = m.at(m.lay.tau + min(d + k, s.n_dof - 1));
+        }
+        R.sig_hit = 0u;
+        R.sig_lim = 0u;
+        R.inv_m = __builtin_amdgcn_rcpf(m.at(m.lay.mass + ll.i));  // v_rcp_f32 (1 ulp): the phase is issue-bound
+        if constexpr (PLANAR) {
+          for (int f = 0; f < n_frames; ++f) substep_planar<TASK>(s, tp, pk, jx, K, ll, r.ctx, m, R);
+        } else {
+          for (int f = 0; f < n_frames; ++f) substep<MULTI, TASK>(s, tp, pk, jx, K, ll, r.ctx, m, R);
+        }
+        if (ll.body) {  // this step's branch record, per link
+          m.atu(m.lay.sig + 2 * ll.i) = R.sig_hit;
+          m.atu(m.lay.sig + 2 * ll.i + 1) = R.sig_lim;
+        }
+        phase_sync();
       }
       const v3d c1 = qrot(m.rot(0), tod(f3(s.com[0])));
       v3d com1 = D(0, 0, 0);
@@ -1710,7 +1870,7 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
       }
       r.elapsed += 1;
       const bool truncated = (b.max_episode_steps > 0) && (r.elapsed >= b.max_episode_steps);
-      observe<MULTI, TASK>(s, pk, m, active, false, s.reward_on_com ? &com1 : nullptr, msum);
+      observe<MULTI, TASK>(s, pk, jx, m, active, false, s.reward_on_com ? &com1 : nullptr, msum);
       if (s.healthy_q_index >= 0) {  // torso pitch (hopper, walker2d) / pole angle: read from the observation
         const float qa = m.at(m.lay.io + s.healthy_q_index - s.exclude_current_positions);
         healthy = healthy && (qa >= s.healthy_q_lo) && (qa <= s.healthy_q_hi);
@@ -1804,7 +1964,7 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
             write_ctx_obs(b, m, n, env, r.cidx);
           }
           }
-          observe<MULTI, TASK>(s, pk, m, done, true);
+          observe<MULTI, TASK>(s, pk, jx, m, done, true);
         }
       }
       record_out(io.obs + step_off * s.obs_dim, (size_t)env, s.obs_dim, m, active);

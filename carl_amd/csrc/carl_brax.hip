@@ -114,11 +114,16 @@ constexpr bool brax_instantiated(int k, bool multi, bool task) {
   return multi ? (k == 2 || k == 11 || k == 16) : (k == 4 || k == 7 || k == 8 || k == 9 || k == 16);
 }
 bool brax_is_task(const carl_brax_sys_t* sh) { return sh->target_link > 0 || sh->push_link > 0; }
-bool brax_is_multi(const carl_brax_sys_t* sh) {  // any link with 0, 2 or 3 hinges (Euler-angle path)?
+// The general kernels (MULTI): any link with 0, 2 or 3 hinges (Euler-angle path), or a link frame that is rotated against
+// its parent's (link_rot != identity: the relative rotation of the joint frames then needs the full 4 x 4 map,
+// brax_kernels.hip.h: JointX) -- of the shipped models Humanoid / HumanoidStandup have both.
+bool brax_is_multi(const carl_brax_sys_t* sh) {
   bool multi = false;
   for (int i = 0; i < sh->n_links; ++i) {
     const bool free_root = sh->parent[i] < 0 && sh->n_link_dof[i] == 6;
     multi |= !free_root && sh->n_link_dof[i] - sh->n_slide[i] != 1;
+    multi |= !free_root && !(sh->link_rot[i][0] == 1.0f && sh->link_rot[i][1] == 0.0f && sh->link_rot[i][2] == 0.0f &&
+                             sh->link_rot[i][3] == 0.0f);
   }
   return multi;
 }
@@ -154,8 +159,9 @@ bool brax_is_planar(const carl_brax_sys_t* sh) {
 int brax_lanes_per_env(int n_links, bool multi, bool task, int n_lanes, int hint) {
   int want = n_links;
   bool pinned = false;
-  if (hint > 0) {  // sys.lanes_per_env (autotuned by the caller)
-    want = hint;
+  if (hint > 0) {  // sys.lanes_per_env (autotuned by the caller); never narrower than one lane per link (the kernels'
+                   // mapping since round 5: a lane keeps its link's body in registers through the substeps)
+    want = hint > n_links ? hint : n_links;
     pinned = true;
   }
   int k = 16;
@@ -189,7 +195,8 @@ int launch_brax(const carl_batch_t* b, const carl_brax_sys_t* sd, const carl_bra
   const carl::brax::Layout lay = carl::brax::Layout::make(sh->n_links, sh->n_dof, carl::brax::io_rows_of(*sh));
   // independent wavefronts per workgroup, sharing the LDS copy of the static tables: as many (<= kMaxWavesPerWg) as fit
   // (the kernel's static LDS: model table, prepared topology / records, the fragment hand-over flags)
-  const size_t static_lds = sizeof(carl_brax_sys_t) + sizeof(carl::brax::Prepared) + sizeof(int) * carl::brax::kMaxWavesPerWg3;
+  const size_t static_lds = sizeof(carl_brax_sys_t) + sizeof(carl::brax::Prepared) +
+                            (size_t)carl::brax::kJointXBytes * CARL_BRAX_MAX_LINKS + sizeof(int) * carl::brax::kMaxWavesPerWg3;
   const size_t wave_bytes = lay.bytes(envs);
   if (wave_bytes + static_lds > 160 * 1024)
     return fail(CARL_ERR_UNSUPPORTED, "%s: model needs %zu B of LDS per wavefront", who, wave_bytes);
@@ -355,8 +362,8 @@ int carl_brax_lane_widths(const carl_brax_sys_t* sys_host, int32_t* widths_out, 
   }
   const bool multi = brax_is_multi(sys_host);
   int n = 0;
-  for (int w : kBraxWidths)
-    if (brax_instantiated(w, multi, brax_is_task(sys_host)) && n < cap) widths_out[n++] = w;
+  for (int w : kBraxWidths)  // one lane per link or wider
+    if (w >= sys_host->n_links && brax_instantiated(w, multi, brax_is_task(sys_host)) && n < cap) widths_out[n++] = w;
   return n;
 }
 

@@ -149,7 +149,7 @@ def test_brax_and_sampler_entry_points_validate_arguments():
     assert lib.carl_brax_step(C.byref(b), None, C.byref(s), None, None) == -1  # sys_dev NULL
     widths = (C.c_int32 * 16)()
     n = lib.carl_brax_lane_widths(C.byref(s), widths, 16)
-    assert [widths[i] for i in range(n)] == [4, 7, 8, 9, 16]
+    assert [widths[i] for i in range(n)] == [9, 16]  # one lane per link (Ant: 9 links) or wider
     assert lib.carl_brax_lane_widths(None, widths, 16) == 0
     spec = (_lib.FeatureSpec * 1)()
     spec[0].kind = 99

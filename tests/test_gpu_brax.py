@@ -649,7 +649,7 @@ def test_lane_width_is_a_pure_scheduling_choice_and_autotune_restores_state(devi
             assert all(torch.equal(a, b) for a, b in zip(ref, cur)), hint
     s2 = ant_sys(NAMES)
     eng = engine(s2, context_rows(rng, 512), 512, device, selector=O.SEL_STATIC, seed=1, ctx_idx0=np.arange(512))
-    assert eng.lane_widths() == [4, 7, 8, 9, 16]
+    assert eng.lane_widths() == [9, 16]  # one lane per link or wider
     eng.reset()
     eng.step(torch.zeros((512, 8), device=device))
     before = {k: getattr(eng, k).clone() for k in ("state", "elapsed", "episode", "n_calls", "ep_return", "obs")}
