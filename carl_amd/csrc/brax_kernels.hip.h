@@ -76,6 +76,39 @@ __host__ __device__ constexpr int max_waves_per_wg(bool multi) { return multi ? 
 // 16, chosen per model and batch size by the host (carl_amd.hip: brax_lanes_per_env)
 constexpr float kPiF = 3.14159265358979323846f;
 
+// Region clocks (measurement build only: -DCARL_BRAX_PROFILE, tools/brax_region_profile.py): s_memtime at the region
+// boundaries of the step kernel, summed per wavefront in scalar registers and added to a device array at the end; the
+// product build compiles every mark to nothing.  Results do not change (the marks only read the clock).
+enum ProfRegion { kProfLoad = 0, kProfPrologue, kProfJoints, kProfBodies, kProfEpilogue, kProfObserve, kProfReward,
+                  kProfDone, kProfOutput, kProfStore, kProfBodySum, kProfContacts, kProfRegions };
+#ifdef CARL_BRAX_PROFILE
+__device__ unsigned long long g_brax_prof[kProfRegions + 1];  // [kProfRegions]: wavefronts
+struct Prof {
+  uint64_t t, acc[kProfRegions];
+  __device__ __forceinline__ void start() {
+    for (int k = 0; k < kProfRegions; ++k) acc[k] = 0;
+    t = __builtin_amdgcn_s_memtime();
+  }
+  __device__ __forceinline__ void mark(int k) {
+    const uint64_t n = __builtin_amdgcn_s_memtime();
+    acc[k] += n - t;
+    t = n;
+  }
+  __device__ __forceinline__ void flush(bool lane0) {
+    if (lane0) {
+      for (int k = 0; k < kProfRegions; ++k) atomicAdd(&g_brax_prof[k], (unsigned long long)acc[k]);
+      atomicAdd(&g_brax_prof[kProfRegions], 1ull);
+    }
+  }
+};
+#else
+struct Prof {
+  __device__ __forceinline__ void start() {}
+  __device__ __forceinline__ void mark(int) {}
+  __device__ __forceinline__ void flush(bool) {}
+};
+#endif
+
 struct v3 {
   float x, y, z;
 };
@@ -211,21 +244,25 @@ struct LaneCtx {
 // consecutive floats, one per env.
 constexpr int kBodyBytes = 80;
 // Behind a wavefront's body records: the WORLD as a body record (what a world-jointed link reads as its parent: origin,
-// identity rotation, at rest) and a 32-byte ZERO reaction record (what a link without a k-th child sums in the body phase),
-// so that neither needs a select in the substep.  Written once per launch.
-constexpr int kWorldRecBytes = kBodyBytes, kZeroRecBytes = 32, kFixedBytes = kWorldRecBytes + kZeroRecBytes;
+// identity rotation, at rest; written once per launch), then one 32-byte CONTEXT record per env -- gravity_z, friction,
+// elasticity, exp(ang_damping dt) | joint-stiffness scale -- which the phases read instead of holding five registers
+// per lane through the substeps.
+constexpr int kWorldRecBytes = kBodyBytes, kCtxRecBytes = 32;
 // A joint's reaction on its parent, handed from the joint phase to the body phase: (force 3, torque 3) as two 16-byte
 // pieces of a 48-byte record per (env, link) -- 48 = 3 x 4 banks, 3 coprime to 16: the lanes of a ds_read_b128 group land
-// on different bank quads.  The records OVERLAY the 12 L wrench rows (same size), which forward kinematics and observe
-// use as scratch between substep loops.
+// on different bank quads.  Record L of an env is kept at ZERO: what a link without a k-th child sums in the body phase
+// (LinkB::children names it), so no select is needed.  The records OVERLAY the wrench rows, which forward kinematics and
+// observe use as scratch between substep loops (the zero records are re-written before every substep loop).
 constexpr int kReactBytes = 48;
-constexpr int kJointXBytes = 192;  // sizeof(Group<>::JointX): the joint phase's float64 constants per link, static LDS
+constexpr int kLinkRecBytes = 368;  // sizeof(Group<>::LinkRec): the substep's per-link constants, static LDS
+constexpr int kStashRows = 12;     // the env's episode scalars, parked in LDS while the substeps run (run(): stash)
 struct Layout {
   int L;       // links: body records per env
-  int wrench;  // 12 * L rows: the substep's reaction records (48 bytes per (env, link)); scratch rows of FK / observe
+  int wrench;  // 12 * (L + 1) rows: the substep's reaction records (48 bytes per (env, link)); scratch rows of FK / observe
   int mass;    // L rows (effective mass per link, context-scaled)
   int sig;     // 2 * L rows (uint32): per-link hash of the step's contact / limit branch decisions
   int goal;    // 3 rows: push task, the env's goal position (context or model default)
+  int stash;   // kStashRows rows
   int tau;     // n_dof rows
   int io;      // staging of the env's action / observation record, and of (q, qd) in reset
   int total;   // float rows
@@ -233,17 +270,20 @@ struct Layout {
     Layout l;
     l.L = L;
     l.wrench = 0;
-    l.mass = l.wrench + 12 * L;
+    l.mass = l.wrench + 12 * (L + 1);
     l.sig = l.mass + L;
     l.goal = l.sig + 2 * L;
-    l.tau = l.goal + 3;
+    l.stash = l.goal + 3;
+    l.tau = l.stash + kStashRows;
     l.io = l.tau + n_dof;
     l.total = l.io + io_rows;
     return l;
   }
   // bytes of dynamic LDS for `envs` envs per workgroup
   __host__ __device__ size_t body_bytes(int envs) const { return (size_t)kBodyBytes * L * envs; }
-  __host__ __device__ size_t rows_offset(int envs) const { return body_bytes(envs) + kFixedBytes; }  // multiple of 16
+  __host__ __device__ size_t rows_offset(int envs) const {  // multiple of 16
+    return body_bytes(envs) + kWorldRecBytes + (size_t)kCtxRecBytes * envs;
+  }
   __host__ __device__ size_t bytes(int envs) const {  // per wavefront, rounded up to 16 (the next wavefront's records)
     return (rows_offset(envs) + (size_t)total * 4 * envs + 15) & ~(size_t)15;
   }
@@ -322,7 +362,7 @@ __host__ __device__ inline int wa_hinges(uint32_t w) { return (int)((w >> 8) & 7
 __host__ __device__ inline int wa_dof(uint32_t w) { return (int)((w >> 11) & 31u); }
 struct alignas(16) LinkB {  // body phase: 4 words
   uint32_t word;            // free root (1) | isotropic inertia (1) | children (4) | first sphere (6) | spheres (6)
-  uint32_t children;        // the first 8 children, 4 bits each, ascending (the oracle's summation order)
+  uint32_t children;        // the first 4 children, one byte each, ascending (the oracle's summation order); none: n_links
   float inv_i0;             // inv_inertia[0] (all there is to an isotropic inertia: R diag(c) R^T = c)
   float reach;              // max over the link's spheres of |centre - COM| + radius (-1: none)
 };
@@ -375,7 +415,8 @@ inline void build_packed_host(const carl_brax_sys_t& s, const Topo& t, Packed& p
     B.word = (free_root ? kWbFree : 0u) | (iso ? kWbIso : 0u) | ((uint32_t)nch << 2) | ((uint32_t)t.coll_begin[i] << 6) |
              ((uint32_t)nsp << 12);
     B.children = 0u;
-    for (int k = 0; k < nch && k < 8; ++k) B.children |= (uint32_t)t.child_idx[t.child_begin[i] + k] << (4 * k);
+    for (int k = 0; k < 4; ++k)
+      B.children |= (uint32_t)(k < nch ? t.child_idx[t.child_begin[i] + k] : s.n_links) << (8 * k);
     B.inv_i0 = s.inv_inertia[i][0];
     float reach = -1.0f;
     for (int kk = t.coll_begin[i]; kk < t.coll_begin[i + 1]; ++kk) {
@@ -474,9 +515,8 @@ struct Lds {
   __device__ __forceinline__ qtd rot(int i) const { return qtd{pd(i, 3), pd(i, 4), pd(i, 5), pd(i, 6)}; }
   __device__ __forceinline__ int body_off(int i) const { return (env * lay.L + i) * kBodyBytes; }
   __device__ __forceinline__ int world_off() const { return kEnvs * lay.L * kBodyBytes; }  // the world record (Layout)
-  __device__ __forceinline__ Body body_at(int off) const {
+  static __device__ __forceinline__ Body body_of(const char* q) {
     typedef double vd2 __attribute__((ext_vector_type(2)));
-    const char* q = rec + off;
     const vd2 a = *reinterpret_cast<const vd2*>(q), b2 = *reinterpret_cast<const vd2*>(q + 16),
               c2 = *reinterpret_cast<const vd2*>(q + 32);
     const vf4 d = *reinterpret_cast<const vf4*>(q + 48), e = *reinterpret_cast<const vf4*>(q + 64);
@@ -488,11 +528,10 @@ struct Lds {
     b.w = V(e.y, e.z, e.w);
     return b;
   }
-  __device__ __forceinline__ Body body(int i) const { return body_at(body_off(i)); }
-  __device__ __forceinline__ void put_at(int off, const Body& b) const {
+  __device__ __forceinline__ Body body(int i) const { return body_of(rec + body_off(i)); }
+  static __device__ __forceinline__ void put_body(char* q, const Body& b) {
     typedef double vd2 __attribute__((ext_vector_type(2)));
     typedef float vf2 __attribute__((ext_vector_type(2)));
-    char* q = rec + off;
     *reinterpret_cast<vd2*>(q) = vd2{b.p.x, b.p.y};
     *reinterpret_cast<vd2*>(q + 16) = vd2{b.p.z, b.r.w};
     *reinterpret_cast<vd2*>(q + 32) = vd2{b.r.x, b.r.y};
@@ -500,24 +539,23 @@ struct Lds {
     *reinterpret_cast<vf4*>(q + 48) = vf4{rz.x, rz.y, b.v.x, b.v.y};
     *reinterpret_cast<vf4*>(q + 64) = vf4{b.v.z, b.w.x, b.w.y, b.w.z};
   }
-  __device__ __forceinline__ void put(int i, const Body& b) const { put_at(body_off(i), b); }
-  // reaction records (kReactBytes; byte offsets from the float rows; the zero record sits just below them)
-  __device__ __forceinline__ int react_off(int i) const { return (env * lay.L + i) * kReactBytes; }
-  __device__ __forceinline__ int zero_off() const { return -kZeroRecBytes; }
-  __device__ __forceinline__ void put_react(int off, v3 f, v3 t) const {
-    char* q = reinterpret_cast<char*>(base) + off;
+  __device__ __forceinline__ void put(int i, const Body& b) const { put_body(rec + body_off(i), b); }
+  // reaction records (kReactBytes; byte offsets from the float rows)
+  __device__ __forceinline__ int react_off(int i) const { return (env * (lay.L + 1) + i) * kReactBytes; }
+  // the env's context record (Layout): just below the float rows
+  __device__ __forceinline__ const float* ctx_rec() const {
+    return reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) - (kEnvs - env) * kCtxRecBytes);
+  }
+  static __device__ __forceinline__ void put_react(char* q, v3 f, v3 t) {
     *reinterpret_cast<vf4*>(q) = vf4{f.x, f.y, f.z, t.x};
     *reinterpret_cast<vf4*>(q + 16) = vf4{t.y, t.z, 0.0f, 0.0f};
   }
   // planar models: (force x, force z, torque y) in the record's first piece
-  __device__ __forceinline__ void put_react1(int off, float fx, float fz, float ty) const {
-    *reinterpret_cast<vf4*>(reinterpret_cast<char*>(base) + off) = vf4{fx, fz, ty, 0.0f};
+  static __device__ __forceinline__ void put_react1(char* q, float fx, float fz, float ty) {
+    *reinterpret_cast<vf4*>(q) = vf4{fx, fz, ty, 0.0f};
   }
-  __device__ __forceinline__ vf4 get_react1(int off) const {
-    return *reinterpret_cast<const vf4*>(reinterpret_cast<const char*>(base) + off);
-  }
-  __device__ __forceinline__ void get_react(int off, v3& f, v3& t) const {
-    const char* q = reinterpret_cast<const char*>(base) + off;
+  static __device__ __forceinline__ vf4 get_react1(const char* q) { return *reinterpret_cast<const vf4*>(q); }
+  static __device__ __forceinline__ void get_react(const char* q, v3& f, v3& t) {
     const vf4 a = *reinterpret_cast<const vf4*>(q), b2 = *reinterpret_cast<const vf4*>(q + 16);
     f = V(a.x, a.y, a.z);
     t = V(a.w, b2.x, b2.y);
@@ -537,12 +575,6 @@ static __device__ __forceinline__ void phase_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-static __device__ __forceinline__ v3 apply_inv_inertia(const carl_brax_sys_t& s, int i, qt r, v3 t, bool iso, float inv_i0) {
-  if (iso) return t * inv_i0;  // every shipped model: spring_inertia_scale = 1 (inv_i0 = inv_inertia[i][0])
-  const v3 l = qrot(qconj(r), t);
-  return qrot(r, V(l.x * s.inv_inertia[i][0], l.y * s.inv_inertia[i][1], l.z * s.inv_inertia[i][2]));
 }
 
 // first column of the rotation matrix of q = q rotating e_x
@@ -570,8 +602,13 @@ struct JointGeom {
   float ang[3], rate[3];  // ... Euler x-y-z angles (third signed by dof_sign3) and their rates
 };
 
-// Per-link constants of the joint phase that are float64, or derived: expanded ON THE DEVICE once per workgroup
-// (expand_joint below; the host-built Packed travels as a kernel argument and stays compact).
+// Everything the substep's two phases need to know about a link, as ONE record per link in static LDS, expanded ON THE
+// DEVICE once per workgroup (expand_link below; the host-built Packed travels as a kernel argument and stays compact).
+// One record = one base address per lane: every field is a ds_read with an immediate offset.  (The phases used to pick
+// their constants from a dozen arrays -- LinkA, LinkB, the float64 block, the model table's dof_* / slide_axis /
+// inv_inertia / dof_sign3 rows -- and the compiler kept one hoisted address register per array and lane: the substep loop
+// ran out of registers and reloaded them from scratch memory.)
+//   ac, ap: joint anchor relative to the child's / parent's COM, widened (float64 operands of the anchor separation)
 //   G: the relative rotation of the two joint frames is LINEAR in q1 = conj(r_parent) (x) r_child:
 //        rel = conj(r_parent (x) rpl) (x) (r_child (x) joint_rot) = conj(rpl) (x) q1 (x) joint_rot = G q1
 //      with G = L(conj(rpl)) R(joint_rot), a constant 4 x 4 matrix: one float64 quaternion product and one matrix-vector
@@ -581,29 +618,36 @@ struct JointGeom {
 //        G00 | G11 G12 G13 | G21 G22 G23 | G31 G32 G33 || G01 G02 G03 | G10 G20 G30
 //      built from the float32 table values widened to float64, i.e. the same numbers the float64 restatement multiplies.
 //   axc: the hinge axis R(joint_rot) e_x in the child's frame (x_c = r_child rotating axc: float32 is enough for a direction)
-struct alignas(16) JointX {
-  double ac[3], ap[3];
-  double G[16];
-  float axc[3], k_pos;
+//   dof[k]: damping, stiffness, lower, upper bound of the joint's k-th dof IN JOINT ORDER (slides first, then hinges)
+struct alignas(16) LinkRec {
+  double ac[3], ap[3];                        //   0
+  double G[16];                               //  48
+  float axc[3], k_pos;                        // 176
+  float rpl[4];                               // 192: parent-side joint frame in the parent frame: link_rot (x) joint_rot
+  float k_vel, k_limit, k_ang_damp, sign3;    // 208
+  float dof[5][4];                            // 224
+  float slide_axis[2][4];                     // 304: prismatic axes in the parent frame
+  float inv_i[3], reach;                      // 336: body phase: inverse principal moments (link frame); sphere reach (-1: none)
+  float axis_sign, pad[3];                    // 352: planar models: +-1, the joint frame's x axis is +-y of the link frame
 };
-static_assert(sizeof(JointX) == kJointXBytes, "JointX is read as twelve 16-byte pieces");
+static_assert(sizeof(LinkRec) == kLinkRecBytes, "LinkRec is read in 16-byte pieces at fixed offsets");
 
-// MULTI: the model has links with 0, 2 or 3 hinges (Humanoid; a pure slider) or rotated link frames; false compiles the
-// Euler-angle path and the general G out (Ant, Halfcheetah: fewer registers, shorter joint phase).
+// MULTI: the general kernels -- links with 0, 2 or 3 hinges (Humanoid), prismatic dofs, or rotated link frames; false
+// compiles the Euler-angle path, the slides and the general G out (Ant: a free root and single hinges).
 // Everything that is a difference of the two poses is formed in float64 and rounded ONCE: the anchor
 // separation `ed`, the relative rotation of the joint frames, the axis-alignment term and the joint angles.
-// `la` / `X`: the link's joint records, already in registers (vector LDS reads of the caller).
 struct JointRec {
   qt rpl;
   uint32_t word;
+  float sign3;
 };
-struct JointXr {  // JointX in registers
+struct JointXr {  // the float64 block of a LinkRec in registers
   v3d ac, ap;
   double G[16];
   v3 axc;
 };
 template <bool MULTI>
-static __device__ __forceinline__ JointXr load_jointx(const JointX& X) {
+static __device__ __forceinline__ JointXr load_jointx(const LinkRec& X) {
   typedef double vd2 __attribute__((ext_vector_type(2)));
   const vd2* p = reinterpret_cast<const vd2*>(&X);
   JointXr r;
@@ -622,8 +666,7 @@ static __device__ __forceinline__ JointXr load_jointx(const JointX& X) {
   return r;
 }
 template <bool MULTI>
-static __device__ __forceinline__ JointGeom joint_geometry(const carl_brax_sys_t& s, const JointRec& la, const JointXr& X, int i,
-                                                    const Body& bc, const Body& bp) {
+static __device__ __forceinline__ JointGeom joint_geometry(const JointRec& la, const JointXr& X, const Body& bc, const Body& bp) {
   JointGeom g;
   {
     const v3d rc_off = qrot(bc.r, X.ac), rp_off = qrot(bp.r, X.ap);
@@ -685,8 +728,7 @@ static __device__ __forceinline__ JointGeom joint_geometry(const carl_brax_sys_t
   g.thetadot = dot(g.x_c, g.wrel);
   if (MULTI) {
     const float al = (float)a1, be = (float)asin_f64(R02), ga = (float)atan2_f64(-R01, R00);
-    const float sg3 = s.dof_sign3[i];
-    const float sg = (nr == 3) ? sg3 : 1.0f;
+    const float sg = (nr == 3) ? la.sign3 : 1.0f;
     g.ang[0] = al; g.ang[1] = be; g.ang[2] = sg * ga;
     g.axis[0] = g.x_p;
     // The second and third hinge axes, rp (x) Rx(al) e_y and rp (x) Rx(al) Ry(be) e_z = rp (x) (0, cos al, sin al) and
@@ -799,21 +841,30 @@ static __device__ __forceinline__ vf4 ld4(const void* p) { return *reinterpret_c
 
 // ONE LANE PER LINK: lane `sub` of an env owns link sub -- its joint (the one to its parent) in the joint phase and
 // its body in the body phase (kSub >= n_links; the host never launches a narrower group).  What a lane needs to find
-// its data is fixed for the launch and kept in registers: a phase starts with every address known and issues all its
-// loads at once.
+// its data is fixed for the launch and kept in registers AS ADDRESSES: a phase starts with every address known, issues
+// all its loads at once, and every access is base register + immediate offset.
 struct LaneLink {
-  int i;            // the lane's link (idle lanes: clamped to L - 1, `body` false)
-  bool body;        // the lane owns a body (sub < L)
-  bool joint;       // ... and that link hangs on a joint (everything but a free root)
-  uint32_t wa, wb;  // the index words of LinkA / LinkB
-  int own, par;     // byte offsets (from the wavefront's records) of the own body record, the parent's (the world record)
-  int react;        // byte offset (from the float rows) of the own joint's reaction record
-  int child[4];     // ... of the first four children's reaction records, ascending (absent: the zero record)
+  int i;                  // the lane's link (idle lanes: clamped to L - 1, `body` false)
+  bool body;              // the lane owns a body (sub < L)
+  bool joint;             // ... and that link hangs on a joint (everything but a free root)
+  uint32_t wa, wb;        // the index words of LinkA / LinkB
+  uint32_t wch;           // LinkB::children: the first four children's links, a byte each (none: L, the env's zero record)
+  const LinkRec* lr;      // the link's constants
+  const Sphere* sph;      // the link's first sphere
+  char* own;              // the own body record
+  const char* par;        // the parent's (the world record)
+  char* react;            // the own joint's reaction record
+  const char* react_env;  // the env's first reaction record
+  const float* ctx;       // the env's context record
+  const float* tau;       // the tau row of the joint's first dof (stride kEnvs floats per dof)
+  __device__ __forceinline__ const char* child(int k) const {  // the k-th child's reaction record
+    return react_env + ((wch >> (8 * k)) & 255u) * (uint32_t)kReactBytes;
+  }
 };
 
 // What a lane carries in registers through the n_frames substeps of an env step: its body (the LDS record is rewritten
 // at the end of every body phase -- the children read it in the next joint phase -- but the owner never reads it back),
-// the joint's actuator torques, the branch hashes and 1 / mass.
+// the joint's hinge torques, the branch hashes and 1 / mass.
 template <bool MULTI>
 struct StepRegs {
   Body b;
@@ -822,7 +873,7 @@ struct StepRegs {
   float inv_m;
 };
 
-static __device__ __forceinline__ LaneLink make_lane_link(const Packed& pk, const SubK& K, const Lds& m) {
+static __device__ __forceinline__ LaneLink make_lane_link(const Packed& pk, const LinkRec* lrec, const SubK& K, const Lds& m) {
   LaneLink ll;
   const bool body = m.sub < K.L;
   const int i = body ? m.sub : K.L - 1;
@@ -830,20 +881,22 @@ static __device__ __forceinline__ LaneLink make_lane_link(const Packed& pk, cons
   ll.body = body;
   ll.wa = body ? pk.a[i].word : kWaFree;
   ll.wb = body ? pk.b[i].word : 0u;
-  const uint32_t wch = body ? pk.b[i].children : 0u;
+  ll.wch = body ? pk.b[i].children : (uint32_t)K.L * 0x01010101u;
   ll.joint = body && (ll.wa & kWaFree) == 0u;
   const int P = wa_parent(ll.wa);
-  ll.own = m.body_off(i);
-  ll.par = P < 0 ? m.world_off() : m.body_off(P);
-  ll.react = m.react_off(i);
-  const int nch = wb_children(ll.wb);
-#pragma unroll
-  for (int k = 0; k < 4; ++k) ll.child[k] = (k < nch) ? m.react_off((int)((wch >> (4 * k)) & 15u)) : m.zero_off();
+  ll.lr = lrec + i;
+  ll.sph = pk.sph + wb_first_sphere(ll.wb);
+  ll.own = m.rec + m.body_off(i);
+  ll.par = m.rec + (P < 0 ? m.world_off() : m.body_off(P));
+  ll.react = reinterpret_cast<char*>(m.base) + m.react_off(i);
+  ll.react_env = reinterpret_cast<const char*>(m.base) + m.react_off(0);
+  ll.ctx = m.ctx_rec();
+  ll.tau = &m.at(m.lay.tau + wa_dof(ll.wa));
   return ll;
 }
 
-// JointX of link i from the host-built record (one lane per link, once per workgroup)
-static __device__ __forceinline__ void expand_joint(const carl_brax_sys_t& s, const Packed& pk, int i, JointX& out) {
+// LinkRec of link i from the model table and the host-built records (one lane per link, once per workgroup)
+static __device__ __forceinline__ void expand_link(const carl_brax_sys_t& s, const Packed& pk, int i, LinkRec& out) {
   const LinkA& A = pk.a[i];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
@@ -869,67 +922,97 @@ static __device__ __forceinline__ void expand_joint(const carl_brax_sys_t& s, co
   const v3 ax = xaxis(f4(A.jrot));
   out.axc[0] = ax.x; out.axc[1] = ax.y; out.axc[2] = ax.z;
   out.k_pos = A.k_pos;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) out.rpl[k] = A.rpl[k];
+  out.k_vel = A.k_vel; out.k_limit = A.k_limit; out.k_ang_damp = A.k_ang_damp;
+  out.sign3 = s.dof_sign3[i];
+  const bool free_root = (A.word & kWaFree) != 0u;
+  const int d0 = wa_dof(A.word), nd = free_root ? 0 : wa_slides(A.word) + wa_hinges(A.word);
+  for (int k = 0; k < 5; ++k) {
+    const int d = min(d0 + k, CARL_BRAX_MAX_DOF - 1);
+    const bool on = k < nd;
+    out.dof[k][0] = on ? s.dof_damping[d] : 0.0f;
+    out.dof[k][1] = on ? s.dof_stiffness[d] : 0.0f;
+    out.dof[k][2] = on ? s.dof_lo[d] : 0.0f;
+    out.dof[k][3] = on ? s.dof_hi[d] : 0.0f;
+  }
+  for (int k = 0; k < 2; ++k) {
+    out.slide_axis[k][0] = s.slide_axis[i][k][0]; out.slide_axis[k][1] = s.slide_axis[i][k][1];
+    out.slide_axis[k][2] = s.slide_axis[i][k][2]; out.slide_axis[k][3] = 0.0f;
+  }
+  out.inv_i[0] = s.inv_inertia[i][0]; out.inv_i[1] = s.inv_inertia[i][1]; out.inv_i[2] = s.inv_inertia[i][2];
+  out.reach = pk.b[i].reach;
+  out.axis_sign = A.axis_sign;
+  out.pad[0] = out.pad[1] = out.pad[2] = 0.0f;
+}
+
+// R diag(inv_i) R^T t; every shipped model has isotropic effective inertia (spring_inertia_scale = 1): inv_i[0] t
+static __device__ __forceinline__ v3 apply_inv_inertia(const LinkRec* lr, qt r, v3 t, bool iso, float inv_i0) {
+  if (iso) return t * inv_i0;
+  const v3 l = qrot(qconj(r), t);
+  return qrot(r, V(l.x * lr->inv_i[0], l.y * lr->inv_i[1], l.z * lr->inv_i[2]));
 }
 
 template <bool MULTI, bool TASK>
-static __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const Topo& tp, const Packed& pk, const JointX* jx,
-                                        const SubK& K, const LaneLink& ll, const LaneCtx& c, const Lds& m,
-                                        StepRegs<MULTI>& R) {
-  const int i = ll.i;
+static __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const Topo& tp, const SubK& K, const LaneLink& ll,
+                                        const Lds& m, StepRegs<MULTI>& R, Prof& prof) {
   Body& b = R.b;
+  const LinkRec* const lr = ll.lr;
   // phase A -- spring.joints.resolve, the lane's own joint.  The wrench on the child stays in registers (the same lane
   // applies it in the body phase); only the reaction on the parent goes through LDS.
   v3 f = V(0, 0, 0), tc = V(0, 0, 0);
   if (ll.joint) {
     const uint32_t wa = ll.wa;
-    const LinkA& rec = pk.a[i];
-    const int ns = wa_slides(wa), d0 = wa_dof(wa);
+    const int ns = MULTI ? wa_slides(wa) : 0;
     const int nr = MULTI ? wa_hinges(wa) : 1;
     // every load of the phase, in one batch
-    const JointXr X = load_jointx<MULTI>(jx[i]);
-    const float k_pos = jx[i].k_pos;
-    const vf4 q2 = ld4(&rec.rpl[0]);
-    const Body bp = m.body_at(ll.par);
-    const vf4 q4 = ld4(&rec.k_vel), q5 = ld4(&rec.stiffness);  // k_vel k_limit k_ang_damp damping | stiffness lo hi
-    const JointRec la{qt{q2.x, q2.y, q2.z, q2.w}, wa};
-    const JointGeom g = joint_geometry<MULTI>(s, la, X, i, b, bp);
+    const JointXr X = load_jointx<MULTI>(*lr);
+    const vf4 q1 = ld4(&lr->axc[0]);  // .w k_pos
+    const vf4 q2 = ld4(&lr->rpl[0]);
+    const Body bp = Lds::body_of(ll.par);
+    const vf4 q4 = ld4(&lr->k_vel);   // k_vel k_limit k_ang_damp sign3
+    const JointRec la{qt{q2.x, q2.y, q2.z, q2.w}, wa, q4.w};
+    const JointGeom g = joint_geometry<MULTI>(la, X, b, bp);
     const float k_limit = q4.y;
-    const float kp = k_pos * c.stiffness_scale;
+    const float kp = q1.w * ll.ctx[4];
     v3d ed = g.ed;
     v3 ev = g.vA_p - g.vA_c;
     uint32_t lim = 0u;
-    for (int k = 0; k < ns; ++k) {  // prismatic dofs: free along the axis, own spring/damper/force
-      const v3d axd = qrot(bp.r, tod(f3(s.slide_axis[i][k])));
-      const double qkd = -dot(ed, axd);
-      ed = ed + axd * qkd;  // a planar root's slide coordinate is its travelled distance: float64 projection
-      const v3 ax = tof(axd);
-      const float qk = (float)qkd, qdk = -dot(ev, ax);
-      ev = ev + ax * qdk;
-      float fa = m.at(m.lay.tau + d0 + k) - s.dof_damping[d0 + k] * qdk - s.dof_stiffness[d0 + k] * qk;
-      if (qk < s.dof_lo[d0 + k]) { fa += k_limit * (s.dof_lo[d0 + k] - qk); lim |= 1u << (2 * k); }  // range of the slide
-      if (qk > s.dof_hi[d0 + k]) { fa -= k_limit * (qk - s.dof_hi[d0 + k]); lim |= 2u << (2 * k); }
-      f = f + ax * fa;
+    if constexpr (MULTI) {
+      for (int k = 0; k < ns; ++k) {  // prismatic dofs: free along the axis, own spring/damper/force
+        const vf4 sa = ld4(&lr->slide_axis[k][0]), dk = ld4(&lr->dof[k][0]);  // dk: damping stiffness lo hi
+        const v3d axd = qrot(bp.r, tod(V(sa.x, sa.y, sa.z)));
+        const double qkd = -dot(ed, axd);
+        ed = ed + axd * qkd;  // a planar root's slide coordinate is its travelled distance: float64 projection
+        const v3 ax = tof(axd);
+        const float qk = (float)qkd, qdk = -dot(ev, ax);
+        ev = ev + ax * qdk;
+        float fa = ll.tau[k * kEnvs] - dk.x * qdk - dk.y * qk;
+        if (qk < dk.z) { fa += k_limit * (dk.z - qk); lim |= 1u << (2 * k); }  // range of the slide
+        if (qk > dk.w) { fa -= k_limit * (qk - dk.w); lim |= 2u << (2 * k); }
+        f = f + ax * fa;
+      }
     }
     f = f + tof(ed) * kp + ev * q4.x;
     v3 t;
     {  // single hinge: keep the hinge axes aligned + the hinge torque about the child-side axis
       uint32_t lim1 = 0u;
-      float ta = R.tau[0] - q4.w * g.thetadot - q5.x * g.theta;
-      if (g.theta < q5.y) { ta += k_limit * (q5.y - g.theta); lim1 |= 16u; }
-      if (g.theta > q5.z) { ta -= k_limit * (g.theta - q5.z); lim1 |= 32u; }
+      const vf4 h0 = ld4(&lr->dof[MULTI ? min(ns, 2) : 0][0]);  // the first hinge: damping stiffness lo hi
+      float ta = R.tau[0] - h0.x * g.thetadot - h0.y * g.theta;
+      if (g.theta < h0.z) { ta += k_limit * (h0.z - g.theta); lim1 |= 16u; }
+      if (g.theta > h0.w) { ta -= k_limit * (g.theta - h0.w); lim1 |= 32u; }
       t = g.axx * kp + g.x_c * ta;
       if constexpr (MULTI) {  // 2 or 3 stacked hinges (or none): per-dof torques about the current axes; a missing dof is
                               // locked by the constraint spring on its Euler angle.  Straight-line like joint_geometry:
                               // evaluated on every lane, selected by the lane's number of hinges.
-        const int d = d0 + ns;
         v3 t2 = V(0, 0, 0);
         uint32_t lim2 = 0u;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-          const int dk = min(d + k, CARL_BRAX_MAX_DOF - 1);
           const bool act = k < nr;
-          const float lo = s.dof_lo[dk], hi = s.dof_hi[dk];
-          float tk = R.tau[k] - s.dof_damping[dk] * g.rate[k] - s.dof_stiffness[dk] * g.ang[k];
+          const vf4 hk = ld4(&lr->dof[min(ns, 2) + k][0]);
+          const float lo = hk.z, hi = hk.w;
+          float tk = R.tau[k] - hk.x * g.rate[k] - hk.y * g.ang[k];
           const bool below = g.ang[k] < lo, above = g.ang[k] > hi;
           tk = below ? tk + k_limit * (lo - g.ang[k]) : tk;
           tk = above ? tk - k_limit * (g.ang[k] - hi) : tk;
@@ -946,95 +1029,107 @@ static __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const T
     t = t - g.wrel * q4.z;
     R.sig_lim = R.sig_lim * 33u + lim;
     v3 pf = f * -1.0f, pt = (cross(g.rp_off, f) + t) * -1.0f;  // on the parent
-    if (TASK && s.n_pair > 0 && i == s.push_link) {
+    if (TASK && s.n_pair > 0 && ll.i == s.push_link) {
       const PairOut po = pair_contact(s, m);
       f = f + po.on_obj;
       pf = po.on_a;
       pt = po.t_a;
     }
     tc = cross(g.rc_off, f) + t;
-    m.put_react(ll.react, pf, pt);
+    Lds::put_react(ll.react, pf, pt);
   }
   phase_sync();
+  prof.mark(kProfJoints);
   // phase B -- per body: wrench sum, semi-implicit Euler, its contacts, integrate
   if (ll.body) {
-    const float dl = K.dl, da = c.da, inv_dt = K.inv_dt, dt = K.dt;
+    const vf4 cx = ld4(ll.ctx);  // gravity_z, friction, elasticity, exp(ang_damping dt)
+    const float dl = K.dl, da = cx.w, inv_dt = K.inv_dt, dt = K.dt;
     const uint32_t wb = ll.wb;
-    const vf4 qb = ld4(&pk.b[i]);  // .z inv_inertia[0], .w reach (the index words are in registers)
+    const vf4 qb = ld4(&lr->inv_i[0]);  // .x inv_inertia[0], .w reach
+    const float inv_i0 = qb.x;
     const bool iso = (wb & kWbIso) != 0u;
     const qt rf = tof(b.r);
     v3 F = f, T = tc;  // own joint's wrench (a free root has none)
-    {  // children's reactions, ascending: a wavefront-uniform trip count and loads whose addresses sit in registers
-       // (a link with fewer children reads the zero record), so the pass is one batch of independent LDS reads
+    {  // children's reactions, ascending: a wavefront-uniform trip count and loads whose addresses come from registers
+       // (a link with fewer children reads the env's zero record), so the pass is one batch of independent LDS reads
       if (K.max_children > 2) {  // (Ant's torso, Humanoid's torso: all four slots in ONE batch of loads)
         v3 fk[4], tk[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) m.get_react(ll.child[k], fk[k], tk[k]);
+        for (int k = 0; k < 4; ++k) Lds::get_react(ll.child(k), fk[k], tk[k]);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { F = F + fk[k]; T = T + tk[k]; }
       } else if (K.max_children > 0) {
         v3 fk[2], tk[2];
 #pragma unroll
-        for (int k = 0; k < 2; ++k) m.get_react(ll.child[k], fk[k], tk[k]);
+        for (int k = 0; k < 2; ++k) Lds::get_react(ll.child(k), fk[k], tk[k]);
 #pragma unroll
         for (int k = 0; k < 2; ++k) { F = F + fk[k]; T = T + tk[k]; }
       }
       if (K.max_children > 4)  // (no shipped model; wavefront-uniform)
-        for (int cc = tp.child_begin[i] + 4; cc < tp.child_begin[i + 1]; ++cc) {
+        for (int cc = tp.child_begin[ll.i] + 4; cc < tp.child_begin[ll.i + 1]; ++cc) {
           v3 fk, tk;
-          m.get_react(m.react_off(tp.child_idx[cc]), fk, tk);
+          Lds::get_react(ll.react_env + tp.child_idx[cc] * kReactBytes, fk, tk);
           F = F + fk;
           T = T + tk;
         }
     }
     const float inv_m = R.inv_m;
-    b.v = b.v + (F * inv_m + V(0, 0, c.gravity_z)) * dt;
-    b.w = b.w + apply_inv_inertia(s, i, rf, T, iso, qb.z) * dt;
+    b.v = b.v + (F * inv_m + V(0, 0, cx.x)) * dt;
+    b.w = b.w + apply_inv_inertia(lr, rf, T, iso, inv_i0) * dt;
+    prof.mark(kProfBodySum);
     // spring.collisions.resolve: this body's spheres vs the plane z = 0
     v3 cdv = V(0, 0, 0), cdw = V(0, 0, 0);
     float cnt = 0.0f;
     uint32_t hit = 0u;
     // no sphere of this link can reach the plane while its COM is higher than the farthest sphere surface
     const int n_sph = ((float)b.p.z < qb.w) ? wb_spheres(wb) : 0;
-    // third row of the rotation matrix in float64: a sphere's height -- hence its depth, which the Baumgarte
-    // term multiplies by erp / dt -- is a pose difference
-    const double R20 = 2.0 * (b.r.x * b.r.z - b.r.w * b.r.y), R21 = 2.0 * (b.r.y * b.r.z + b.r.w * b.r.x),
-                 R22 = 1.0 - 2.0 * (b.r.x * b.r.x + b.r.y * b.r.y);
-    const Sphere* sph = pk.sph + wb_first_sphere(wb);
-    for (int j = 0; j < n_sph; ++j) {
-      const vf4 sp = ld4(&sph[j]);
-      const v3 off = V(sp.x, sp.y, sp.z);
-      const float radius = sp.w;
-      const float depth =
-          (float)((double)radius - (b.p.z + (R20 * (double)off.x + R21 * (double)off.y + R22 * (double)off.z)));
-      if (!(depth > 0.0f)) continue;
-      // (the plane normal n = e_z is folded in by hand: `dot(n, x)`, `cross(r, n)`, `n * imp` spelled with n as a
-      // vector leave the multiplications by its zeros in the instruction stream -- 0 * x is not 0 for IEEE)
-      const v3 ro = qrot(rf, off);
-      const v3 r = V(ro.x, ro.y, ro.z - radius);
-      const v3 rel = b.v + cross(b.w, r);
-      const float vn = rel.z;  // n . rel
-      const v3 in = apply_inv_inertia(s, i, rf, V(r.y, -r.x, 0.0f), iso, qb.z);  // I^-1 (r x n)
-      const float ang = in.x * r.y - in.y * r.x;                                  // n . (I^-1 (r x n) x r)
-      const float imp = div_fast(-(1.0f + c.elasticity) * vn + K.erp * depth * inv_dt, inv_m + ang);
-      if (!(imp > 0.0f) || !(vn < 0.0f)) continue;
-      hit |= 1u << j;
-      float Jx = 0.0f, Jy = 0.0f;  // J = n imp - dir imp_d, dir = the tangential velocity's direction (dir.z = 0)
-      const float vt_len = sqrtf(rel.x * rel.x + rel.y * rel.y);
-      if (vt_len > 1e-9f) {
-        const float il = __builtin_amdgcn_rcpf(vt_len), dx = rel.x * il, dy = rel.y * il;
-        const v3 id = apply_inv_inertia(s, i, rf, V(-r.z * dy, r.z * dx, r.x * dy - r.y * dx), iso, qb.z);  // I^-1 (r x dir)
-        const v3 c2 = cross(id, r);
-        const float ang_d = dx * c2.x + dy * c2.y;
-        const float imp_d = fminf(div_fast(vt_len, inv_m + ang_d), c.friction * imp);
-        Jx = -dx * imp_d;
-        Jy = -dy * imp_d;
+    if (ballot(n_sph > 0) != 0ull) {  // (nothing at all while every link the wavefront holds is out of reach)
+      // third row of the rotation matrix in float64: a sphere's height -- hence its depth, which the Baumgarte
+      // term multiplies by erp / dt -- is a pose difference
+      const double R20 = 2.0 * (b.r.x * b.r.z - b.r.w * b.r.y), R21 = 2.0 * (b.r.y * b.r.z + b.r.w * b.r.x),
+                   R22 = 1.0 - 2.0 * (b.r.x * b.r.x + b.r.y * b.r.y);
+      auto depth_of = [&](const vf4 sp) {
+        return (float)((double)sp.w - (b.p.z + (R20 * (double)sp.x + R21 * (double)sp.y + R22 * (double)sp.z)));
+      };
+      // the impulse of sphere j (ordinal on its link) at penetration `depth`
+      auto respond = [&](const vf4 sp, const float depth, const int j) {
+        // (the plane normal n = e_z is folded in by hand: `dot(n, x)`, `cross(r, n)`, `n * imp` spelled with n as a
+        // vector leave the multiplications by its zeros in the instruction stream -- 0 * x is not 0 for IEEE)
+        const float radius = sp.w;
+        const v3 ro = qrot(rf, V(sp.x, sp.y, sp.z));
+        const v3 r = V(ro.x, ro.y, ro.z - radius);
+        const v3 rel = b.v + cross(b.w, r);
+        const float vn = rel.z;  // n . rel
+        const v3 in = apply_inv_inertia(lr, rf, V(r.y, -r.x, 0.0f), iso, inv_i0);  // I^-1 (r x n)
+        const float ang = in.x * r.y - in.y * r.x;                                   // n . (I^-1 (r x n) x r)
+        const float imp = div_fast(-(1.0f + cx.z) * vn + K.erp * depth * inv_dt, inv_m + ang);
+        if (!(imp > 0.0f) || !(vn < 0.0f)) return;
+        hit |= 1u << j;
+        float Jx = 0.0f, Jy = 0.0f;  // J = n imp - dir imp_d, dir = the tangential velocity's direction (dir.z = 0)
+        const float vt_len = sqrtf(rel.x * rel.x + rel.y * rel.y);
+        if (vt_len > 1e-9f) {
+          const float il = __builtin_amdgcn_rcpf(vt_len), dx = rel.x * il, dy = rel.y * il;
+          const v3 id = apply_inv_inertia(lr, rf, V(-r.z * dy, r.z * dx, r.x * dy - r.y * dx), iso, inv_i0);  // I^-1 (r x dir)
+          const v3 c2 = cross(id, r);
+          const float ang_d = dx * c2.x + dy * c2.y;
+          const float imp_d = fminf(div_fast(vt_len, inv_m + ang_d), cx.y * imp);
+          Jx = -dx * imp_d;
+          Jy = -dy * imp_d;
+        }
+        const v3 J = V(Jx, Jy, imp);
+        cdv = cdv + J * inv_m;
+        cdw = cdw + apply_inv_inertia(lr, rf, cross(r, J), iso, inv_i0);
+        cnt += 1.0f;
+      };
+      vf4 nxt = ld4(&ll.sph[0]);
+      for (int j = 0; j < n_sph; ++j) {  // the next sphere's record is in flight while this one is evaluated
+        const vf4 sp = nxt;
+        nxt = ld4(&ll.sph[j + 1]);
+        const float depth = depth_of(sp);
+        if (depth > 0.0f) respond(sp, depth, j);
       }
-      const v3 J = V(Jx, Jy, imp);
-      cdv = cdv + J * inv_m;
-      cdw = cdw + apply_inv_inertia(s, i, rf, cross(r, J), iso, qb.z);
-      cnt += 1.0f;
     }
+    prof.mark(kProfContacts);
     R.sig_hit = R.sig_hit * 33u + hit;
     // spring.integrator.integrate
     b.v = b.v * dl;
@@ -1051,9 +1146,10 @@ static __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const T
     qtd r2 = qtd{fma(h, dq.w, b.r.w), fma(h, dq.x, b.r.x), fma(h, dq.y, b.r.y), fma(h, dq.z, b.r.z)};
     const double inv = rsqrt_f64(r2.w * r2.w + r2.x * r2.x + r2.y * r2.y + r2.z * r2.z);
     b.r = qtd{r2.w * inv, r2.x * inv, r2.y * inv, r2.z * inv};
-    m.put_at(ll.own, b);
+    Lds::put_body(ll.own, b);
   }
   phase_sync();
+  prof.mark(kProfBodies);
 }
 
 // ---- the same substep for PLANAR models (Halfcheetah, Hopper, Walker2d: a root on two world slides x, z and a hinge
@@ -1068,26 +1164,25 @@ static __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const T
 // y += h omega w.  Pose differences stay float64.  Results agree with the general substep to rounding
 // (tests/test_gpu_brax.py: both paths against each other and against the float64 restatement of the 3-D pipeline).
 template <bool TASK>
-static __device__ __forceinline__ void substep_planar(const carl_brax_sys_t& s, const Topo& tp, const Packed& pk, const JointX* jx,
-                                               const SubK& K, const LaneLink& ll, const LaneCtx& c, const Lds& m,
-                                               StepRegs<false>& R) {
+static __device__ __forceinline__ void substep_planar(const carl_brax_sys_t& s, const Topo& tp, const SubK& K, const LaneLink& ll,
+                                               const Lds& m, StepRegs<false>& R, Prof& prof) {
   static_assert(!TASK, "planar models are not task models");
-  const int i = ll.i;
   Body& b = R.b;
+  const LinkRec* const lr = ll.lr;
   // phase A -- spring.joints.resolve (every link of a planar model has a joint: the root hangs on the world)
   float fx = 0.0f, fz = 0.0f, tcy = 0.0f;  // the wrench on the child: stays in registers
   if (ll.joint) {
     const uint32_t wa = ll.wa;
-    const LinkA& rec = pk.a[i];
-    const int ns = wa_slides(wa), d0 = wa_dof(wa);
+    const int ns = wa_slides(wa);
     typedef double vd2 __attribute__((ext_vector_type(2)));
-    const vd2* xp = reinterpret_cast<const vd2*>(&jx[i]);
+    const vd2* xp = reinterpret_cast<const vd2*>(lr);
     const vd2 x0 = xp[0], x1 = xp[1], x2 = xp[2];  // ac.x ac.y | ac.z ap.x | ap.y ap.z
-    const float k_pos = jx[i].k_pos;
-    const Body bp = m.body_at(ll.par);
-    const vf4 q4 = ld4(&rec.k_vel), q5 = ld4(&rec.stiffness);  // k_vel k_limit k_ang_damp damping | stiffness lo hi
-    const float tau_s0 = ns > 0 ? m.at(m.lay.tau + d0) : 0.0f, tau_s1 = ns > 0 ? m.at(m.lay.tau + d0 + 1) : 0.0f;
-    const float k_limit = q4.y, kp = k_pos * c.stiffness_scale;
+    const float k_pos = lr->k_pos;
+    const Body bp = Lds::body_of(ll.par);
+    const vf4 q4 = ld4(&lr->k_vel);                  // k_vel k_limit k_ang_damp .
+    const vf4 q5 = ld4(&lr->dof[ns > 0 ? 2 : 0][0]);  // the hinge: damping stiffness lo hi
+    const float sg = lr->axis_sign;                  // +-1: the hinge axis is +-y (joint_rot maps x to +-y)
+    const float k_limit = q4.y, kp = k_pos * ll.ctx[4];
     // rotation of both bodies as (cos, sin) of the full angle, float64
     const double cc = b.r.w * b.r.w - b.r.y * b.r.y, sc = 2.0 * (b.r.w * b.r.y);
     const double cp = bp.r.w * bp.r.w - bp.r.y * bp.r.y, sp = 2.0 * (bp.r.w * bp.r.y);
@@ -1103,88 +1198,100 @@ static __device__ __forceinline__ void substep_planar(const carl_brax_sys_t& s, 
     // relative rotation conj(u_p) u_c: the hinge angle is twice its argument
     double Wr = bp.r.w * b.r.w + bp.r.y * b.r.y, Yr = bp.r.w * b.r.y - bp.r.y * b.r.w;
     if (Wr < 0.0) { Wr = -Wr; Yr = -Yr; }
-    const float sg = q5.w;  // +-1: the hinge axis is +-y (joint_rot maps x to +-y)
     const float theta = sg * (float)(2.0 * atan2_f64(Yr, Wr));
     const float wrel = b.w.y - bp.w.y, thetadot = sg * wrel;
     uint32_t lim = 0u;
     if (ns > 0) {  // the root: slides along world x and z (the parent is the world), unlimited
+      const vf4 sx = ld4(&lr->dof[0][0]), sz = ld4(&lr->dof[1][0]);  // damping stiffness lo hi
       const float qx = (float)(-edx), qz = (float)(-edz), qdx = -evx, qdz = -evz;
       edx = 0.0; edz = 0.0; evx = 0.0f; evz = 0.0f;
-      fx = tau_s0 - s.dof_damping[d0] * qdx - s.dof_stiffness[d0] * qx;
-      fz = tau_s1 - s.dof_damping[d0 + 1] * qdz - s.dof_stiffness[d0 + 1] * qz;
-      if (qx < s.dof_lo[d0]) { fx += k_limit * (s.dof_lo[d0] - qx); lim |= 1u; }
-      if (qx > s.dof_hi[d0]) { fx -= k_limit * (qx - s.dof_hi[d0]); lim |= 2u; }
-      if (qz < s.dof_lo[d0 + 1]) { fz += k_limit * (s.dof_lo[d0 + 1] - qz); lim |= 4u; }
-      if (qz > s.dof_hi[d0 + 1]) { fz -= k_limit * (qz - s.dof_hi[d0 + 1]); lim |= 8u; }
+      fx = ll.tau[0] - sx.x * qdx - sx.y * qx;
+      fz = ll.tau[kEnvs] - sz.x * qdz - sz.y * qz;
+      if (qx < sx.z) { fx += k_limit * (sx.z - qx); lim |= 1u; }
+      if (qx > sx.w) { fx -= k_limit * (qx - sx.w); lim |= 2u; }
+      if (qz < sz.z) { fz += k_limit * (sz.z - qz); lim |= 4u; }
+      if (qz > sz.w) { fz -= k_limit * (qz - sz.w); lim |= 8u; }
     }
     fx = fx + (float)edx * kp + evx * q4.x;
     fz = fz + (float)edz * kp + evz * q4.x;
-    float ta = R.tau[0] - q4.w * thetadot - q5.x * theta;
-    if (theta < q5.y) { ta += k_limit * (q5.y - theta); lim |= 16u; }
-    if (theta > q5.z) { ta -= k_limit * (theta - q5.z); lim |= 32u; }
+    float ta = R.tau[0] - q5.x * thetadot - q5.y * theta;
+    if (theta < q5.z) { ta += k_limit * (q5.z - theta); lim |= 16u; }
+    if (theta > q5.w) { ta -= k_limit * (theta - q5.w); lim |= 32u; }
     const float ty = sg * ta - wrel * q4.z;  // about y: hinge torque, angular damping (the axes are parallel: no alignment term)
     R.sig_lim = R.sig_lim * 33u + lim;
     // (a x f).y = a.z f.x - a.x f.z
     tcy = (rczf * fx - rcxf * fz) + ty;
-    m.put_react1(ll.react, -fx, -fz, -((rpzf * fx - rpxf * fz) + ty));
+    Lds::put_react1(ll.react, -fx, -fz, -((rpzf * fx - rpxf * fz) + ty));
   }
   phase_sync();
+  prof.mark(kProfJoints);
   // phase B -- per body: wrench sum, semi-implicit Euler, its contacts, integrate
   if (ll.body) {
-    const float dl = K.dl, da = c.da, inv_dt = K.inv_dt, dt = K.dt;
+    const vf4 cx = ld4(ll.ctx);  // gravity_z, friction, elasticity, exp(ang_damping dt)
+    const float dl = K.dl, da = cx.w, inv_dt = K.inv_dt, dt = K.dt;
     const uint32_t wb = ll.wb;
-    const vf4 qb = ld4(&pk.b[i]);  // .z inv_inertia[0], .w reach
+    const vf4 qb = ld4(&lr->inv_i[0]);  // .x inv_inertia[0], .w reach
     float Fx = fx, Fz = fz, Ty = tcy;
     {
       if (K.max_children > 2) {
         vf4 r[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) r[k] = m.get_react1(ll.child[k]);
+        for (int k = 0; k < 4; ++k) r[k] = Lds::get_react1(ll.child(k));
 #pragma unroll
         for (int k = 0; k < 4; ++k) { Fx += r[k].x; Fz += r[k].y; Ty += r[k].z; }
       } else if (K.max_children > 0) {
-        const vf4 r0 = m.get_react1(ll.child[0]), r1 = m.get_react1(ll.child[1]);
+        const vf4 r0 = Lds::get_react1(ll.child(0)), r1 = Lds::get_react1(ll.child(1));
         Fx = (Fx + r0.x) + r1.x; Fz = (Fz + r0.y) + r1.y; Ty = (Ty + r0.z) + r1.z;
       }
       if (K.max_children > 4)  // (no shipped model; wavefront-uniform)
-        for (int cc2 = tp.child_begin[i] + 4; cc2 < tp.child_begin[i + 1]; ++cc2) {
-          const vf4 r = m.get_react1(m.react_off(tp.child_idx[cc2]));
+        for (int cc2 = tp.child_begin[ll.i] + 4; cc2 < tp.child_begin[ll.i + 1]; ++cc2) {
+          const vf4 r = Lds::get_react1(ll.react_env + tp.child_idx[cc2] * kReactBytes);
           Fx += r.x; Fz += r.y; Ty += r.z;
         }
     }
-    const float inv_m = R.inv_m, inv_i = qb.z;
-    float vx = b.v.x + (Fx * inv_m) * dt, vz = b.v.z + (Fz * inv_m + c.gravity_z) * dt;
+    const float inv_m = R.inv_m, inv_i = qb.x;
+    float vx = b.v.x + (Fx * inv_m) * dt, vz = b.v.z + (Fz * inv_m + cx.x) * dt;
     float om = b.w.y + (Ty * inv_i) * dt;
+    prof.mark(kProfBodySum);
     // spring.collisions.resolve: this body's spheres vs the plane z = 0
     float cdvx = 0.0f, cdvz = 0.0f, cdw = 0.0f, cnt = 0.0f;
     uint32_t hit = 0u;
     const int n_sph = ((float)b.p.z < qb.w) ? wb_spheres(wb) : 0;
-    const double cth = 1.0 - 2.0 * (b.r.y * b.r.y), sth = 2.0 * (b.r.w * b.r.y);  // R22, -R20 of the general form
-    const float cf = (float)cth, sf = (float)sth;
-    const Sphere* sph = pk.sph + wb_first_sphere(wb);
-    for (int j = 0; j < n_sph; ++j) {
-      const vf4 sp = ld4(&sph[j]);
-      const float radius = sp.w;
-      const float depth = (float)((double)radius - (b.p.z + (cth * (double)sp.z - sth * (double)sp.x)));
-      if (!(depth > 0.0f)) continue;
-      const float rx = cf * sp.x + sf * sp.z, rz = (cf * sp.z - sf * sp.x) - radius;  // sphere's lowest point - COM
-      const float relx = vx + om * rz, relz = vz - om * rx;
-      const float vn = relz;
-      const float imp = div_fast(-(1.0f + c.elasticity) * vn + K.erp * depth * inv_dt, inv_m + inv_i * (rx * rx));
-      if (!(imp > 0.0f) || !(vn < 0.0f)) continue;
-      hit |= 1u << j;
-      float Jx = 0.0f;
-      const float vt_len = fabsf(relx);
-      if (vt_len > 1e-9f) {
-        const float dx = relx > 0.0f ? 1.0f : -1.0f;
-        const float imp_d = fminf(div_fast(vt_len, inv_m + inv_i * (rz * rz)), c.friction * imp);
-        Jx = -dx * imp_d;
+    if (ballot(n_sph > 0) != 0ull) {
+      const double cth = 1.0 - 2.0 * (b.r.y * b.r.y), sth = 2.0 * (b.r.w * b.r.y);  // R22, -R20 of the general form
+      const float cf = (float)cth, sf = (float)sth;
+      auto depth_of = [&](const vf4 sp) {
+        return (float)((double)sp.w - (b.p.z + (cth * (double)sp.z - sth * (double)sp.x)));
+      };
+      auto respond = [&](const vf4 sp, const float depth, const int j) {
+        const float radius = sp.w;
+        const float rx = cf * sp.x + sf * sp.z, rz = (cf * sp.z - sf * sp.x) - radius;  // sphere's lowest point - COM
+        const float relx = vx + om * rz, relz = vz - om * rx;
+        const float vn = relz;
+        const float imp = div_fast(-(1.0f + cx.z) * vn + K.erp * depth * inv_dt, inv_m + inv_i * (rx * rx));
+        if (!(imp > 0.0f) || !(vn < 0.0f)) return;
+        hit |= 1u << j;
+        float Jx = 0.0f;
+        const float vt_len = fabsf(relx);
+        if (vt_len > 1e-9f) {
+          const float dx = relx > 0.0f ? 1.0f : -1.0f;
+          const float imp_d = fminf(div_fast(vt_len, inv_m + inv_i * (rz * rz)), cx.y * imp);
+          Jx = -dx * imp_d;
+        }
+        cdvx += Jx * inv_m;
+        cdvz += imp * inv_m;
+        cdw += inv_i * (rz * Jx - rx * imp);  // (r x J).y
+        cnt += 1.0f;
+      };
+      vf4 nxt = ld4(&ll.sph[0]);
+      for (int j = 0; j < n_sph; ++j) {  // the next sphere's record is in flight while this one is evaluated
+        const vf4 sp = nxt;
+        nxt = ld4(&ll.sph[j + 1]);
+        const float depth = depth_of(sp);
+        if (depth > 0.0f) respond(sp, depth, j);
       }
-      cdvx += Jx * inv_m;
-      cdvz += imp * inv_m;
-      cdw += inv_i * (rz * Jx - rx * imp);  // (r x J).y
-      cnt += 1.0f;
     }
+    prof.mark(kProfContacts);
     R.sig_hit = R.sig_hit * 33u + hit;
     vx *= dl; vz *= dl; om *= da;
     if (cnt > 0.0f) {
@@ -1198,9 +1305,10 @@ static __device__ __forceinline__ void substep_planar(const carl_brax_sys_t& s, 
     const double inv = rsqrt_f64(w2 * w2 + y2 * y2);
     b.r.w = w2 * inv; b.r.y = y2 * inv;
     b.v.x = vx; b.v.z = vz; b.w.y = om;
-    m.put_at(ll.own, b);
+    Lds::put_body(ll.own, b);
   }
   phase_sync();
+  prof.mark(kProfBodies);
 }
 
 // whole-body centre of mass (brax.envs.humanoid.Humanoid._com), float64 (the forward reward is the difference
@@ -1224,7 +1332,7 @@ static __device__ __forceinline__ v3d system_com(const carl_brax_sys_t& s, const
 template <bool MULTI, bool TASK>
 // `com_in` / `mass_in`: the whole-body centre of mass and total mass when the caller has just formed them at this very
 // state (the step's forward reward of reward_on_com models: one 11-link pass less per Humanoid env step).
-static __device__ __forceinline__ void observe(const carl_brax_sys_t& s, const Packed& pk, const JointX* jx, const Lds& m, bool go,
+static __device__ __forceinline__ void observe(const carl_brax_sys_t& s, const Packed& pk, const LinkRec* jx, const Lds& m, bool go,
                                         bool zero_frc, const v3d* com_in = nullptr, float mass_in = 0.0f) {
   const int skip = s.exclude_current_positions;
   // q[from:] as sin ++ cos (inverted double pendulum): the raw angles are written to the sin rows and
@@ -1268,8 +1376,8 @@ static __device__ __forceinline__ void observe(const carl_brax_sys_t& s, const P
       const LinkA& rec = pk.a[i];
       const JointXr X = load_jointx<MULTI>(jx[i]);
       const vf4 q2 = ld4(&rec.rpl[0]);
-      const JointRec la{qt{q2.x, q2.y, q2.z, q2.w}, rec.word};
-      const JointGeom g = joint_geometry<MULTI>(s, la, X, i, b, bp);
+      const JointRec la{qt{q2.x, q2.y, q2.z, q2.w}, rec.word, s.dof_sign3[i]};
+      const JointGeom g = joint_geometry<MULTI>(la, X, b, bp);
       const int ns = s.n_slide[i];
       for (int k = 0; k < ns; ++k) {
         const v3d axd = qrot(bp.r, tod(f3(s.slide_axis[i][k])));
@@ -1524,6 +1632,11 @@ static __device__ __forceinline__ LaneCtx load_ctx(const carl_brax_sys_t& s, con
     lc.stiffness_scale = get(cm.joint_stiffness_scale, 1.0f);
     lc.da = __expf(lc.ang_damping * s.dt);
     for (int i = m.sub; i < s.n_links; i += kSub) m.at(m.lay.mass + i) = s.mass[i];
+    if (m.sub == 0) {  // the env's context record: what the substep's phases read
+      float* cr = const_cast<float*>(m.ctx_rec());
+      *reinterpret_cast<vf4*>(cr) = vf4{lc.gravity_z, lc.friction, lc.elasticity, lc.da};
+      cr[4] = lc.stiffness_scale;
+    }
   }
   if (TASK && s.push_link > 0) put_goal(s, b, m, c, go);
   phase_sync();
@@ -1599,25 +1712,31 @@ static __device__ __forceinline__ void record_store(float* __restrict__ dst, con
   }
   for (int k = m.sub; k < NV; k += kSub) dst[2 * NP + k] = m.velk(k);
 }
-// Round the pose to what the record holds (head + tail, 48 bits).  Done at the end of EVERY env step, so a fused
-// rollout continues from exactly the state a per-call step would have stored and reloaded: rollout == repeated step,
-// bit for bit.
-static __device__ __forceinline__ void pose_round(const Lds& m, int L, bool go) {
-  if (!go) return;
-  for (int k = m.sub; k < 7 * L; k += kSub) {
-    const double d = m.pdk(k);
-    const float hi = (float)d;
-    m.pdk(k) = (double)hi + (double)(float)(d - (double)hi);
-  }
+// a pose coordinate as the state record holds it: float32 head + float32 tail (48 significant bits)
+static __device__ __forceinline__ double round48(double d) {
+  const float hi = (float)d;
+  return (double)hi + (double)(float)(d - (double)hi);
 }
 
 struct LaneState {
   float ep_return;
   int elapsed, cidx, n_new_calls, n_new_episodes;
   uint32_t episode;
-  LaneCtx ctx;
   float goal_x, goal_y, goal_radius, pos_x, pos_y;  // goal mode only
 };
+
+static __device__ __forceinline__ void stash_put(const Lds& m, const LaneState& r) {
+  const int k = m.lay.stash;
+  m.at(k) = r.ep_return; m.atu(k + 1) = (uint32_t)r.elapsed; m.atu(k + 2) = (uint32_t)r.cidx;
+  m.atu(k + 3) = (uint32_t)r.n_new_calls; m.atu(k + 4) = (uint32_t)r.n_new_episodes; m.atu(k + 5) = r.episode;
+  m.at(k + 6) = r.goal_x; m.at(k + 7) = r.goal_y; m.at(k + 8) = r.goal_radius; m.at(k + 9) = r.pos_x; m.at(k + 10) = r.pos_y;
+}
+static __device__ __forceinline__ void stash_get(const Lds& m, LaneState& r) {
+  const int k = m.lay.stash;
+  r.ep_return = m.at(k); r.elapsed = (int)m.atu(k + 1); r.cidx = (int)m.atu(k + 2);
+  r.n_new_calls = (int)m.atu(k + 3); r.n_new_episodes = (int)m.atu(k + 4); r.episode = m.atu(k + 5);
+  r.goal_x = m.at(k + 6); r.goal_y = m.at(k + 7); r.goal_radius = m.at(k + 8); r.pos_x = m.at(k + 9); r.pos_y = m.at(k + 10);
+}
 
 // BraxWalkerGoalWrapper (carl/envs/brax/brax_walker_goal_wrapper.py:69-121): compass code ->
 // goal position = direction * target_distance; radius
@@ -1666,7 +1785,7 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
   __shared__ carl_brax_sys_t s;
   __shared__ Topo tp;
   __shared__ Packed pk;
-  __shared__ JointX jx_lds[CARL_BRAX_MAX_LINKS];
+  __shared__ LinkRec jx_lds[CARL_BRAX_MAX_LINKS];
   __shared__ int head_done[kMaxWavesPerWg3];  // fragment hand-over flags (MODE 1, see below)
   if (threadIdx.x < kMaxWavesPerWg3) head_done[threadIdx.x] = 0;
   extern __shared__ vf4 lds_dyn[];  // per wavefront: body records, then the float rows (16-byte aligned slices)
@@ -1701,9 +1820,9 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
     for (int k = (int)threadIdx.x; k < kWordsD; k += (int)blockDim.x) dd[k] = sd[k];
   }
   __syncthreads();
-  if ((int)threadIdx.x < s.n_links) expand_joint(s, pk, (int)threadIdx.x, jx_lds[threadIdx.x]);
+  if ((int)threadIdx.x < s.n_links) expand_link(s, pk, (int)threadIdx.x, jx_lds[threadIdx.x]);
   __syncthreads();
-  const JointX* const jx = jx_lds;
+  const LinkRec* const jx = jx_lds;
   // kSub need not divide 64 (one lane per link: 7, 9, 11): the wavefront's spare lanes idle -- they
   // point at the last env's column, own no link (sub beyond every loop bound) and are never active
   const int tid = (int)threadIdx.x & (kLanes - 1), wave = (int)threadIdx.x >> 6;
@@ -1780,12 +1899,13 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
     const int n_frag = piece.n_frag;
     const float dt_env = s.dt * (float)s.n_frames;
     const SubK K = make_subk(s, tp, pk);
-    const LaneLink ll = make_lane_link(pk, K, m);
     const int n_frames = __builtin_amdgcn_readfirstlane(s.n_frames);
-    if (tid < kFixedBytes / 4) {  // the world record and the zero reaction record (the first phase_sync below orders it)
+    if (tid < kWorldRecBytes / 4) {  // the world record (the first phase_sync below orders it)
       // world: pose (0, 0, 0 | 1, 0, 0, 0) as doubles, velocities 0; double 1.0 = words (0, 0x3ff00000) at double index 3
       reinterpret_cast<uint32_t*>(m.rec + m.world_off())[tid] = (tid == 7) ? 0x3ff00000u : 0u;
     }
+    Prof prof;
+    prof.start();
     for (int fi = 0; fi < n_frag; ++fi) {
     const Fragment frag = fragment_of(piece, T, fi);
     const int grp = frag.grp, t_lo = frag.t_lo, t_hi = frag.t_hi;
@@ -1808,15 +1928,44 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
       r.ep_return = b.ep_return[env];
     }
     record_load(b.state + (size_t)env * S, m, s.n_links, active);
-    r.ctx = load_ctx<TASK>(s, b, m, r.cidx, active);
+    load_ctx<TASK>(s, b, m, r.cidx, active);
     if (goal && active) {
       load_goal(s, b, r.cidx, r);
       r.pos_x = b.goal_pos[env];
       r.pos_y = b.goal_pos[n + env];
     }
+    prof.mark(kProfLoad);
+    // The env's action record of step t + 1 is fetched while step t computes (two registers per lane: every shipped
+    // model has n_act <= 2 kSub) -- a load issued at the step's own start costs the wavefront one HBM round trip per env
+    // step before anything can begin.  Models with more actuators per lane take the direct path.
+    const int n_act = __builtin_amdgcn_readfirstlane(s.n_act);
+    const bool act_prefetch = n_act <= 2 * kSub;
+    const float* const act_env = static_cast<const float*>(io.action) + (size_t)env * n_act;
+    const size_t act_step = n * (size_t)n_act;
+    const int ak0 = m.sub, ak1 = m.sub + kSub;
+    float a_next0 = 0.0f, a_next1 = 0.0f;
+    if (act_prefetch && active) {
+      if (ak0 < n_act) a_next0 = act_env[(size_t)t_lo * act_step + ak0];
+      if (ak1 < n_act) a_next1 = act_env[(size_t)t_lo * act_step + ak1];
+    }
     for (int t = t_lo; t < t_hi; ++t) {
       const size_t step_off = (size_t)t * n;
-      record_in(static_cast<const float*>(io.action) + step_off * s.n_act, (size_t)env, s.n_act, m, active);
+      // The env's episode scalars (identical in all its lanes) wait in LDS until the reward needs them: a dozen registers
+      // per lane that the substeps and observe need more.
+      if (lead) stash_put(m, r);
+      if (act_prefetch) {
+        if (active) {
+          if (ak0 < n_act) m.at(m.lay.io + ak0) = a_next0;
+          if (ak1 < n_act) m.at(m.lay.io + ak1) = a_next1;
+          if (t + 1 < t_hi) {
+            if (ak0 < n_act) a_next0 = act_env[(size_t)(t + 1) * act_step + ak0];
+            if (ak1 < n_act) a_next1 = act_env[(size_t)(t + 1) * act_step + ak1];
+          }
+        }
+        phase_sync();
+      } else {
+        record_in(static_cast<const float*>(io.action) + step_off * s.n_act, (size_t)env, s.n_act, m, active);
+      }
       // actuator.to_tau: tau = 0, then every actuator adds gear * clip(action) to its dof
       float ctrl = 0.0f;
       for (int k = 0; k < s.n_act; ++k) {
@@ -1831,9 +1980,17 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
       float msum;
       // forward progress and root height: pose differences, float64
       const double x0 = s.reward_on_com ? system_com(s, m, &msum).x : m.pos(0).x - qrot(m.rot(0), tod(f3(s.com[0]))).x;
+      prof.mark(kProfPrologue);
+      if (active && m.sub == 1 % kSub) Lds::put_react(reinterpret_cast<char*>(m.base) + m.react_off(m.lay.L), V(0, 0, 0), V(0, 0, 0));  // the env's zero record
       {  // the n_frames substeps, the lane's body / torques / branch hashes in registers (StepRegs)
+        // The lane's addresses are rebuilt per env step from an opaque copy of its lane coordinates: as launch
+        // invariants the compiler kept all twelve in registers through observe / reward / the reset path as well, which
+        // have none to spare (a scratch reload there waits for every store of the step before it).
+        Lds ms = m;
+        asm volatile("" : "+v"(ms.sub), "+v"(ms.env));
+        const LaneLink ll = make_lane_link(pk, jx, K, ms);
         StepRegs<MULTI> R;
-        R.b = m.body_at(ll.own);
+        R.b = Lds::body_of(ll.own);
         {
           const int d = wa_dof(ll.wa) + wa_slides(ll.wa);  // the joint's first hinge dof
 #pragma unroll
@@ -1843,13 +2000,20 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
         R.sig_lim = 0u;
         R.inv_m = __builtin_amdgcn_rcpf(m.at(m.lay.mass + ll.i));  // v_rcp_f32 (1 ulp): the phase is issue-bound
         if constexpr (PLANAR) {
-          for (int f = 0; f < n_frames; ++f) substep_planar<TASK>(s, tp, pk, jx, K, ll, r.ctx, m, R);
+          for (int f = 0; f < n_frames; ++f) substep_planar<TASK>(s, tp, K, ll, m, R, prof);
         } else {
-          for (int f = 0; f < n_frames; ++f) substep<MULTI, TASK>(s, tp, pk, jx, K, ll, r.ctx, m, R);
+          for (int f = 0; f < n_frames; ++f) substep<MULTI, TASK>(s, tp, K, ll, m, R, prof);
         }
         if (ll.body) {  // this step's branch record, per link
           m.atu(m.lay.sig + 2 * ll.i) = R.sig_hit;
           m.atu(m.lay.sig + 2 * ll.i + 1) = R.sig_lim;
+          // Round the pose to what the state record holds (float32 head + tail, 48 bits) at the end of EVERY env step,
+          // on the register copy: a fused rollout then continues from exactly the state a per-call step stores and
+          // reloads -- rollout == repeated step, bit for bit -- and the step's observation, reward and health checks
+          // read the rounded pose in both.
+          R.b.p = D(round48(R.b.p.x), round48(R.b.p.y), round48(R.b.p.z));
+          R.b.r = qtd{round48(R.b.r.w), round48(R.b.r.x), round48(R.b.r.y), round48(R.b.r.z)};
+          Lds::put_body(ll.own, R.b);
         }
         phase_sync();
       }
@@ -1868,9 +2032,12 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
         io.branch_sig[(step_off + env) * 2] = hc;
         io.branch_sig[(step_off + env) * 2 + 1] = hl;
       }
+      prof.mark(kProfEpilogue);
+      observe<MULTI, TASK>(s, pk, jx, m, active, false, s.reward_on_com ? &com1 : nullptr, msum);
+      prof.mark(kProfObserve);
+      stash_get(m, r);
       r.elapsed += 1;
       const bool truncated = (b.max_episode_steps > 0) && (r.elapsed >= b.max_episode_steps);
-      observe<MULTI, TASK>(s, pk, jx, m, active, false, s.reward_on_com ? &com1 : nullptr, msum);
       if (s.healthy_q_index >= 0) {  // torso pitch (hopper, walker2d) / pole angle: read from the observation
         const float qa = m.at(m.lay.io + s.healthy_q_index - s.exclude_current_positions);
         healthy = healthy && (qa >= s.healthy_q_lo) && (qa <= s.healthy_q_hi);
@@ -1919,6 +2086,7 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
         io.truncated[step_off + env] = (uint8_t)truncated;
         if (io.done != nullptr && n_steps == 1) io.done[env] = (uint8_t)(terminated | truncated);  // per-call step
       }
+      prof.mark(kProfReward);
       if (ballot(done) != 0ull) {
         const float fin_ret = r.ep_return;
         const int fin_len = r.elapsed;
@@ -1950,10 +2118,9 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
             phase_sync();
           }
           reset_state<TASK>(s, tp, b.seed, m, genv, r.episode, done);
-          const LaneCtx nc = load_ctx<TASK>(s, b, m, r.cidx, done);
+          load_ctx<TASK>(s, b, m, r.cidx, done);
           if (done) {
             r.episode += 1u;
-            r.ctx = nc;
             if (goal) {
               load_goal(s, b, r.cidx, r);
               r.pos_x = r.pos_y = 0.0f;
@@ -1967,9 +2134,10 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
           observe<MULTI, TASK>(s, pk, jx, m, done, true);
         }
       }
+      prof.mark(kProfDone);
       record_out(io.obs + step_off * s.obs_dim, (size_t)env, s.obs_dim, m, active);
-      pose_round(m, s.n_links, active);
       phase_sync();  // the next step's actions overwrite the io rows
+      prof.mark(kProfOutput);
     }
     if (active) {
       record_store(b.state + (size_t)env * S, m, s.n_links, true);
@@ -1993,7 +2161,9 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
       if (tid == 0) __hip_atomic_store(&head_done[wave], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     phase_sync();  // the next fragment reloads this wavefront's rows
+    prof.mark(kProfStore);
     }  // fragments
+    prof.flush(tid == 0);
   }
 }
 

@@ -114,18 +114,22 @@ constexpr bool brax_instantiated(int k, bool multi, bool task) {
   return multi ? (k == 2 || k == 11 || k == 16) : (k == 4 || k == 7 || k == 8 || k == 9 || k == 16);
 }
 bool brax_is_task(const carl_brax_sys_t* sh) { return sh->target_link > 0 || sh->push_link > 0; }
-// The general kernels (MULTI): any link with 0, 2 or 3 hinges (Euler-angle path), or a link frame that is rotated against
+bool brax_is_planar(const carl_brax_sys_t* sh);
+// The general kernels (MULTI): any link with 0, 2 or 3 hinges (Euler-angle path), a link frame that is rotated against
 // its parent's (link_rot != identity: the relative rotation of the joint frames then needs the full 4 x 4 map,
-// brax_kernels.hip.h: JointX) -- of the shipped models Humanoid / HumanoidStandup have both.
+// brax_kernels.hip.h: LinkRec), or prismatic dofs outside the planar kernels (whose root slides are their own code) --
+// of the shipped models Humanoid / HumanoidStandup (stacked hinges, rotated frames), the inverted pendulums (the cart).
+// The lean kernels (MULTI = false) are "a free root and single hinges": Ant.
 bool brax_is_multi(const carl_brax_sys_t* sh) {
-  bool multi = false;
+  bool multi = false, slides = false;
   for (int i = 0; i < sh->n_links; ++i) {
     const bool free_root = sh->parent[i] < 0 && sh->n_link_dof[i] == 6;
     multi |= !free_root && sh->n_link_dof[i] - sh->n_slide[i] != 1;
     multi |= !free_root && !(sh->link_rot[i][0] == 1.0f && sh->link_rot[i][1] == 0.0f && sh->link_rot[i][2] == 0.0f &&
                              sh->link_rot[i][3] == 0.0f);
+    slides |= !free_root && sh->n_slide[i] > 0;
   }
-  return multi;
+  return multi || (slides && !brax_is_planar(sh));
 }
 // Planar single-hinge model (Halfcheetah, Hopper, Walker2d as this package builds them): the root hangs on the world by
 // two slides along x and z and a hinge about y, every other link by one hinge about +-y; link frames are unrotated, the
@@ -133,7 +137,7 @@ bool brax_is_multi(const carl_brax_sys_t* sh) {
 // by reset never leaves that plane and brax_kernels.hip.h's substep_planar computes the same substep without the
 // zero components.  Anything else -- and any batch with CARL_FLAG_BRAX_GENERIC -- takes the general substep.
 bool brax_is_planar(const carl_brax_sys_t* sh) {
-  if (brax_is_task(sh) || brax_is_multi(sh) || sh->n_links < 1 || sh->n_pair > 0) return false;
+  if (brax_is_task(sh) || sh->n_links < 1 || sh->n_pair > 0) return false;  // (the per-link checks below cover the rest)
   const float r = 0.70710678f;
   auto near = [](float a, float b) { return a - b < 1e-6f && b - a < 1e-6f; };
   for (int i = 0; i < sh->n_links; ++i) {
@@ -188,15 +192,18 @@ int launch_brax(const carl_batch_t* b, const carl_brax_sys_t* sd, const carl_bra
                        const carl_step_io_t* io, const uint8_t* mask, float* reset_obs, int n_steps, hipStream_t st,
                        const char* who) {
   if (b->n_lanes == 0 || (MODE == 1 && n_steps == 0)) return 0;
-  const bool multi = brax_is_multi(sh), task = brax_is_task(sh);  // task models have a hinge-less last link: multi
+  const bool task = brax_is_task(sh);  // task models have a hinge-less last link: multi
+  const bool planar_model = brax_is_planar(sh);
+  const bool planar = MODE == 1 && !(b->flags & CARL_FLAG_BRAX_GENERIC) && planar_model;
+  // a planar model stepped by the general substep (CARL_FLAG_BRAX_GENERIC): its root's slides need the general kernels
+  const bool multi = brax_is_multi(sh) || (MODE == 1 && planar_model && !planar);
   const int K = brax_lanes_per_env(sh->n_links, multi, task, b->n_lanes, sh->lanes_per_env);
-  const bool planar = MODE == 1 && !(b->flags & CARL_FLAG_BRAX_GENERIC) && brax_is_planar(sh);
   const int envs = carl::brax::kLanes / K;  // one wavefront = envs x K lanes; LDS rows are `envs` floats wide
   const carl::brax::Layout lay = carl::brax::Layout::make(sh->n_links, sh->n_dof, carl::brax::io_rows_of(*sh));
   // independent wavefronts per workgroup, sharing the LDS copy of the static tables: as many (<= kMaxWavesPerWg) as fit
   // (the kernel's static LDS: model table, prepared topology / records, the fragment hand-over flags)
   const size_t static_lds = sizeof(carl_brax_sys_t) + sizeof(carl::brax::Prepared) +
-                            (size_t)carl::brax::kJointXBytes * CARL_BRAX_MAX_LINKS + sizeof(int) * carl::brax::kMaxWavesPerWg3;
+                            (size_t)carl::brax::kLinkRecBytes * CARL_BRAX_MAX_LINKS + sizeof(int) * carl::brax::kMaxWavesPerWg3;
   const size_t wave_bytes = lay.bytes(envs);
   if (wave_bytes + static_lds > 160 * 1024)
     return fail(CARL_ERR_UNSUPPORTED, "%s: model needs %zu B of LDS per wavefront", who, wave_bytes);
@@ -346,6 +353,17 @@ int carl_brax_fragment_plan(int32_t n_groups, int32_t n_workgroups, int32_t wave
   }
   return p.n_frag;
 }
+
+#ifdef CARL_BRAX_PROFILE
+// measurement build only (not declared in include/carl_amd.h): the region clocks of brax_kernels.hip.h, summed over every
+// wavefront since the last reset; out[kProfRegions] = wavefronts
+int carl_brax_profile_read(unsigned long long* out, int reset) {
+  unsigned long long zero[carl::brax::kProfRegions + 1] = {0};
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(carl::brax::g_brax_prof), sizeof(zero)) != hipSuccess) return -1;
+  if (reset && hipMemcpyToSymbol(HIP_SYMBOL(carl::brax::g_brax_prof), zero, sizeof(zero)) != hipSuccess) return -1;
+  return carl::brax::kProfRegions;
+}
+#endif
 
 int carl_brax_model_is_planar(const carl_brax_sys_t* sys_host) {
   if (sys_host == nullptr) {
