@@ -32,6 +32,8 @@
 // rotate^-1 on three floats per lane.
 #pragma once
 
+#include <type_traits>
+
 #include "carl_device.hip.h"
 #include "fast_math.hip.h"
 
@@ -203,13 +205,16 @@ struct Body {
 // atan2 in float64 to ~3e-13 (one octant reduction, one division, degree-7 polynomial in t^2 on
 // [0, tan^2(pi/8)], Chebyshev-node fit): a joint angle is multiplied by the limit / joint / locking stiffness
 // (k dt / I up to 30 per substep), so the 2.8e-7 of atan2_fast would reach the velocities at 1e-5 within one env
-// step.  ~40 instructions.
+// step.  ~36 instructions.  XPOS: the caller guarantees x >= 0 (a hinge's half angle: the relative rotation's scalar
+// part after the sign flip) -- the quadrant fix-up for x < 0 is compiled out.
+// The division: v_rcp_f64 (~26 bits) and ONE Newton step (4e-15, fast_math.hip.h: rcp_fast1).
+template <bool XPOS = false>
 __device__ __forceinline__ double atan2_f64(double y, double x) {
   const double ax = fabs(x), ay = fabs(y);
   const double mx = fmax(ax, ay), mn = fmin(ax, ay);
   const bool mid = mn > 0.41421356237309503 * mx;  // atan(t) = pi/4 + atan((t - 1) / (t + 1))
   const double num = mid ? mn - mx : mn, den = mid ? mn + mx : mx;
-  double t = num * rcp_fast(den);
+  double t = num * rcp_fast1(den);
   t = (mx > 0.0) ? t : 0.0;
   const double z = t * t;
   double p = fma(z, -3.76549087472088720e-02, 6.97418621847181036e-02);
@@ -221,11 +226,22 @@ __device__ __forceinline__ double atan2_f64(double y, double x) {
   p = fma(z, p, 9.99999999999244826e-01);
   double r = fma(t, p, mid ? 0.78539816339744831 : 0.0);
   r = (ay > ax) ? 1.5707963267948966 - r : r;
-  r = (x < 0.0) ? 3.1415926535897932 - r : r;
+  if (!XPOS) r = (x < 0.0) ? 3.1415926535897932 - r : r;
   return copysign(r, y);
 }
+// sqrt(x), 0 <= x <= 1, to ~2e-16 relative: v_rsq_f32 seed (1 ulp of float32) and two coupled Newton steps -- the library
+// sqrt is v_rsq_f64 (a sixteen-cycle instruction) plus scaling and a correctly rounded finish the angle does not need.
+__device__ __forceinline__ double sqrt01_f64(double x) {
+  const double y = (double)__builtin_amdgcn_rsqf((float)x);
+  double g = x * y, h = 0.5 * y;
+  const double r = fma(-g, h, 0.5);
+  g = fma(g, r, g);
+  h = fma(h, r, h);
+  g = fma(fma(-g, g, x), h, g);
+  return (x > 1e-30) ? g : 0.0;  // (x = 0: the seed is inf)
+}
 // asin(x) = atan2(x, sqrt((1 - x)(1 + x))), |x| <= 1
-__device__ __forceinline__ double asin_f64(double x) { return atan2_f64(x, sqrt((1.0 - x) * (1.0 + x))); }
+__device__ __forceinline__ double asin_f64(double x) { return atan2_f64<true>(x, sqrt01_f64((1.0 - x) * (1.0 + x))); }
 
 // per-env context scalars: carl_brax_env.py:255-292 in its intended form
 struct LaneCtx {
@@ -379,7 +395,8 @@ struct Packed {
   LinkB b[CARL_BRAX_MAX_LINKS];
   Sphere sph[CARL_BRAX_MAX_COLL];
   int max_children;  // over the links (bound of the body phase's wavefront-uniform child loop)
-  int pad[3];
+  int all_iso;       // every link: inv_inertia[0] == [1] == [2]
+  int pad[2];
 };
 
 inline void build_packed_host(const carl_brax_sys_t& s, const Topo& t, Packed& pk) {
@@ -430,6 +447,9 @@ inline void build_packed_host(const carl_brax_sys_t& s, const Topo& t, Packed& p
     B.reach = reach;
   }
   pk.max_children = mc;
+  pk.all_iso = 1;
+  for (int i = 0; i < s.n_links; ++i)
+    if (!(pk.b[i].word & kWbIso)) pk.all_iso = 0;
 }
 
 // what the host precomputes per launch (kernel argument, ~2.6 KB)
@@ -722,7 +742,7 @@ static __device__ __forceinline__ JointGeom joint_geometry(const JointRec& la, c
     a_y = eul ? m12 : a_y;
     a_x = eul ? r22 : a_x;
   }
-  const double a1 = atan2_f64(a_y, a_x);
+  const double a1 = atan2_f64<!MULTI>(a_y, a_x);  // (a single hinge: a_x = rel.w >= 0 after the flip)
   g.theta = (float)(2.0 * a1);  // (meaningful on single-hinge lanes)
   g.wrel = bc.w - bp.w;
   g.thetadot = dot(g.x_c, g.wrel);
@@ -822,6 +842,7 @@ static __device__ __forceinline__ double rsqrt_f64(double x) {
 struct SubK {
   float dt, dl, inv_dt, erp;
   int L, first_joint, max_children;
+  bool all_iso;  // every link's effective inertia is isotropic (spring_inertia_scale = 1: every shipped model)
 };
 static __device__ __forceinline__ float uniform(float x) {
   return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x)));
@@ -835,6 +856,7 @@ static __device__ __forceinline__ SubK make_subk(const carl_brax_sys_t& s, const
   k.L = __builtin_amdgcn_readfirstlane(s.n_links);
   k.first_joint = __builtin_amdgcn_readfirstlane(tp.first_joint);
   k.max_children = __builtin_amdgcn_readfirstlane(pk.max_children);
+  k.all_iso = __builtin_amdgcn_readfirstlane(pk.all_iso) != 0;
   return k;
 }
 static __device__ __forceinline__ vf4 ld4(const void* p) { return *reinterpret_cast<const vf4*>(p); }
@@ -1075,7 +1097,7 @@ static __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const T
     }
     const float inv_m = R.inv_m;
     b.v = b.v + (F * inv_m + V(0, 0, cx.x)) * dt;
-    b.w = b.w + apply_inv_inertia(lr, rf, T, iso, inv_i0) * dt;
+    b.w = b.w + (K.all_iso ? T * inv_i0 : apply_inv_inertia(lr, rf, T, iso, inv_i0)) * dt;
     prof.mark(kProfBodySum);
     // spring.collisions.resolve: this body's spheres vs the plane z = 0
     v3 cdv = V(0, 0, 0), cdw = V(0, 0, 0);
@@ -1091,8 +1113,11 @@ static __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const T
       auto depth_of = [&](const vf4 sp) {
         return (float)((double)sp.w - (b.p.z + (R20 * (double)sp.x + R21 * (double)sp.y + R22 * (double)sp.z)));
       };
-      // the impulse of sphere j (ordinal on its link) at penetration `depth`
-      auto respond = [&](const vf4 sp, const float depth, const int j) {
+      // the impulse of sphere j (ordinal on its link) at penetration `depth`.  ISO (wavefront-uniform: every link of the
+      // model has isotropic effective inertia c) folds R diag(c) R^T = c into the formulas:
+      //   n . (I^-1 (r x n) x r) = c (r.x^2 + r.y^2),   dir . (I^-1 (r x dir) x r) = c |r x dir|^2
+      auto respond = [&](const vf4 sp, const float depth, const int j, auto iso_tag) {
+        constexpr bool ISO = decltype(iso_tag)::value;
         // (the plane normal n = e_z is folded in by hand: `dot(n, x)`, `cross(r, n)`, `n * imp` spelled with n as a
         // vector leave the multiplications by its zeros in the instruction stream -- 0 * x is not 0 for IEEE)
         const float radius = sp.w;
@@ -1100,8 +1125,13 @@ static __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const T
         const v3 r = V(ro.x, ro.y, ro.z - radius);
         const v3 rel = b.v + cross(b.w, r);
         const float vn = rel.z;  // n . rel
-        const v3 in = apply_inv_inertia(lr, rf, V(r.y, -r.x, 0.0f), iso, inv_i0);  // I^-1 (r x n)
-        const float ang = in.x * r.y - in.y * r.x;                                   // n . (I^-1 (r x n) x r)
+        float ang;
+        if constexpr (ISO) {
+          ang = inv_i0 * (r.x * r.x + r.y * r.y);
+        } else {
+          const v3 in = apply_inv_inertia(lr, rf, V(r.y, -r.x, 0.0f), iso, inv_i0);  // I^-1 (r x n)
+          ang = in.x * r.y - in.y * r.x;                                              // n . (I^-1 (r x n) x r)
+        }
         const float imp = div_fast(-(1.0f + cx.z) * vn + K.erp * depth * inv_dt, inv_m + ang);
         if (!(imp > 0.0f) || !(vn < 0.0f)) return;
         hit |= 1u << j;
@@ -1109,16 +1139,26 @@ static __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const T
         const float vt_len = sqrtf(rel.x * rel.x + rel.y * rel.y);
         if (vt_len > 1e-9f) {
           const float il = __builtin_amdgcn_rcpf(vt_len), dx = rel.x * il, dy = rel.y * il;
-          const v3 id = apply_inv_inertia(lr, rf, V(-r.z * dy, r.z * dx, r.x * dy - r.y * dx), iso, inv_i0);  // I^-1 (r x dir)
-          const v3 c2 = cross(id, r);
-          const float ang_d = dx * c2.x + dy * c2.y;
+          const v3 rxd = V(-r.z * dy, r.z * dx, r.x * dy - r.y * dx);  // r x dir
+          float ang_d;
+          if constexpr (ISO) {
+            ang_d = inv_i0 * dot(rxd, rxd);
+          } else {
+            const v3 id = apply_inv_inertia(lr, rf, rxd, iso, inv_i0);  // I^-1 (r x dir)
+            const v3 c2 = cross(id, r);
+            ang_d = dx * c2.x + dy * c2.y;
+          }
           const float imp_d = fminf(div_fast(vt_len, inv_m + ang_d), cx.y * imp);
           Jx = -dx * imp_d;
           Jy = -dy * imp_d;
         }
         const v3 J = V(Jx, Jy, imp);
         cdv = cdv + J * inv_m;
-        cdw = cdw + apply_inv_inertia(lr, rf, cross(r, J), iso, inv_i0);
+        if constexpr (ISO) {
+          cdw = cdw + cross(r, J) * inv_i0;
+        } else {
+          cdw = cdw + apply_inv_inertia(lr, rf, cross(r, J), iso, inv_i0);
+        }
         cnt += 1.0f;
       };
       vf4 nxt = ld4(&ll.sph[0]);
@@ -1126,7 +1166,10 @@ static __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const T
         const vf4 sp = nxt;
         nxt = ld4(&ll.sph[j + 1]);
         const float depth = depth_of(sp);
-        if (depth > 0.0f) respond(sp, depth, j);
+        if (depth > 0.0f) {
+          if (K.all_iso) respond(sp, depth, j, std::true_type{});
+          else respond(sp, depth, j, std::false_type{});
+        }
       }
     }
     prof.mark(kProfContacts);
@@ -1198,7 +1241,7 @@ static __device__ __forceinline__ void substep_planar(const carl_brax_sys_t& s, 
     // relative rotation conj(u_p) u_c: the hinge angle is twice its argument
     double Wr = bp.r.w * b.r.w + bp.r.y * b.r.y, Yr = bp.r.w * b.r.y - bp.r.y * b.r.w;
     if (Wr < 0.0) { Wr = -Wr; Yr = -Yr; }
-    const float theta = sg * (float)(2.0 * atan2_f64(Yr, Wr));
+    const float theta = sg * (float)(2.0 * atan2_f64<true>(Yr, Wr));
     const float wrel = b.w.y - bp.w.y, thetadot = sg * wrel;
     uint32_t lim = 0u;
     if (ns > 0) {  // the root: slides along world x and z (the parent is the world), unlimited
@@ -2087,7 +2130,7 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
         if (io.done != nullptr && n_steps == 1) io.done[env] = (uint8_t)(terminated | truncated);  // per-call step
       }
       prof.mark(kProfReward);
-      if (ballot(done) != 0ull) {
+      if (__builtin_expect(ballot(done) != 0ull, 0)) {  // (cold: the register allocator may spill around it, not through the step)
         const float fin_ret = r.ep_return;
         const int fin_len = r.elapsed;
         if (done) {
