@@ -259,9 +259,11 @@ class Workload:
         else:
             self.eng.rollout(self.acts[s][0], self.outs[s][0])
 
-    def train(self, K, W, barrier, collect=True):
+    def train(self, K, W, barrier, collect=True, per_launch=False):
         """W untimed launches, then exactly K timed ones -> (wall seconds incl. the syncs, average launch
-        seconds from one HIP-event pair on the launch stream)."""
+        seconds from one HIP-event pair on the launch stream).  per_launch: a HIP event between every two launches as
+        well -> additionally the K launch-to-launch times in seconds (a region of its own: the contract's regions
+        carry one event pair, nothing between their launches)."""
         import torch
 
         import gc
@@ -285,14 +287,21 @@ class Workload:
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        marks = []
         e0.record()
         for _ in range(K):
             self.launch()
+            if per_launch:
+                marks.append(torch.cuda.Event(enable_timing=True))
+                marks[-1].record()
         e1.record()
         torch.cuda.synchronize()
         barrier()
         wall = time.perf_counter() - t0
         gc.enable()
+        if per_launch:
+            ev = [e0] + marks
+            return wall, e0.elapsed_time(e1) * 1e-3 / K, [ev[i].elapsed_time(ev[i + 1]) * 1e-3 for i in range(K)]
         return wall, e0.elapsed_time(e1) * 1e-3 / K
 
     def train_free_running(self, K, W, barrier):
@@ -501,9 +510,11 @@ def roofline_valu_of(key, avg_launch_s):
     if not rec:
         return None
     floor_s = rec["insts_valu_per_launch"] * VALU_CYCLES_PER_INST / N_SIMDS / SCLK_HZ
+    spec_s = rec["insts_valu_per_launch"] * 2.0 / N_SIMDS / SCLK_HZ  # the guide's 2-cycle wave64 issue (157.3 TF vector peak)
     return {"bound": "valu-issue", "insts_valu_per_launch": rec["insts_valu_per_launch"],
             "cycles_per_inst": VALU_CYCLES_PER_INST, "simds": N_SIMDS, "sclk_hz": SCLK_HZ,
             "issue_floor_ms": floor_s * 1e3, "kernel_ms": avg_launch_s * 1e3, "frac": floor_s / avg_launch_s,
+            "frac_at_spec_2_cycles": spec_s / avg_launch_s,
             "source": rec.get("source"), "insts_salu_per_launch": rec.get("insts_salu_per_launch"),
             "insts_lds_per_launch": rec.get("insts_lds_per_launch")}
 
@@ -525,19 +536,32 @@ def roofline_of(wl, avg_launch_s):
     if rec:
         r["traffic"] = rec["hbm_bytes_per_launch"]
         r["traffic_source"] = rec["source"]
-    # `frac` = frac_period: bytes / the launch-to-launch PERIOD measured live (HIP events on the launch stream; what a
-    # caller gets).  frac_kernel: the same bytes / the kernel's own duration as rocprofv3 --kernel-trace --stats reports
-    # it for this workload (committed under profiles/: a bench run cannot trace itself).  The difference is the launch
-    # boundary: end-of-kernel write-back of the L2-resident tail of the output stream + dispatch of the next launch.
+    # `frac` = frac_period: bytes / the launch-to-launch PERIOD of the timed region (one HIP-event pair over its K
+    # launches; what a caller gets).  frac_kernel: the same bytes / the MEDIAN single-launch time of THIS process (a HIP
+    # event between every two launches of one further region: main()).  Every fraction of the line comes from this
+    # process on this box.  profile_reference: the committed rocprofv3 --kernel-trace --stats figure of the same
+    # workload (another run, possibly another box: a bench run cannot trace itself), with that run's own fraction -- for
+    # reading beside profiles/, never mixed into this line's numbers.
     r["frac_period"] = r["frac"]
+    r["frac_kernel"] = None
     kt = profile_record("kernel_times", key)
     if kt:
-        r["kernel_avg_us_rocprofv3"] = kt["kernel_avg_us"]
-        r["frac_kernel"] = wl.bytes_per_launch / (kt["kernel_avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
-        r["kernel_time_source"] = kt["source"]
-    else:
-        r["kernel_avg_us_rocprofv3"] = r["frac_kernel"] = None
+        r["profile_reference"] = {"kernel_avg_us_rocprofv3": kt["kernel_avg_us"],
+                                  "frac_of_that_run": wl.bytes_per_launch / (kt["kernel_avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                  "source": kt["source"]}
     return r
+
+
+def launch_stats(wl, roofline, K, barrier):
+    """One further region of K launches with a HIP event between every two -> min / median / max launch time of this
+    process and `frac_kernel` from the median (VERDICT r04 #2b)."""
+    _, _, per = wl.train(K, 0, barrier, collect=False, per_launch=True)
+    per = sorted(per)
+    med = per[(len(per) - 1) // 2]
+    roofline["launch_us"] = {"n": len(per), "min": per[0] * 1e6, "median": med * 1e6, "max": per[-1] * 1e6,
+                             "how": "HIP event between every two launches of one extra K-launch region, this process"}
+    roofline["frac_kernel"] = wl.bytes_per_launch / med / 1e9 / HBM_PEAK_GBS
+    return roofline
 
 
 def _cpu_worker(job):
@@ -706,6 +730,64 @@ def graph_per_call(rec, eng, action, env, n, Kc, device):
     })
 
 
+def dropin_per_call(device, n_big, cpu_single_core_value):
+    """The drop-in boundary's own cost per env step: what a maintainer of the reference binds is not the
+    engine but `Mi355xVecEnv` under the reference's `CARLEnv` (carl/envs/carl_env.py:321-342 ->
+    carl/envs/gymnasium/carl_gymnasium_env.py:63-77), and the mirror class `carl_amd.envs.CARLCartPole`.
+      scalar:  num_envs = 1, the reference's own calling convention -- Python action in, float32 ndarray / float / bool
+               out, i.e. one launch AND one device-to-host read per env step;
+      batched: num_envs = n_big, device tensors in and out, no host read inside the loop."""
+    import numpy as np
+    import torch
+
+    from carl_amd.dropin import Mi355xVecEnv
+    from carl_amd.envs import CARLCartPole
+
+    rec = {"unit": "us per step() call", "family": "CartPole-v1",
+           "cpu_reference_style_us_per_step": (1e6 / cpu_single_core_value) if cpu_single_core_value else None}
+    env = Mi355xVecEnv("CartPole-v1", num_envs=1, device=device)
+    env.reset(seed=0)
+    rng = np.random.default_rng(0)
+    acts = rng.integers(0, 2, 2200)
+    for a in acts[:200]:
+        _, _, term, trunc, _ = env.step(int(a))
+        if term or trunc:
+            env.reset()
+    t0 = time.perf_counter()
+    for a in acts[200:]:
+        _, _, term, trunc, _ = env.step(int(a))
+        if term or trunc:
+            env.reset()
+    rec["scalar_num_envs_1"] = (time.perf_counter() - t0) / 2000 * 1e6
+    del env
+    big = Mi355xVecEnv("CartPole-v1", num_envs=n_big, device=device)
+    big.reset(seed=0)
+    a = torch.randint(0, 2, (n_big,), device=device, dtype=torch.int32)
+    for _ in range(100):
+        big.step(a)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(1000):
+        big.step(a)
+    torch.cuda.synchronize()
+    rec[f"batched_num_envs_{n_big}"] = (time.perf_counter() - t0) / 1000 * 1e6
+    del big
+    mirror = CARLCartPole(num_envs=n_big, device=str(device), seed=0)
+    mirror.reset(seed=0)
+    for _ in range(100):
+        mirror.step(a)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(1000):
+        mirror.step(a)
+    torch.cuda.synchronize()
+    rec[f"mirror_CARLCartPole_num_envs_{n_big}"] = (time.perf_counter() - t0) / 1000 * 1e6
+    rec["note"] = ("scalar = one launch + one device-to-host read per env step (the reference's return types); if it is slower "
+                   "than cpu_reference_style_us_per_step, a single env is better served by the CPU -- the shim pays off from "
+                   "num_envs > 1 (INTEGRATION.md)")
+    return rec
+
+
 class _stdout_to_stderr:
     """RCCL prints a version banner with C stdio on stdout when a communicator is created; the contract of this
     script is ONE JSON line on stdout.  File descriptor 1 points at stderr while the group is built (and the C
@@ -724,17 +806,59 @@ class _stdout_to_stderr:
         os.close(self._saved)
 
 
+def launch_plan(gpus, env, n_devices):
+    """What `bench.py --gpus N` does, given the environment it was started in (pure function: tests/test_bench_contract.py).
+    ("run", None): this process is the rank the environment names (RANK / WORLD_SIZE from torch.distributed.run, or the
+    single-GPU case).  ("spawn", n): started WITHOUT a launcher for N > 1 -- re-execute under
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N`, one rank per GPU, so that a bare
+    `python bench.py --gpus 8` measures eight GPUs and never prints a one-GPU number as n_gpus 8.
+    ("error", message): the line could not be what it says."""
+    if gpus < 1:
+        return "error", f"--gpus {gpus}"
+    share = env.get("CARL_BENCH_SHARE_GPU") == "1"  # plumbing check of the N > 1 path on a one-GPU box (every rank on GPU 0)
+    if "WORLD_SIZE" in env:
+        world = int(env["WORLD_SIZE"])
+        if world != gpus:
+            return "error", f"--gpus {gpus} but WORLD_SIZE={world}: the line's n_gpus would not be the ranks that ran"
+        if world > 1 and not share and n_devices < world:
+            return "error", f"--gpus {gpus} but {n_devices} device(s) visible (CARL_BENCH_SHARE_GPU=1 puts every rank on GPU 0)"
+        return "run", None
+    if gpus == 1:
+        return "run", None
+    if not share and n_devices < gpus:
+        return "error", f"--gpus {gpus} but {n_devices} device(s) visible (CARL_BENCH_SHARE_GPU=1 puts every rank on GPU 0)"
+    return "spawn", gpus
+
+
+def spawn_ranks(n):
+    """Re-execute this command line under torch.distributed.run (one process per GPU; rendezvous on 127.0.0.1)."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:  # a free port for the rendezvous
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
     import torch
 
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback exists)")
+    what, arg = launch_plan(args.gpus, os.environ, torch.cuda.device_count())
+    if what == "error":
+        raise SystemExit(arg)
+    if what == "spawn":
+        raise SystemExit(spawn_ranks(arg))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback exists)")
     # Plumbing check of the N > 1 path on a ONE-GPU box (tools/bench_2proc_sim.sh): every rank on GPU 0, gloo
     # for the collectives (RCCL refuses two ranks on one device).  Never what the driver runs.
     share_gpu = os.environ.get("CARL_BENCH_SHARE_GPU") == "1"
@@ -789,7 +913,7 @@ def main():
     # ---- timed region: exactly K fused launches (K x T env steps of every lane), repeated --reps times ----
     regions, med = timed_regions(wl, K, W, args.reps, barrier, max_over_ranks)
     elapsed, avg_launch_s = regions[med]
-    roofline = roofline_of(wl, avg_launch_s)
+    roofline = launch_stats(wl, roofline_of(wl, avg_launch_s), K, barrier)
     per_rank_launch_ms = gather_over_ranks(avg_launch_s * 1e3)
     repetitions = {"n": len(regions), "median_index": med, "steps_each": K,
                    "ms_per_step": [w / K * 1e3 for w, _ in regions], "launch_period_ms": [p_ * 1e3 for _, p_ in regions],
@@ -880,6 +1004,12 @@ def main():
         except Exception as e:  # the CPU line is a reported baseline: its failure must not take the GPU measurement with it
             cpu = {"value": None, "unit": "env-steps/s", "cores": os.cpu_count(), "kind": "port", "error": repr(e)[:200]}
 
+    if per_call is not None and rank == 0 and world == 1 and tuple(args.families) == ("cartpole",):
+        try:
+            per_call["dropin"] = dropin_per_call(device, n_fam, (cpu or {}).get("single_core_value"))
+        except Exception as e:  # a reported side record: its failure must not take the measurement with it
+            per_call["dropin"] = {"error": repr(e)[:300]}
+
     # ---- the other BASELINE workloads, same launch train ---------------------------
     also = {}
     names = [] if args.also in ("", "none") else args.also.split(",")
@@ -897,7 +1027,7 @@ def main():
         w2 = Workload(fams, lanes, Ta, args.buffer_sets, rank, world, device, narrow_actions=narrow)
         regs2, m2 = timed_regions(w2, K, W, args.reps, barrier, max_over_ranks)
         el2, avg2 = regs2[m2]
-        r2 = roofline_of(w2, avg2)
+        r2 = launch_stats(w2, roofline_of(w2, avg2), K, barrier)
         also[name] = {
             "workload": " + ".join(f"CARL{f} x {lanes}" for f in fams) + f" contexts/GPU, {Ta} env steps per launch"
                         + (", uint8 actions" if name.endswith("_u8") else ", float16 actions" if narrow else ""),
@@ -905,7 +1035,7 @@ def main():
             "lanes_per_gpu": w2.n, "chunk": Ta, "ms_per_step": el2 / K * 1e3,
             "avg_launch_ms": avg2 * 1e3, "frac": r2["frac"], "achieved_GBs": r2["achieved"],
             "bytes_per_unit": r2["bytes_per_unit"], "traffic": r2["traffic"],
-            "frac_kernel": r2["frac_kernel"], "kernel_avg_us_rocprofv3": r2["kernel_avg_us_rocprofv3"],
+            "frac_kernel": r2["frac_kernel"], "launch_us": r2["launch_us"], "profile_reference": r2.get("profile_reference"),
             "repetitions_ms_per_step": [w / K * 1e3 for w, _ in regs2],
             "mean_last_episode_return": w2.mean_last_return(), "lanes_per_env": w2.launch_shape(),
             "classes": [type(e).__name__ for e in w2.envs],

@@ -77,3 +77,40 @@ def test_clock_sampler_degrades_without_sysfs(tmp_path):
     rec = c.record()
     assert rec["temp_mem_c"]["median"] == 61.0 and rec["power_w"]["max"] == 512.0 and rec["sclk_mhz"]["median"] == 2352
     assert bench.ClockSampler.discover_hwmon(None) == {}
+
+
+def test_launch_plan_never_lets_n_gpus_differ_from_the_ranks_that_ran():
+    """`bench.py --gpus N` (VERDICT r04 #2a): started without a launcher it spawns N ranks itself; under a launcher
+    WORLD_SIZE must equal --gpus; fewer visible devices than ranks is an error unless the one-GPU plumbing check
+    (CARL_BENCH_SHARE_GPU=1) asks for it.  SURVEY 8e process model: one process per GPU."""
+    lp = bench.launch_plan
+    assert lp(1, {}, 1) == ("run", None)
+    assert lp(1, {}, 8) == ("run", None)
+    assert lp(8, {}, 8) == ("spawn", 8)  # plain `python bench.py --gpus 8`: re-executed under torch.distributed.run
+    assert lp(2, {}, 1)[0] == "error"  # one device, two ranks, not asked for
+    assert lp(2, {"CARL_BENCH_SHARE_GPU": "1"}, 1) == ("spawn", 2)
+    assert lp(8, {"WORLD_SIZE": "8", "RANK": "3"}, 8) == ("run", None)  # the driver's torch.distributed.run command
+    assert lp(8, {"WORLD_SIZE": "4"}, 8)[0] == "error"
+    assert lp(1, {"WORLD_SIZE": "2"}, 2)[0] == "error"
+    assert lp(4, {"WORLD_SIZE": "4"}, 1)[0] == "error"
+    assert lp(4, {"WORLD_SIZE": "4", "CARL_BENCH_SHARE_GPU": "1"}, 1) == ("run", None)
+    assert lp(0, {}, 1)[0] == "error"
+
+
+def test_spawn_command_is_one_rank_per_gpu_on_loopback(monkeypatch):
+    import subprocess
+
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 0
+
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(bench.sys, "argv", ["bench.py", "--gpus", "4", "--steps", "10", "--warmup", "3"])
+    assert bench.spawn_ranks(4) == 0
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "10", "--warmup", "3"] and cmd[-7].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
