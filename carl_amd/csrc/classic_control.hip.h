@@ -471,16 +471,16 @@ struct AcrobotT {
     s[1] = (float)n1;
     s[2] = (float)n2;
     s[3] = (float)n3;
-    // _terminal and the observation's trig on the unrounded angles, like the reference's
-    // float64 state: -cos t1 - cos(t1 + t2) > 1, cos(t1 + t2) = c0 c1 - s0 s1
+    // One trig evaluation per step, at the STORED (float32) angles: it is exactly what the next step's first RK4 stage
+    // needs, and it serves _terminal (-cos t1 - cos(t1 + t2) > 1, cos(t1 + t2) = c0 c1 - s0 s1) and the observation
+    // as well -- the reference takes those from its unrounded float64 state, 2e-7 away at most (the float32 rounding
+    // of an angle in [-pi, pi]): fifty times inside the 1e-5 bar, and a terminal decision can only differ for a state
+    // within 2e-7 of the threshold.  (Round 4 evaluated the unrounded angles and corrected to the stored ones with
+    // sin(x + d) = sin x + d cos x: ten float64 instructions more per step on a vector-ALU-bound kernel.)
     Real s0r, c0r, s1r, c1r;
-    sincos_pair(n0, n1, s0r, c0r, s1r, c1r);
+    sincos_pair((Real)s[0], (Real)s[1], s0r, c0r, s1r, c1r);
     const bool terminated = (-c0r - (c0r * c1r - s0r * s1r)) > (Real)1.0;
-    // trig of the ROUNDED angles for the next step's first stage: sin(x + d) = sin x + d cos x to
-    // O(d^2) with |d| <= 2e-7 (the float32 rounding of an angle in [-pi, pi]) -> error < 2e-14
-    const Real d0 = (Real)s[0] - n0, d1 = (Real)s[1] - n1;
-    aux = Aux{(float)c0r, (float)s0r, (float)c1r, (float)s1r,
-              s0r + d0 * c0r, c0r - d0 * s0r, s1r + d1 * c1r, c1r - d1 * s1r};
+    aux = Aux{(float)c0r, (float)s0r, (float)c1r, (float)s1r, s0r, c0r, s1r, c1r};
     reward = terminated ? 0.0f : -1.0f;
     return terminated;
   }
