@@ -15,7 +15,7 @@ import torch  # noqa: F401  (must precede the CDLL load, see module docstring)
 
 from carl_amd import build as _build
 
-CARL_ABI_VERSION = 7
+CARL_ABI_VERSION = 8
 CARL_MAX_CTX_OBS = 32
 
 # carl_family_t
@@ -199,6 +199,7 @@ class BraxSys(C.Structure):
         ("push_lo", _f * 2), ("push_hi", _f * 2),
         ("n_pair", _i), ("pair_link", _i), ("pair_pos", (_f * 3) * BRAX_MAX_PAIR), ("pair_radius", _f * BRAX_MAX_PAIR),
         ("pair_obj_radius", _f), ("pair_obj_half", _f), ("pair_k", _f), ("pair_c", _f),
+        ("pair_ct", _f), ("plane_z", _f), ("obj_support", _i), ("reserved2", _i),
         ("slide_axis", ((_f * 3) * 2) * BRAX_MAX_LINKS),
         ("ctx", BraxCtxMap),
     ]

@@ -790,7 +790,7 @@ static __device__ __forceinline__ JointGeom joint_geometry(const JointRec& la, c
 struct PairOut {
   v3 on_obj, on_a, t_a;
 };
-static __device__ __forceinline__ PairOut pair_contact(const carl_brax_sys_t& s, const Lds& m) {
+static __device__ __forceinline__ PairOut pair_contact(const carl_brax_sys_t& s, const Lds& m, const float friction) {
   const int a = s.pair_link;
   const Body ba = m.body(a), bo = m.body(s.push_link);
   const v3d o = bo.p - qrot(bo.r, tod(f3(s.com[s.push_link])));
@@ -808,9 +808,17 @@ static __device__ __forceinline__ PairOut pair_contact(const carl_brax_sys_t& s,
     if (!(depth > 0.0f) || !(dist > 1e-9f)) continue;
     const v3 n = V((float)dxd / dist, (float)dyd / dist, 0.0f);
     const v3 vs = ba.v + cross(ba.w, rel);
-    const float fm = s.pair_k * depth + s.pair_c * dot(vs - bo.v, n);
+    const v3 vr = vs - bo.v;
+    const float closing = dot(vr, n);
+    const float fm = s.pair_k * depth + s.pair_c * closing;
     if (!(fm > 0.0f)) continue;
-    const v3 fc = n * fm;
+    v3 fc = n * fm;
+    if (s.pair_ct > 0.0f) {  // Coulomb friction, regularised (carl_amd.h: pair_ct): min(pair_ct |vt|, friction fm) along vt
+      v3 vt = vr - n * closing;
+      vt.z = 0.0f;  // (the object's free directions are horizontal: the table carries the vertical part)
+      const float vt_len = sqrtf(dot(vt, vt));
+      if (vt_len > 1e-9f) fc = fc + vt * (fminf(s.pair_ct * vt_len, friction * fm) / vt_len);
+    }
     r.on_obj = r.on_obj + fc;
     r.on_a = r.on_a - fc;
     r.t_a = r.t_a - cross(rel, fc);
@@ -840,7 +848,7 @@ static __device__ __forceinline__ double rsqrt_f64(double x) {
 // 1 / dt ... were re-read and re-derived in every one of the n_frames substeps.  Wave-uniform ones are pinned in
 // scalar registers (readfirstlane), which also takes them out of the vector-register budget.
 struct SubK {
-  float dt, dl, inv_dt, erp;
+  float dt, dl, inv_dt, erp, plane_z;
   int L, first_joint, max_children;
   bool all_iso;  // every link's effective inertia is isotropic (spring_inertia_scale = 1: every shipped model)
 };
@@ -853,6 +861,7 @@ static __device__ __forceinline__ SubK make_subk(const carl_brax_sys_t& s, const
   k.dl = uniform(__expf(s.vel_damping * s.dt));
   k.inv_dt = uniform(__builtin_amdgcn_rcpf(s.dt));
   k.erp = uniform(s.baumgarte_erp);
+  k.plane_z = uniform(s.plane_z);
   k.L = __builtin_amdgcn_readfirstlane(s.n_links);
   k.first_joint = __builtin_amdgcn_readfirstlane(tp.first_joint);
   k.max_children = __builtin_amdgcn_readfirstlane(pk.max_children);
@@ -1052,7 +1061,7 @@ static __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const T
     R.sig_lim = R.sig_lim * 33u + lim;
     v3 pf = f * -1.0f, pt = (cross(g.rp_off, f) + t) * -1.0f;  // on the parent
     if (TASK && s.n_pair > 0 && ll.i == s.push_link) {
-      const PairOut po = pair_contact(s, m);
+      const PairOut po = pair_contact(s, m, ll.ctx[1]);
       f = f + po.on_obj;
       pf = po.on_a;
       pt = po.t_a;
@@ -1098,20 +1107,32 @@ static __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const T
     const float inv_m = R.inv_m;
     b.v = b.v + (F * inv_m + V(0, 0, cx.x)) * dt;
     b.w = b.w + (K.all_iso ? T * inv_i0 : apply_inv_inertia(lr, rf, T, iso, inv_i0)) * dt;
+    if (TASK && s.obj_support != 0 && ll.i == s.push_link) {
+      // the push task's object on the table (carl_amd.h: obj_support): Coulomb friction under the normal load m |g| as an
+      // impulse -- the horizontal velocity shrinks by friction |g| dt, at most to zero
+      const float load = cx.x < 0.0f ? -cx.x : 0.0f;
+      const float vh = sqrtf(b.v.x * b.v.x + b.v.y * b.v.y);
+      if (vh > 1e-9f) {
+        const float cut = fminf(cx.y * load * dt, vh) / vh;
+        b.v.x -= b.v.x * cut;
+        b.v.y -= b.v.y * cut;
+      }
+    }
     prof.mark(kProfBodySum);
     // spring.collisions.resolve: this body's spheres vs the plane z = 0
     v3 cdv = V(0, 0, 0), cdw = V(0, 0, 0);
     float cnt = 0.0f;
     uint32_t hit = 0u;
     // no sphere of this link can reach the plane while its COM is higher than the farthest sphere surface
-    const int n_sph = ((float)b.p.z < qb.w) ? wb_spheres(wb) : 0;
+    const double pz = b.p.z - (double)K.plane_z;  // height above the collision plane (the ground; the push task's table)
+    const int n_sph = ((float)pz < qb.w) ? wb_spheres(wb) : 0;
     if (ballot(n_sph > 0) != 0ull) {  // (nothing at all while every link the wavefront holds is out of reach)
       // third row of the rotation matrix in float64: a sphere's height -- hence its depth, which the Baumgarte
       // term multiplies by erp / dt -- is a pose difference
       const double R20 = 2.0 * (b.r.x * b.r.z - b.r.w * b.r.y), R21 = 2.0 * (b.r.y * b.r.z + b.r.w * b.r.x),
                    R22 = 1.0 - 2.0 * (b.r.x * b.r.x + b.r.y * b.r.y);
       auto depth_of = [&](const vf4 sp) {
-        return (float)((double)sp.w - (b.p.z + (R20 * (double)sp.x + R21 * (double)sp.y + R22 * (double)sp.z)));
+        return (float)((double)sp.w - (pz + (R20 * (double)sp.x + R21 * (double)sp.y + R22 * (double)sp.z)));
       };
       // the impulse of sphere j (ordinal on its link) at penetration `depth`.  ISO (wavefront-uniform: every link of the
       // model has isotropic effective inertia c) folds R diag(c) R^T = c into the formulas:
@@ -1299,12 +1320,13 @@ static __device__ __forceinline__ void substep_planar(const carl_brax_sys_t& s, 
     // spring.collisions.resolve: this body's spheres vs the plane z = 0
     float cdvx = 0.0f, cdvz = 0.0f, cdw = 0.0f, cnt = 0.0f;
     uint32_t hit = 0u;
-    const int n_sph = ((float)b.p.z < qb.w) ? wb_spheres(wb) : 0;
+    const double pz = b.p.z - (double)K.plane_z;
+    const int n_sph = ((float)pz < qb.w) ? wb_spheres(wb) : 0;
     if (ballot(n_sph > 0) != 0ull) {
       const double cth = 1.0 - 2.0 * (b.r.y * b.r.y), sth = 2.0 * (b.r.w * b.r.y);  // R22, -R20 of the general form
       const float cf = (float)cth, sf = (float)sth;
       auto depth_of = [&](const vf4 sp) {
-        return (float)((double)sp.w - (b.p.z + (cth * (double)sp.z - sth * (double)sp.x)));
+        return (float)((double)sp.w - (pz + (cth * (double)sp.z - sth * (double)sp.x)));
       };
       auto respond = [&](const vf4 sp, const float depth, const int j) {
         const float radius = sp.w;

@@ -779,7 +779,11 @@ def pusher_sys(feature_names: list[str] | None = None, reference_compat: bool = 
     marker body (two slides, no collisions) is not simulated.  Link masses are the reference's defaults
     (carl_pusher.py:37-79).  This build's choices: rotational inertias 1 (shoulder) ... 0.05 (wrist) in
     place of armature 0.04 + geometry; gripper-puck contact = 7 spheres along the fork against the puck
-    (frictionless penalty contact, ``carl_brax_sys_t::n_pair``), no table plane; dt 0.001 x 50 so that
+    (penalty contact with regularised Coulomb friction, ``carl_brax_sys_t::n_pair`` / ``pair_ct``); the table
+    (round 5, ABI 8): the same 7 fork spheres collide with the plane z = -0.325 (``plane_z``: the MJCF's table
+    geom, on which the puck's bottom face lies), and the puck slides on it with Coulomb friction under its
+    weight (``obj_support``: friction x m |g| -- nothing with the MJCF's own zero gravity, the context's
+    friction x 9.8 m/s^2 with CARL's default gravity); dt 0.001 x 50 so that
     the 1.8 g puck and the 5 g wrist link sit on explicit springs.  NOTE the reference's context default
     gravity = -9.8 applies in the intended form (the MJCF has none): the 2 N m motors do not hold the arm
     against it.  PARITY UNPINNED."""
@@ -842,7 +846,6 @@ def pusher_sys(feature_names: list[str] | None = None, reference_compat: bool = 
     s.k_pos[7], s.k_vel[7], s.k_limit[7], s.k_ang_damp[7] = 500.0, 0.5, 100.0, 1.0
     for i in range(8):
         s.dof_sign3[i] = 1.0
-    s.n_coll = 0
     # the fork of r_wrist_roll_link: cross bar (0, +-0.1, 0) and two prongs reaching x = 0.1
     fork = [(0.0, -0.1, 0.0), (0.0, 0.0, 0.0), (0.0, 0.1, 0.0), (0.05, -0.1, 0.0), (0.1, -0.1, 0.0),
             (0.05, 0.1, 0.0), (0.1, 0.1, 0.0)]
@@ -851,6 +854,14 @@ def pusher_sys(feature_names: list[str] | None = None, reference_compat: bool = 
         _set3(s.pair_pos, k, pos)
         s.pair_radius[k] = 0.02
     s.pair_obj_radius, s.pair_obj_half, s.pair_k, s.pair_c = 0.05, 0.05, 500.0, 0.5
+    # the table: the fork's spheres against the plane the puck lies on; friction in both contacts.  pair_ct: the
+    # regularisation slope of the pair friction -- explicit, so pair_ct dt / m_puck (0.28) stays below 1
+    s.plane_z, s.pair_ct, s.obj_support = -0.325, 0.5, 1
+    s.n_coll = len(fork)
+    for k, pos in enumerate(fork):
+        s.coll_link[k] = 6
+        _set3(s.coll_pos, k, pos)
+        s.coll_radius[k] = 0.02
     _wire_context(s, feature_names, reference_compat, {n: i for i, n in enumerate(names)}, PUSHER_MASSES)
     return s
 

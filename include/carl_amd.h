@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define CARL_ABI_VERSION 7
+#define CARL_ABI_VERSION 8
 #define CARL_MAX_CTX_OBS 32
 
 #define CARL_ERR_INVALID_ARGUMENT (-1)
@@ -333,7 +333,7 @@ typedef struct carl_brax_sys {
   float dof_damping[CARL_BRAX_MAX_DOF], dof_stiffness[CARL_BRAX_MAX_DOF];
   int32_t act_dof[CARL_BRAX_MAX_ACT];
   float act_gear[CARL_BRAX_MAX_ACT], act_lo[CARL_BRAX_MAX_ACT], act_hi[CARL_BRAX_MAX_ACT];
-  int32_t coll_link[CARL_BRAX_MAX_COLL];    /* collision spheres vs the ground plane z = 0 */
+  int32_t coll_link[CARL_BRAX_MAX_COLL];    /* collision spheres vs the plane z = plane_z (0: the ground) */
   float coll_pos[CARL_BRAX_MAX_COLL][3], coll_radius[CARL_BRAX_MAX_COLL];
   float init_q[CARL_BRAX_MAX_Q];
   /* goal-directed reward epilogue (carl/envs/brax/brax_walker_goal_wrapper.py:113-140): position +=
@@ -397,12 +397,23 @@ typedef struct carl_brax_sys {
    * frame, radius pair_radius[k]) against the object, an upright cylinder (radius pair_obj_radius, half
    * height pair_obj_half) centred at the frame origin of push_link.  A sphere whose centre is within
    * pair_obj_half + r_k of the object's mid-height and closer than r_k + R in the horizontal plane pushes
-   * the object along the horizontal normal n with max(0, pair_k depth + pair_c closing speed); the
-   * opposite force acts on pair_link at the sphere's centre (frictionless; the object's own rotation is
-   * locked by its joint) */
+   * the object along the horizontal normal n with fm = max(0, pair_k depth + pair_c closing speed); the
+   * opposite force acts on pair_link at the sphere's centre (the object's own rotation is locked by its
+   * joint).  ABI 8 -- contact friction and the table:
+   *   pair_ct > 0: Coulomb friction in the pair contact, regularised -- with vt the HORIZONTAL part of the sphere's
+   *     velocity relative to the object minus its normal part, the object is dragged along vt by min(pair_ct |vt|, friction fm)
+   *     (`friction`: the env's context value, as in the plane contacts) and the sphere held back by the same;
+   *   obj_support = 1: the object rests on the plane z = plane_z (its joint has no vertical freedom, so the
+   *     plane carries its weight): every substep, after the force update, its horizontal velocity shrinks by
+   *     min(friction |gravity_z| dt, |v_h|) -- Coulomb friction under the normal load m |g| as an impulse, the
+   *     form the sphere / plane contacts use (a sliding puck stops dead after v0^2 / (2 mu g));
+   *   plane_z: the height of THE collision plane (0 for the locomotion models; the push task's table): every
+   *     sphere of coll_* collides with z = plane_z. */
   int32_t n_pair, pair_link;
   float pair_pos[CARL_BRAX_MAX_PAIR][3], pair_radius[CARL_BRAX_MAX_PAIR];
   float pair_obj_radius, pair_obj_half, pair_k, pair_c;
+  float pair_ct, plane_z;
+  int32_t obj_support, reserved2;
   float slide_axis[CARL_BRAX_MAX_LINKS][2][3]; /* unit axes in the PARENT frame, mutually orthogonal */
   carl_brax_ctx_map_t ctx;
 } carl_brax_sys_t;

@@ -16,9 +16,10 @@
  * form of the joint constraint are this build's reconstruction.  PARITY UNPINNED against brax --
  * the reference's tests hold no Brax step value (test/test_brax_env.py:8-23 is a smoke test).
  * What this file pins is the HIP kernel against an independent fp64 implementation of the
- * same specification; what pins THIS file: eight analytic known-answer cases (closed forms of the
+ * same specification; what pins THIS file: ten analytic known-answer cases (closed forms of the
  * scheme and of the physics: free fall, restitution, the reduced-mass oscillator, the physical
- * pendulum's period, actuator + damping series, limit equilibrium, Coulomb stop, torque-free spin:
+ * pendulum's period, actuator + damping series, limit equilibrium, Coulomb stop, torque-free spin,
+ * the push task's puck sliding to rest on the table after v0^2 / (2 mu g), its fork resting on the table plane:
  * tests/test_brax_physics_kat.py), a second, independently written NumPy restatement of the joint
  * pass (oracle/spring_ref.py) and physical invariants (tests/test_brax_oracle.py).
  *
@@ -31,7 +32,7 @@
  *       about the axis n: tau - dof_damping * thetadot - k_stiff * theta + limit spring
  *       relative angular damping: -k_ang_damp (w_c - w_p)
  *  3. v += dt (F / m + g);  w += dt R diag(inv_inertia) R^T T             (no gyroscopic term)
- *  4. contacts, sphere vs plane z = 0 (spring.collisions.resolve): for penetrating,
+ *  4. contacts, sphere vs plane z = plane_z (0: the ground; the push task's table) (spring.collisions.resolve): for penetrating,
  *     approaching points an impulse with restitution `elasticity`, Baumgarte term
  *     erp * depth / dt and Coulomb friction (<= friction * normal impulse), averaged over the
  *     link's active contacts
@@ -386,7 +387,22 @@ static void joint_wrenches(const carl_brax_sys_t* s, const lane_ctx* c, const do
         const double closing = vdot(vsub(vs, b[i].v), n);
         const double fm = s->pair_k * depth + s->pair_c * closing;
         if (!(fm > 0.0)) continue;
-        const v3 fc = vscale(n, fm);
+        v3 fc = vscale(n, fm);
+        if (s->pair_ct > 0.0f) { /* Coulomb friction, regularised (carl_amd.h: pair_ct): the object is dragged along the
+                                  * sphere's tangential velocity, never harder than friction x the normal force --
+                                  * what brax's contact friction does between the gripper and puck geoms
+                                  * [upstream-memory: brax/envs/assets/pusher.xml gives both geoms friction] */
+          const v3 vr = vsub(vs, b[i].v);
+          v3 vt = vsub(vr, vscale(n, closing));
+          vt.z = 0.0; /* the object's free directions are horizontal: the table carries the vertical part */
+          const double vt_len = sqrt(vdot(vt, vt));
+          if (vt_len > 1e-9) {
+            double ft = s->pair_ct * vt_len;
+            const double cap = c->friction * fm;
+            if (ft > cap) ft = cap;
+            fc = vadd(fc, vscale(vt, ft / vt_len));
+          }
+        }
         F[i] = vadd(F[i], fc);
         F[a] = vsub(F[a], fc);
         T[a] = vsub(T[a], vcross(rel, fc));
@@ -404,7 +420,23 @@ static void substep(const carl_brax_sys_t* s, const lane_ctx* c, const double* t
     b[i].v = vadd(b[i].v, vscale(vadd(vscale(F[i], 1.0 / c->mass[i]), V(0, 0, c->gravity_z)), s->dt));
     b[i].w = vadd(b[i].w, vscale(apply_inv_inertia(s, i, b[i].r, T[i]), s->dt));
   }
-  /* --- spring.collisions.resolve: spheres vs the plane z = 0 ------------------------ */
+  /* --- the push task's object on the table (carl_amd.h: obj_support): Coulomb friction under the normal load m |g|,
+   * as an impulse like the plane contacts' -- the horizontal velocity shrinks by friction |g| dt, at most to zero.
+   * [upstream-memory: the puck of brax's pusher lies on the table geom; its two slides leave it no vertical freedom, so
+   * whatever holds it up carries m |g|; with the MJCF's own gravity 0 0 0 there is no load and no friction, with CARL's
+   * context default gravity = -9.8 (carl_pusher.py:17-21) there is] */
+  if (s->obj_support && s->push_link > 0) {
+    const int i = s->push_link;
+    const double load = c->gravity_z < 0.0 ? -c->gravity_z : 0.0;
+    const double vh = sqrt(b[i].v.x * b[i].v.x + b[i].v.y * b[i].v.y);
+    if (vh > 1e-9) {
+      double cut = c->friction * load * s->dt;
+      if (cut > vh) cut = vh;
+      b[i].v.x -= b[i].v.x / vh * cut;
+      b[i].v.y -= b[i].v.y / vh * cut;
+    }
+  }
+  /* --- spring.collisions.resolve: spheres vs the plane z = plane_z (0: the ground; the push task's table) ------ */
   v3 dv[L_MAX], dw[L_MAX];
   int cnt[L_MAX], seen[L_MAX];
   uint32_t hit[L_MAX];
@@ -415,7 +447,7 @@ static void substep(const carl_brax_sys_t* s, const lane_ctx* c, const double* t
     const int ordinal = seen[i]++; /* of this sphere among its link's spheres */
     const v3 o = vsub(b[i].p, qrot(b[i].r, f3(s->com[i])));
     const v3 ctr = vadd(o, qrot(b[i].r, f3(s->coll_pos[k])));
-    const double depth = s->coll_radius[k] - ctr.z; /* > 0: penetrating */
+    const double depth = s->coll_radius[k] - (ctr.z - (double)s->plane_z); /* > 0: penetrating */
     if (!(depth > 0)) continue;
     const v3 pos = V(ctr.x, ctr.y, ctr.z - s->coll_radius[k]); /* lowest point of the sphere */
     const v3 r = vsub(pos, b[i].p);

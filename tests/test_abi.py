@@ -41,7 +41,7 @@ def test_action_dtype_codes_match_the_header():
     assert codes == {"CARL_ACTION_I32": _lib.ACTION_I32, "CARL_ACTION_I64": _lib.ACTION_I64,
                      "CARL_ACTION_F32": _lib.ACTION_F32, "CARL_ACTION_U8": _lib.ACTION_U8,
                      "CARL_ACTION_F16": _lib.ACTION_F16, "CARL_ACTION_BF16": _lib.ACTION_BF16}
-    assert int(re.search(r"#define CARL_ABI_VERSION (\d+)", src).group(1)) == _lib.CARL_ABI_VERSION == 7
+    assert int(re.search(r"#define CARL_ABI_VERSION (\d+)", src).group(1)) == _lib.CARL_ABI_VERSION == 8
 
 
 def test_family_info_is_host_side():

@@ -241,3 +241,85 @@ def test_k8_torque_free_spin_turns_by_two_atan_half_w_dt_per_substep(runner):
     np.testing.assert_allclose(np.linalg.norm(st[:, 3:7], axis=1), 1.0, atol=1e-12)
     # the integrator under-rotates against the continuous w t by (w dt)^2 / 12 relative
     assert abs((angle[3] - W[3] * n * dtf) / (W[3] * n * dtf) + (W[3] * dtf) ** 2 / 12) < 2e-4
+
+
+def _pusher_case(n):
+    """CARLBraxPusher's model table on the four context columns of this file, a reset arm pose from the restatement's
+    forward kinematics, and nothing damping the puck's slides but the table."""
+    from carl_amd.envs.brax.models import pusher_sys
+    from oracle import brax as B
+
+    s = pusher_sys(K.CTX_NAMES)
+    s.max_episode_steps = K.BIG
+    s.dof_damping[7] = s.dof_damping[8] = 0.0  # (the MJCF's joint damping 0.5: off, Coulomb friction alone stops the puck)
+    q = np.zeros(9)
+    st = B.forward_kinematics(s, q, np.zeros(9)).reshape(8, 13)
+    return s, np.tile(st[None], (n, 1, 1))
+
+
+@pytest.mark.parametrize("runner", RUNNERS)
+def test_k9_puck_slides_to_rest_on_the_table_after_v0_squared_over_2_mu_g(runner):
+    """The push task's object on the table (carl_brax_sys_t::obj_support, ABI 8): under the context's gravity the puck
+    carries the normal load m |g|, the table answers with Coulomb friction -- per substep the horizontal speed drops by
+    mu |g| dt until what is left is smaller, then the puck stops dead; distance = the scheme's arithmetic series, and the
+    textbook v0^2 / (2 mu g) to the discretisation.  With the MJCF's own zero gravity there is no load: it keeps sliding.
+    (carl/envs/brax/carl_pusher.py:17-21: gravity is a context feature with default -9.8.)"""
+    _need_gpu(runner)
+    mu = np.array([0.5, 1.0, 0.3, 0.7, 0.5])
+    g = np.array([-9.8, -9.8, -9.8, -3.0, 0.0])
+    v0 = np.array([0.5, 1.0, 0.4, 0.3, 0.25])
+    n = len(mu)
+    s, st0 = _pusher_case(n)
+    rows = K.ctx_rows(n, gravity=g, friction=mu)
+    mu, g = rows[:, 1], rows[:, 0]
+    ang = np.array([0.0, 0.5, 2.0, -1.0, 0.3])  # direction of travel: the friction is isotropic in the plane
+    st0[:, 7, 0:2] = (-0.6, 0.8)                # far from the arm (which sags onto the table meanwhile)
+    st0[:, 7, 7], st0[:, 7, 8] = v0 * np.cos(ang), v0 * np.sin(ang)
+    run = runner(s, rows, st0.reshape(n, -1))
+    dtf = float(np.float32(s.dt))
+    dec = mu * np.abs(g) * dtf
+    n_stop = np.where(dec > 0, np.floor(v0 / np.where(dec > 0, dec, 1.0)), 0).astype(int)
+    steps = int(n_stop.max() // s.n_frames) + 2
+    for _ in range(steps):
+        st = run.step(0.0)
+    d = np.hypot(st[:, 7, 0] + 0.6, st[:, 7, 1] - 0.8)
+    for lane in range(n - 1):
+        k = np.arange(1, n_stop[lane] + 1)
+        dist = dtf * np.sum(v0[lane] - k * dec[lane])
+        assert d[lane] == pytest.approx(dist, rel=tol(runner, 1e-9, 2e-5))
+        assert d[lane] == pytest.approx(v0[lane] ** 2 / (2 * mu[lane] * abs(g[lane])), rel=2.5 * dec[lane] / v0[lane])
+        assert np.hypot(st[lane, 7, 7], st[lane, 7, 8]) <= tol(runner, 0.0, 1e-6)  # at rest
+        # along the initial direction, on the table's height all the way
+        assert np.arctan2(st[lane, 7, 1] - 0.8, st[lane, 7, 0] + 0.6) == pytest.approx(ang[lane], abs=1e-5)
+    # its height: held by the slide joint's constraint spring, which gives by m |g| / k_pos under the weight
+    sag = np.array(s.mass[7]) * np.abs(g) / s.k_pos[7]
+    np.testing.assert_allclose(st[:, 7, 2], -0.275 - sag, atol=2e-6)
+    # no gravity, no load, no friction: still moving at v0
+    assert np.hypot(st[-1, 7, 7], st[-1, 7, 8]) == pytest.approx(v0[-1], rel=tol(runner, 1e-12, 1e-6))
+    assert d[-1] == pytest.approx(v0[-1] * dtf * s.n_frames * steps, rel=tol(runner, 1e-9, 1e-5))
+
+
+@pytest.mark.parametrize("runner", RUNNERS)
+def test_k10_the_fork_comes_to_rest_on_the_table_plane(runner):
+    """`plane_z` (ABI 8): the push task's colliders -- the fork's seven spheres -- meet the plane z = -0.325 the puck lies
+    on, not z = 0 (where every locomotion model's ground is).  Under gravity the unpowered arm sags until the fork rests
+    on the table: its lowest sphere ends within the Baumgarte slack of plane_z + radius, and never goes through."""
+    _need_gpu(runner)
+    n = 3
+    s, st0 = _pusher_case(n)
+    assert s.plane_z == pytest.approx(-0.325) and s.n_coll == 7 and all(s.coll_link[k] == 6 for k in range(7))
+    rows = K.ctx_rows(n, gravity=np.array([-9.8, -4.0, -9.8]), friction=np.array([1.0, 1.0, 0.2]))
+    st0[:, 7, 0:2] = (-0.6, 0.8)  # the puck out of the way
+    run = runner(s, rows, st0.reshape(n, -1))
+    lowest = []
+    for _ in range(40):  # 2 s
+        st = run.step(0.0)
+        r = st[:, 6, 3:7]
+        R2 = np.stack([2 * (r[:, 1] * r[:, 3] - r[:, 0] * r[:, 2]), 2 * (r[:, 2] * r[:, 3] + r[:, 0] * r[:, 1]),
+                       1 - 2 * (r[:, 1] ** 2 + r[:, 2] ** 2)], 1)  # third row of the rotation matrix
+        z = [st[:, 6, 2] + R2 @ (np.array(s.coll_pos[k][:]) - np.array(s.com[6][:])) for k in range(7)]
+        lowest.append(np.min(z, 0))
+    lowest = np.array(lowest)
+    assert (lowest.min(0) > s.plane_z + 0.02 - 0.012).all()   # never deeper than ~1 cm into the table
+    assert (np.abs(lowest[-1] - (s.plane_z + 0.02)) < 0.004).all()  # and it rests ON it
+    assert (lowest[0] > s.plane_z + 0.1).all()                # (it started well above)
