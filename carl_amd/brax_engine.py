@@ -28,6 +28,8 @@ class _BraxInfo:
 
 
 class BraxVecEngine(VecEngine):
+    _narrow_actions = False  # carl_brax_step / carl_brax_rollout read float32 actions: narrower dtypes are widened here
+
     def __init__(self, sys_table: _lib.BraxSys, n_features: int, ctx_table, n_lanes: int, device="cuda", *,
                  autoreset_mode: str = "redraw", **kw):
         """``autoreset_mode``: what the in-kernel auto-reset does with a done env --

@@ -301,7 +301,13 @@ class VecEngine:
     def n_contexts(self) -> int:
         return int(self.b.n_contexts)
 
+    # the narrow rollout-only action formats (uint8 / float16 / bfloat16: include/carl_amd.h) exist in the classic-control
+    # kernels' loader wave; the Brax entry points take float32 only -- BraxVecEngine turns this off, so that half-precision
+    # actions (a policy under autocast) are widened once instead of being rejected by carl_brax_rollout
+    _narrow_actions = True
+
     def _action_tensor(self, action, lead: tuple[int, ...], allow_narrow: bool = False) -> tuple[torch.Tensor, int]:
+        allow_narrow = allow_narrow and self._narrow_actions
         a = action if torch.is_tensor(action) else torch.as_tensor(np.asarray(action))
         if self.info.action_is_discrete:
             if allow_narrow and a.dtype == torch.uint8:  # rollout-only input format (include/carl_amd.h: CARL_ACTION_U8)

@@ -205,6 +205,24 @@ class MixedVecEngine:
             return None
         if any(torch.is_tensor(a) and a.dtype in (torch.uint8, torch.float16, torch.bfloat16) for a in actions[:2]):
             return None  # the pair kernel reads int32 / float32 actions; narrow-format parts take their own launches
+        # What carl_rollout_pair declines (carl_amd.hip: pair_part_ok) is decided HERE, before any tensor is touched: an
+        # eligible family pair in a non-lean configuration (round-robin / random selector, int64 actions, terminal
+        # observations, a finished-episode log, a lane count that is not a multiple of 16) used to convert both action
+        # tensors and allocate full [T, N, ...] outputs on every call only to hear UNSUPPORTED and do it all again in the
+        # per-part path.
+        fams = {pa.family, pb.family}
+        if fams - set(range(_lib.CARL_N_FAMILIES)) or _lib.ACROBOT not in fams or pa.family == pb.family or \
+                any(p.family == _lib.ACROBOT and (p.b.flags & _lib.FLAG_ACROBOT_FP32) for p in self.parts):
+            self._pair_ok = False  # never eligible: stop asking
+            return None
+        for k, p in enumerate(self.parts):
+            a = actions[k]
+            lean = (p.b.selector in (_lib.SEL_STATIC, _lib.SEL_HOST) and p.n % 16 == 0 and p.fin_capacity == 0
+                    and not (p.b.flags & _lib.FLAG_ROLLOUT_DIRECT)
+                    and not (torch.is_tensor(a) and a.dtype == torch.int64)
+                    and not (outs is not None and outs[k].get("final_obs") is not None))
+            if not lean:
+                return None
         aa, dta = pa._action_tensor(actions[0], (T,))
         ab, dtb = pb._action_tensor(actions[1], (T,))
         if outs is None:

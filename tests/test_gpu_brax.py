@@ -124,6 +124,29 @@ def test_rollout_equals_repeated_step_bit_exact(device):
     assert l1.numel() == int(e1.episodes_done.sum()) > 0
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float64])
+def test_half_precision_actions_are_widened_once_for_the_brax_entry_points(device, dtype):
+    """A policy under autocast emits float16 / bfloat16 actions.  The classic-control lean rollout reads them as they
+    are (CARL_ACTION_F16 / BF16); the Brax entry points take float32 only -- the engine widens such actions once, so
+    rollout / step return exactly what the float32 widening gives (it used to raise INVALID_ARGUMENT)."""
+    s = ant_sys(NAMES)
+    rng = np.random.default_rng(9)
+    n, T = 96, 5
+    rows = context_rows(rng, 5)
+    a16 = torch.as_tensor(rng.uniform(-1, 1, (T, n, 8)).astype(np.float32), device=device).to(dtype)
+    kw = dict(selector=O.SEL_STATIC, seed=3)
+    e1, e2 = engine(s, rows, n, device, **kw), engine(s, rows, n, device, **kw)
+    e1.reset()
+    e2.reset()
+    o1 = e1.rollout(a16)
+    o2 = e2.rollout(a16.to(torch.float32))
+    for k in ("obs", "reward", "terminated", "truncated"):
+        assert torch.equal(o1[k], o2[k]), k
+    obs1, *_ = e1.step(a16[0])
+    obs2, *_ = e2.step(a16[0].float())
+    assert torch.equal(obs1, obs2) and torch.equal(e1.state, e2.state)
+
+
 @pytest.mark.parametrize("width", [0, 16])
 def test_large_batch_fragment_schedule_equals_repeated_step_bit_exact(device, width):
     """More env groups than the chip holds wavefronts: the rollout kernel then runs as many workgroups as are resident
