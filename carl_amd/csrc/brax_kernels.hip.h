@@ -648,7 +648,9 @@ struct alignas(16) LinkRec {
   float dof[5][4];                            // 224
   float slide_axis[2][4];                     // 304: prismatic axes in the parent frame
   float inv_i[3], reach;                      // 336: body phase: inverse principal moments (link frame); sphere reach (-1: none)
-  float axis_sign, pad[3];                    // 352: planar models: +-1, the joint frame's x axis is +-y of the link frame
+  float axis_sign, ext[3];                    // 352: planar models: +-1, the joint frame's x axis is +-y of the link frame;
+                                              //      ext: max over the link's spheres of |centre - COM| per link-frame axis, each
+                                              //      + the largest radius (reach = the ball that holds every sphere; ext the box)
 };
 static_assert(sizeof(LinkRec) == kLinkRecBytes, "LinkRec is read in 16-byte pieces at fixed offsets");
 
@@ -974,7 +976,18 @@ static __device__ __forceinline__ void expand_link(const carl_brax_sys_t& s, con
   out.inv_i[0] = s.inv_inertia[i][0]; out.inv_i[1] = s.inv_inertia[i][1]; out.inv_i[2] = s.inv_inertia[i][2];
   out.reach = pk.b[i].reach;
   out.axis_sign = A.axis_sign;
-  out.pad[0] = out.pad[1] = out.pad[2] = 0.0f;
+  {
+    float ex = 0.0f, ey = 0.0f, ez = 0.0f, rmax = 0.0f;
+    const uint32_t wb = pk.b[i].word;
+    for (int k = 0; k < wb_spheres(wb); ++k) {
+      const Sphere& sp = pk.sph[wb_first_sphere(wb) + k];
+      ex = fmaxf(ex, fabsf(sp.off[0])); ey = fmaxf(ey, fabsf(sp.off[1])); ez = fmaxf(ez, fabsf(sp.off[2]));
+      rmax = fmaxf(rmax, sp.radius);
+    }
+    // the largest radius rides on EVERY axis: a sphere's lowest point is at most |R row 2| . (ex, ey, ez) + rmax below the
+    // COM, and |R row 2| . (rmax, rmax, rmax) >= rmax because the row has unit length
+    out.ext[0] = ex + rmax; out.ext[1] = ey + rmax; out.ext[2] = ez + rmax;
+  }
 }
 
 // R diag(inv_i) R^T t; every shipped model has isotropic effective inertia (spring_inertia_scale = 1): inv_i[0] t
@@ -1321,7 +1334,14 @@ static __device__ __forceinline__ void substep_planar(const carl_brax_sys_t& s, 
     float cdvx = 0.0f, cdvz = 0.0f, cdw = 0.0f, cnt = 0.0f;
     uint32_t hit = 0u;
     const double pz = b.p.z - (double)K.plane_z;
-    const int n_sph = ((float)pz < qb.w) ? wb_spheres(wb) : 0;
+    // Which links can touch the plane at all: the COM lower than the ball that holds every sphere (reach), and lower
+    // than the link's box at its present pitch -- |sin| ext.x + |cos| ext.z: a level torso (Halfcheetah's: four
+    // spheres along a 1.2 m rod, always inside the ball) stays out of the loop, whose trip count is the wavefront's
+    // largest sphere count.  Float32 with a 1e-4 guard; the depths themselves stay float64.
+    const vf4 qe = ld4(&lr->axis_sign);  // . ext.x ext.y ext.z
+    const float cthf = 1.0f - 2.0f * ((float)b.r.y * (float)b.r.y), sthf = 2.0f * ((float)b.r.w * (float)b.r.y);
+    const bool near = (float)pz < qb.w && (float)pz < fabsf(sthf) * qe.y + fabsf(cthf) * qe.w + 1e-4f;
+    const int n_sph = near ? wb_spheres(wb) : 0;
     if (ballot(n_sph > 0) != 0ull) {
       const double cth = 1.0 - 2.0 * (b.r.y * b.r.y), sth = 2.0 * (b.r.w * b.r.y);  // R22, -R20 of the general form
       const float cf = (float)cth, sf = (float)sth;
