@@ -2064,7 +2064,10 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
       phase_sync();
       float msum;
       // forward progress and root height: pose differences, float64
-      const double x0 = s.reward_on_com ? system_com(s, m, &msum).x : m.pos(0).x - qrot(m.rot(0), tod(f3(s.com[0]))).x;
+      // (the root's frame origin = its COM where com[0] = 0 -- Ant's torso: no float64 rotation of a zero vector)
+      const bool root_com_off = s.com[0][0] != 0.0f || s.com[0][1] != 0.0f || s.com[0][2] != 0.0f;  // wavefront-uniform
+      const double x0 = s.reward_on_com ? system_com(s, m, &msum).x
+                                        : m.pos(0).x - (root_com_off ? qrot(m.rot(0), tod(f3(s.com[0]))).x : 0.0);
       prof.mark(kProfPrologue);
       if (active && m.sub == 1 % kSub) Lds::put_react(reinterpret_cast<char*>(m.base) + m.react_off(m.lay.L), V(0, 0, 0), V(0, 0, 0));  // the env's zero record
       {  // the n_frames substeps, the lane's body / torques / branch hashes in registers (StepRegs)
@@ -2102,7 +2105,7 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
         }
         phase_sync();
       }
-      const v3d c1 = qrot(m.rot(0), tod(f3(s.com[0])));
+      const v3d c1 = root_com_off ? qrot(m.rot(0), tod(f3(s.com[0]))) : D(0, 0, 0);
       v3d com1 = D(0, 0, 0);
       if (s.reward_on_com) com1 = system_com(s, m, &msum);
       const double x1 = s.reward_on_com ? com1.x : m.pos(0).x - c1.x, z1d = m.pos(0).z - c1.z;
