@@ -782,6 +782,63 @@ static __device__ __forceinline__ JointGeom joint_geometry(const JointRec& la, c
   return g;
 }
 
+// The same geometry for the OBSERVATION (kinematics.world_to_joint / inverse), in float32.  The dynamics need the joint
+// angles and anchor separations to ~1e-10 -- they are multiplied by constraint stiffnesses -- and take them from
+// joint_geometry; an observation entry is compared at 1e-5 (1 + |x|), and float32 quaternion algebra with atan2_fast
+// delivers the angles to ~1e-6: the observation pass costs a third of the float64 one (one pass per env step: 4-9 % of
+// a launch was observe).  Positions enter as the float64 difference of the two COMs, rounded once.
+struct ObsGeom {
+  v3 ed, vA_c, vA_p;
+  float theta, thetadot;
+  float ang[3], rate[3];
+};
+template <bool MULTI>
+static __device__ __forceinline__ ObsGeom obs_geometry(const LinkA& rec, const float sign3, const Body& bc, const Body& bp) {
+  ObsGeom g;
+  const vf4 q0 = ld4(&rec.ac[0]), q1 = ld4(&rec.ap[0]), q2 = ld4(&rec.rpl[0]), q3 = ld4(&rec.jrot[0]);
+  const uint32_t word = __float_as_uint(q0.w);
+  const qt rc = tof(bc.r), rp = tof(bp.r);
+  const v3 rc_off = qrot(rc, V(q0.x, q0.y, q0.z)), rp_off = qrot(rp, V(q1.x, q1.y, q1.z));
+  g.ed = tof(bp.p - bc.p) + (rp_off - rc_off);
+  g.vA_c = bc.v + cross(bc.w, rc_off);
+  g.vA_p = bp.v + cross(bp.w, rp_off);
+  const qt rcj = qmul(rc, qt{q3.x, q3.y, q3.z, q3.w}), rpj = qmul(rp, qt{q2.x, q2.y, q2.z, q2.w});
+  qt rel = qmul(qconj(rpj), rcj);
+  if (rel.w < 0.0f) { rel.w = -rel.w; rel.x = -rel.x; }
+  const v3 x_c = xaxis(rcj), wrel = bc.w - bp.w;
+  g.thetadot = dot(x_c, wrel);
+  const int nr = MULTI ? wa_hinges(word) : 1;
+  float a_y = rel.x, a_x = rel.w;
+  [[maybe_unused]] float R00 = 0.0f, R01 = 0.0f, R02 = 0.0f;
+  const bool eul = MULTI && nr != 1;
+  if (MULTI) {
+    R00 = 1.0f - 2.0f * (rel.y * rel.y + rel.z * rel.z);
+    R01 = 2.0f * (rel.x * rel.y - rel.w * rel.z);
+    R02 = fminf(fmaxf(2.0f * (rel.x * rel.z + rel.w * rel.y), -1.0f), 1.0f);
+    const float m12 = -(2.0f * (rel.y * rel.z - rel.w * rel.x)), r22 = 1.0f - 2.0f * (rel.x * rel.x + rel.y * rel.y);
+    a_y = eul ? m12 : a_y;
+    a_x = eul ? r22 : a_x;
+  }
+  const float a1 = atan2_fast(a_y, a_x);
+  g.theta = 2.0f * a1;
+  if (MULTI) {
+    const float h2 = a_y * a_y + a_x * a_x;  // (Euler lanes: cos^2 be)
+    const bool pole = !(h2 > 1e-20f);
+    const float ih = pole ? 0.0f : __builtin_amdgcn_rsqf(h2);
+    const float be = atan2_fast(R02, h2 * ih), ga = atan2_fast(-R01, R00);
+    const float sg = (nr == 3) ? sign3 : 1.0f;
+    g.ang[0] = a1; g.ang[1] = be; g.ang[2] = sg * ga;
+    const float ca = pole ? 1.0f : a_x * ih, sa = a_y * ih;
+    const v3 ax0 = xaxis(rpj), ax1 = qrot_yz(rpj, ca, sa), ax2 = qrot(rpj, V(R02, -a_y, a_x)) * sg;
+    const float w0 = dot(wrel, ax0), w1 = dot(wrel, ax1), w2 = dot(wrel, ax2);
+    g.rate[1] = w1;
+    const float cc = dot(ax0, ax2), iden = __builtin_amdgcn_rcpf(1.0f - cc * cc);
+    g.rate[0] = (nr == 3) ? (w0 - cc * w2) * iden : w0;
+    g.rate[2] = (nr == 3) ? (w2 - cc * w0) * iden : w2;
+  }
+  return g;
+}
+
 // link-pair contact of the push task (carl_brax_sys_t::n_pair): run by the object's joint lane.  Returns
 // the push on the object and the reaction on the gripper link (force, torque about that link's COM).
 // The object hangs on the world, so its parent-side wrench rows are free: the reaction is parked there,
@@ -1458,16 +1515,12 @@ static __device__ __forceinline__ void observe(const carl_brax_sys_t& s, const P
       for (int k = 0; k < 6; ++k) put_qd(s.dof_start[i] + k, dvv[k]);
     } else {
       const Body bp = (P < 0) ? world_body() : m.body(P);
-      const LinkA& rec = pk.a[i];
-      const JointXr X = load_jointx<MULTI>(jx[i]);
-      const vf4 q2 = ld4(&rec.rpl[0]);
-      const JointRec la{qt{q2.x, q2.y, q2.z, q2.w}, rec.word, s.dof_sign3[i]};
-      const JointGeom g = joint_geometry<MULTI>(la, X, b, bp);
+      const ObsGeom g = obs_geometry<MULTI>(pk.a[i], s.dof_sign3[i], b, bp);
       const int ns = s.n_slide[i];
       for (int k = 0; k < ns; ++k) {
-        const v3d axd = qrot(bp.r, tod(f3(s.slide_axis[i][k])));
-        if (s.q_start[i] + k >= skip) m.at(m.lay.io + s.q_start[i] + k - skip) = (float)-dot(g.ed, axd);
-        put_qd(s.dof_start[i] + k, dot(g.vA_c - g.vA_p, tof(axd)));
+        const v3 ax = qrot(tof(bp.r), f3(s.slide_axis[i][k]));
+        if (s.q_start[i] + k >= skip) m.at(m.lay.io + s.q_start[i] + k - skip) = -dot(g.ed, ax);
+        put_qd(s.dof_start[i] + k, dot(g.vA_c - g.vA_p, ax));
       }
       const int nr = MULTI ? s.n_link_dof[i] - ns : 1;
       if (!MULTI || nr == 1) {
@@ -1487,7 +1540,9 @@ static __device__ __forceinline__ void observe(const carl_brax_sys_t& s, const P
       const v3 d = tof(b.p - com);
       const qt rf = tof(b.r);
       const float mi = m.at(m.lay.mass + i), dd = dot(d, d);
-      const float I0 = 1.0f / s.inv_inertia[i][0], I1 = 1.0f / s.inv_inertia[i][1], I2 = 1.0f / s.inv_inertia[i][2];
+      // (v_rcp_f32, 1 ulp: an observation entry; an IEEE division is ~10 instructions)
+      const float I0 = __builtin_amdgcn_rcpf(s.inv_inertia[i][0]), I1 = __builtin_amdgcn_rcpf(s.inv_inertia[i][1]),
+                  I2 = __builtin_amdgcn_rcpf(s.inv_inertia[i][2]);
       const v3 ex = qrot(rf, V(1, 0, 0)), ey = qrot(rf, V(0, 1, 0)), ez = qrot(rf, V(0, 0, 1));
       const float e[3][3] = {{ex.x, ey.x, ez.x}, {ex.y, ey.y, ez.y}, {ex.z, ey.z, ez.z}};
       const float dc[3] = {d.x, d.y, d.z};
@@ -1504,7 +1559,7 @@ static __device__ __forceinline__ void observe(const carl_brax_sys_t& s, const P
         }
       m.at(k) = mi;
       k = e0 + 10 * L + 6 * i;
-      const float f = mi / M;
+      const float f = mi * __builtin_amdgcn_rcpf(M);
       m.at(k) = f * b.v.x; m.at(k + 1) = f * b.v.y; m.at(k + 2) = f * b.v.z;
       m.at(k + 3) = b.w.x; m.at(k + 4) = b.w.y; m.at(k + 5) = b.w.z;
     }
