@@ -2,7 +2,7 @@
 """profiles/kernel_times.json, profiles/brax_valu.json and the r04 entries of profiles/traffic.json from the passes of
 tools/r04_evidence.sh, plus a text summary (profiles/r04_rocprofv3_summary.txt).
 
-    python tools/make_r04_profiles.py gpurun_out/prof_r04 "<source label>"
+    python tools/make_r04_profiles.py gpurun_out/prof_r04 "<source label>" [r05]
 
 Per workload directory <env>_<lanes>_<chunk>/: kt/ (kernel trace + stats), fetch/, write/ (PMC), sq/ (Brax).  Only the
 ROLLOUT kernels count (rollout_staged_kernel / rollout_staged_pair_kernel / brax_kernel<1, ...>); a workload with two
@@ -18,6 +18,7 @@ import sys
 from collections import defaultdict
 
 root, source = sys.argv[1], sys.argv[2]
+ROUND = sys.argv[3] if len(sys.argv) > 3 else "r04"  # names the text summary: profiles/<round>_rocprofv3_summary.txt
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BRAX = ("ant", "halfcheetah", "humanoid")
 
@@ -100,5 +101,5 @@ for wdir in sorted(glob.glob(os.path.join(root, "*_*_*"))):
         lines.append("  pmc           " + "  ".join(f"{c} {v:.4g}" for c, v in sorted(tot.items())) + " per pass of the hot path")
 for name, obj in (("kernel_times", ktimes), ("brax_valu", valu), ("traffic", traffic)):
     json.dump(obj, open(os.path.join(ROOT, "profiles", name + ".json"), "w"), indent=1)
-open(os.path.join(ROOT, "profiles", "r04_rocprofv3_summary.txt"), "w").write("\n".join(lines) + "\n")
+open(os.path.join(ROOT, "profiles", f"{ROUND}_rocprofv3_summary.txt"), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
