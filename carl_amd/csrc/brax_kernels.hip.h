@@ -2089,13 +2089,18 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
       if (ak1 < n_act) a_next1 = act_env[(size_t)t_lo * act_step + ak1];
     }
     const Lds& m_launch = m;
+    const int env_frag = env;
     for (int t = t_lo; t < t_hi; ++t) {
       // Every LDS address of the step is derived from an opaque copy of the lane's coordinates: as loop invariants the
       // compiler hoisted dozens of them (row addresses of the staging, tau, mass and stash rows ...) out of the step
       // loop, ran out of registers and reloaded them from scratch memory all through the step.
       Lds m_step = m_launch;
-      asm volatile("" : "+v"(m_step.sub), "+v"(m_step.env));
+      int env_step = env_frag;  // (likewise the env's index: every per-env global address -- observation, reward, flag rows --
+                                // is base + env x width, a 64-bit per-lane value each when hoisted)
+      asm volatile("" : "+v"(m_step.sub), "+v"(m_step.env), "+v"(env_step));
       const Lds& m = m_step;
+      const int env = env_step;
+      const uint64_t genv = (uint64_t)(b.lane_offset + env);
       const size_t step_off = (size_t)t * n;
       // The env's episode scalars (identical in all its lanes) wait in LDS until the reward needs them: a dozen registers
       // per lane that the substeps and observe need more.
