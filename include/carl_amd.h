@@ -73,7 +73,15 @@ enum {
                                        default replicates Quirk C1) */
   CARL_FLAG_ACROBOT_FP32 = 4,       /* evaluate Acrobot's _dsdt/rk4 in fp32 instead of
                                        fp64 (faster; up to ~1e-3 relative error on
-                                       states near the velocity bounds) */
+                                       states near the velocity bounds).  Without the flag the step is float64
+                                       ARITHMETIC, not a float64 reference: sin / cos come from a 512-entry table with a
+                                       short correction (6e-11), 1 / det from v_rcp_f64 + one Newton step (4e-15), the
+                                       angle wrap is x - rint(x / 2 pi) 2 pi (the reference's strict > pi / < -pi
+                                       compares differ for the doubles within one ulp of +-pi), the state is stored as
+                                       float32 and the observation / _terminal trig is taken at the STORED angles
+                                       (2e-7 from the reference's unrounded ones).  Each transition is within 1e-5 of
+                                       gymnasium's arithmetic; Acrobot is chaotic, so free-running trajectories
+                                       separate from a true float64 run at the float32 state rounding's rate */
   CARL_FLAG_ROLLOUT_DIRECT = 16,    /* carl_rollout: launch the direct-store kernel even where the staged one
                                        applies (A/B measurements and tests; ~50 % slower, same results) */
   CARL_FLAG_AUTORESET_FIRST_STATE = 8 /* Brax families, with AUTORESET: a done env is put back to the state
