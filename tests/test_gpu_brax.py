@@ -510,7 +510,9 @@ def test_every_lane_group_width_matches_oracle(device, model, lanes_per_env):
     """The host picks the lanes per env (one per link, rounded up to an instantiated width: 2, 4, 7,
     9, 11, 16) from the model and the batch size
     (carl_brax.hip: brax_lanes_per_env); `carl_brax_sys_t::lanes_per_env` pins it so that every instantiation is
-    checked on every model, with a ragged last wavefront and auto-reset inside the window."""
+    checked on every model, with a ragged last wavefront and auto-reset inside the window.  (Since round 5 a hint
+    narrower than the model's link count is rounded UP to one lane per link -- the kernels keep a lane's link in
+    registers -- so the small hints exercise the rounding, the large ones the wider instantiations.)"""
     from carl_amd.brax_engine import BraxVecEngine
 
     if model == "ant":
