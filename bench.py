@@ -782,9 +782,9 @@ def dropin_per_call(device, n_big, cpu_single_core_value):
         mirror.step(a)
     torch.cuda.synchronize()
     rec[f"mirror_CARLCartPole_num_envs_{n_big}"] = (time.perf_counter() - t0) / 1000 * 1e6
-    rec["note"] = ("scalar = one launch + one device-to-host read per env step (the reference's return types); if it is slower "
-                   "than cpu_reference_style_us_per_step, a single env is better served by the CPU -- the shim pays off from "
-                   "num_envs > 1 (INTEGRATION.md)")
+    rec["note"] = ("scalar = one launch + one device-to-host read per env step (the reference's return types; pinned action "
+                   "staging, one copy for the whole transition); cpu_reference_style_us_per_step is the loop it replaces -- the "
+                   "shim pays off from num_envs > 1 (INTEGRATION.md)")
     return rec
 
 

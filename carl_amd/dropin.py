@@ -156,8 +156,11 @@ class Mi355xVecEnv(_EnvBase):
     def step(self, action):
         eng = self.eng
         if self.num_envs == 1:
-            a = np.asarray(action).reshape(1)
+            a = eng.stage_scalar_action(action) if hasattr(eng, "stage_scalar_action") else np.asarray(action).reshape(1)
             obs, reward, term, trunc = eng.step(a)
+            if hasattr(eng, "read_transition"):  # the lane engine: the whole transition in one device-to-host copy
+                o, r, te, tr = eng.read_transition()
+                return o[0].astype(np.float32), float(r[0]), bool(te[0]), bool(tr[0]), {}
             return (self._host(obs)[0].astype(np.float32), float(self._host(reward)[0]), bool(self._host(term)[0]),
                     bool(self._host(trunc)[0]), {})
         obs, reward, term, trunc = eng.step(action)
@@ -340,6 +343,10 @@ class Mi355xBraxVecEnv(_EnvBase):
     def step(self, action):
         h = Mi355xVecEnv._host
         if self.num_envs == 1:
+            if hasattr(self.eng, "read_transition"):  # the lane engine: pinned action staging, one device-to-host copy
+                self.eng.step(self.eng.stage_scalar_action(np.asarray(action, dtype=np.float32)))
+                o, r, te, tr = self.eng.read_transition()
+                return o[0].astype(np.float32), float(r[0]), bool(te[0]) or bool(tr[0]), False, {}
             a = np.asarray(action, dtype=np.float32).reshape(1, -1)
             obs, reward, term, trunc = self.eng.step(a)
             done = bool(h(term)[0]) or bool(h(trunc)[0])

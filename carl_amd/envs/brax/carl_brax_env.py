@@ -275,16 +275,16 @@ class CARLBraxEnv(CARLEnv):
 
     def step(self, action: Any):
         if self._scalar_api:  # one env: action is a length-A vector
-            a = np.asarray(action, dtype=np.float32).reshape(1, -1)
-            obs, reward, term, trunc = self.env.step(a)
-            state = obs[0].cpu().numpy()
+            self.env.step(self.env.stage_scalar_action(np.asarray(action, dtype=np.float32)))
+            o, r, te, tr = self.env.read_transition()  # one device-to-host copy for the whole transition
+            state = o[0].astype(np.float32)
             info: dict[str, Any] = {"context_id": self.context_id}
             # wrappers.py:76-77: terminated = done, truncated = False; brax's EpisodeWrapper
             # folds its 1000-step truncation into `done`
-            done = bool(term[0]) or bool(trunc[0])
+            done = bool(te[0]) or bool(tr[0])
             if self.env.sys.goal_mode:
                 info["success"] = int(self.env.success[0])
-            return self._with_goal_text(self._add_context_to_state(state), None), float(reward[0]), done, False, info
+            return self._with_goal_text(self._add_context_to_state(state), None), float(r[0]), done, False, info
         out = super().step(action)
         if self.env.sys.goal_mode:
             out[4]["success"] = self.env.success

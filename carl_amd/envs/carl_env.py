@@ -294,15 +294,11 @@ class CARLEnv(abc.ABC):
     def step(self, action: Any):
         """carl_env.py:321-342."""
         if self._scalar_api:
-            a = np.asarray(action).reshape(1)
-            obs, reward, term, trunc = self.env.step(a)
-            out = torch.cat([obs.reshape(-1), reward.reshape(-1), term.float().reshape(-1),
-                             trunc.float().reshape(-1)]).cpu().numpy()
-            D = self.env.D
-            state = out[:D].astype(np.float32)
+            self.env.step(self.env.stage_scalar_action(action))
+            o, r, te, tr = self.env.read_transition()  # one device-to-host copy for the whole transition
+            state = o[0].astype(np.float32)
             info: dict[str, Any] = {"context_id": self.context_id}
-            return (self._add_context_to_state(state), float(out[D]), bool(out[D + 1] != 0),
-                    bool(out[D + 2] != 0), info)
+            return self._add_context_to_state(state), float(r[0]), bool(te[0] != 0), bool(tr[0] != 0), info
         # Batched hot call: everything returned is a view of an engine buffer whose address never changes, so
         # the views (and the observation dict) are built once; per call this is the engine's launch plus one
         # small dict.  `_final_observation` is the done mask the step kernel writes (carl_step_io_t::done).
