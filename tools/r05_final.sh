@@ -21,6 +21,6 @@ python tools/trace_by_shape.py $O > $O/driver_cmd_trace_by_shape.txt 2>&1; cat $
 # round 5: the self-launching N > 1 path on this one GPU, Brax parity records of the FINAL binary, region clocks
 CARL_BENCH_SHARE_GPU=1 CARL_BENCH_BACKEND=gloo timeout 300 python bench.py --gpus 2 --steps 10 --warmup 3 --also none --no-shard8 --no-per-call --no-cpu-baseline > $O/bench_selflaunch_2ranks.json 2> $O/bench_selflaunch_2ranks.err
 timeout 600 python tools/brax_parity_percentiles.py > $O/brax_parity_percentiles.txt 2>&1
-timeout 900 python tools/brax_parity_long.py > $O/brax_parity_long.txt 2>&1
+timeout 1500 python tools/brax_parity_long.py 16384 300 ant halfcheetah humanoid hopper walker2d > $O/brax_parity_long.txt 2>&1
 if [ -f gpurun_in/libcarl_prof.so ]; then CARL_AMD_LIB_PATH=$PWD/gpurun_in/libcarl_prof.so timeout 120 python tools/brax_region_profile.py ant halfcheetah humanoid > $O/brax_region_profile.txt 2>&1; fi
 tail -3 $O/brax_parity_long.txt
