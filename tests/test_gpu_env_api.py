@@ -287,3 +287,40 @@ def test_sb3_vecenv_facade_protocol(device):
         assert all(infos[i] == {} for i in np.nonzero(~dones)[0][:16])
     assert seen_term > 100 and seen_trunc > 0
     assert venv.get_attr("num_envs")[0] == n and venv.env_is_wrapped(object) == [False] * n
+
+
+@pytest.mark.parametrize("fam,n", [("cartpole", 1), ("pendulum", 1), ("acrobot", 7), ("mountaincar_cont", 33)])
+def test_single_copy_readback_and_pinned_action_staging(device, fam, n):
+    """The scalar step path of the shim and of the mirror classes: the engine's five step outputs are
+    views of ONE allocation, `read_transition` brings them to the host with one copy, `stage_scalar_action` carries a host
+    action through a pinned buffer into THE device action tensor.  Same transition as the tensors `step` returns, for a
+    device action tensor built the ordinary way; the views start on 256-byte boundaries like separate allocations."""
+    from carl_amd import _lib
+    from carl_amd.engine import VecEngine
+
+    family = {"cartpole": _lib.CARTPOLE, "pendulum": _lib.PENDULUM, "acrobot": _lib.ACROBOT,
+              "mountaincar_cont": _lib.MOUNTAINCAR_CONT}[fam]
+    cls = {"cartpole": E.CARLCartPole, "pendulum": E.CARLPendulum, "acrobot": E.CARLAcrobot,
+           "mountaincar_cont": E.CARLMountainCarContinuous}[fam]
+    row = [float(f.default_value) for f in cls.get_context_features().values()]
+    kw = dict(selector=_lib.SEL_STATIC, seed=5, auto_reset=True)
+    e1, e2 = VecEngine(family, [row], n, device, **kw), VecEngine(family, [row], n, device, **kw)
+    for e in (e1, e2):
+        e.reset()
+        assert all(t.data_ptr() % 256 == 0 for t in (e.obs, e.reward, e.terminated, e.truncated, e.done))
+    rng = np.random.default_rng(3)
+    for t in range(30):
+        if e1.info.action_is_discrete:
+            a = rng.integers(0, int(e1.info.n_actions), n)
+            ref = torch.as_tensor(a.astype(np.int32), device=device)
+        else:
+            a = rng.uniform(float(e1.info.action_low), float(e1.info.action_high), (n, 1)).astype(np.float32)
+            ref = torch.as_tensor(a, device=device)
+        obs, rew, term, trunc = e1.step(ref)
+        e2.step(e2.stage_scalar_action(a))
+        o, r, te, tr = e2.read_transition()
+        np.testing.assert_array_equal(o, obs.cpu().numpy())
+        np.testing.assert_array_equal(r, rew.cpu().numpy())
+        np.testing.assert_array_equal(te, term.cpu().numpy())
+        np.testing.assert_array_equal(tr, trunc.cpu().numpy())
+    assert torch.equal(e1.state, e2.state)
