@@ -1131,6 +1131,9 @@ def main():
                        "env_steps_per_step": n * world * T, "buffer_sets": args.buffer_sets,
                        "parallelism": f"lane-shard x{world}", "lanes_per_env": shape},
             "bench_version": BENCH_VERSION, "workload_id": f"{'+'.join(args.families)}{'_narrow' if args.narrow_actions else ''}:{n}:{T}:v{BENCH_VERSION}",
+            # the figure comparable with BENCH_r01 - r03 (same workload, 250-step launches: the headline definition of those
+            # rounds; r04 moved `value` to SURVEY 8d's 1 000-step launches) -- ADVICE r04
+            "value_r03_definition": (also.get("cartpole_T250") or {}).get("value"),
             "repetitions": repetitions, "clocks": clocks, "shard8": shard8,
             "roofline": roofline, "cpu_baseline": cpu, "sustained": sustained,
             ("weak" if args.strong else "strong"): other, "per_call": per_call, "also": also,

@@ -1490,6 +1490,7 @@ static __device__ __forceinline__ void observe(const carl_brax_sys_t& s, const P
   };
   float M = 1.0f;
   v3d com = D(0, 0, 0);
+  const bool all_iso = __builtin_amdgcn_readfirstlane(pk.all_iso) != 0;
   if (MULTI && s.obs_extended) {
     if (com_in != nullptr) {
       com = *com_in;
@@ -1543,20 +1544,27 @@ static __device__ __forceinline__ void observe(const carl_brax_sys_t& s, const P
       // (v_rcp_f32, 1 ulp: an observation entry; an IEEE division is ~10 instructions)
       const float I0 = __builtin_amdgcn_rcpf(s.inv_inertia[i][0]), I1 = __builtin_amdgcn_rcpf(s.inv_inertia[i][1]),
                   I2 = __builtin_amdgcn_rcpf(s.inv_inertia[i][2]);
-      const v3 ex = qrot(rf, V(1, 0, 0)), ey = qrot(rf, V(0, 1, 0)), ez = qrot(rf, V(0, 0, 1));
-      const float e[3][3] = {{ex.x, ey.x, ez.x}, {ex.y, ey.y, ez.y}, {ex.z, ey.z, ez.z}};
       const float dc[3] = {d.x, d.y, d.z};
       int k = e0 + 10 * i;
+      if (all_iso) {  // R diag(c, c, c) R^T = c: no rotation needed (every shipped model; wavefront-uniform)
 #pragma unroll
-      for (int r = 0; r < 3; ++r)
+        for (int r = 0; r < 3; ++r)
 #pragma unroll
-        for (int cc = 0; cc < 3; ++cc) {
-          float v = e[r][0] * I0 * e[cc][0];
-          v += e[r][1] * I1 * e[cc][1];
-          v += e[r][2] * I2 * e[cc][2];
-          v += mi * ((r == cc ? dd : 0.0f) - dc[r] * dc[cc]);
-          m.at(k++) = v;
-        }
+          for (int cc = 0; cc < 3; ++cc) m.at(k++) = (r == cc ? I0 : 0.0f) + mi * ((r == cc ? dd : 0.0f) - dc[r] * dc[cc]);
+      } else {
+        const v3 ex = qrot(rf, V(1, 0, 0)), ey = qrot(rf, V(0, 1, 0)), ez = qrot(rf, V(0, 0, 1));
+        const float e[3][3] = {{ex.x, ey.x, ez.x}, {ex.y, ey.y, ez.y}, {ex.z, ey.z, ez.z}};
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+          for (int cc = 0; cc < 3; ++cc) {
+            float v = e[r][0] * I0 * e[cc][0];
+            v += e[r][1] * I1 * e[cc][1];
+            v += e[r][2] * I2 * e[cc][2];
+            v += mi * ((r == cc ? dd : 0.0f) - dc[r] * dc[cc]);
+            m.at(k++) = v;
+          }
+      }
       m.at(k) = mi;
       k = e0 + 10 * L + 6 * i;
       const float f = mi * __builtin_amdgcn_rcpf(M);
@@ -2054,7 +2062,6 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
     const int env = gwave * kEnvs + m.env;
     const bool active = lane_ok && env < b.n_lanes;
     const bool lead = active && m.sub == 0;  // the lane that writes the env's scalars
-    const uint64_t genv = (uint64_t)(b.lane_offset + env);
     if (wait_head) {  // the head of this group: the previous wavefront's first fragment
       while (__hip_atomic_load(&head_done[wave - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0)
         __builtin_amdgcn_s_sleep(16);

@@ -73,6 +73,11 @@ def _dominated(spheres):
 
 @pytest.mark.parametrize("name", ["ant", "halfcheetah", "humanoid", "humanoidstandup"])
 def test_model_table_equals_the_independent_restatement_field_by_field(name):
+    # NOTE: oracle/mjcf/*.xml were written from memory by the author of models.py.  For the GEOMETRY this
+    # comparison is anchored outside the build (the link masses the capsule volumes give equal the reference's context
+    # defaults: the test above); for the non-geometric fields -- joint stiffness / damping / ranges, gears -- it only says
+    # that two from-memory restatements agree (round 4 changed Humanoid's knee stiffness and left-hip range on that
+    # basis).  When brax's assets become available: diff oracle/mjcf/*.xml against them and record a hash.
     s, _ = _table(name)
     m = M.load(ASSET.get(name, name))
     L = len(m.links)
