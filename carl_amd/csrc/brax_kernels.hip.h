@@ -7,29 +7,28 @@
 // specification implemented here is written out in oracle/brax_spring.c's header and
 // DESIGN.md; PARITY UNPINNED].
 //
-// Mapping: one env = a group of kSub adjacent lanes -- normally one lane per link (Ant 9, Halfcheetah
-// and Walker2d 7, Humanoid 11, Hopper 4), 16 for small batches; one wavefront (= one workgroup) =
-// floor(64 / kSub) envs, spare lanes idle.
-// Within an env the lanes split the work by link: lane `sub` owns joint / body sub (and sub + kSub,
-// ... when kSub < n_links).  The kernel is bound by the instruction stream a wavefront issues, so a
-// second round with one busy lane per env costs a whole round: one lane per link keeps every phase
-// to a single round.  32 768 Ant envs are 4 682 wavefronts = 4.6 per SIMD, where the earlier
-// one-lane-per-env kernel (r01c) had 512 wavefronts for 1 024 SIMDs, each walking all links
-// serially through LDS.  An env's maximal-coordinate state (one 80-byte record per link: pose 7
-// doubles, velocity 6 floats), the per-joint wrenches, masses, joint torques and the action /
-// observation record ([row][envs] float rows) live in LDS for the whole launch; the n_frames substeps
-// -- and in the fused rollout all T env steps of a fragment -- never touch HBM for state.  A substep is two lockstep phases with a wavefront-wide LDS
-// hand-over between them:
-//   A  per joint:  joint geometry -> spring/damper/limit/actuator wrench on the child and the
-//                  reaction on the parent, written to the joint's own wrench rows (no atomics);
-//   B  per body:   own wrench + its children's reactions -> semi-implicit Euler velocity
-//                  update -> this body's sphere-plane contacts (registers) -> integrate.
+// Mapping (round 5): one env = a group of kSub adjacent lanes, ONE LANE PER LINK (Ant 9, Halfcheetah and Walker2d 7,
+// Humanoid 11, Hopper 4; 16 for small batches; never narrower than the model's link count); one wavefront =
+// floor(64 / kSub) envs, spare lanes idle.  Lane `sub` of an env owns link sub: its joint (the one to its parent) in the
+// joint phase, its body in the body phase.  The kernel is bound by the instruction stream a wavefront issues, so every
+// phase is a single round.  32 768 Ant envs are 4 682 wavefronts = 4.6 per SIMD (the round-1 one-lane-per-env kernel:
+// 512 wavefronts for 1 024 SIMDs, each walking all links serially through LDS).  An env's maximal-coordinate state
+// (one 80-byte record per link: pose 7 doubles, velocity 6 floats), the joints' reactions, masses, torques and the
+// action / observation staging ([row][envs] float rows) live in LDS for the whole launch; the n_frames substeps -- and
+// in the fused rollout all T env steps of a fragment -- never touch HBM for state.  THROUGH the substeps of an env step
+// a lane keeps its own body, its joint's wrench on the child, the hinge torques and the branch hashes in REGISTERS
+// (StepRegs); LDS carries what crosses lanes.  A substep is two lockstep phases with a wavefront-local hand-over:
+//   A  the lane's joint:  geometry (float64 for every difference of poses) -> spring / damper / limit / actuator wrench
+//                         on the child (registers) and the reaction on the parent (a 48-byte LDS record, no atomics);
+//   B  the lane's body:   own wrench + its children's reactions (ascending) -> semi-implicit Euler velocity update ->
+//                         this body's sphere / plane contacts -> integrate -> the new pose to its LDS record (the
+//                         children read it in the next phase A; the owner never reads it back).
 // Sums run in the oracle's order (own joint, then children ascending; colliders ascending).
-// Per-env scalars (reward, done, counters, context scalars) are computed redundantly by the
-// 8 lanes of the env from the same LDS data, so they agree without any exchange; lane sub == 0
-// writes them.  The model table is copied to LDS once per workgroup.  No MFMA: with
-// spring_inertia_scale = 1 the world inverse inertia R diag(1/I) R^T is rotate . scale .
-// rotate^-1 on three floats per lane.
+// Per-env scalars (reward, done, counters) are computed redundantly by the lanes of the env from the same LDS data, so
+// they agree without any exchange; lane sub == 0 writes them; between reward and reward they wait in LDS rows (stash).
+// Every per-link constant of the two phases sits in ONE LinkRec per link (static LDS, expanded on the device once per
+// workgroup).  No MFMA: with spring_inertia_scale = 1 the world inverse inertia R diag(1/I) R^T is a scalar.
+// DESIGN.md 5.2 has the structure and what was measured; -DCARL_BRAX_PROFILE adds region clocks (Prof below).
 #pragma once
 
 #include <type_traits>
@@ -1474,7 +1473,7 @@ static __device__ __forceinline__ v3d system_com(const carl_brax_sys_t& s, const
 template <bool MULTI, bool TASK>
 // `com_in` / `mass_in`: the whole-body centre of mass and total mass when the caller has just formed them at this very
 // state (the step's forward reward of reward_on_com models: one 11-link pass less per Humanoid env step).
-static __device__ __forceinline__ void observe(const carl_brax_sys_t& s, const Packed& pk, const LinkRec* jx, const Lds& m, bool go,
+static __device__ __forceinline__ void observe(const carl_brax_sys_t& s, const Packed& pk, const Lds& m, bool go,
                                         bool zero_frc, const v3d* com_in = nullptr, float mass_in = 0.0f) {
   const int skip = s.exclude_current_positions;
   // q[from:] as sin ++ cos (inverted double pendulum): the raw angles are written to the sin rows and
@@ -2022,7 +2021,7 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
       write_ctx_obs(b, m, n, env, r.cidx);
     }
     if (s.obs_extended) load_ctx<TASK>(s, b, m, r.cidx, go);  // com inertia / velocity use the env's masses
-    observe<MULTI, TASK>(s, pk, jx, m, go, true);
+    observe<MULTI, TASK>(s, pk, m, go, true);
     if (reset_obs != nullptr) record_out(reset_obs, (size_t)env, s.obs_dim, m, go);
     return;
   } else {
@@ -2195,7 +2194,7 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
         io.branch_sig[(step_off + env) * 2 + 1] = hl;
       }
       prof.mark(kProfEpilogue);
-      observe<MULTI, TASK>(s, pk, jx, m, active, false, s.reward_on_com ? &com1 : nullptr, msum);
+      observe<MULTI, TASK>(s, pk, m, active, false, s.reward_on_com ? &com1 : nullptr, msum);
       prof.mark(kProfObserve);
       stash_get(m, r);
       r.elapsed += 1;
@@ -2293,7 +2292,7 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
             write_ctx_obs(b, m, n, env, r.cidx);
           }
           }
-          observe<MULTI, TASK>(s, pk, jx, m, done, true);
+          observe<MULTI, TASK>(s, pk, m, done, true);
         }
       }
       prof.mark(kProfDone);
