@@ -147,7 +147,7 @@ BRAX_MAX_PAIR = 8
 (BRAX_ANT, BRAX_HALFCHEETAH, BRAX_HUMANOID, BRAX_HOPPER, BRAX_WALKER2D, BRAX_INVERTED_PENDULUM, BRAX_HUMANOIDSTANDUP, BRAX_INVERTED_DOUBLE_PENDULUM,
  BRAX_REACHER, BRAX_PUSHER) = range(10)
 BRAX_LINK_STATE = 13
-BRAX_LINK_RECORD = 20  # floats per link in HBM: pose head 7 | pose tail 7 | velocities 6 (include/carl_amd.h)
+BRAX_LINK_RECORD = 20  # floats per (env, link) in HBM: pose head 7 | pose tail 7 | velocities 6 (include/carl_amd.h, ABI 8)
 _f, _i = C.c_float, C.c_int32
 
 

@@ -51,9 +51,9 @@ class BraxVecEngine(VecEngine):
         if autoreset_mode == "first_state":
             self.b.flags |= _lib.FLAG_AUTORESET_FIRST_STATE
             self.first_state = torch.zeros((self.n, self.S), dtype=torch.float32, device=self.device)
-        # Brax state is env-major in HBM ([N][20 L], one contiguous record per env: pose heads 7 L | pose tails
-        # 7 L | velocities 6 L, include/carl_amd.h); ``self.state`` is the [20 L, N] VIEW of that storage (the
-        # classic-control engine's indexing); ``state64()`` returns it as float64 [N, L, 13].
+        # Brax state is env-major in HBM ([N][L][20]: per link pose head 7 | pose tail 7 | velocities 6,
+        # include/carl_amd.h ABI 8); ``self.state`` is the [20 L, N] VIEW of that storage (the classic-control
+        # engine's indexing); ``state64()`` returns it as float64 [N, L, 13].
         self._state_storage = torch.zeros((self.n, self.S), dtype=torch.float32, device=self.device)
         self.state = self._state_storage.t()
         if branch_record:  # per-step hash of the physics' discrete decisions (carl_step_io_t::branch_sig)
@@ -93,10 +93,8 @@ class BraxVecEngine(VecEngine):
         """The envs' maximal-coordinate state as float64 ``[N, L, 13]`` (per link COM position 3, rotation 4
         (w, x, y, z), linear velocity 3, angular velocity 3): pose = head + tail of the HBM record."""
         L = self.sys.n_links
-        rec = self._state_storage.to(torch.float64)
-        pose = (rec[:, : 7 * L] + rec[:, 7 * L: 14 * L]).reshape(self.n, L, 7)
-        vel = rec[:, 14 * L:].reshape(self.n, L, 6)
-        return torch.cat([pose, vel], dim=2)
+        rec = self._state_storage.to(torch.float64).reshape(self.n, L, _lib.BRAX_LINK_RECORD)
+        return torch.cat([rec[:, :, :7] + rec[:, :, 7:14], rec[:, :, 14:]], dim=2)
 
     def state_np(self):
         """``state64()`` on the host as ``[N, 13 L]`` float64 (the oracle's layout)"""
@@ -111,10 +109,10 @@ class BraxVecEngine(VecEngine):
         L = self.sys.n_links
         st = torch.as_tensor(state, dtype=torch.float64, device=self.device).reshape(self.n, L, 13)
         self._check_planar_state(st)
-        pose = st[:, :, :7].reshape(self.n, 7 * L)
+        pose = st[:, :, :7]
         head = pose.to(torch.float32)
         tail = (pose - head.to(torch.float64)).to(torch.float32)
-        self._state_storage.copy_(torch.cat([head, tail, st[:, :, 7:].reshape(self.n, 6 * L).to(torch.float32)], dim=1))
+        self._state_storage.copy_(torch.cat([head, tail, st[:, :, 7:].to(torch.float32)], dim=2).reshape(self.n, -1))
 
     def is_planar_model(self) -> bool:
         """True when the library steps this model with the planar substep (Halfcheetah, Hopper, Walker2d: every joint

@@ -305,11 +305,10 @@ struct Layout {
 };
 
 // Persistent state record of one env in HBM (carl_batch_t::state, ::first_state): CARL_BRAX_LINK_RECORD = 20
-// floats per link, as three blocks
-//   [0, 7 L)    pose, float32 head:  per link COM position 3, rotation 4 (w, x, y, z)
-//   [7 L, 14 L) pose, float32 tail:  pose = (double)head + (double)tail  (48 significant bits)
-//   [14 L, 20 L) per link linear velocity 3, angular velocity 3
-// The head block alone is the pose to float32.
+// floats PER LINK, link-major (ABI 8), each link's record being
+//   [0, 7)    pose, float32 head:  COM position 3, rotation 4 (w, x, y, z)
+//   [7, 14)   pose, float32 tail:  pose = (double)head + (double)tail  (48 significant bits)
+//   [14, 20)  linear velocity 3, angular velocity 3
 __host__ __device__ inline int io_rows_of(const carl_brax_sys_t& s) {
   const int qrows = s.n_q + s.n_dof;
   int r = s.obs_dim > qrows ? s.obs_dim : qrows;
@@ -1814,50 +1813,39 @@ static __device__ __forceinline__ void record_out(float* __restrict__ dst, size_
     for (int k = m.sub; k < W; k += kSub) dst[env * W + k] = m.at(m.lay.io + k);
 }
 
-// ---- the env's persistent record (Layout comment above: pose head | pose tail | velocities) <-> LDS --------
-// loads are issued four at a time before the first LDS write (a load-store loop pays one memory round trip per
-// element)
+// ---- the env's persistent record <-> LDS.  HBM holds one 80-byte record per (env, link) -- pose head 7 | pose tail 7 |
+// velocities 6 floats (include/carl_amd.h: CARL_BRAX_LINK_RECORD) -- and the lane that owns the link moves it as five
+// 16-byte pieces: a wavefront's envs x links are one contiguous run of whole 16-byte pieces in memory (round 4 kept
+// three blocks per env -- heads, tails, velocities -- and moved them 4 bytes per lane, 36-byte pieces at 720-byte stride:
+// the counter traffic of an Ant launch was 1.87 x its algorithmic bytes).
 static __device__ __forceinline__ void record_load(const float* __restrict__ src, const Lds& m, int L, bool go) {
-  if (!go) return;
-  const int NP = 7 * L, NV = 6 * L;
-  for (int k0 = m.sub; k0 < NP; k0 += 4 * kSub) {
-    float hi[4], lo[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int k = k0 + j * kSub;
-      hi[j] = (k < NP) ? src[k] : 0.0f;
-      lo[j] = (k < NP) ? src[NP + k] : 0.0f;
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int k = k0 + j * kSub;
-      if (k < NP) m.pdk(k) = (double)hi[j] + (double)lo[j];
-    }
-  }
-  for (int k0 = m.sub; k0 < NV; k0 += 4 * kSub) {
-    float v[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int k = k0 + j * kSub;
-      v[j] = (k < NV) ? src[2 * NP + k] : 0.0f;
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int k = k0 + j * kSub;
-      if (k < NV) m.velk(k) = v[j];
-    }
-  }
+  if (!go || m.sub >= L) return;
+  const vf4* p = reinterpret_cast<const vf4*>(src + CARL_BRAX_LINK_RECORD * m.sub);
+  const vf4 a = p[0], b4 = p[1], c = p[2], d = p[3], e = p[4];
+  // a: p.x p.y p.z r.w | b4: r.x r.y r.z tp.x | c: tp.y tp.z tr.w tr.x | d: tr.y tr.z v.x v.y | e: v.z w.x w.y w.z
+  Body b;
+  b.p = D((double)a.x + (double)b4.w, (double)a.y + (double)c.x, (double)a.z + (double)c.y);
+  b.r = qtd{(double)a.w + (double)c.z, (double)b4.x + (double)c.w, (double)b4.y + (double)d.x, (double)b4.z + (double)d.y};
+  b.v = V(d.z, d.w, e.x);
+  b.w = V(e.y, e.z, e.w);
+  m.put(m.sub, b);
 }
 static __device__ __forceinline__ void record_store(float* __restrict__ dst, const Lds& m, int L, bool go) {
-  if (!go) return;
-  const int NP = 7 * L, NV = 6 * L;
-  for (int k = m.sub; k < NP; k += kSub) {
-    const double d = m.pdk(k);
-    const float hi = (float)d;
-    dst[k] = hi;
-    dst[NP + k] = (float)(d - (double)hi);
+  if (!go || m.sub >= L) return;
+  const Body b = m.body(m.sub);
+  const double pose[7] = {b.p.x, b.p.y, b.p.z, b.r.w, b.r.x, b.r.y, b.r.z};
+  float hi[7], lo[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) {
+    hi[k] = (float)pose[k];
+    lo[k] = (float)(pose[k] - (double)hi[k]);
   }
-  for (int k = m.sub; k < NV; k += kSub) dst[2 * NP + k] = m.velk(k);
+  vf4* p = reinterpret_cast<vf4*>(dst + CARL_BRAX_LINK_RECORD * m.sub);
+  p[0] = vf4{hi[0], hi[1], hi[2], hi[3]};
+  p[1] = vf4{hi[4], hi[5], hi[6], lo[0]};
+  p[2] = vf4{lo[1], lo[2], lo[3], lo[4]};
+  p[3] = vf4{lo[5], lo[6], b.v.x, b.v.y};
+  p[4] = vf4{b.v.z, b.w.x, b.w.y, b.w.z};
 }
 // a pose coordinate as the state record holds it: float32 head + float32 tail (48 significant bits)
 static __device__ __forceinline__ double round48(double d) {

@@ -430,16 +430,18 @@ typedef struct carl_brax_sys {
  * (world frame) = 13 quantities.  The pose (the first 7) is carried to 48 significant bits as a float32 head
  * plus a float32 tail -- the spring pipeline multiplies pose DIFFERENCES by k dt / m = 20 .. 50 per substep, so a
  * pose rounded to float32 between steps costs 1e-5 of velocity per env step -- which makes
- * CARL_BRAX_LINK_RECORD = 20 floats per link in HBM.  One env's record, L links:
- *   [0, 7 L)      pose heads, link-major (p.x p.y p.z r.w r.x r.y r.z per link): the pose to float32
- *   [7 L, 14 L)   pose tails: pose = (double)head + (double)tail
- *   [14 L, 20 L)  velocities, link-major (v.x v.y v.z w.x w.y w.z per link) */
+ * CARL_BRAX_LINK_RECORD = 20 floats per link in HBM.  One env's record = its L links' 80-byte records one after the
+ * other (ABI 8; ABI 5 - 7 kept three blocks per env: heads, tails, velocities), a link's record being
+ *   [0, 7)    pose head (p.x p.y p.z r.w r.x r.y r.z): the pose to float32
+ *   [7, 14)   pose tail: pose = (double)head + (double)tail
+ *   [14, 20)  velocities (v.x v.y v.z w.x w.y w.z)
+ * -- the lane that owns a link moves it as five 16-byte pieces, a wavefront's envs x links one contiguous run. */
 #define CARL_BRAX_LINK_STATE 13
 #define CARL_BRAX_LINK_RECORD 20
 
 /* carl_batch_t is reused: family = CARL_N_FAMILIES + env_kind is ignored here (sys decides),
- * state is [n_lanes][CARL_BRAX_LINK_RECORD * n_links] (env-major: the lanes that share an env move its 20 L
- * floats as one contiguous record; the classic-control families keep [S][n_lanes]), ctx_table rows follow the CARL
+ * state is [n_lanes][n_links][CARL_BRAX_LINK_RECORD] (env-major, then link-major: the lanes that share an env move
+ * its 20 L floats as one contiguous run; the classic-control families keep [S][n_lanes]), ctx_table rows follow the CARL
  * class's feature table.
  * action is float32 [n_lanes][n_act] (lane-major, like obs).  `sys` is a DEVICE pointer to
  * one carl_brax_sys_t.  */
