@@ -741,3 +741,39 @@ def test_mass_ratio_floor_clamps_the_effective_mass_per_env():
     assert torso_dv(row) == pytest.approx(base / 0.5, rel=1e-9)        # one light link: the single-feature floor
     row[cm.mass_row[k_foot]] = 0.9 * default[cm.mass_row[k_foot]]
     assert torso_dv(row) == pytest.approx(base / float(np.float32(0.8)), rel=1e-9)  # two light links: the combined floor
+
+
+def test_relative_joint_rotation_is_linear_in_the_body_quaternions_product():
+    """The algebra the round-5 joint phase rests on (carl_amd/csrc/brax_kernels.hip.h: LinkRec::G): with
+    q1 = conj(r_parent) (x) r_child, the relative rotation of the two joint frames
+        rel = conj(r_parent (x) rpl) (x) (r_child (x) joint_rot) = conj(rpl) (x) q1 (x) joint_rot = G q1,
+    G = L(conj(rpl)) R(joint_rot) a constant 4 x 4 matrix whose column c is conj(rpl) (x) e_c (x) joint_rot -- exactly
+    how expand_link builds it; and with an unrotated link frame (rpl = joint_rot) G is block diagonal:
+    rel = (|j|^2 q1.w, M q1.xyz).  Checked against the three quaternion products the restatement forms."""
+    rng = np.random.default_rng(11)
+
+    def qmul(a, b):
+        return np.array([a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3],
+                         a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2],
+                         a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1],
+                         a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0]])
+
+    def conj(a):
+        return a * np.array([1.0, -1.0, -1.0, -1.0])
+
+    for case in range(200):
+        rp, rc = rng.normal(size=4), rng.normal(size=4)
+        rp, rc = rp / np.linalg.norm(rp), rc / np.linalg.norm(rc)
+        jrot = rng.normal(size=4).astype(np.float32).astype(np.float64)  # table values: float32, not exactly unit
+        jrot /= np.linalg.norm(jrot) * (1.0 + 1e-7 * rng.normal())
+        lrot = np.array([1.0, 0, 0, 0]) if case % 2 == 0 else rng.normal(size=4)
+        lrot /= np.linalg.norm(lrot)
+        rpl = qmul(lrot, jrot)
+        want = qmul(conj(qmul(rp, rpl)), qmul(rc, jrot))
+        G = np.stack([qmul(qmul(conj(rpl), e), jrot) for e in np.eye(4)], axis=1)
+        q1 = qmul(conj(rp), rc)
+        np.testing.assert_allclose(G @ q1, want, rtol=0, atol=5e-16)
+        if case % 2 == 0:  # unrotated link frame: the lean kernels' 10 numbers
+            assert np.abs(G[0, 1:]).max() < 1e-16 and np.abs(G[1:, 0]).max() < 1e-16
+            np.testing.assert_allclose(np.concatenate([[G[0, 0] * q1[0]], G[1:, 1:] @ q1[1:]]), want, rtol=0, atol=5e-16)
+            np.testing.assert_allclose(G[0, 0], jrot @ jrot, rtol=1e-15)
