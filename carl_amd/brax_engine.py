@@ -147,7 +147,26 @@ class BraxVecEngine(VecEngine):
             out["success"] = torch.zeros((n_steps, self.n), dtype=torch.uint8, device=self.device)
         return out
 
+    def _shape_for(self, n_steps: int) -> None:
+        """Once ``autotune`` has been used on this engine, launches keep to the lane-group width that was fastest for THEIR
+        length class: launches of >= 4 env steps run the balanced fragment schedule, shorter ones one wavefront per group
+        (carl_brax.hip: launch_brax), and the best width differs (Halfcheetah x 32 768: a 2-step probe picks 8 lanes per
+        env, 50-step rollouts are 30 % faster at 7).  The class not probed yet is probed on first use (state saved and
+        restored; results never depend on the width)."""
+        tuned = getattr(self, "_tuned", None)
+        if tuned is None or getattr(self, "_tuning", False) or torch.cuda.is_current_stream_capturing():
+            return  # (never probe inside a hipGraph capture: the width in force is recorded as it is)
+        long_launch = n_steps >= 4
+        if long_launch not in tuned:
+            self.autotune(n_steps=8 if long_launch else 2)
+        self.sys.lanes_per_env = tuned[long_launch]
+
+    def step(self, action):
+        self._shape_for(1)
+        return super().step(action)
+
     def rollout(self, actions, out: dict | None = None) -> dict:
+        self._shape_for(int(actions.shape[0]))
         if not self.sys.goal_mode:
             return super().rollout(actions, out)
         if out is None:
@@ -188,6 +207,7 @@ class BraxVecEngine(VecEngine):
             self.reset()
         best, best_ms = 0, float("inf")
         timings = {}
+        self._tuning = True  # (the probe's own launches keep the width under test)
         for w in self.lane_widths():
             self.sys.lanes_per_env = w
             self.rollout(acts, out)  # warm-up (code object load)
@@ -205,6 +225,10 @@ class BraxVecEngine(VecEngine):
             getattr(self, k).copy_(v)
         self.sys.lanes_per_env = best
         self.autotune_ms = timings
+        self._tuning = False
+        if getattr(self, "_tuned", None) is None:
+            self._tuned = {}
+        self._tuned[n_steps >= 4] = best  # per launch-length class (_shape_for)
         return best
 
     def reset_indexed(self, idx, count):
