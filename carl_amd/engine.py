@@ -42,6 +42,12 @@ class CapturedStep:
             raise ValueError("capture_step needs the action buffer in its final form (device, dtype, contiguous): "
                              "the graph reads this exact address on every replay")
         self.eng, self.action, self.n_steps = eng, action_buffer, int(n_steps)
+        self.graph = None
+        if self.n_steps == 1:
+            # ONE step per replay: a graph launch costs ~11 us where the prepared eager call costs ~4 (measured, 65 536
+            # CartPole lanes) -- the replayable object then IS the eager fast path on the fixed buffer (same results, same
+            # interface), and a capture only happens where it pays (n_steps >= 2).
+            return
         dev = eng.device
         # the first launch of a kernel loads its code object, which is not capturable: run one real step on
         # the capture stream first, on a snapshot that is put back afterwards
@@ -58,6 +64,8 @@ class CapturedStep:
         torch.cuda.current_stream(dev).wait_stream(side)
 
     def replay(self):
+        if self.graph is None:
+            return self.eng.step(self.action)
         self.graph.replay()
         e = self.eng
         return e.obs, e.reward, e.terminated, e.truncated
@@ -455,11 +463,11 @@ class VecEngine:
         """Capture ``n_steps`` per-call step launches that read ``action_buffer`` (a device tensor whose
         ADDRESS stays fixed: the policy writes the next action into it) into a hipGraph.  ``replay()`` then
         costs ONE graph launch for ``n_steps`` env steps.  Measured (65 536 CartPole lanes): a graph launch costs
-        ~11 us, so a ONE-step graph (10.9 us per env step) is SLOWER than the eager ``step`` (4.3 us: prepared ctypes
-        call, raw stream handle) -- a policy-in-the-loop caller that acts on every observation calls ``step``; the
-        captured form pays off from ~4 steps per replay (``n_steps=100``: 3.7 us per env step, the same as a
-        ``torch.cuda.graph`` around 100 ``step`` calls) and is meant for a policy that is captured into the same graph
-        region or for open-loop replays.  Engine state is untouched by the capture."""
+        ~11 us, so a ONE-step graph (10.9 us per env step) would be SLOWER than the eager ``step`` (4.3 us: prepared
+        ctypes call, raw stream handle) -- ``n_steps=1`` therefore returns a replayable object that makes the eager call
+        on the fixed buffer (round 5; no graph); the captured form pays off from ~4 steps per replay (``n_steps=100``:
+        3.7 us per env step, the same as a ``torch.cuda.graph`` around 100 ``step`` calls) and is meant for a policy that
+        is captured into the same graph region or for open-loop replays.  Engine state is untouched by the capture."""
         return CapturedStep(self, action_buffer, n_steps)
 
     def alloc_rollout(self, n_steps: int, final_obs: bool = False) -> dict:

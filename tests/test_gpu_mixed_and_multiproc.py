@@ -211,6 +211,24 @@ def test_captured_step_equals_eager_step(fam, device):
         assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(te1, te2) and torch.equal(tr1, tr2), t
     for name in _BOOKKEEPING:
         assert torch.equal(getattr(e1, name), getattr(e2, name)), name
+    assert g.graph is None  # (round 5: ONE step per replay is served by the eager fast path -- a graph launch costs more)
+    # the hipGraph form proper: two env steps per replay on the fixed buffer
+    e3, e4 = _engine(fam, table, n, device, **kw), _engine(fam, table, n, device, **kw)
+    e3.reset()
+    e4.reset()
+    before = e3.snapshot()
+    g2 = e3.capture_step(buf, n_steps=2)
+    assert g2.graph is not None
+    for k, v in before.items():
+        assert torch.equal(getattr(e3, k), v), k
+    for t in range(T // 2):
+        buf.copy_(acts[t])
+        o1, r1, te1, tr1 = g2.replay()
+        e4.step(acts[t])
+        o2, r2, te2, tr2 = e4.step(acts[t])
+        assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(te1, te2) and torch.equal(tr1, tr2), t
+    for name in _BOOKKEEPING:
+        assert torch.equal(getattr(e3, name), getattr(e4, name)), name
 
 
 def test_step_fast_path_tracks_a_changed_action_tensor(device):
