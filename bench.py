@@ -537,30 +537,32 @@ def roofline_of(wl, avg_launch_s):
         r["traffic"] = rec["hbm_bytes_per_launch"]
         r["traffic_source"] = rec["source"]
     # `frac` = frac_period: bytes / the launch-to-launch PERIOD of the timed region (one HIP-event pair over its K
-    # launches; what a caller gets).  frac_kernel: the same bytes / the MEDIAN single-launch time of THIS process (a HIP
-    # event between every two launches of one further region: main()).  Every fraction of the line comes from this
-    # process on this box.  profile_reference: the committed rocprofv3 --kernel-trace --stats figure of the same
-    # workload (another run, possibly another box: a bench run cannot trace itself), with that run's own fraction -- for
-    # reading beside profiles/, never mixed into this line's numbers.
+    # launches; what a caller gets).  frac_launch_median: the same bytes / the MEDIAN launch-to-launch interval of THIS
+    # process (a HIP event between every two launches of one further region: main()) -- still a period (kernel + dispatch
+    # gap; the kernel trace shows a 0.00 us median gap inside a train), so it is NOT called a kernel figure.
+    # Every fraction at this level comes from this process on this box.  profile_reference: the committed rocprofv3
+    # --kernel-trace --stats figure of the same workload (another run, possibly another box: a bench run cannot trace
+    # itself), with that run's own fraction = `frac_kernel` -- the only figure of the line that carries "kernel" in its
+    # name is the one from a kernel trace; for reading beside profiles/, never mixed into this line's own numbers.
     r["frac_period"] = r["frac"]
-    r["frac_kernel"] = None
+    r["frac_launch_median"] = None
     kt = profile_record("kernel_times", key)
     if kt:
-        r["profile_reference"] = {"kernel_avg_us_rocprofv3": kt["kernel_avg_us"],
-                                  "frac_of_that_run": wl.bytes_per_launch / (kt["kernel_avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                                  "source": kt["source"]}
+        fk = wl.bytes_per_launch / (kt["kernel_avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
+        r["profile_reference"] = {"kernel_avg_us_rocprofv3": kt["kernel_avg_us"], "frac_kernel": fk,
+                                  "frac_of_that_run": fk, "source": kt["source"]}
     return r
 
 
 def launch_stats(wl, roofline, K, barrier):
     """One further region of K launches with a HIP event between every two -> min / median / max launch time of this
-    process and `frac_kernel` from the median (VERDICT r04 #2b)."""
+    process and `frac_launch_median` from the median (VERDICT r04 #2b; named for what it is: ADVICE r05)."""
     _, _, per = wl.train(K, 0, barrier, collect=False, per_launch=True)
     per = sorted(per)
     med = per[(len(per) - 1) // 2]
     roofline["launch_us"] = {"n": len(per), "min": per[0] * 1e6, "median": med * 1e6, "max": per[-1] * 1e6,
                              "how": "HIP event between every two launches of one extra K-launch region, this process"}
-    roofline["frac_kernel"] = wl.bytes_per_launch / med / 1e9 / HBM_PEAK_GBS
+    roofline["frac_launch_median"] = wl.bytes_per_launch / med / 1e9 / HBM_PEAK_GBS
     return roofline
 
 
@@ -666,6 +668,31 @@ def cpu_baseline(args, env, table, lanes):
         "single_core_value": single,
         "c_oracle_f64_1thread_value": c_rate,
     }
+
+
+# `also` records that carry their own CPU baseline: north_star's env and BASELINE configs 2 - 5
+CPU_BESIDE = ("cartpole", "pendulum", "config3", "config4", "config5")
+
+
+def cpu_baseline_beside(args, fams, tables, lanes):
+    """`cpu_baseline` for one `also` workload: the single family's record, or -- a mixed batch -- one record per family
+    and the rate at which the host cores would step the WHOLE batch (every family's lanes once per step: harmonic
+    combination of the per-family rates, equal lanes per family).  A failure is recorded, never raised: the CPU figure is
+    a reported baseline and must not take the GPU measurement with it."""
+    recs = {}
+    for f, tab in zip(fams, tables):
+        try:
+            recs[f] = cpu_baseline(args, f, tab, lanes)
+        except Exception as e:
+            recs[f] = {"value": None, "unit": "env-steps/s", "cores": os.cpu_count(), "kind": "port", "error": repr(e)[:200]}
+    if len(fams) == 1:
+        return recs[fams[0]]
+    vals = [recs[f].get("value") for f in fams]
+    combined = (len(vals) / sum(1.0 / v for v in vals)) if all(vals) else None
+    return {"value": combined, "unit": "env-steps/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": "per family below (bounded samples of the same context sets); value = the rate of stepping every "
+                      "family's lanes once per step on all host cores = n / sum(1 / rate_f), equal lanes per family",
+            "per_family": recs}
 
 
 def per_call_record(eng, action, n_total, Kc, device, world, barrier):
@@ -1035,7 +1062,8 @@ def main():
             "lanes_per_gpu": w2.n, "chunk": Ta, "ms_per_step": el2 / K * 1e3,
             "avg_launch_ms": avg2 * 1e3, "frac": r2["frac"], "achieved_GBs": r2["achieved"],
             "bytes_per_unit": r2["bytes_per_unit"], "traffic": r2["traffic"],
-            "frac_kernel": r2["frac_kernel"], "launch_us": r2["launch_us"], "profile_reference": r2.get("profile_reference"),
+            "frac_launch_median": r2["frac_launch_median"], "launch_us": r2["launch_us"],
+            "profile_reference": r2.get("profile_reference"),
             "repetitions_ms_per_step": [w / K * 1e3 for w, _ in regs2],
             "mean_last_episode_return": w2.mean_last_return(), "lanes_per_env": w2.launch_shape(),
             "classes": [type(e).__name__ for e in w2.envs],
@@ -1065,10 +1093,12 @@ def main():
                 "value": w2.n * world * Ta * K / wall4, "unit": "env-steps/s", "ms_per_step": wall4 / K * 1e3,
                 "note": "each family's launch train on its own HIP stream, joined only at the end of the train: consecutive "
                         "launches of the two families overlap; not the one-stream figure above"}
-        if name == "cartpole" and rank == 0 and world == 1 and not args.no_cpu_baseline:
-            # north_star: the CartPole number "next to the reference Python step() timed on the host cores (core
-            # count stated) in the same run" -- the restatement of that loop (kind "port"), same context set
-            also[name]["cpu_baseline"] = cpu_baseline(args, "cartpole", w2.tables[0], lanes)
+        if name in CPU_BESIDE and rank == 0 and world == 1 and not args.no_cpu_baseline:
+            # north_star: every number "next to the reference Python step() timed on the host cores (core count stated)
+            # in the same run" -- the restatement of that loop (kind "port"; Brax: the fp64 C restatement of the spring
+            # pipeline), same context sets, one record per family and their lane-weighted combination (VERDICT r05 #4;
+            # the loop being timed: carl/envs/carl_env.py:321-342)
+            also[name]["cpu_baseline"] = cpu_baseline_beside(args, fams, w2.tables, lanes)
         del w2
         torch.cuda.empty_cache()
 

@@ -15,7 +15,7 @@ import torch  # noqa: F401  (must precede the CDLL load, see module docstring)
 
 from carl_amd import build as _build
 
-CARL_ABI_VERSION = 8
+CARL_ABI_VERSION = 9
 CARL_MAX_CTX_OBS = 32
 
 # carl_family_t
@@ -64,7 +64,7 @@ class Batch(C.Structure):
 
 class StepIO(C.Structure):
     _fields_ = [
-        ("action", _vp), ("action_dtype", C.c_int32), ("reserved", C.c_int32),
+        ("action", _vp), ("action_dtype", C.c_int32), ("row_pitch", C.c_int32),
         ("obs", _vp), ("reward", _vp), ("terminated", _vp), ("truncated", _vp), ("final_obs", _vp), ("done", _vp),
         ("branch_sig", _vp),
     ]
@@ -80,6 +80,8 @@ EXPORTS = {
     "carl_rollout": (C.c_int, [C.POINTER(Batch), C.POINTER(StepIO), C.c_int32, _vp]),
     "carl_rollout_pair": (C.c_int, [C.POINTER(Batch), C.POINTER(StepIO), C.POINTER(Batch), C.POINTER(StepIO), C.c_int32, _vp]),
     "carl_rollout_variant": (C.c_int, [C.POINTER(Batch)]),
+    "carl_rollout_variant_io": (C.c_int, [C.POINTER(Batch), C.POINTER(StepIO)]),
+    "carl_rollout_pitch": (C.c_int32, [C.c_int32]),
     "carl_done_compact": (C.c_int, [_vp, _vp, C.c_int32, _vp, _vp, _vp, _vp]),
     "carl_done_compact_scratch_elems": (C.c_int32, [C.c_int32]),
 }
@@ -209,7 +211,7 @@ EXPORTS.update({
     "carl_brax_reset": (C.c_int, [C.POINTER(Batch), _vp, C.POINTER(BraxSys), _vp, _vp, _vp]),
     "carl_brax_step": (C.c_int, [C.POINTER(Batch), _vp, C.POINTER(BraxSys), C.POINTER(StepIO), _vp]),
     "carl_brax_rollout": (C.c_int, [C.POINTER(Batch), _vp, C.POINTER(BraxSys), C.POINTER(StepIO), C.c_int32, _vp]),
-    "carl_brax_lane_widths": (C.c_int, [C.POINTER(BraxSys), _vp, C.c_int32]),
+    "carl_brax_lane_widths": (C.c_int, [C.POINTER(BraxSys), C.c_uint32, _vp, C.c_int32]),
     "carl_brax_model_is_planar": (C.c_int, [C.POINTER(BraxSys)]),
     "carl_brax_fragment_plan": (C.c_int, [C.c_int32] * 6 + [_vp, C.c_int32]),
 })

@@ -139,6 +139,11 @@ class BraxVecEngine(VecEngine):
         """Brax families have ONE rollout kernel (no staged / direct-store pair): nothing to warn about."""
         return _lib.ROLLOUT_STAGED
 
+    _has_direct_kernel = False
+
+    def _row_pitch(self) -> int:
+        return self.n  # dense rows: the Brax kernel writes per-env pieces, not 16-byte pieces of lane rows
+
     def alloc_rollout(self, n_steps: int, final_obs: bool = False, branch_record: bool = False) -> dict:
         out = super().alloc_rollout(n_steps, final_obs)
         if branch_record:
@@ -157,8 +162,8 @@ class BraxVecEngine(VecEngine):
         if tuned is None or getattr(self, "_tuning", False) or torch.cuda.is_current_stream_capturing():
             return  # (never probe inside a hipGraph capture: the width in force is recorded as it is)
         long_launch = n_steps >= 4
-        if long_launch not in tuned:
-            self.autotune(n_steps=8 if long_launch else 2)
+        if long_launch not in tuned:  # only after autotune(both_classes=False)
+            self._probe_widths(8 if long_launch else 2, 2)
         self.sys.lanes_per_env = tuned[long_launch]
 
     def step(self, action):
@@ -181,10 +186,14 @@ class BraxVecEngine(VecEngine):
     def lane_widths(self) -> list[int]:
         """Lane-group widths (lanes sharing one env) the library can launch for this model."""
         out = (C.c_int32 * 16)()
-        n = self.lib.carl_brax_lane_widths(C.byref(self.sys), out, 16)
+        n = self.lib.carl_brax_lane_widths(C.byref(self.sys), int(self.b.flags), out, 16)
         return [int(out[i]) for i in range(n)]
 
-    def autotune(self, n_steps: int = 2, reps: int = 2) -> int:
+    _PROBE_SAVED = ("state", "elapsed", "ctx_idx", "episode", "n_calls", "ep_return", "last_return", "last_length",
+                    "episodes_done", "obs", "ctx_obs", "reward", "terminated", "truncated", "done", "final_obs",
+                    "goal_pos", "success", "fin_count", "first_state", "branch_sig")
+
+    def autotune(self, n_steps: int = 2, reps: int = 2, both_classes: bool = True) -> int:
         """Time ``carl_brax_rollout`` on THIS batch for every launchable lane-group width and keep
         the fastest (``sys.lanes_per_env``).  The width is a pure scheduling choice -- results are
         bit-identical across widths (tests/test_gpu_brax.py) -- but the best one depends on the
@@ -193,42 +202,58 @@ class BraxVecEngine(VecEngine):
         larger than the chip holds at once -- how the kernel's (group, step-range) fragments divide
         (Halfcheetah x 32 768: width 4 wins a 2-step probe, width 7 is 10 % faster at 20 steps:
         ``tools/autotune_probe.py``).  Pass the ``n_steps`` the launches will have (per-call stepping:
-        the default).  All engine state is saved and restored around the probe."""
-        saved = {k: getattr(self, k).clone() for k in ("state", "elapsed", "ctx_idx", "episode", "n_calls", "ep_return",
-                                                      "last_return", "last_length", "episodes_done", "obs", "ctx_obs")}
-        if self.goal_pos is not None:
-            saved["goal_pos"] = self.goal_pos.clone()
-        if getattr(self, "fin_count", None) is not None:
-            saved["fin_count"] = self.fin_count.clone()
+        the default); with ``both_classes`` (default) the OTHER launch-length class (>= 4 env steps / shorter) is
+        probed here too, so that ``step`` / ``rollout`` never stop to probe -- a probe synchronises the device.
+        Every buffer a launch can change is saved and restored around the probe (also when a probe launch raises);
+        the probe's actions come from a private generator (the caller's CUDA RNG stream is not advanced)."""
+        best = self._probe_widths(n_steps, reps)
+        if both_classes:
+            other = not (n_steps >= 4)
+            if other not in self._tuned:
+                self._probe_widths(8 if other else 2, reps)
+            self.sys.lanes_per_env = best
+        return best
+
+    def _probe_widths(self, n_steps: int, reps: int) -> int:
+        saved = {k: getattr(self, k).clone() for k in self._PROBE_SAVED
+                 if isinstance(getattr(self, k, None), torch.Tensor)}
+        width0, tuning0 = int(self.sys.lanes_per_env), getattr(self, "_tuning", False)
         lo, hi = float(min(self.sys.act_lo[: self.sys.n_act])), float(max(self.sys.act_hi[: self.sys.n_act]))
-        acts = torch.rand((n_steps, self.n, self.sys.n_act), device=self.device) * (hi - lo) + lo
+        gen = torch.Generator(device=self.device).manual_seed(0x5EED)
+        acts = torch.rand((n_steps, self.n, self.sys.n_act), device=self.device, generator=gen) * (hi - lo) + lo
         out = self.alloc_rollout(n_steps)
-        if int(self.episode.max()) == 0:  # never reset: give the probe a valid state
-            self.reset()
         best, best_ms = 0, float("inf")
         timings = {}
         self._tuning = True  # (the probe's own launches keep the width under test)
-        for w in self.lane_widths():
-            self.sys.lanes_per_env = w
-            self.rollout(acts, out)  # warm-up (code object load)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(reps):
-                self.rollout(acts, out)
-            e1.record()
-            torch.cuda.synchronize(self.device)
-            ms = e0.elapsed_time(e1) / reps
-            timings[w] = ms
-            if ms < best_ms:
-                best, best_ms = w, ms
-        for k, v in saved.items():
-            getattr(self, k).copy_(v)
-        self.sys.lanes_per_env = best
-        self.autotune_ms = timings
-        self._tuning = False
-        if getattr(self, "_tuned", None) is None:
-            self._tuned = {}
-        self._tuned[n_steps >= 4] = best  # per launch-length class (_shape_for)
+        try:
+            if int(self.episode.max()) == 0:  # never reset: give the probe a valid state
+                self.reset()
+            for w in self.lane_widths():
+                self.sys.lanes_per_env = w
+                self.rollout(acts, out)  # warm-up (code object load)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(reps):
+                    self.rollout(acts, out)
+                e1.record()
+                e1.synchronize()
+                ms = e0.elapsed_time(e1) / reps
+                timings[w] = ms
+                if ms < best_ms:
+                    best, best_ms = w, ms
+        except BaseException:
+            self.sys.lanes_per_env = width0  # (a failed probe changes nothing)
+            raise
+        else:
+            self.sys.lanes_per_env = best
+            self.autotune_ms = timings
+            if getattr(self, "_tuned", None) is None:
+                self._tuned = {}
+            self._tuned[n_steps >= 4] = best  # per launch-length class (_shape_for)
+        finally:
+            self._tuning = tuning0
+            for k, v in saved.items():
+                getattr(self, k).copy_(v)
         return best
 
     def reset_indexed(self, idx, count):

@@ -110,6 +110,8 @@ int validate_io(const carl_batch_t* b, const carl_step_io_t* io, const char* who
     return fail(CARL_ERR_INVALID_ARGUMENT, "%s: continuous family needs float32 (carl_rollout: or float16 / bfloat16) actions", who);
   if (half && (reinterpret_cast<uintptr_t>(io->action) & 7) != 0)
     return fail(CARL_ERR_INVALID_ARGUMENT, "%s: float16 / bfloat16 actions must be 8-byte aligned", who);
+  if (io->row_pitch != 0 && io->row_pitch < b->n_lanes)  // (carl_step ignores the pitch; a wrong one is refused anyway)
+    return fail(CARL_ERR_INVALID_ARGUMENT, "%s: io.row_pitch %d < n_lanes %d (0 = dense rows)", who, io->row_pitch, b->n_lanes);
   return 0;
 }
 
@@ -121,9 +123,14 @@ bool use_lds_ctx(const carl_batch_t* b) {
   return bytes <= 32 * 1024 && (int64_t)b->n_contexts * 8 <= (int64_t)b->n_lanes;
 }
 
-int rollout_variant(const carl_batch_t* b) {
+// lanes per row of the action / output arrays of a rollout (carl_step_io_t::row_pitch; 0 = dense rows)
+int row_pitch_of(const carl_batch_t* b, const carl_step_io_t* io) {
+  return (io != nullptr && io->row_pitch > 0) ? io->row_pitch : b->n_lanes;
+}
+
+int rollout_variant(const carl_batch_t* b, const carl_step_io_t* io = nullptr) {
   if (b->flags & CARL_FLAG_ROLLOUT_DIRECT) return CARL_ROLLOUT_DIRECT_FLAG;
-  return (b->n_lanes % 16 == 0) ? CARL_ROLLOUT_STAGED : CARL_ROLLOUT_DIRECT_SHAPE;
+  return (row_pitch_of(b, io) % 16 == 0) ? CARL_ROLLOUT_STAGED : CARL_ROLLOUT_DIRECT_SHAPE;
 }
 
 // 64-thread workgroups spread a small batch over all 256 CUs x 4 SIMDs (65 536
@@ -166,9 +173,9 @@ int launch_step(const carl_batch_t* b, const carl_step_io_t* io, int n_steps, hi
   if (au8 || af16 || abf16) {
     const bool keeps_context = b->selector == CARL_SEL_STATIC || b->selector == CARL_SEL_HOST;
     const bool lean = b->fin_count == nullptr && io->final_obs == nullptr;
-    if (!rollout || rollout_variant(b) != CARL_ROLLOUT_STAGED || !keeps_context || !lean || !carl::predraw_of<Fam>::value)
+    if (!rollout || rollout_variant(b, io) != CARL_ROLLOUT_STAGED || !keeps_context || !lean || !carl::predraw_of<Fam>::value)
       return fail(CARL_ERR_UNSUPPORTED,
-                  "uint8 / float16 / bfloat16 actions: carl_rollout in its lean staged configuration only (n_lanes %% 16 == 0, "
+                  "uint8 / float16 / bfloat16 actions: carl_rollout in its lean staged configuration only (row pitch %% 16 == 0, "
                   "static / host selector, no finished-episode log, no final_obs); pass int32 / int64 / float32 actions");
   }
   const dim3 g(grid), t(block);
@@ -183,12 +190,15 @@ int launch_step(const carl_batch_t* b, const carl_step_io_t* io, int n_steps, hi
     CARL_LAUNCH(step_kernel, *b, *io);
     return check_launch("carl_step");
   }
-  // n_lanes % 16 == 0: records are staged in LDS and written out by the workgroup's storer waves with 16-byte
-  // stores (rollout_staged_kernel).  Other shapes -- and CARL_FLAG_ROLLOUT_DIRECT, the A/B switch -- take
+  carl_step_io_t io_resolved = *io;  // the kernels read the pitch as given: never 0
+  io_resolved.row_pitch = row_pitch_of(b, io);
+  io = &io_resolved;
+  // row pitch % 16 == 0 (dense rows: n_lanes % 16 == 0): records are staged in LDS and written out by the workgroup's
+  // storer waves with 16-byte stores (rollout_staged_kernel).  Other shapes -- and CARL_FLAG_ROLLOUT_DIRECT, the A/B switch -- take
   // rollout_kernel (per-lane stores, ~50 % slower); carl_rollout_variant() tells a caller which one it gets.
   // (also for tables small enough for LDS: a fused rollout gathers parameters once per launch and on
   // resets, so the global table costs nothing there; the LDS copy pays off in the per-call kernel)
-  if (rollout_variant(b) == CARL_ROLLOUT_STAGED) {  // 16-byte pieces of every output row stay inside the batch
+  if (rollout_variant(b, io) == CARL_ROLLOUT_STAGED) {  // 16-byte pieces of every output row stay inside the row
     size_t sh_staged = carl::rollout_staged_lds_bytes<Fam>();
     using kern_t = void (*)(carl_batch_t, carl_step_io_t, int);
     kern_t kern = a64 ? static_cast<kern_t>(carl::rollout_staged_kernel<Fam, true>)
@@ -293,7 +303,10 @@ int launch_pair(const carl_batch_t* a, const carl_step_io_t* ioa, const carl_bat
   if (int e = carl_host::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), sh, "carl_rollout_pair")) return e;
   const int grid_a = (a->n_lanes + carl::kRolloutLanes - 1) / carl::kRolloutLanes;
   const int grid_b = (b->n_lanes + carl::kRolloutLanes - 1) / carl::kRolloutLanes;
-  hipLaunchKernelGGL(kern, dim3(grid_a + grid_b), dim3(carl::kStagedThreads), sh, s, *a, *ioa, *b, *iob, n_steps, grid_a);
+  carl_step_io_t ra = *ioa, rb = *iob;  // the kernels read the pitch as given: never 0
+  ra.row_pitch = row_pitch_of(a, ioa);
+  rb.row_pitch = row_pitch_of(b, iob);
+  hipLaunchKernelGGL(kern, dim3(grid_a + grid_b), dim3(carl::kStagedThreads), sh, s, *a, ra, *b, rb, n_steps, grid_a);
   return check_launch("carl_rollout_pair");
 }
 
@@ -301,7 +314,7 @@ int launch_pair(const carl_batch_t* a, const carl_step_io_t* ioa, const carl_bat
 // rollout_staged_kernel<Fam, false, PLAIN = true>)
 bool pair_part_ok(const carl_batch_t* b, const carl_step_io_t* io) {
   const bool keeps_context = b->selector == CARL_SEL_STATIC || b->selector == CARL_SEL_HOST;
-  return b->n_lanes > 0 && rollout_variant(b) == CARL_ROLLOUT_STAGED && keeps_context && b->fin_count == nullptr &&
+  return b->n_lanes > 0 && rollout_variant(b, io) == CARL_ROLLOUT_STAGED && keeps_context && b->fin_count == nullptr &&
          io->final_obs == nullptr && (io->action_dtype == CARL_ACTION_I32 || io->action_dtype == CARL_ACTION_F32);
 }
 
@@ -414,7 +427,7 @@ int carl_rollout_pair(const carl_batch_t* batch_a, const carl_step_io_t* io_a, c
   if (batch_b->family == CARL_ACROBOT)
     return fail(CARL_ERR_UNSUPPORTED, "carl_rollout_pair: the second family cannot be Acrobot");
   if (!pair_part_ok(batch_a, io_a) || !pair_part_ok(batch_b, io_b))
-    return fail(CARL_ERR_UNSUPPORTED, "carl_rollout_pair: both parts must be lean staged rollouts (n_lanes %% 16 == 0, static / host "
+    return fail(CARL_ERR_UNSUPPORTED, "carl_rollout_pair: both parts must be lean staged rollouts (row pitch %% 16 == 0, static / host "
                 "selector, no finished-episode log, no terminal observations, int32 / float32 actions)");
   hipStream_t s = (hipStream_t)stream;
   switch (batch_b->family) {
@@ -437,6 +450,18 @@ int carl_rollout_variant(const carl_batch_t* batch) {
   }
   return rollout_variant(batch);
 }
+
+int carl_rollout_variant_io(const carl_batch_t* batch, const carl_step_io_t* io) {
+  const int dense = carl_rollout_variant(batch);
+  if (dense == CARL_ERR_INVALID_ARGUMENT || io == nullptr) return dense;
+  if (io->row_pitch != 0 && io->row_pitch < batch->n_lanes) {
+    fail(CARL_ERR_INVALID_ARGUMENT, "carl_rollout_variant_io: io.row_pitch %d < n_lanes %d", io->row_pitch, batch->n_lanes);
+    return CARL_ERR_INVALID_ARGUMENT;
+  }
+  return rollout_variant(batch, io);
+}
+
+int32_t carl_rollout_pitch(int32_t n_lanes) { return n_lanes <= 0 ? 0 : (n_lanes + 15) / 16 * 16; }
 
 int32_t carl_done_compact_scratch_elems(int32_t n) {
   return n <= 0 ? 1 : (n + carl::kCompactBlock - 1) / carl::kCompactBlock;

@@ -307,6 +307,8 @@ int validate_brax_io(const carl_step_io_t* io, const char* who) {
     return fail(CARL_ERR_INVALID_ARGUMENT, "%s: a required io pointer is NULL", who);
   if (io->action_dtype != CARL_ACTION_F32)
     return fail(CARL_ERR_INVALID_ARGUMENT, "%s: Brax families take float32 actions", who);
+  if (io->row_pitch != 0)
+    return fail(CARL_ERR_INVALID_ARGUMENT, "%s: Brax families take dense rows (io.row_pitch = 0)", who);
   return 0;
 }
 
@@ -373,12 +375,14 @@ int carl_brax_model_is_planar(const carl_brax_sys_t* sys_host) {
   return brax_is_planar(sys_host) ? 1 : 0;
 }
 
-int carl_brax_lane_widths(const carl_brax_sys_t* sys_host, int32_t* widths_out, int32_t cap) {
+int carl_brax_lane_widths(const carl_brax_sys_t* sys_host, uint32_t batch_flags, int32_t* widths_out, int32_t cap) {
   if (sys_host == nullptr || widths_out == nullptr || cap < 1) {
     fail(CARL_ERR_INVALID_ARGUMENT, "carl_brax_lane_widths: NULL argument");
     return 0;
   }
-  const bool multi = brax_is_multi(sys_host);
+  // the kernels a STEP / ROLLOUT launch of such a batch takes (launch_brax<1>): a planar model stepped by the general
+  // substep (CARL_FLAG_BRAX_GENERIC) runs the multi-hinge kernels, whose widths differ from the planar ones
+  const bool multi = brax_is_multi(sys_host) || (brax_is_planar(sys_host) && (batch_flags & CARL_FLAG_BRAX_GENERIC));
   int n = 0;
   for (int w : kBraxWidths)  // one lane per link or wider
     if (w >= sys_host->n_links && brax_instantiated(w, multi, brax_is_task(sys_host)) && n < cap) widths_out[n++] = w;

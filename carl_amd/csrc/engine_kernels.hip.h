@@ -682,7 +682,7 @@ __global__ void __launch_bounds__(kRolloutThreads) rollout_kernel(const carl_bat
   const int lane = lane_base + (loader ? 0 : (int)threadIdx.x);
   const bool active = !loader && lane < b.n_lanes;
   const uint64_t glane = (uint64_t)(b.lane_offset + lane);
-  const size_t n = (size_t)b.n_lanes;
+  const size_t n = (size_t)io.row_pitch;  // lanes per row of the action / output arrays (>= n_lanes; resolved by the host)
   const int max_steps = b.max_episode_steps;
   const AStore* act = static_cast<const AStore*>(io.action);
   LaneRegs<Fam> r{};
@@ -907,8 +907,9 @@ template <class Fam>
 __device__ __forceinline__ void drain_records(char* buf, const carl_step_io_t& io, size_t n, int lane_base, int l,
                                               int which, int t0, int steps) {
   using SK = LdsSink<Fam>;
-  // lanes of this workgroup inside the batch: 256, or a multiple of 16 in the ragged last workgroup
-  // (n % 16 == 0), so every 16-byte piece below is entirely inside or entirely outside
+  // lanes of this workgroup inside the ROW (n = the row pitch): 256, or a multiple of 16 in the ragged last workgroup
+  // (n % 16 == 0), so every 16-byte piece below is entirely inside or entirely outside; columns [n_lanes, n) of a
+  // padded row receive the records of the padding lanes (clones of the batch's last lane)
   const int valid = min(kRolloutLanes, (int)n - lane_base);
   typedef float vf4 __attribute__((ext_vector_type(4)));
   // streamed once, never re-read by this kernel: non-temporal stores (temporal ones: +6 %, measured)
@@ -951,8 +952,8 @@ __device__ __forceinline__ void zero_flag_rows(char* out_buf, int l, int which) 
       *reinterpret_cast<vf4*>(out_buf + (size_t)u * SK::kStepBytes + SK::kFlagOff + 16 * l) = vf4{0.0f, 0.0f, 0.0f, 0.0f};
 }
 
-// Preconditions (checked by the host): n_lanes % 16 == 0 (the last workgroup may be ragged), global
-// context table.
+// Preconditions (checked by the host): row pitch % 16 == 0 and >= n_lanes (the last workgroup may be ragged; lanes
+// [n_lanes, pitch) are padding), global context table.
 // LDSCTX (short-episode families under a round-robin / random selector, small tables; chosen by the host):
 // the [F][C] context table is staged in LDS behind the record buffers, so the parameter re-gather of a
 // lane that moves to another context -- on the done path of nearly every step for CartPole -- is an LDS
@@ -1002,7 +1003,7 @@ __device__ __forceinline__ void rollout_staged_body(const carl_batch_t& b, const
   const int lane = lane_base + (compute ? (int)threadIdx.x : 0);
   const bool active = compute && lane < b.n_lanes;
   const uint64_t glane = (uint64_t)(b.lane_offset + lane);
-  const size_t n = (size_t)b.n_lanes;
+  const size_t n = (size_t)io.row_pitch;  // lanes per row of the action / output arrays (>= n_lanes; resolved by the host)
   const int max_steps = b.max_episode_steps;
   const AStore* act = static_cast<const AStore*>(io.action);
   constexpr int kBufActs = kStageChunk * kRolloutLanes;

@@ -428,8 +428,17 @@ class VecEngine:
             self._a_host = torch.empty(self.n * self._action_dim, dtype=dt).pin_memory()
             self._a_dev = torch.empty((self.n, self._action_dim) if self._action_dim > 1 or not self.info.action_is_discrete
                                       else (self.n,), dtype=dt, device=self.device)
-        self._a_host.numpy()[:] = np.asarray(action).reshape(-1)
+            self._a_event = torch.cuda.Event()
+            self._a_pending = False
+        a = np.asarray(action).reshape(-1)
+        if a.size != self._a_host.numel():  # (NumPy would broadcast one value over every actuator silently)
+            raise ValueError(f"action has {a.size} elements, this engine takes {self.n} x {self._action_dim}")
+        if self._a_pending:  # the previous asynchronous upload still reads the pinned buffer
+            self._a_event.synchronize()
+        self._a_host.numpy()[:] = a
         self._a_dev.view(-1).copy_(self._a_host, non_blocking=True)
+        self._a_event.record(torch.cuda.current_stream(self.device))
+        self._a_pending = True
         return self._a_dev
 
     def read_transition(self):
@@ -470,16 +479,36 @@ class VecEngine:
         is captured into the same graph region or for open-loop replays.  Engine state is untouched by the capture."""
         return CapturedStep(self, action_buffer, n_steps)
 
+    _has_direct_kernel = True  # (the classic-control families: staged / direct-store pair of rollout kernels)
+
+    def _row_pitch(self) -> int:
+        """Lanes per ROW of a rollout's action / output arrays (``carl_step_io_t.row_pitch``): the lane count rounded up
+        to a multiple of 16, so that every row's 16-byte pieces stay aligned and ANY lane count -- 10, 65 537, the uneven
+        shards of ``distributed.lane_shard`` -- takes the staged kernel (round 6; such batches used to fall back to the
+        ~50 % slower direct-store kernel).  Dense rows under ``FLAG_ROLLOUT_DIRECT`` (the A/B switch)."""
+        if self.b.flags & _lib.FLAG_ROLLOUT_DIRECT:
+            return self.n
+        return int(self.lib.carl_rollout_pitch(self.n))
+
     def alloc_rollout(self, n_steps: int, final_obs: bool = False) -> dict:
-        dev, n, D = self.device, self.n, self.D
+        """Output buffers of a ``rollout`` of ``n_steps``: ``obs [T, N, D]``, ``reward`` / ``terminated`` / ``truncated``
+        ``[T, N]``.  For a lane count that is not a multiple of 16 they are VIEWS ``[:, :N]`` of arrays whose rows are
+        ``_row_pitch()`` lanes long (non-contiguous; ``.contiguous()`` copies) -- the padding columns receive the
+        records of the padding lanes."""
+        dev, n, D, P = self.device, self.n, self.D, self._row_pitch()
+
+        def rows(tail, dtype, zero=False):
+            full = (torch.zeros if zero else torch.empty)((n_steps, P) + tail, dtype=dtype, device=dev)
+            return full if P == n else full[:, :n]
+
         out = {
-            "obs": torch.empty((n_steps, n, D), dtype=torch.float32, device=dev),
-            "reward": torch.empty((n_steps, n), dtype=torch.float32, device=dev),
-            "terminated": torch.empty((n_steps, n), dtype=torch.uint8, device=dev),
-            "truncated": torch.empty((n_steps, n), dtype=torch.uint8, device=dev),
+            "obs": rows((D,), torch.float32),
+            "reward": rows((), torch.float32),
+            "terminated": rows((), torch.uint8),
+            "truncated": rows((), torch.uint8),
         }
         if final_obs:
-            out["final_obs"] = torch.zeros((n_steps, n, D), dtype=torch.float32, device=dev)
+            out["final_obs"] = rows((D,), torch.float32, zero=True)
         return out
 
     def rollout(self, actions, out: dict | None = None) -> dict:
@@ -490,22 +519,24 @@ class VecEngine:
         bit for bit as the wide launch fed the same values."""
         T = int(actions.shape[0])
         a, dt = self._action_tensor(actions, (T,), allow_narrow=True)
-        if not self._warned_direct and self.rollout_variant() == _lib.ROLLOUT_DIRECT_SHAPE:
-            import warnings
-
-            self._warned_direct = True
-            warnings.warn(f"carl_rollout: {self.n} lanes is not a multiple of 16 -- this batch takes the direct-store "
-                          "kernel (~50 % slower than the staged one; same results).  Pad the batch to a multiple of 16 "
-                          "lanes for the fast path.", RuntimeWarning, stacklevel=2)
         if out is None:
             out = self.alloc_rollout(T)
         io = self._rollout_io(a, dt, out, T)
+        if self._has_direct_kernel and not self._warned_direct and (io.row_pitch or self.n) % 16 and \
+                not (self.b.flags & _lib.FLAG_ROLLOUT_DIRECT):
+            import warnings
+
+            self._warned_direct = True
+            warnings.warn(f"carl_rollout: the output buffers' rows are {io.row_pitch or self.n} lanes long, not a multiple "
+                          "of 16 -- this launch takes the direct-store kernel (~50 % slower than the staged one; same "
+                          "results).  Use alloc_rollout()'s buffers (rows padded to a multiple of 16) for the fast path.",
+                          RuntimeWarning, stacklevel=2)
         with torch.cuda.device(self.device):
             code = self._c_rollout(io, T)
             if code == _lib.ERR_UNSUPPORTED and dt in (_lib.ACTION_U8, _lib.ACTION_F16, _lib.ACTION_BF16):
                 # the narrow formats are read by the lean staged rollout only (moving selectors, the finished-episode
-                # log, terminal observations and odd lane counts take kernels that read int32 / float32): widen once,
-                # same results
+                # log, terminal observations and dense rows of an odd lane count take kernels that read int32 /
+                # float32): widen once, same results
                 a, dt = self._action_tensor(a.to(torch.int32 if dt == _lib.ACTION_U8 else torch.float32), (T,))
                 io = self._rollout_io(a, dt, out, T)
                 code = self._c_rollout(io, T)
@@ -513,21 +544,55 @@ class VecEngine:
         return out
 
     def _rollout_io(self, a: torch.Tensor, dt: int, out: dict, T: int) -> "_lib.StepIO":
-        """``carl_step_io_t`` of a fused rollout: validated actions + the caller's ``[T, ...]`` output buffers"""
+        """``carl_step_io_t`` of a fused rollout: validated actions + the caller's ``[T, ...]`` output buffers.  The row
+        pitch is read off the buffers (``alloc_rollout`` pads rows to a multiple of 16 lanes; dense caller-made buffers
+        keep working); actions of a padded layout are copied once into rows of the same pitch, the padding columns
+        repeating the last lane's action (the padding lanes run as clones of that lane: valid numbers)."""
         if out["reward"].shape[0] < T:
             raise ValueError("rollout output buffers are shorter than the action sequence")
+        n, D = self.n, self.D
+        P = max(n, int(out["reward"].stride(0))) if out["reward"].dim() == 2 else n  # (a one-row buffer may carry any stride)
+        for k, tail in (("obs", (D,)), ("reward", ()), ("terminated", ()), ("truncated", ()), ("final_obs", (D,))):
+            t = out.get(k)
+            if t is None:
+                continue
+            inner = int(np.prod(tail, dtype=np.int64)) if tail else 1
+            want = (P * inner, inner, 1) if tail else (P, 1)
+            if tuple(t.shape[1:]) != (n,) + tail or P < n or any(
+                    sz > 1 and st != w for sz, st, w in zip(t.shape, t.stride(), want)):
+                raise ValueError(f"rollout output '{k}': shape {tuple(t.shape)} / strides {tuple(t.stride())} do not form "
+                                 f"[T, {n}{', ' + str(D) if tail else ''}] rows of one common pitch ({P} lanes)")
         io = _lib.StepIO()
+        if P != n:
+            a = self._pad_action_rows(a, T, P)
+            io.row_pitch = P
         io.action, io.action_dtype = a.data_ptr(), dt
         io.obs, io.reward = _ptr(out["obs"]), _ptr(out["reward"])
         io.terminated, io.truncated = _ptr(out["terminated"]), _ptr(out["truncated"])
         io.final_obs = _ptr(out.get("final_obs"))
         io.branch_sig = _ptr(out.get("branch_sig"))
+        self._rollout_actions = a  # (keeps a padded copy alive until the launch has been enqueued and beyond)
         return io
 
+    def _pad_action_rows(self, a: torch.Tensor, T: int, P: int) -> torch.Tensor:
+        key = (T, P, a.dtype)
+        buf = self._act_pad.get(key) if getattr(self, "_act_pad", None) else None
+        if buf is None:
+            self._act_pad = {key: torch.empty((T, P), dtype=a.dtype, device=self.device)}  # (one size kept)
+            buf = self._act_pad[key]
+        rows = a.view(T, self.n)
+        buf[:, : self.n] = rows
+        buf[:, self.n:] = rows[:, self.n - 1:]
+        return buf
+
     def rollout_variant(self) -> int:
-        """Which kernel ``rollout`` launches for this batch: ``_lib.ROLLOUT_STAGED`` (fast path, needs
-        ``n_lanes % 16 == 0``), ``ROLLOUT_DIRECT_SHAPE`` or ``ROLLOUT_DIRECT_FLAG`` (carl_rollout_variant)."""
-        return int(self.lib.carl_rollout_variant(C.byref(self.b)))
+        """Which kernel ``rollout`` launches for this batch into ``alloc_rollout``'s buffers: ``_lib.ROLLOUT_STAGED``
+        (fast path: rows of a pitch that is a multiple of 16 -- any lane count since round 6), ``ROLLOUT_DIRECT_FLAG``
+        (the A/B switch); ``ROLLOUT_DIRECT_SHAPE`` only for caller-made dense buffers of an odd lane count
+        (carl_rollout_variant_io)."""
+        io = _lib.StepIO()
+        io.row_pitch = self._row_pitch()
+        return int(self.lib.carl_rollout_variant_io(C.byref(self.b), C.byref(io)))
 
     def drain_finished(self):
         """Finished-episode log since the last drain -> (global lane ids, returns, lengths,

@@ -248,8 +248,11 @@ def halfcheetah_sys(feature_names: list[str] | None = None, reference_compat: bo
         _set3(s.inv_inertia, i, (1.0, 1.0, 1.0))
         s.k_pos[i], s.k_vel[i], s.k_limit[i], s.k_ang_damp[i] = 15000.0, 100.0, 1000.0, 20.0
         qi, di = qi + ns + 1, di + ns + 1
+    # gears: half_cheetah.py's spring-backend branch replaces the MJCF's (120, 90, 60, 120, 60, 30) with
+    # [120, 90, 60, 120, 100, 100] together with the timestep / n_frames above [upstream-memory]; applied since round 6
+    # (rounds 1-5 kept the MJCF's front shin / foot gears: DESIGN.md section 7, provenance ledger)
     for k, (name, gear) in enumerate([("bthigh", 120.0), ("bshin", 90.0), ("bfoot", 60.0), ("fthigh", 120.0),
-                                      ("fshin", 60.0), ("ffoot", 30.0)]):
+                                      ("fshin", 100.0), ("ffoot", 100.0)]):
         s.act_dof[k], s.act_gear[k], s.act_lo[k], s.act_hi[k] = joint_dof[name], gear, -1.0, 1.0
     s.n_coll = len(coll)
     for k, (link, pos, rad) in enumerate(coll):
@@ -421,10 +424,14 @@ def humanoid_sys(feature_names: list[str] | None = None, reference_compat: bool 
         _set3(s.inv_inertia, i, (1.0, 1.0, 1.0))
         s.k_pos[i], s.k_vel[i], s.k_limit[i], s.k_ang_damp[i] = 20000.0, 100.0, 1000.0, 20.0
     assert qi == s.n_q and di == s.n_dof
-    motors = [("abdomen_y", 100), ("abdomen_z", 100), ("abdomen_x", 100), ("right_hip_x", 100), ("right_hip_z", 100),
-              ("right_hip_y", 300), ("right_knee", 200), ("left_hip_x", 100), ("left_hip_z", 100), ("left_hip_y", 300),
-              ("left_knee", 200), ("right_shoulder1", 25), ("right_shoulder2", 25), ("right_elbow", 25),
-              ("left_shoulder1", 25), ("left_shoulder2", 25), ("left_elbow", 25)]
+    # gears: humanoid.py / humanoidstandup.py replace the MJCF's (100 / 300 / 200 on torso and legs, 25 on the arms) with
+    # [350] * 11 + [100] * 6 in the same `backend in ['spring', 'positional']` branch that sets timestep 0.0015 and
+    # n_frames 10 [upstream-memory]; CARLBraxEnv always asks for "spring" (carl_brax_env.py:117,163-167).  Applied since
+    # round 6 (rounds 1-5 took the timestep half of that branch and kept the MJCF gears)
+    motors = [("abdomen_y", 350), ("abdomen_z", 350), ("abdomen_x", 350), ("right_hip_x", 350), ("right_hip_z", 350),
+              ("right_hip_y", 350), ("right_knee", 350), ("left_hip_x", 350), ("left_hip_z", 350), ("left_hip_y", 350),
+              ("left_knee", 350), ("right_shoulder1", 100), ("right_shoulder2", 100), ("right_elbow", 100),
+              ("left_shoulder1", 100), ("left_shoulder2", 100), ("left_elbow", 100)]
     for k, (jn, gear) in enumerate(motors):
         s.act_dof[k], s.act_gear[k], s.act_lo[k], s.act_hi[k] = joint_dof[jn], float(gear), -0.4, 0.4
     s.n_coll = len(coll)

@@ -207,7 +207,7 @@ class MixedVecEngine:
             return None  # the pair kernel reads int32 / float32 actions; narrow-format parts take their own launches
         # What carl_rollout_pair declines (carl_amd.hip: pair_part_ok) is decided HERE, before any tensor is touched: an
         # eligible family pair in a non-lean configuration (round-robin / random selector, int64 actions, terminal
-        # observations, a finished-episode log, a lane count that is not a multiple of 16) used to convert both action
+        # observations, a finished-episode log, rows whose pitch is not a multiple of 16 lanes) used to convert both action
         # tensors and allocate full [T, N, ...] outputs on every call only to hear UNSUPPORTED and do it all again in the
         # per-part path.
         fams = {pa.family, pb.family}
@@ -217,7 +217,8 @@ class MixedVecEngine:
             return None
         for k, p in enumerate(self.parts):
             a = actions[k]
-            lean = (p.b.selector in (_lib.SEL_STATIC, _lib.SEL_HOST) and p.n % 16 == 0 and p.fin_capacity == 0
+            pitch = p._row_pitch() if outs is None else max(p.n, int(outs[k]["reward"].stride(0)))  # (engine.py: _rollout_io)
+            lean = (p.b.selector in (_lib.SEL_STATIC, _lib.SEL_HOST) and pitch % 16 == 0 and p.fin_capacity == 0
                     and not (p.b.flags & _lib.FLAG_ROLLOUT_DIRECT)
                     and not (torch.is_tensor(a) and a.dtype == torch.int64)
                     and not (outs is not None and outs[k].get("final_obs") is not None))

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define CARL_ABI_VERSION 8
+#define CARL_ABI_VERSION 9
 #define CARL_MAX_CTX_OBS 32
 
 #define CARL_ERR_INVALID_ARGUMENT (-1)
@@ -187,7 +187,13 @@ typedef struct carl_step_io {
   const void* action;   /* [n_lanes * action_dim], dtype per action_dtype */
   int32_t action_dtype; /* CARL_ACTION_* ; discrete families take I32/I64 (carl_rollout also U8), Box F32 (carl_rollout
                            also F16 / BF16) */
-  int32_t reserved;
+  int32_t row_pitch;    /* carl_rollout / carl_rollout_pair (classic-control families; ABI 9): lanes per ROW of `action` and of
+                           every [T][...] output -- row t of an array starts row_pitch lanes after row t - 1; 0 = n_lanes (dense
+                           rows).  A pitch that is a multiple of 16 keeps every row's 16-byte pieces aligned whatever
+                           n_lanes is, so ANY lane count takes the staged kernel: columns [n_lanes, row_pitch) of the action
+                           rows must hold valid actions (the engine repeats the last lane's) and the same columns of the outputs
+                           receive the records of the padding lanes.  Must be 0 or >= n_lanes; ignored by carl_step; the Brax
+                           entry points take 0 only.  (this field was `reserved`, always 0, in ABI <= 8) */
   float* obs;           /* [n_lanes][D]; with AUTORESET the post-reset observation
                            for done lanes (gymnasium vector-env convention) */
   float* reward;        /* [n_lanes] */
@@ -258,6 +264,13 @@ int carl_rollout_pair(const carl_batch_t* batch_a, const carl_step_io_t* io_a, c
  * Python engine warns once). */
 enum { CARL_ROLLOUT_STAGED = 0, CARL_ROLLOUT_DIRECT_SHAPE = 1, CARL_ROLLOUT_DIRECT_FLAG = 2 };
 int carl_rollout_variant(const carl_batch_t* batch); /* CARL_ERR_INVALID_ARGUMENT for a non-classic family */
+/* ... for this batch WITH these buffers (ABI 9): the staged kernel needs (io->row_pitch ? io->row_pitch : n_lanes) % 16
+ * == 0 -- a caller whose lane count is not a multiple of 16 lays its rows out at carl_rollout_pitch(n_lanes) and gets
+ * the staged kernel (carl_amd.engine.VecEngine.alloc_rollout does; uneven lane shards of a multi-GPU run end up here:
+ * carl_amd/distributed.py::lane_shard).  No reference counterpart: the reference has no batched layout at all
+ * (carl/envs/carl_env.py:321-342 returns one env's tuple). */
+int carl_rollout_variant_io(const carl_batch_t* batch, const carl_step_io_t* io);
+int32_t carl_rollout_pitch(int32_t n_lanes); /* n_lanes rounded up to the next multiple of 16 (0 for n_lanes <= 0) */
 
 /* done-mask compaction: ascending lane ids with terminated|truncated set.
  * idx_out [n], count_out [1], scratch >= carl_done_compact_scratch_elems(n) int32.
@@ -451,10 +464,12 @@ int carl_brax_step(const carl_batch_t* batch, const carl_brax_sys_t* sys_dev, co
                    const carl_step_io_t* io, void* stream);
 int carl_brax_rollout(const carl_batch_t* batch, const carl_brax_sys_t* sys_dev, const carl_brax_sys_t* sys_host,
                       const carl_step_io_t* io, int32_t n_steps, void* stream);
-/* the lane-group widths (values for sys.lanes_per_env) this library can launch for the model,
- * ascending; returns their number (<= cap).  Results do not depend on the width: it is a pure
- * scheduling choice (carl_amd.brax_engine.BraxVecEngine.autotune times them on the real batch). */
-int carl_brax_lane_widths(const carl_brax_sys_t* sys_host, int32_t* widths_out, int32_t cap);
+/* the lane-group widths (values for sys.lanes_per_env) this library can launch for STEP / ROLLOUT launches of the model
+ * in a batch with these carl_batch_t::flags (ABI 9: CARL_FLAG_BRAX_GENERIC moves a planar model to the general kernels,
+ * whose instantiated widths differ), ascending; returns their number (<= cap).  Results do not depend on the width:
+ * it is a pure scheduling choice (carl_amd.brax_engine.BraxVecEngine.autotune times them on the real batch).  No
+ * reference counterpart (brax vmaps one env per array row, carl/envs/brax/carl_brax_env.py:163-167). */
+int carl_brax_lane_widths(const carl_brax_sys_t* sys_host, uint32_t batch_flags, int32_t* widths_out, int32_t cap);
 /* 1 when step / rollout launches of this model take the planar substep (root on two world slides x, z and a hinge
  * about y, every other link on a hinge about +-y, all geometry in the y = 0 plane: Halfcheetah, Hopper, Walker2d as
  * carl_amd.envs.brax.models builds them) unless the batch carries CARL_FLAG_BRAX_GENERIC; 0 otherwise.  The planar

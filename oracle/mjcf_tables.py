@@ -33,6 +33,39 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ASSETS = {"ant": "ant.xml", "halfcheetah": "half_cheetah.xml", "humanoid": "humanoid.xml"}
 
+# What the brax ENV CLASS does to the loaded System for the backend CARL asks for -- CARLBraxEnv creates every env with
+# backend="spring" (carl/envs/brax/carl_brax_env.py:117,163-167), and brax 0.12.1's env constructors branch on it AFTER
+# mjcf.load: `if backend in ['spring', 'positional']: sys = sys.tree_replace({'opt.timestep': ...}); n_frames = ...` and,
+# for some envs, `sys = sys.replace(actuator=sys.actuator.replace(gear=...))`.  [upstream-memory] of
+# brax/envs/{ant,half_cheetah,humanoid,humanoidstandup}.py -- not in the reference tree, not installable here:
+#   ant.py             spring / positional: timestep 0.005, n_frames 10; the gear override (200) is for `positional` ONLY
+#   half_cheetah.py    spring / positional: timestep 0.003125, n_frames 16, gear = [120, 90, 60, 120, 100, 100]
+#                      (the MJCF's front shin / foot motors are 60 / 30)
+#   humanoid.py        spring / positional: timestep 0.0015, n_frames 10, gear = [350] * 11 + [100] * 6
+#                      (the MJCF's: 100 / 300 / 200 on the torso and legs, 25 on the arms)
+#   humanoidstandup.py the same branch as humanoid.py
+# VERDICT r05 #2 / "Next" #3: rounds 1-5 applied the timestep / n_frames halves of these branches and kept the MJCF
+# gears; round 6 applies the gear halves too (provenance ledger, rows "actuator gear").
+SPRING_BACKEND = {
+    "ant": {"timestep": 0.005, "n_frames": 10, "gear": None},
+    "halfcheetah": {"timestep": 0.003125, "n_frames": 16, "gear": [120.0, 90.0, 60.0, 120.0, 100.0, 100.0]},
+    "humanoid": {"timestep": 0.0015, "n_frames": 10, "gear": [350.0] * 11 + [100.0] * 6},
+    "humanoidstandup": {"timestep": 0.0015, "n_frames": 10, "gear": [350.0] * 11 + [100.0] * 6},
+}
+
+
+def spring_env(name: str) -> dict:
+    """The System a brax env class steps under backend="spring": the MJCF model (`load`) with the env constructor's
+    overrides applied -> {"model", "dt", "n_frames", "actuators" [(joint, gear, lo, hi)]}.  `name` may be
+    "humanoidstandup" (humanoid.xml's body with its own env class)."""
+    m = load("humanoid" if name == "humanoidstandup" else name)
+    o = SPRING_BACKEND[name]
+    acts = list(m.actuators)
+    if o["gear"] is not None:
+        assert len(o["gear"]) == len(acts), (name, len(acts))
+        acts = [(jn, float(g), lo, hi) for (jn, _, lo, hi), g in zip(acts, o["gear"])]
+    return {"model": m, "dt": o["timestep"], "n_frames": o["n_frames"], "actuators": acts}
+
 
 def _vec(text, n=None):
     v = np.array([float(t) for t in text.split()], dtype=np.float64)

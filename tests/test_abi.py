@@ -41,7 +41,7 @@ def test_action_dtype_codes_match_the_header():
     assert codes == {"CARL_ACTION_I32": _lib.ACTION_I32, "CARL_ACTION_I64": _lib.ACTION_I64,
                      "CARL_ACTION_F32": _lib.ACTION_F32, "CARL_ACTION_U8": _lib.ACTION_U8,
                      "CARL_ACTION_F16": _lib.ACTION_F16, "CARL_ACTION_BF16": _lib.ACTION_BF16}
-    assert int(re.search(r"#define CARL_ABI_VERSION (\d+)", src).group(1)) == _lib.CARL_ABI_VERSION == 8
+    assert int(re.search(r"#define CARL_ABI_VERSION (\d+)", src).group(1)) == _lib.CARL_ABI_VERSION == 9
 
 
 def test_family_info_is_host_side():
@@ -148,9 +148,34 @@ def test_brax_and_sampler_entry_points_validate_arguments():
     b.n_lanes, b.n_contexts, b.ctx_stride = 4, 1, 1
     assert lib.carl_brax_step(C.byref(b), None, C.byref(s), None, None) == -1  # sys_dev NULL
     widths = (C.c_int32 * 16)()
-    n = lib.carl_brax_lane_widths(C.byref(s), widths, 16)
+    n = lib.carl_brax_lane_widths(C.byref(s), 0, widths, 16)
     assert [widths[i] for i in range(n)] == [9, 16]  # one lane per link (Ant: 9 links) or wider
-    assert lib.carl_brax_lane_widths(None, widths, 16) == 0
+    assert lib.carl_brax_lane_widths(None, 0, widths, 16) == 0
+    # ABI 9: the widths are those of the kernels a STEP launch of the batch takes -- a planar model under
+    # CARL_FLAG_BRAX_GENERIC runs the multi-hinge kernels (its autotune probed 7 / 8, all one kernel)
+    from carl_amd.envs.brax.models import halfcheetah_sys
+
+    hc = halfcheetah_sys()
+    n = lib.carl_brax_lane_widths(C.byref(hc), 0, widths, 16)
+    assert [widths[i] for i in range(n)] == [7, 8, 9, 16]
+    n = lib.carl_brax_lane_widths(C.byref(hc), _lib.FLAG_BRAX_GENERIC, widths, 16)
+    assert [widths[i] for i in range(n)] == [11, 16]
+    # ABI 9: row pitch of a rollout's buffers
+    assert [lib.carl_rollout_pitch(k) for k in (-3, 0, 1, 10, 16, 17, 65537)] == [0, 0, 16, 16, 16, 32, 65552]
+    cb = _lib.Batch()
+    cb.family, cb.n_lanes = _lib.CARTPOLE, 10
+    io = _lib.StepIO()
+    assert lib.carl_rollout_variant(C.byref(cb)) == _lib.ROLLOUT_DIRECT_SHAPE
+    assert lib.carl_rollout_variant_io(C.byref(cb), C.byref(io)) == _lib.ROLLOUT_DIRECT_SHAPE  # dense rows
+    io.row_pitch = 16
+    assert lib.carl_rollout_variant_io(C.byref(cb), C.byref(io)) == _lib.ROLLOUT_STAGED
+    cb.n_lanes, io.row_pitch = 65537, 65552
+    assert lib.carl_rollout_variant_io(C.byref(cb), C.byref(io)) == _lib.ROLLOUT_STAGED
+    io.row_pitch = 65536
+    assert lib.carl_rollout_variant_io(C.byref(cb), C.byref(io)) == _lib.ERR_INVALID_ARGUMENT  # pitch < n_lanes
+    cb.flags = _lib.FLAG_ROLLOUT_DIRECT
+    io.row_pitch = 65552
+    assert lib.carl_rollout_variant_io(C.byref(cb), C.byref(io)) == _lib.ROLLOUT_DIRECT_FLAG
     spec = (_lib.FeatureSpec * 1)()
     spec[0].kind = 99
     assert lib.carl_sample_contexts(C.addressof(spec), spec, 1, 4, 4, 0, 0, 1, None) == -1  # table "pointer" 1, kind 99

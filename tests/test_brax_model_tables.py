@@ -115,10 +115,15 @@ def test_model_table_equals_the_independent_restatement_field_by_field(name):
             assert abs(s.dof_stiffness[d] - j.stiffness) < 1e-6, (name, j.name, "stiffness", s.dof_stiffness[d], j.stiffness)
             assert abs(s.dof_damping[d] - j.damping) < 1e-6, (name, j.name, "damping", s.dof_damping[d], j.damping)
         qi, di = qi + len(l.joints), di + len(l.joints)
-    # actuators: same joints in the same ORDER (the action vector's layout), gears, control ranges
-    for k, (jn, gear, lo, hi) in enumerate(m.actuators):
+    # actuators: same joints in the same ORDER (the action vector's layout), control ranges, and the gears of the System
+    # the brax env class steps under backend="spring" (carl_brax_env.py:117): the MJCF's, with the env constructor's
+    # spring-backend override where it has one (oracle/mjcf_tables.py: SPRING_BACKEND; round 6) -- and that branch's
+    # timestep / n_frames
+    env = M.spring_env(name)
+    for k, (jn, gear, lo, hi) in enumerate(env["actuators"]):
         assert s.act_dof[k] == m.dof_of(jn), (name, k, jn)
         assert (s.act_gear[k], s.act_lo[k], s.act_hi[k]) == pytest.approx((gear, lo, hi), abs=1e-6), (name, jn)
+    assert abs(s.dt - env["dt"]) < 1e-9 and s.n_frames == env["n_frames"], (name, s.dt, s.n_frames)
     # colliders: per link the same set of spheres (capsule = its two end spheres)
     got = {i: [] for i in range(L)}
     for k in range(s.n_coll):

@@ -377,7 +377,7 @@ def test_goal_reward_epilogue_matches_oracle_and_reference_test(device):
         sig = eng.branch_sig.cpu().numpy().view(np.uint32)
         same = sig[:, 0] == ora.branch_sig[:, 0]
         agree = ok == ora.success
-        assert agree.mean() > 0.995  # success flips only within rounding of the radius
+        assert agree.mean() >= 0.999  # success flips only within rounding of the radius (1e-3 everywhere)
         n_success += int(ok.sum())
         done = ((term | trunc) != 0).cpu().numpy()
         live = same & agree & ~done  # (a done env's position is back at the origin on both sides)
@@ -677,10 +677,31 @@ def test_lane_width_is_a_pure_scheduling_choice_and_autotune_restores_state(devi
     assert eng.lane_widths() == [9, 16]  # one lane per link or wider
     eng.reset()
     eng.step(torch.zeros((512, 8), device=device))
-    before = {k: getattr(eng, k).clone() for k in ("state", "elapsed", "episode", "n_calls", "ep_return", "obs")}
+    before = {k: getattr(eng, k).clone() for k in ("state", "elapsed", "episode", "n_calls", "ep_return", "obs", "reward",
+                                                   "terminated", "truncated", "done")}
+    rng_state = torch.cuda.get_rng_state(torch.device(device))
     best = eng.autotune()
     assert best in eng.lane_widths() and eng.sys.lanes_per_env == best and set(eng.autotune_ms) == set(eng.lane_widths())
     assert all(torch.equal(v, getattr(eng, k)) for k, v in before.items())
+    assert torch.equal(rng_state, torch.cuda.get_rng_state(torch.device(device)))  # the caller's RNG stream is untouched
+    assert set(eng._tuned) == {False, True}  # both launch-length classes probed HERE: step / rollout never stop to probe
+    # a probe launch that raises leaves the engine as it was: width, state, and the probing switch
+    width = int(eng.sys.lanes_per_env)
+    real, calls = eng.rollout, [0]
+
+    def failing_rollout(*a, **k):
+        calls[0] += 1
+        if calls[0] == 3:  # (the second width's warm-up launch)
+            raise RuntimeError("probe launch failed")
+        return real(*a, **k)
+
+    eng.rollout = failing_rollout
+    with pytest.raises(RuntimeError, match="probe launch failed"):
+        eng._probe_widths(2, 1)
+    del eng.rollout
+    assert int(eng.sys.lanes_per_env) == width and not eng._tuning
+    assert all(torch.equal(v, getattr(eng, k)) for k, v in before.items())
+    eng.step(torch.zeros((512, 8), device=device))  # and keeps working
 
 
 def test_reacher_env_api_and_goal_stays_put(device):
@@ -922,7 +943,7 @@ def test_config4_and_config5_full_size_step_parity(device):
         agree = (sig[:, 0] == ora.branch_sig[:, 0]) & ~flag
         e = np.maximum(rel_err(obs.cpu().numpy()[sel], out.obs).max(1), rel_err(rew.cpu().numpy()[sel], out.reward))
         print(f"{label}: {len(sel)} lanes, agreeing max {e[agree].max():.2e}, excluded {1 - agree.mean():.5f}")
-        assert agree.mean() >= 0.995 and e[agree].max() <= 1e-5, (label, e[agree].max(), agree.mean())
+        assert agree.mean() >= 0.999 and e[agree].max() <= 1e-5, (label, e[agree].max(), agree.mean())
         assert bool(torch.isfinite(obs).all())
 
 
@@ -948,7 +969,7 @@ def test_committed_brax_transitions(fam, device, golden_dir):
     obs, rew, term, trunc = eng.step(torch.as_tensor(g["action"]))
     sig = eng.branch_sig.cpu().numpy().view(np.uint32)
     same = sig[:, 0] == g["branch_sig"][:, 0]
-    assert same.mean() >= 0.95
+    assert same.mean() >= 0.999, same.mean()  # at most 1e-3 of the rows excluded
     np.testing.assert_array_equal(term.cpu().numpy()[same], g["terminated"][same])
     e = np.maximum(rel_err(obs.cpu().numpy(), g["obs"]).max(1), rel_err(rew.cpu().numpy(), g["reward"]))
     assert e[same].max() <= 1e-5, e[same].max()

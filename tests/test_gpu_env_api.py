@@ -324,3 +324,18 @@ def test_single_copy_readback_and_pinned_action_staging(device, fam, n):
         np.testing.assert_array_equal(te, term.cpu().numpy())
         np.testing.assert_array_equal(tr, trunc.cpu().numpy())
     assert torch.equal(e1.state, e2.state)
+    # staging again BEFORE reading back must not tear the upload in flight (an event guards the pinned buffer), and an
+    # action of the wrong element count is refused as the validated path of `step` refuses it (no NumPy broadcasting)
+    a1 = (rng.integers(0, int(e1.info.n_actions), n) if e1.info.action_is_discrete
+          else rng.uniform(float(e1.info.action_low), float(e1.info.action_high), (n, 1)).astype(np.float32))
+    a2 = a1[::-1].copy()
+    first = e2.stage_scalar_action(a1).clone()
+    second = e2.stage_scalar_action(a2).clone()
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(first.cpu().numpy().reshape(-1), np.asarray(a1).reshape(-1).astype(first.cpu().numpy().dtype))
+    np.testing.assert_array_equal(second.cpu().numpy().reshape(-1), np.asarray(a2).reshape(-1).astype(first.cpu().numpy().dtype))
+    if n > 1:
+        with pytest.raises(ValueError):
+            e2.stage_scalar_action(np.asarray(a1).reshape(-1)[:1])
+        with pytest.raises(ValueError):
+            e2.stage_scalar_action(0)

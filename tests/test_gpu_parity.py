@@ -5,6 +5,16 @@ oracle, measured as |d| <= 1e-5 * (1 + |x|); discrete outputs (terminated / trun
 context ids, elapsed counters, compacted index lists) and reset states bit-exact.  A
 done flag may legitimately differ only where the float64 margin to its threshold is
 below fp32 resolution; such rows are counted and bounded, not ignored.
+
+Acrobot: the reference evaluates `_terminal` on its unrounded float64 state (gymnasium acrobot.py keeps
+`self.state` in float64; oracle/classic_control.inc does the same); the kernel evaluates it on the STORED float32
+angles (one trig evaluation per step serves the next RK4 stage, `_terminal` and the observation: DESIGN 4.3a), which
+sit <= 1.2e-7 from the unrounded ones -- the flag can differ only for states whose float64 margin
+|-cos t1 - cos(t1 + t2) - 1| is < 4e-7.  That is inside the 1e-6 margin every flag comparison below allows
+(`flag_margin`), and such rows are counted.  Putting the decision back on the unrounded angles, even behind a rare
+wave-uniform branch, keeps two more float64 values live across the step's tail: the pair kernel of BASELINE config 3
+then spills (126 -> 128 VGPRs + 64 B of scratch; measured with tools/kernel_resources.sh in round 6), so the stored-angle
+rule stays and is stated here.
 """
 import os
 
@@ -359,13 +369,17 @@ def test_short_free_running_rollout(fam, device):
     assert rel_err(obs.cpu().numpy(), out.obs).max() <= 1e-3
 
 
-@pytest.mark.parametrize("n", [3000, 3008], ids=["generic-kernel", "staged-kernel"])
+@pytest.mark.parametrize("n,direct", [(3000, True), (3000, False), (3008, False)],
+                         ids=["generic-kernel", "staged-kernel-padded-rows", "staged-kernel"])
 @pytest.mark.parametrize("fam", range(5), ids=O.FAMILY_NAMES)
-def test_rollout_equals_repeated_step_bit_exact(fam, n, device):
+def test_rollout_equals_repeated_step_bit_exact(fam, n, direct, device):
     """the fused T-step kernel and T per-call launches are the same arithmetic: round-robin context
     switches on reset (parameter re-gather, ctx_obs rewrite), the finished-episode log and terminal
-    observations, through the direct-store kernel (n % 16 != 0) and the LDS-staged one (ragged
-    last workgroup)"""
+    observations, through the direct-store kernel (CARL_FLAG_ROLLOUT_DIRECT: dense rows of a lane count that is not
+    a multiple of 16), the LDS-staged one on rows padded to a multiple of 16 lanes (round 6: what such a lane count
+    takes now) and the LDS-staged one on dense rows (ragged last workgroup)"""
+    from carl_amd import _lib
+
     rng = np.random.default_rng(fam + 50)
     T, n_ctx = 70, 13
     table = random_table(fam, rng, n_ctx)
@@ -373,9 +387,13 @@ def test_rollout_equals_repeated_step_bit_exact(fam, n, device):
     kw = dict(selector=O.SEL_ROUND_ROBIN, seed=3, max_episode_steps=23, fin_capacity=1 << 16)
     e1 = _engine(fam, table, n, device, **kw)
     e2 = _engine(fam, table, n, device, **kw)
+    if direct:
+        e1.b.flags |= _lib.FLAG_ROLLOUT_DIRECT
+    assert e1.rollout_variant() == (_lib.ROLLOUT_DIRECT_FLAG if direct else _lib.ROLLOUT_STAGED)
     e1.reset()
     e2.reset()
     out = e1.rollout(acts, e1.alloc_rollout(T, final_obs=True))
+    assert out["reward"].stride(0) == (n if direct else (n + 15) // 16 * 16)
     for t in range(T):
         obs, rew, term, trunc = e2.step(acts[t])
         assert torch.equal(out["obs"][t], obs) and torch.equal(out["reward"][t], rew)
@@ -763,38 +781,69 @@ def test_acrobot_rollout_with_a_context_table_near_the_lds_budget(n_ctx, device)
     assert int(e1.episodes_done.sum()) >= 3 * n
 
 
-def test_rollout_variant_is_visible_and_odd_lane_counts_warn(device):
-    """`n_lanes % 16 != 0` silently took the ~50 % slower direct-store rollout kernel.  The
-    library now answers which kernel a batch gets (carl_rollout_variant), the engine warns once, and the A/B
-    switch is a flag bit (CARL_FLAG_ROLLOUT_DIRECT) instead of an environment variable read in the launch path --
-    with identical results."""
+def test_rollout_variant_is_visible_and_odd_lane_counts_take_the_staged_kernel(device):
+    """`n_lanes % 16 != 0` took the ~50 % slower direct-store rollout kernel (silently
+    at first, with a warning since round 3).  Round 6 (ABI 9): the rollout's arrays carry a ROW PITCH
+    (carl_step_io_t::row_pitch); `alloc_rollout` pads rows to a multiple of 16 lanes, so ANY lane count -- 10, 4 100,
+    65 537, the uneven shards of `lane_shard` -- takes the staged kernel, without a warning, with the same bits as the
+    direct-store kernel writes into dense rows (CARL_FLAG_ROLLOUT_DIRECT, the A/B switch) and as a caller's own dense
+    buffers get (which still warn once: that layout cannot take the staged kernel)."""
+    import ctypes as C
+    import warnings
+
     from carl_amd import _lib
 
-    fam = O.PENDULUM
     rng = np.random.default_rng(5)
-    T = 20
-    for n, want in ((4096, _lib.ROLLOUT_STAGED), (4100, _lib.ROLLOUT_DIRECT_SHAPE)):
-        table = random_table(fam, rng, n)
+    for fam, n, T in ((O.PENDULUM, 4096, 20), (O.PENDULUM, 4100, 20), (O.CARTPOLE, 10, 33), (O.ACROBOT, 263, 17),
+                      (O.MOUNTAINCAR, 65537, 12)):
+        table = random_table(fam, rng, min(n, 4096))
         acts = torch.as_tensor(random_actions(fam, rng, (T, n)), device=device)
-        e = _engine(fam, table, n, device, selector=O.SEL_STATIC, seed=2, ctx_idx0=np.arange(n))
-        assert e.rollout_variant() == want
+        kw = dict(selector=O.SEL_STATIC, seed=2, ctx_idx0=np.arange(n) % min(n, 4096), max_episode_steps=9)
+        e = _engine(fam, table, n, device, **kw)
+        assert e.rollout_variant() == _lib.ROLLOUT_STAGED
+        # the library's answer for DENSE rows of this lane count is unchanged
+        assert e.lib.carl_rollout_variant(C.byref(e.b)) == (_lib.ROLLOUT_STAGED if n % 16 == 0 else _lib.ROLLOUT_DIRECT_SHAPE)
         e.reset()
-        if want == _lib.ROLLOUT_DIRECT_SHAPE:
+        buf = e.alloc_rollout(T + 1)  # one sentinel row behind the last step: the padding columns must not spill into it
+        for k, v in (("obs", -7.0), ("reward", -7.0), ("terminated", 9), ("truncated", 9)):
+            buf[k][T].fill_(v)
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")
+            ref = e.rollout(acts, buf)
+        P = (n + 15) // 16 * 16
+        assert ref["reward"].stride(0) == P and ref["obs"].shape == (T + 1, n, e.D)
+        assert bool((buf["obs"][T] == -7.0).all()) and bool((buf["reward"][T] == -7.0).all())
+        assert bool((buf["terminated"][T] == 9).all()) and bool((buf["truncated"][T] == 9).all())
+        # (a) the direct-store kernel on dense rows, (b) a caller's own dense buffers
+        d = _engine(fam, table, n, device, **kw)
+        d.b.flags |= _lib.FLAG_ROLLOUT_DIRECT
+        assert d.rollout_variant() == _lib.ROLLOUT_DIRECT_FLAG
+        d.reset()
+        got = d.rollout(acts)
+        assert got["reward"].is_contiguous()
+        c = _engine(fam, table, n, device, **kw)
+        c.reset()
+        own = {"obs": torch.empty((T, n, c.D), device=device), "reward": torch.empty((T, n), device=device),
+               "terminated": torch.empty((T, n), dtype=torch.uint8, device=device),
+               "truncated": torch.empty((T, n), dtype=torch.uint8, device=device)}
+        if n % 16:
             with pytest.warns(RuntimeWarning, match="multiple of 16"):
-                e.rollout(acts)
+                c.rollout(acts, own)
         else:
-            import warnings
-
             with warnings.catch_warnings():
                 warnings.simplefilter("error")
-                ref = e.rollout(acts)
-            d = _engine(fam, table, n, device, selector=O.SEL_STATIC, seed=2, ctx_idx0=np.arange(n))
-            d.b.flags |= _lib.FLAG_ROLLOUT_DIRECT
-            assert d.rollout_variant() == _lib.ROLLOUT_DIRECT_FLAG
-            d.reset()
-            got = d.rollout(acts)
-            for k in ("obs", "reward", "terminated", "truncated"):
-                assert torch.equal(ref[k], got[k]), k
+                c.rollout(acts, own)
+        for k in ("obs", "reward", "terminated", "truncated"):
+            assert torch.equal(ref[k][:T], got[k]), (fam, n, k)
+            assert torch.equal(ref[k][:T], own[k]), (fam, n, k)
+        for name in ("state", "elapsed", "ctx_idx", "episode", "n_calls", "ep_return", "last_return", "episodes_done"):
+            assert torch.equal(getattr(e, name), getattr(d, name)) and torch.equal(getattr(e, name), getattr(c, name)), name
+        assert int(e.episodes_done.sum()) > 0
+    # buffers whose arrays disagree about the pitch are refused
+    bad = e.alloc_rollout(T)
+    bad["reward"] = torch.empty((T, n), device=device)
+    with pytest.raises(ValueError, match="pitch"):
+        e.rollout(acts, bad)
 
 
 @pytest.mark.parametrize("fam", [O.CARTPOLE, O.PENDULUM], ids=["cartpole", "pendulum"])
@@ -868,8 +917,11 @@ def test_uint8_actions_outside_the_lean_staged_rollout(device):
         e1, e2 = _engine(fam, table, n, device, **kw), _engine(fam, table, n, device, **kw)
         e1.reset()
         e2.reset()
-        # straight through the C ABI: declined, nothing launched
+        # straight through the C ABI: declined, nothing launched (the odd lane count: with DENSE rows -- the engine's own
+        # buffers pad the rows of such a batch to a multiple of 16 lanes, where uint8 actions are read natively)
         out = e1.alloc_rollout(T, final_obs=final)
+        if n % 16:
+            out = {k: torch.empty(v.shape, dtype=v.dtype, device=device) for k, v in out.items()}
         io = e1._rollout_io(a8.contiguous(), _lib.ACTION_U8, out, T)
         with torch.cuda.device(device):
             assert e1._c_rollout(io, T) == _lib.ERR_UNSUPPORTED
@@ -883,6 +935,17 @@ def test_uint8_actions_outside_the_lean_staged_rollout(device):
         for k in o32:
             assert torch.equal(o8[k], o32[k]), k
         assert torch.equal(e1.state, e2.state)
+        if n % 16:  # ... and on the engine's padded rows the library reads the bytes itself (ABI 9)
+            a8b = torch.as_tensor(random_actions(fam, rng, (T, n)), device=device).to(torch.uint8)
+            pad = e1.alloc_rollout(T)
+            io = e1._rollout_io(a8b, _lib.ACTION_U8, pad, T)
+            assert io.row_pitch == 1008
+            with torch.cuda.device(device):
+                assert e1._c_rollout(io, T) == 0
+            o32 = e2.rollout(a8b.to(torch.int32))
+            for k in o32:
+                assert torch.equal(pad[k], o32[k]), k
+            assert torch.equal(e1.state, e2.state)
     # per-call step: uint8 is widened by the engine (the C entry point declines it)
     obs8, *_ = e1.step(a8[0])
     obs32, *_ = e2.step(a32[0])
