@@ -422,7 +422,13 @@ def humanoid_sys(feature_names: list[str] | None = None, reference_compat: bool 
         _set3(s.com, i, sum(v * c for v, c in zip(vols, ctrs)) / sum(vols))
         s.mass[i] = 1.0
         _set3(s.inv_inertia, i, (1.0, 1.0, 1.0))
-        s.k_pos[i], s.k_vel[i], s.k_limit[i], s.k_ang_damp[i] = 20000.0, 100.0, 1000.0, 20.0
+        # spring-constraint constants: rounds 1-5 used this build's own (20 000 / 100 / 1 000 / 20).  Under the spring
+        # branch's actuator gears (below) HumanoidStandup -- which never terminates -- then blew up in 37 of 16 384 envs within
+        # 1 000 steps of full-range random actions (tools/diag_standup_sweep.py, profiles/r06_standup_gear_stability.txt);
+        # the set remembered from humanoid.xml's `<custom>` numerics (constraint_stiffness 27 000, constraint_vel_damping
+        # 80, constraint_limit_stiffness 2 500, constraint_ang_damping 30) [upstream-memory, medium confidence] is stable
+        # with them (0 of 16 384) -- gears and constants are tuned together upstream.  Adopted in round 6.
+        s.k_pos[i], s.k_vel[i], s.k_limit[i], s.k_ang_damp[i] = 27000.0, 80.0, 2500.0, 30.0
     assert qi == s.n_q and di == s.n_dof
     # gears: humanoid.py / humanoidstandup.py replace the MJCF's (100 / 300 / 200 on torso and legs, 25 on the arms) with
     # [350] * 11 + [100] * 6 in the same `backend in ['spring', 'positional']` branch that sets timestep 0.0015 and

@@ -102,7 +102,8 @@ enum {
  * produced (gymnasium Discrete: np.int64; carl/envs/carl_env.py:321 passes it through): I32 / I64 everywhere.
  * U8 (ABI 7) is a ROLLOUT-ONLY input format for discrete families: one byte per lane-step -- the action stream is the
  * fused rollout's only per-step read, and at 4 bytes it costs a fifth of a CartPole launch.  Accepted by carl_rollout
- * in its lean staged configuration (n_lanes % 16 == 0, STATIC / HOST selector, no finished-episode log, no final_obs;
+ * in its lean staged configuration (row pitch % 16 == 0 -- dense rows: n_lanes % 16 == 0 --, STATIC / HOST selector, no
+ * finished-episode log, no final_obs;
  * action pointer 4-byte aligned); anything else returns CARL_ERR_UNSUPPORTED and the caller widens the actions.
  * Same values in, same transitions out: bit-identical to the I32 launch (tests/test_gpu_parity.py). */
 enum { CARL_ACTION_I32 = 0, CARL_ACTION_I64 = 1, CARL_ACTION_F32 = 2, CARL_ACTION_U8 = 3,
@@ -249,7 +250,7 @@ int carl_rollout(const carl_batch_t* batch, const carl_step_io_t* io, int32_t n_
  * batch ("CARLAcrobot + CARLMountainCar", carl/envs/gymnasium/classic_control/carl_acrobot.py:11-115 +
  * carl_mountaincar.py:11-85 -- in the reference two unrelated env objects, carl/envs/carl_env.py:245-342 holds no
  * cross-env state).  One part must be the float64 Acrobot, the other any other family; both in the lean staged
- * configuration (n_lanes % 16 == 0, static / host selector, no finished-episode log, io.final_obs NULL, int32 /
+ * configuration (row pitch % 16 == 0, static / host selector, no finished-episode log, io.final_obs NULL, int32 /
  * float32 actions).  Each family's workgroups run the same staged rollout as carl_rollout at 4-step chunks, so one
  * workgroup of each fits a compute unit and the second family's wavefronts issue in the gaps of Acrobot's RK4:
  * results are bit-identical to two carl_rollout calls, the launch takes ~max instead of the sum.
@@ -259,9 +260,10 @@ int carl_rollout_pair(const carl_batch_t* batch_a, const carl_step_io_t* io_a, c
                       const carl_step_io_t* io_b, int32_t n_steps, void* stream);
 
 /* Which kernel carl_rollout launches for this batch (classic-control families).  The staged kernel (transition
- * records assembled in LDS, written with 16-byte stores by dedicated waves) needs n_lanes % 16 == 0; any other
- * lane count silently took the ~50 % slower direct-store kernel in ABI <= 4 -- now a caller can ask (and the
- * Python engine warns once). */
+ * records assembled in LDS, written with 16-byte stores by dedicated waves) needs rows of a pitch that is a multiple of
+ * 16 lanes; this entry point answers for DENSE rows (io.row_pitch = 0: n_lanes % 16 == 0).  Any other lane count
+ * silently took the ~50 % slower direct-store kernel in ABI <= 4; a caller could ask since ABI 5; since ABI 9 it lays
+ * its rows out at carl_rollout_pitch(n_lanes) and gets the staged kernel (carl_rollout_variant_io). */
 enum { CARL_ROLLOUT_STAGED = 0, CARL_ROLLOUT_DIRECT_SHAPE = 1, CARL_ROLLOUT_DIRECT_FLAG = 2 };
 int carl_rollout_variant(const carl_batch_t* batch); /* CARL_ERR_INVALID_ARGUMENT for a non-classic family */
 /* ... for this batch WITH these buffers (ABI 9): the staged kernel needs (io->row_pitch ? io->row_pitch : n_lanes) % 16

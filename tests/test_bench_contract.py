@@ -1,5 +1,5 @@
 """bench.py's bookkeeping that needs no GPU: the workload tables, the committed profiler records the line quotes
-(`frac_kernel`, `traffic`, `roofline_valu`) and the arithmetic of the two rooflines."""
+(`profile_reference.frac_kernel`, `traffic`, `roofline_valu`) and the arithmetic of the two rooflines."""
 import json
 import os
 import sys
@@ -114,3 +114,28 @@ def test_spawn_command_is_one_rank_per_gpu_on_loopback(monkeypatch):
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
     assert cmd[-6:] == ["--gpus", "4", "--steps", "10", "--warmup", "3"] and cmd[-7].endswith("bench.py")
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_committed_profiler_records_come_from_one_run():
+    """VERDICT r05 weak #4 / "Next" #1b: `profiles/kernel_times.json` (what the bench line embeds as `profile_reference`) had
+    been regenerated by a different script run than `traffic.json`, `brax_valu.json` and the text summary.  All four are
+    written by ONE invocation of tools/make_r04_profiles.py with ONE source label: for the BASELINE workloads the labels
+    must be identical, and the summary must carry the same label and the same kernel averages."""
+    import re
+
+    kt = json.load(open(os.path.join(ROOT, "profiles", "kernel_times.json")))
+    tr = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    bv = json.load(open(os.path.join(ROOT, "profiles", "brax_valu.json")))
+    keys = ["cartpole:65536:1000", "pendulum:65536:1000", "acrobot+mountaincar:65536:1000", "ant:32768:20",
+            "halfcheetah+humanoid:32768:20"]
+    labels = {kt[k]["source"] for k in keys} | {tr[k]["source"] for k in keys} | {bv[k]["source"] for k in keys[3:]}
+    assert len(labels) == 1, labels
+    label = labels.pop()
+    rnd = re.search(r"\br(\d\d)\b", label)
+    assert rnd, label  # the label names its round (tools/r04_evidence.sh <tag>)
+    summary = open(os.path.join(ROOT, "profiles", f"r{rnd.group(1)}_rocprofv3_summary.txt")).read()
+    assert label in summary.splitlines()[0]
+    for k in keys:  # the summary's averages are the JSON's
+        block = summary.split(f"== {k}\n")[1].split("\n== ")[0]
+        avgs = [float(x) for x in re.findall(r"avg ([0-9.]+) us", block)]
+        assert abs(sum(avgs) - kt[k]["kernel_avg_us"]) < 0.02 * len(avgs), (k, avgs, kt[k]["kernel_avg_us"])
