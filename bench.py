@@ -106,6 +106,11 @@ ALSO = {
     # with rounds 2-5), never instead of them.
     "config4_T100": (("ant",), 32768, "strong", 100),
     "config5_T100": (("halfcheetah", "humanoid"), 32768, "strong", 100),
+    # OPT-IN, labelled, never the headline and never config4 / config5 themselves (VERDICT r05 "Next" #7): the substeps'
+    # pose algebra in float32 -- brax's own precision under JAX's default -- with the deviation it costs beside the rate
+    # (CARL_FLAG_BRAX_FP32; the product path above forms pose differences in float64 to meet north_star's 1e-5)
+    "config4_fp32": (("ant",), 32768, "strong", None),
+    "config5_fp32": (("halfcheetah", "humanoid"), 32768, "strong", None),
 }
 # the 8-GPU operating point of the BASELINE configs, measured on ONE GPU (N = 1 runs only): what each GPU of a node
 # holds when BASELINE's totals are split eight ways.  name -> (families, lanes per family per GPU, full-size record)
@@ -141,7 +146,7 @@ def parse():
     p.add_argument("--rccl", action="store_true",
                    help="single GPU: build a one-rank RCCL process group and run the reporting all-gather through it")
     p.add_argument("--sustained-seconds", type=float, default=0.3)
-    p.add_argument("--also", default="cartpole_T250,cartpole_u8,pendulum,pendulum_f16,config3,config4,config5,config4_T100,config5_T100",
+    p.add_argument("--also", default="cartpole_T250,cartpole_u8,pendulum,pendulum_f16,config3,config4,config5,config4_T100,config5_T100,config4_fp32,config5_fp32",
                    help="comma list of extra workloads reported under 'also' (" + ", ".join(ALSO) + "), or 'none'")
     p.add_argument("--narrow-actions", action="store_true",
                    help="feed the MAIN workload uint8 (discrete) / float16 (Box) actions (ABI 7); profiling runs of "
@@ -180,7 +185,7 @@ def context_dists(env):
     }[env]
 
 
-def make_env(env, n, rank, world, device, lane_base=0):
+def make_env(env, n, rank, world, device, lane_base=0, brax_fp32=False):
     """One family: `n` lanes on this rank = global lanes [lane_base + rank n, lane_base + (rank+1) n) of one
     global context set (seed 0); each rank uploads only its lanes' rows."""
     from carl_amd import envs as E
@@ -195,6 +200,8 @@ def make_env(env, n, rank, world, device, lane_base=0):
     table = ContextSampler(context_dists(env), cls.get_context_space(), seed=0).sample_context_table(n * world)
     local = ContextTable(table.names, table.values_2d[rank * n:(rank + 1) * n])
     size_kw = {"batch_size": n, "autotune": False} if env in BRAX_ENVS else {"num_envs": n}
+    if env in BRAX_ENVS and brax_fp32:
+        size_kw["substep_precision"] = "float32"
     carl_env = cls(contexts=local, device=device, context_selector=StaticSelector, seed=0,
                    lane_offset=lane_base + rank * n, context_offset=lane_base + rank * n, fin_capacity=0, **size_kw)
     return carl_env, table
@@ -220,7 +227,7 @@ class Workload:
 
     pinned_lanes_per_env: dict = {}  # --lanes-per-env
 
-    def __init__(self, families, lanes_per_gpu, T, sets, rank, world, device, narrow_actions=False):
+    def __init__(self, families, lanes_per_gpu, T, sets, rank, world, device, narrow_actions=False, brax_fp32=False):
         import torch
 
         from carl_amd.mixed import MixedVecEngine
@@ -228,7 +235,7 @@ class Workload:
         self.families, self.T, self.device, self.narrow_actions = tuple(families), T, device, narrow_actions
         self.envs, self.tables = [], []
         for k, f in enumerate(self.families):
-            e, t = make_env(f, lanes_per_gpu, rank, world, device, lane_base=k * lanes_per_gpu * world)
+            e, t = make_env(f, lanes_per_gpu, rank, world, device, lane_base=k * lanes_per_gpu * world, brax_fp32=brax_fp32)
             self.envs.append(e)
             self.tables.append(t)
         self.mixed = len(self.families) > 1
@@ -676,6 +683,37 @@ def cpu_baseline(args, env, table, lanes):
     }
 
 
+def brax_fp32_deviation(env, device, n=4096, warm=8):
+    """What CARL_FLAG_BRAX_FP32 costs in accuracy: ONE env step (n_frames substeps) from identical states through the float64
+    and the float32 substeps of this library, `warm` random-policy steps away from reset; |d| / (1 + |x|) over every
+    observation entry.  The float64 path is the one the parity tests hold within 1e-5 of the float64 restatement; the
+    deviation from the restatement itself (same order) is in profiles/r06_brax_fp32_deviation.txt."""
+    import torch
+
+    e64, _ = make_env(env, n, 0, 1, device)
+    e32, _ = make_env(env, n, 0, 1, device, brax_fp32=True)
+    a, b = e64.env, e32.env
+    e64.reset(seed=0)
+    e32.reset(seed=0)
+    g = torch.Generator(device=device).manual_seed(11)
+    lo, hi = float(min(a.sys.act_lo[: a.sys.n_act])), float(max(a.sys.act_hi[: a.sys.n_act]))
+    qs, worst = [], 0.0
+    for t in range(warm + 4):
+        act = torch.rand((n, a.sys.n_act), generator=g, device=device) * (hi - lo) + lo
+        b._state_storage.copy_(a._state_storage)
+        for k in ("elapsed", "ep_return", "episode", "n_calls", "ctx_idx"):
+            getattr(b, k).copy_(getattr(a, k))
+        o64 = a.step(act)[0].clone()
+        o32 = b.step(act)[0]
+        if t >= warm:
+            d = ((o32 - o64).abs() / (1 + o64.abs())).flatten()
+            qs.append(torch.quantile(d, torch.tensor([0.5, 0.99, 0.9999], device=device)).cpu())
+            worst = max(worst, float(d.max()))
+    q = torch.stack(qs).mean(0)
+    return {"p50": float(q[0]), "p99": float(q[1]), "p99.99": float(q[2]), "max": worst, "envs": n, "steps_compared": 4,
+            "what": "|obs_f32 - obs_f64| / (1 + |obs_f64|) after ONE env step from identical states (auto-reset on both)"}
+
+
 def uneven_shard_record(env, total, rank, world, device, backend, barrier, gather_over_ranks):
     """`total` lanes (not a multiple of the world size) split by carl_amd.distributed.lane_shard: one 64-step rollout
     per rank on its shard, then the episodic-return all-gather with uneven counts.  A plumbing record (which kernel each
@@ -1110,7 +1148,8 @@ def main():
         lanes = total // world if split else total
         mode = "strong" if split else "weak"
         Ta = chunk or DEFAULT_CHUNK[fams[0]]
-        w2 = Workload(fams, lanes, Ta, args.buffer_sets, rank, world, device, narrow_actions=narrow)
+        fp32 = name.endswith("_fp32")
+        w2 = Workload(fams, lanes, Ta, args.buffer_sets, rank, world, device, narrow_actions=narrow, brax_fp32=fp32)
         regs2, m2 = timed_regions(w2, K, W, args.reps, barrier, max_over_ranks)
         el2, avg2 = regs2[m2]
         r2 = launch_stats(w2, roofline_of(w2, avg2), K, barrier)
@@ -1128,6 +1167,13 @@ def main():
             "classes": [type(e).__name__ for e in w2.envs],
             "one_launch_pair": (w2.eng.pair_launches > 0) if w2.mixed else None,
         }
+        if fp32:
+            also[name]["precision"] = ("OPT-IN float32 substeps (CARL_FLAG_BRAX_FP32): brax's own arithmetic under JAX's default; NOT "
+                                       "within north_star's 1e-5 of the float64 restatement -- see `deviation`")
+            try:
+                also[name]["deviation"] = {f: brax_fp32_deviation(f, device) for f in fams}
+            except Exception as e:  # a reported side record
+                also[name]["deviation"] = {"error": repr(e)[:200]}
         if all(f in BRAX_ENVS for f in fams):
             # the Brax path moves ~1 % of what HBM could: its bound is the vector ALU (committed counters, not measured here)
             also[name]["bound"] = ("vector-ALU issue (roofline_valu: SQ_INSTS_VALU of the full-size launch x cycles per wavefront-"

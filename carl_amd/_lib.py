@@ -30,6 +30,7 @@ FLAG_ACROBOT_FP32 = 4
 FLAG_AUTORESET_FIRST_STATE = 8
 FLAG_ROLLOUT_DIRECT = 16
 FLAG_BRAX_GENERIC = 32
+FLAG_BRAX_FP32 = 64  # opt-in: float32 pose algebra in the substeps (include/carl_amd.h: CARL_FLAG_BRAX_FP32)
 ROLLOUT_STAGED, ROLLOUT_DIRECT_SHAPE, ROLLOUT_DIRECT_FLAG = range(3)
 ACTION_I32, ACTION_I64, ACTION_F32, ACTION_U8, ACTION_F16, ACTION_BF16 = range(6)
 

@@ -45,9 +45,16 @@ class BraxVecEngine(VecEngine):
         self.autoreset_mode = autoreset_mode
         branch_record = bool(kw.pop("branch_record", False))
         generic = bool(kw.pop("generic_substep", False))  # planar models: step with the general 3-D substep (A/B, tests)
+        # OPT-IN, never a default: the substeps' pose algebra in float32 -- brax's own precision under JAX's default; faster,
+        # and off the float64 restatement by more than north_star's 1e-5 (include/carl_amd.h: CARL_FLAG_BRAX_FP32)
+        pose_float32 = bool(kw.pop("pose_float32", False))
+        if pose_float32 and (sys_table.target_link > 0 or sys_table.push_link > 0):
+            raise ValueError("pose_float32 is not built for the reach / push task models")
         super().__init__(-1, ctx_table, n_lanes, device, **kw)
         if generic:
             self.b.flags |= _lib.FLAG_BRAX_GENERIC
+        if pose_float32:
+            self.b.flags |= _lib.FLAG_BRAX_FP32
         if autoreset_mode == "first_state":
             self.b.flags |= _lib.FLAG_AUTORESET_FIRST_STATE
             self.first_state = torch.zeros((self.n, self.S), dtype=torch.float32, device=self.device)

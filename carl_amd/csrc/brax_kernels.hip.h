@@ -67,6 +67,9 @@ __host__ __device__ constexpr int max_waves_per_wg(bool multi) { return multi ? 
 // reset_state / forward_kinematics as non-inlined calls the 168-register Ant build faulted on the device
 // (HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION in the spilled call path).  Multi-hinge / task models (Humanoid, ...):
 // two wavefronts (256 VGPRs; they are LDS-bound at 2.5 and lose 4-28 % at 168 / 128).  profiles/r03_brax_occupancy.txt.
+#ifndef CARL_BRAX_WAVES_PER_EU_F32  // the float32-substep kernels (CARL_FLAG_BRAX_FP32) need fewer registers
+#define CARL_BRAX_WAVES_PER_EU_F32(MULTI) ((MULTI) ? 2 : 3)
+#endif
 #ifndef CARL_BRAX_WAVES_PER_EU
 #define CARL_BRAX_WAVES_PER_EU(MULTI) ((MULTI) ? 2 : 3)
 #endif
@@ -195,11 +198,41 @@ __device__ __forceinline__ qt tof(qtd a) { return qt{(float)a.w, (float)a.x, (fl
 __device__ __forceinline__ v3d tod(v3 a) { return D(a.x, a.y, a.z); }
 __device__ __forceinline__ qtd tod(qt a) { return qtd{a.w, a.x, a.y, a.z}; }
 
-struct Body {
-  v3d p;
-  qtd r;
+// ---- the arithmetic type of the substep's POSE algebra: double (the product path: everything above) or float --
+// CARL_FLAG_BRAX_FP32, opt-in: what brax itself computes in under JAX's default precision, reported beside the product
+// figures with its measured deviation.  The float forms reuse the float32 vector types.
+template <class R> struct PoseT;
+template <> struct PoseT<double> {
+  using V3 = v3d;
+  using Q = qtd;
+  static __device__ __forceinline__ v3d mk(double x, double y, double z) { return D(x, y, z); }
+  static __device__ __forceinline__ v3d from(v3 a) { return tod(a); }
+};
+template <> struct PoseT<float> {
+  using V3 = v3;
+  using Q = qt;
+  static __device__ __forceinline__ v3 mk(float x, float y, float z) { return V(x, y, z); }
+  static __device__ __forceinline__ v3 from(v3 a) { return a; }
+};
+__device__ __forceinline__ v3 tof(v3 a) { return a; }
+__device__ __forceinline__ qt tof(qt a) { return a; }
+__device__ __forceinline__ qt qmul_vec(v3 w, qt b) {
+  return qt{-(w.x * b.x) - w.y * b.y - w.z * b.z, w.x * b.w + w.y * b.z - w.z * b.y,
+            w.y * b.w - w.x * b.z + w.z * b.x, w.z * b.w + w.x * b.y - w.y * b.x};
+}
+__device__ __forceinline__ double fma_r(double a, double b, double c) { return fma(a, b, c); }
+__device__ __forceinline__ float fma_r(float a, float b, float c) { return fmaf(a, b, c); }
+
+template <class R>
+struct BodyT {
+  typename PoseT<R>::V3 p;
+  typename PoseT<R>::Q r;
   v3 v, w;
 };
+using Body = BodyT<double>;
+__device__ __forceinline__ BodyT<float> narrow_body(const Body& b) { return BodyT<float>{tof(b.p), tof(b.r), b.v, b.w}; }
+__device__ __forceinline__ Body widen_body(const BodyT<float>& b) { return Body{tod(b.p), tod(b.r), b.v, b.w}; }
+__device__ __forceinline__ Body widen_body(const Body& b) { return b; }
 
 // atan2 in float64 to ~3e-13 (one octant reduction, one division, degree-7 polynomial in t^2 on
 // [0, tan^2(pi/8)], Chebyshev-node fit): a joint angle is multiplied by the limit / joint / locking stiffness
@@ -241,6 +274,16 @@ __device__ __forceinline__ double sqrt01_f64(double x) {
 }
 // asin(x) = atan2(x, sqrt((1 - x)(1 + x))), |x| <= 1
 __device__ __forceinline__ double asin_f64(double x) { return atan2_f64<true>(x, sqrt01_f64((1.0 - x) * (1.0 + x))); }
+// the same three by the substep's arithmetic type (float: the observation pass's float32 forms)
+template <bool XPOS = false>
+__device__ __forceinline__ double atan2_r(double y, double x) { return atan2_f64<XPOS>(y, x); }
+template <bool XPOS = false>
+__device__ __forceinline__ float atan2_r(float y, float x) { return atan2_fast(y, x); }
+__device__ __forceinline__ double asin_r(double x) { return asin_f64(x); }
+__device__ __forceinline__ float asin_r(float x) {
+  const float c2 = fmaxf((1.0f - x) * (1.0f + x), 0.0f);
+  return atan2_fast(x, c2 * __builtin_amdgcn_rsqf(fmaxf(c2, 1e-30f)));
+}
 
 // per-env context scalars: carl_brax_env.py:255-292 in its intended form
 struct LaneCtx {
@@ -269,7 +312,7 @@ constexpr int kWorldRecBytes = kBodyBytes, kCtxRecBytes = 32;
 // (LinkB::children names it), so no select is needed.  The records OVERLAY the wrench rows, which forward kinematics and
 // observe use as scratch between substep loops (the zero records are re-written before every substep loop).
 constexpr int kReactBytes = 48;
-constexpr int kLinkRecBytes = 368;  // sizeof(Group<>::LinkRec): the substep's per-link constants, static LDS
+constexpr int kLinkRecBytes = 464;  // sizeof(Group<>::LinkRec): the substep's per-link constants, static LDS
 constexpr int kStashRows = 12;     // the env's episode scalars, parked in LDS while the substeps run (run(): stash)
 struct Layout {
   int L;       // links: body records per env
@@ -558,6 +601,26 @@ struct Lds {
     *reinterpret_cast<vf4*>(q + 64) = vf4{b.v.z, b.w.x, b.w.y, b.w.z};
   }
   __device__ __forceinline__ void put(int i, const Body& b) const { put_body(rec + body_off(i), b); }
+  // The record while a CARL_FLAG_BRAX_FP32 launch runs an env step's substeps: the pose as seven floats in the first two
+  // 16-byte pieces, the velocities where the float64 layout has them (pieces 3 and 4) -- converted from / back to the float64
+  // layout at the env step's ends (run()), so everything outside the substeps reads what it always reads.
+  static __device__ __forceinline__ BodyT<float> body_of(const char* q, float) {
+    const vf4 a = *reinterpret_cast<const vf4*>(q), b2 = *reinterpret_cast<const vf4*>(q + 16);
+    const vf4 d = *reinterpret_cast<const vf4*>(q + 48), e = *reinterpret_cast<const vf4*>(q + 64);
+    BodyT<float> b;
+    b.p = V(a.x, a.y, a.z);
+    b.r = qt{a.w, b2.x, b2.y, b2.z};
+    b.v = V(d.z, d.w, e.x);
+    b.w = V(e.y, e.z, e.w);
+    return b;
+  }
+  static __device__ __forceinline__ Body body_of(const char* q, double) { return body_of(q); }
+  static __device__ __forceinline__ void put_body(char* q, const BodyT<float>& b) {
+    *reinterpret_cast<vf4*>(q) = vf4{b.p.x, b.p.y, b.p.z, b.r.w};
+    *reinterpret_cast<vf4*>(q + 16) = vf4{b.r.x, b.r.y, b.r.z, 0.0f};
+    *reinterpret_cast<vf4*>(q + 48) = vf4{0.0f, 0.0f, b.v.x, b.v.y};
+    *reinterpret_cast<vf4*>(q + 64) = vf4{b.v.z, b.w.x, b.w.y, b.w.z};
+  }
   // reaction records (kReactBytes; byte offsets from the float rows)
   __device__ __forceinline__ int react_off(int i) const { return (env * (lay.L + 1) + i) * kReactBytes; }
   // the env's context record (Layout): just below the float rows
@@ -610,15 +673,17 @@ static __device__ __forceinline__ bool is_free_root(const carl_brax_sys_t& s, in
 }
 
 // joint geometry shared by joints.resolve and inverse kinematics
-struct JointGeom {
+template <class R>
+struct JointGeomT {
   v3 rc_off, rp_off;      // anchor relative to the child's / parent's COM, world frame
-  v3d ed;                 // A_p - A_c at zero slide, float64
+  typename PoseT<R>::V3 ed;  // A_p - A_c at zero slide, float64 (R = double: the product path)
   v3 vA_c, vA_p, x_c, x_p, wrel;
   v3 axx;                 // cross(x_c, x_p) from the float64 relative rotation
   float theta, thetadot;  // single hinge
   v3 axis[3];             // 2-3 stacked hinges: current world axes ...
   float ang[3], rate[3];  // ... Euler x-y-z angles (third signed by dof_sign3) and their rates
 };
+using JointGeom = JointGeomT<double>;
 
 // Everything the substep's two phases need to know about a link, as ONE record per link in static LDS, expanded ON THE
 // DEVICE once per workgroup (expand_link below; the host-built Packed travels as a kernel argument and stays compact).
@@ -649,6 +714,7 @@ struct alignas(16) LinkRec {
   float axis_sign, ext[3];                    // 352: planar models: +-1, the joint frame's x axis is +-y of the link frame;
                                               //      ext: max over the link's spheres of |centre - COM| per link-frame axis, each
                                               //      + the largest radius (reach = the ball that holds every sphere; ext the box)
+  float acf[4], apf[4], Gf[16];               // 368: ac, ap, G rounded to float32 (CARL_FLAG_BRAX_FP32 launches read these)
 };
 static_assert(sizeof(LinkRec) == kLinkRecBytes, "LinkRec is read in 16-byte pieces at fixed offsets");
 
@@ -661,11 +727,29 @@ struct JointRec {
   uint32_t word;
   float sign3;
 };
-struct JointXr {  // the float64 block of a LinkRec in registers
-  v3d ac, ap;
-  double G[16];
+template <class R>
+struct JointXrT {  // the float64 block of a LinkRec in registers (R = float: its float32 copy)
+  typename PoseT<R>::V3 ac, ap;
+  R G[16];
   v3 axc;
 };
+using JointXr = JointXrT<double>;
+template <bool MULTI>
+static __device__ __forceinline__ JointXrT<float> load_jointx_f32(const LinkRec& X) {
+  JointXrT<float> r;
+  const vf4 a = *reinterpret_cast<const vf4*>(&X.acf[0]), b = *reinterpret_cast<const vf4*>(&X.apf[0]);
+  r.ac = V(a.x, a.y, a.z);
+  r.ap = V(b.x, b.y, b.z);
+  constexpr int kQuads = MULTI ? 4 : 3;  // (the lean kernels read G[0..9])
+#pragma unroll
+  for (int k = 0; k < kQuads; ++k) {
+    const vf4 g = *reinterpret_cast<const vf4*>(&X.Gf[4 * k]);
+    r.G[4 * k] = g.x; r.G[4 * k + 1] = g.y; r.G[4 * k + 2] = g.z; r.G[4 * k + 3] = g.w;
+  }
+  const vf4 ax = *reinterpret_cast<const vf4*>(&X.axc[0]);
+  r.axc = V(ax.x, ax.y, ax.z);
+  return r;
+}
 template <bool MULTI>
 static __device__ __forceinline__ JointXr load_jointx(const LinkRec& X) {
   typedef double vd2 __attribute__((ext_vector_type(2)));
@@ -686,10 +770,17 @@ static __device__ __forceinline__ JointXr load_jointx(const LinkRec& X) {
   return r;
 }
 template <bool MULTI>
-static __device__ __forceinline__ JointGeom joint_geometry(const JointRec& la, const JointXr& X, const Body& bc, const Body& bp) {
-  JointGeom g;
+static __device__ __forceinline__ JointXrT<float> load_jointx(const LinkRec& X, float) { return load_jointx_f32<MULTI>(X); }
+template <bool MULTI>
+static __device__ __forceinline__ JointXr load_jointx(const LinkRec& X, double) { return load_jointx<MULTI>(X); }
+template <bool MULTI, class R>
+static __device__ __forceinline__ JointGeomT<R> joint_geometry(const JointRec& la, const JointXrT<R>& X, const BodyT<R>& bc,
+                                                               const BodyT<R>& bp) {
+  using P3 = typename PoseT<R>::V3;
+  using PQ = typename PoseT<R>::Q;
+  JointGeomT<R> g;
   {
-    const v3d rc_off = qrot(bc.r, X.ac), rp_off = qrot(bp.r, X.ap);
+    const P3 rc_off = qrot(bc.r, X.ac), rp_off = qrot(bp.r, X.ap);
     g.ed = (bp.p - bc.p) + (rp_off - rc_off);  // A_p - A_c (at zero slide)
     g.rc_off = tof(rc_off);
     g.rp_off = tof(rp_off);
@@ -700,11 +791,11 @@ static __device__ __forceinline__ JointGeom joint_geometry(const JointRec& la, c
   // cross(x_c, x_p) = rp (x) cross(xaxis(rel), e_x) = rp (x) (0, a2, -a1): the SMALL components of xaxis(rel)
   // keep their relative accuracy.  The directions themselves (hinge axes, the frame that carries (0, a2, -a1) to the
   // world) are float32 work on the rounded rotations.
-  qtd rel;
+  PQ rel;
   const qt rp = qmul(tof(bp.r), la.rpl);
   {
-    const qtd q1 = qmul(qconj(bp.r), bc.r);
-    const double* G = X.G;
+    const PQ q1 = qmul(qconj(bp.r), bc.r);
+    const R* G = X.G;
     if constexpr (MULTI) {
       rel.w = G[0] * q1.w + G[10] * q1.x + G[11] * q1.y + G[12] * q1.z;
       rel.x = G[13] * q1.w + G[1] * q1.x + G[2] * q1.y + G[3] * q1.z;
@@ -716,38 +807,38 @@ static __device__ __forceinline__ JointGeom joint_geometry(const JointRec& la, c
       rel.y = G[4] * q1.x + G[5] * q1.y + G[6] * q1.z;
       rel.z = G[7] * q1.x + G[8] * q1.y + G[9] * q1.z;
     }
-    const double a1 = 2.0 * (rel.x * rel.y + rel.w * rel.z), a2 = 2.0 * (rel.x * rel.z - rel.w * rel.y);
+    const R a1 = (R)2.0 * (rel.x * rel.y + rel.w * rel.z), a2 = (R)2.0 * (rel.x * rel.z - rel.w * rel.y);
     g.x_c = qrot(tof(bc.r), X.axc);
     g.x_p = xaxis(rp);
     g.axx = qrot_yz(rp, (float)a2, (float)-a1);
   }
-  if (rel.w < 0.0) { rel.w = -rel.w; rel.x = -rel.x; }
+  if (rel.w < (R)0.0) { rel.w = -rel.w; rel.x = -rel.x; }
   const int nr = MULTI ? wa_hinges(la.word) : 1;
   // The first float64 arctangent serves both kinds of joint: the twist about the hinge (theta / 2, joint frame x) on a
   // single-hinge lane, the first Euler angle on a stacked-hinge lane.  A wavefront of a multi-hinge model holds both
   // kinds, so two separate calls under complementary lane masks cost it two evaluations (~30 float64 instructions each).
-  [[maybe_unused]] double R00 = 0.0, R01 = 0.0, R02 = 0.0;
-  double a_y = rel.x, a_x = rel.w;
+  [[maybe_unused]] R R00 = (R)0.0, R01 = (R)0.0, R02 = (R)0.0;
+  R a_y = rel.x, a_x = rel.w;
   // STRAIGHT-LINE for the multi-hinge kernels: the Euler-angle path is evaluated on every lane and the single-hinge
   // lanes just do not use it.  A wavefront of such a model always holds both kinds of joint, so `if (nr != 1)` never
   // skipped anything -- it only cost the exec-mask bookkeeping and the register copies at the joins (31 saveexec, 30
   // branches, ~90 moves in the substep loop's ISA).
   const bool eul = MULTI && nr != 1;
   if (MULTI) {  // rel = Rx(al) Ry(be) Rz(ga): decompose, ga = sign * theta_3 (nr = 0: all locked)
-    R00 = 1.0 - 2.0 * (rel.y * rel.y + rel.z * rel.z);
-    R01 = 2.0 * (rel.x * rel.y - rel.w * rel.z);
-    R02 = fmin(fmax(2.0 * (rel.x * rel.z + rel.w * rel.y), -1.0), 1.0);
-    const double m12 = -(2.0 * (rel.y * rel.z - rel.w * rel.x));  // -R12
-    const double r22 = 1.0 - 2.0 * (rel.x * rel.x + rel.y * rel.y);  // R22
+    R00 = (R)1.0 - (R)2.0 * (rel.y * rel.y + rel.z * rel.z);
+    R01 = (R)2.0 * (rel.x * rel.y - rel.w * rel.z);
+    R02 = fmin(fmax((R)2.0 * (rel.x * rel.z + rel.w * rel.y), (R)-1.0), (R)1.0);
+    const R m12 = -((R)2.0 * (rel.y * rel.z - rel.w * rel.x));  // -R12
+    const R r22 = (R)1.0 - (R)2.0 * (rel.x * rel.x + rel.y * rel.y);  // R22
     a_y = eul ? m12 : a_y;
     a_x = eul ? r22 : a_x;
   }
-  const double a1 = atan2_f64<!MULTI>(a_y, a_x);  // (a single hinge: a_x = rel.w >= 0 after the flip)
-  g.theta = (float)(2.0 * a1);  // (meaningful on single-hinge lanes)
+  const R a1 = atan2_r<!MULTI>(a_y, a_x);  // (a single hinge: a_x = rel.w >= 0 after the flip)
+  g.theta = (float)((R)2.0 * a1);  // (meaningful on single-hinge lanes)
   g.wrel = bc.w - bp.w;
   g.thetadot = dot(g.x_c, g.wrel);
   if (MULTI) {
-    const float al = (float)a1, be = (float)asin_f64(R02), ga = (float)atan2_f64(-R01, R00);
+    const float al = (float)a1, be = (float)asin_r(R02), ga = (float)atan2_r(-R01, R00);
     const float sg = (nr == 3) ? la.sign3 : 1.0f;
     g.ang[0] = al; g.ang[1] = be; g.ang[2] = sg * ga;
     g.axis[0] = g.x_p;
@@ -884,6 +975,10 @@ static __device__ __forceinline__ PairOut pair_contact(const carl_brax_sys_t& s,
 }
 
 // 1 / sqrt(x), x near 1 (a quaternion's squared norm after one integration step): v_rsq_f64 + two Newton steps
+static __device__ __forceinline__ float rsqrt_r(float x) {  // float32 pose (CARL_FLAG_BRAX_FP32): v_rsq_f32 + one Newton step
+  const float y = __builtin_amdgcn_rsqf(x);
+  return y * fmaf(-0.5f * x, y * y, 1.5f);
+}
 static __device__ __forceinline__ double rsqrt_f64(double x) {
   // seed: v_rsq_f32 of the rounded argument (1 ulp of float32, 6e-8); one Newton step squares the error: 5e-15, under the
   // 48 bits the pose record keeps.  (v_rsq_f64 + two steps: twice the dependent float64 chain at the end of the body
@@ -892,6 +987,8 @@ static __device__ __forceinline__ double rsqrt_f64(double x) {
   y = y * fma(-0.5 * x, y * y, 1.5);
   return y;
 }
+
+static __device__ __forceinline__ double rsqrt_r(double x) { return rsqrt_f64(x); }
 
 // ---- one brax.spring.pipeline.step ---------------------------------------------------------
 // Branch record: every DISCRETE decision of the substep that the float64 restatement also takes is hashed per
@@ -953,9 +1050,9 @@ struct LaneLink {
 // What a lane carries in registers through the n_frames substeps of an env step: its body (the LDS record is rewritten
 // at the end of every body phase -- the children read it in the next joint phase -- but the owner never reads it back),
 // the joint's hinge torques, the branch hashes and 1 / mass.
-template <bool MULTI>
+template <bool MULTI, class R = double>
 struct StepRegs {
-  Body b;
+  BodyT<R> b;
   float tau[MULTI ? 3 : 1];
   uint32_t sig_hit, sig_lim;
   float inv_m;
@@ -1028,6 +1125,14 @@ static __device__ __forceinline__ void expand_link(const carl_brax_sys_t& s, con
     out.slide_axis[k][0] = s.slide_axis[i][k][0]; out.slide_axis[k][1] = s.slide_axis[i][k][1];
     out.slide_axis[k][2] = s.slide_axis[i][k][2]; out.slide_axis[k][3] = 0.0f;
   }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    out.acf[k] = (float)out.ac[k];
+    out.apf[k] = (float)out.ap[k];
+  }
+  out.acf[3] = out.apf[3] = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) out.Gf[k] = (float)out.G[k];
   out.inv_i[0] = s.inv_inertia[i][0]; out.inv_i[1] = s.inv_inertia[i][1]; out.inv_i[2] = s.inv_inertia[i][2];
   out.reach = pk.b[i].reach;
   out.axis_sign = A.axis_sign;
@@ -1052,10 +1157,12 @@ static __device__ __forceinline__ v3 apply_inv_inertia(const LinkRec* lr, qt r, 
   return qrot(r, V(l.x * lr->inv_i[0], l.y * lr->inv_i[1], l.z * lr->inv_i[2]));
 }
 
-template <bool MULTI, bool TASK>
+template <bool MULTI, bool TASK, class Real = double>
 static __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const Topo& tp, const SubK& K, const LaneLink& ll,
-                                        const Lds& m, StepRegs<MULTI>& R, Prof& prof) {
-  Body& b = R.b;
+                                        const Lds& m, StepRegs<MULTI, Real>& R, Prof& prof) {
+  using P3 = typename PoseT<Real>::V3;
+  using PQ = typename PoseT<Real>::Q;
+  BodyT<Real>& b = R.b;
   const LinkRec* const lr = ll.lr;
   // phase A -- spring.joints.resolve, the lane's own joint.  The wrench on the child stays in registers (the same lane
   // applies it in the body phase); only the reaction on the parent goes through LDS.
@@ -1065,23 +1172,23 @@ static __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const T
     const int ns = MULTI ? wa_slides(wa) : 0;
     const int nr = MULTI ? wa_hinges(wa) : 1;
     // every load of the phase, in one batch
-    const JointXr X = load_jointx<MULTI>(*lr);
+    const JointXrT<Real> X = load_jointx<MULTI>(*lr, Real{});
     const vf4 q1 = ld4(&lr->axc[0]);  // .w k_pos
     const vf4 q2 = ld4(&lr->rpl[0]);
-    const Body bp = Lds::body_of(ll.par);
+    const BodyT<Real> bp = Lds::body_of(ll.par, Real{});
     const vf4 q4 = ld4(&lr->k_vel);   // k_vel k_limit k_ang_damp sign3
     const JointRec la{qt{q2.x, q2.y, q2.z, q2.w}, wa, q4.w};
-    const JointGeom g = joint_geometry<MULTI>(la, X, b, bp);
+    const JointGeomT<Real> g = joint_geometry<MULTI, Real>(la, X, b, bp);
     const float k_limit = q4.y;
     const float kp = q1.w * ll.ctx[4];
-    v3d ed = g.ed;
+    P3 ed = g.ed;
     v3 ev = g.vA_p - g.vA_c;
     uint32_t lim = 0u;
     if constexpr (MULTI) {
       for (int k = 0; k < ns; ++k) {  // prismatic dofs: free along the axis, own spring/damper/force
         const vf4 sa = ld4(&lr->slide_axis[k][0]), dk = ld4(&lr->dof[k][0]);  // dk: damping stiffness lo hi
-        const v3d axd = qrot(bp.r, tod(V(sa.x, sa.y, sa.z)));
-        const double qkd = -dot(ed, axd);
+        const P3 axd = qrot(bp.r, PoseT<Real>::from(V(sa.x, sa.y, sa.z)));
+        const Real qkd = -dot(ed, axd);
         ed = ed + axd * qkd;  // a planar root's slide coordinate is its travelled distance: float64 projection
         const v3 ax = tof(axd);
         const float qk = (float)qkd, qdk = -dot(ev, ax);
@@ -1192,15 +1299,15 @@ static __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const T
     float cnt = 0.0f;
     uint32_t hit = 0u;
     // no sphere of this link can reach the plane while its COM is higher than the farthest sphere surface
-    const double pz = b.p.z - (double)K.plane_z;  // height above the collision plane (the ground; the push task's table)
+    const Real pz = b.p.z - (Real)K.plane_z;  // height above the collision plane (the ground; the push task's table)
     const int n_sph = ((float)pz < qb.w) ? wb_spheres(wb) : 0;
     if (ballot(n_sph > 0) != 0ull) {  // (nothing at all while every link the wavefront holds is out of reach)
       // third row of the rotation matrix in float64: a sphere's height -- hence its depth, which the Baumgarte
       // term multiplies by erp / dt -- is a pose difference
-      const double R20 = 2.0 * (b.r.x * b.r.z - b.r.w * b.r.y), R21 = 2.0 * (b.r.y * b.r.z + b.r.w * b.r.x),
-                   R22 = 1.0 - 2.0 * (b.r.x * b.r.x + b.r.y * b.r.y);
+      const Real R20 = (Real)2.0 * (b.r.x * b.r.z - b.r.w * b.r.y), R21 = (Real)2.0 * (b.r.y * b.r.z + b.r.w * b.r.x),
+                 R22 = (Real)1.0 - (Real)2.0 * (b.r.x * b.r.x + b.r.y * b.r.y);
       auto depth_of = [&](const vf4 sp) {
-        return (float)((double)sp.w - (pz + (R20 * (double)sp.x + R21 * (double)sp.y + R22 * (double)sp.z)));
+        return (float)((Real)sp.w - (pz + (R20 * (Real)sp.x + R21 * (Real)sp.y + R22 * (Real)sp.z)));
       };
       // the impulse of sphere j (ordinal on its link) at penetration `depth`.  ISO (wavefront-uniform: every link of the
       // model has isotropic effective inertia c) folds R diag(c) R^T = c into the formulas:
@@ -1271,13 +1378,13 @@ static __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const T
       b.v = b.v + cdv * ic;
       b.w = b.w + cdw * ic;
     }
-    const double dtd = (double)dt;
-    b.p = D(fma((double)b.v.x, dtd, b.p.x), fma((double)b.v.y, dtd, b.p.y), fma((double)b.v.z, dtd, b.p.z));
-    const qtd dq = qmul_vec(D((double)b.w.x, (double)b.w.y, (double)b.w.z), b.r);
-    const double h = 0.5 * dtd;
-    qtd r2 = qtd{fma(h, dq.w, b.r.w), fma(h, dq.x, b.r.x), fma(h, dq.y, b.r.y), fma(h, dq.z, b.r.z)};
-    const double inv = rsqrt_f64(r2.w * r2.w + r2.x * r2.x + r2.y * r2.y + r2.z * r2.z);
-    b.r = qtd{r2.w * inv, r2.x * inv, r2.y * inv, r2.z * inv};
+    const Real dtd = (Real)dt;
+    b.p = PoseT<Real>::mk(fma_r((Real)b.v.x, dtd, b.p.x), fma_r((Real)b.v.y, dtd, b.p.y), fma_r((Real)b.v.z, dtd, b.p.z));
+    const PQ dq = qmul_vec(PoseT<Real>::mk((Real)b.w.x, (Real)b.w.y, (Real)b.w.z), b.r);
+    const Real h = (Real)0.5 * dtd;
+    PQ r2 = PQ{fma_r(h, dq.w, b.r.w), fma_r(h, dq.x, b.r.x), fma_r(h, dq.y, b.r.y), fma_r(h, dq.z, b.r.z)};
+    const Real inv = rsqrt_r(r2.w * r2.w + r2.x * r2.x + r2.y * r2.y + r2.z * r2.z);
+    b.r = PQ{r2.w * inv, r2.x * inv, r2.y * inv, r2.z * inv};
     Lds::put_body(ll.own, b);
   }
   phase_sync();
@@ -1295,48 +1402,54 @@ static __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const T
 // rel = (W, +-Y, 0, 0), the sign that of the hinge axis); a torque is its y component; the first-order quaternion update is w += -h omega y,
 // y += h omega w.  Pose differences stay float64.  Results agree with the general substep to rounding
 // (tests/test_gpu_brax.py: both paths against each other and against the float64 restatement of the 3-D pipeline).
-template <bool TASK>
+template <bool TASK, class Real = double>
 static __device__ __forceinline__ void substep_planar(const carl_brax_sys_t& s, const Topo& tp, const SubK& K, const LaneLink& ll,
-                                               const Lds& m, StepRegs<false>& R, Prof& prof) {
+                                               const Lds& m, StepRegs<false, Real>& R, Prof& prof) {
   static_assert(!TASK, "planar models are not task models");
-  Body& b = R.b;
+  BodyT<Real>& b = R.b;
   const LinkRec* const lr = ll.lr;
   // phase A -- spring.joints.resolve (every link of a planar model has a joint: the root hangs on the world)
   float fx = 0.0f, fz = 0.0f, tcy = 0.0f;  // the wrench on the child: stays in registers
   if (ll.joint) {
     const uint32_t wa = ll.wa;
     const int ns = wa_slides(wa);
-    typedef double vd2 __attribute__((ext_vector_type(2)));
-    const vd2* xp = reinterpret_cast<const vd2*>(lr);
-    const vd2 x0 = xp[0], x1 = xp[1], x2 = xp[2];  // ac.x ac.y | ac.z ap.x | ap.y ap.z
+    Real acx, acz, apx, apz;
+    if constexpr (std::is_same_v<Real, double>) {
+      typedef double vd2 __attribute__((ext_vector_type(2)));
+      const vd2* xp = reinterpret_cast<const vd2*>(lr);
+      const vd2 x0 = xp[0], x1 = xp[1], x2 = xp[2];  // ac.x ac.y | ac.z ap.x | ap.y ap.z
+      acx = x0.x; acz = x1.x; apx = x1.y; apz = x2.y;
+    } else {
+      const vf4 a4 = ld4(&lr->acf[0]), p4 = ld4(&lr->apf[0]);
+      acx = a4.x; acz = a4.z; apx = p4.x; apz = p4.z;
+    }
     const float k_pos = lr->k_pos;
-    const Body bp = Lds::body_of(ll.par);
+    const BodyT<Real> bp = Lds::body_of(ll.par, Real{});
     const vf4 q4 = ld4(&lr->k_vel);                  // k_vel k_limit k_ang_damp .
     const vf4 q5 = ld4(&lr->dof[ns > 0 ? 2 : 0][0]);  // the hinge: damping stiffness lo hi
     const float sg = lr->axis_sign;                  // +-1: the hinge axis is +-y (joint_rot maps x to +-y)
     const float k_limit = q4.y, kp = k_pos * ll.ctx[4];
     // rotation of both bodies as (cos, sin) of the full angle, float64
-    const double cc = b.r.w * b.r.w - b.r.y * b.r.y, sc = 2.0 * (b.r.w * b.r.y);
-    const double cp = bp.r.w * bp.r.w - bp.r.y * bp.r.y, sp = 2.0 * (bp.r.w * bp.r.y);
-    const double acx = x0.x, acz = x1.x, apx = x1.y, apz = x2.y;
-    const double rcx = cc * acx + sc * acz, rcz = cc * acz - sc * acx;  // anchor - COM, child side, world
-    const double rpx = cp * apx + sp * apz, rpz = cp * apz - sp * apx;  // ... parent side
-    double edx = (bp.p.x - b.p.x) + (rpx - rcx), edz = (bp.p.z - b.p.z) + (rpz - rcz);  // A_p - A_c
+    const Real cc = b.r.w * b.r.w - b.r.y * b.r.y, sc = (Real)2.0 * (b.r.w * b.r.y);
+    const Real cp = bp.r.w * bp.r.w - bp.r.y * bp.r.y, sp = (Real)2.0 * (bp.r.w * bp.r.y);
+    const Real rcx = cc * acx + sc * acz, rcz = cc * acz - sc * acx;  // anchor - COM, child side, world
+    const Real rpx = cp * apx + sp * apz, rpz = cp * apz - sp * apx;  // ... parent side
+    Real edx = (bp.p.x - b.p.x) + (rpx - rcx), edz = (bp.p.z - b.p.z) + (rpz - rcz);  // A_p - A_c
     const float rcxf = (float)rcx, rczf = (float)rcz, rpxf = (float)rpx, rpzf = (float)rpz;
     // anchor velocities v + omega x r, omega = (0, w.y, 0)
     const float vcx = b.v.x + b.w.y * rczf, vcz = b.v.z - b.w.y * rcxf;
     const float vpx = bp.v.x + bp.w.y * rpzf, vpz = bp.v.z - bp.w.y * rpxf;
     float evx = vpx - vcx, evz = vpz - vcz;
     // relative rotation conj(u_p) u_c: the hinge angle is twice its argument
-    double Wr = bp.r.w * b.r.w + bp.r.y * b.r.y, Yr = bp.r.w * b.r.y - bp.r.y * b.r.w;
-    if (Wr < 0.0) { Wr = -Wr; Yr = -Yr; }
-    const float theta = sg * (float)(2.0 * atan2_f64<true>(Yr, Wr));
+    Real Wr = bp.r.w * b.r.w + bp.r.y * b.r.y, Yr = bp.r.w * b.r.y - bp.r.y * b.r.w;
+    if (Wr < (Real)0.0) { Wr = -Wr; Yr = -Yr; }
+    const float theta = sg * (float)((Real)2.0 * atan2_r<true>(Yr, Wr));
     const float wrel = b.w.y - bp.w.y, thetadot = sg * wrel;
     uint32_t lim = 0u;
     if (ns > 0) {  // the root: slides along world x and z (the parent is the world), unlimited
       const vf4 sx = ld4(&lr->dof[0][0]), sz = ld4(&lr->dof[1][0]);  // damping stiffness lo hi
       const float qx = (float)(-edx), qz = (float)(-edz), qdx = -evx, qdz = -evz;
-      edx = 0.0; edz = 0.0; evx = 0.0f; evz = 0.0f;
+      edx = (Real)0.0; edz = (Real)0.0; evx = 0.0f; evz = 0.0f;
       fx = ll.tau[0] - sx.x * qdx - sx.y * qx;
       fz = ll.tau[kEnvs] - sz.x * qdz - sz.y * qz;
       if (qx < sx.z) { fx += k_limit * (sx.z - qx); lim |= 1u; }
@@ -1388,7 +1501,7 @@ static __device__ __forceinline__ void substep_planar(const carl_brax_sys_t& s, 
     // spring.collisions.resolve: this body's spheres vs the plane z = 0
     float cdvx = 0.0f, cdvz = 0.0f, cdw = 0.0f, cnt = 0.0f;
     uint32_t hit = 0u;
-    const double pz = b.p.z - (double)K.plane_z;
+    const Real pz = b.p.z - (Real)K.plane_z;
     // Which links can touch the plane at all: the COM lower than the ball that holds every sphere (reach), and lower
     // than the link's box at its present pitch -- |sin| ext.x + |cos| ext.z: a level torso (Halfcheetah's: four
     // spheres along a 1.2 m rod, always inside the ball) stays out of the loop, whose trip count is the wavefront's
@@ -1398,10 +1511,10 @@ static __device__ __forceinline__ void substep_planar(const carl_brax_sys_t& s, 
     const bool near = (float)pz < qb.w && (float)pz < fabsf(sthf) * qe.y + fabsf(cthf) * qe.w + 1e-4f;
     const int n_sph = near ? wb_spheres(wb) : 0;
     if (ballot(n_sph > 0) != 0ull) {
-      const double cth = 1.0 - 2.0 * (b.r.y * b.r.y), sth = 2.0 * (b.r.w * b.r.y);  // R22, -R20 of the general form
+      const Real cth = (Real)1.0 - (Real)2.0 * (b.r.y * b.r.y), sth = (Real)2.0 * (b.r.w * b.r.y);  // R22, -R20 of the general form
       const float cf = (float)cth, sf = (float)sth;
       auto depth_of = [&](const vf4 sp) {
-        return (float)((double)sp.w - (pz + (cth * (double)sp.z - sth * (double)sp.x)));
+        return (float)((Real)sp.w - (pz + (cth * (Real)sp.z - sth * (Real)sp.x)));
       };
       auto respond = [&](const vf4 sp, const float depth, const int j) {
         const float radius = sp.w;
@@ -1438,11 +1551,11 @@ static __device__ __forceinline__ void substep_planar(const carl_brax_sys_t& s, 
       const float ic = __builtin_amdgcn_rcpf(cnt);
       vx += cdvx * ic; vz += cdvz * ic; om += cdw * ic;
     }
-    const double dtd = (double)dt, h = 0.5 * dtd, omd = (double)om;
-    b.p.x = fma((double)vx, dtd, b.p.x);
-    b.p.z = fma((double)vz, dtd, b.p.z);
-    const double w2 = fma(h, -(omd * b.r.y), b.r.w), y2 = fma(h, omd * b.r.w, b.r.y);  // r + h (0, omega) (x) r
-    const double inv = rsqrt_f64(w2 * w2 + y2 * y2);
+    const Real dtd = (Real)dt, h = (Real)0.5 * dtd, omd = (Real)om;
+    b.p.x = fma_r((Real)vx, dtd, b.p.x);
+    b.p.z = fma_r((Real)vz, dtd, b.p.z);
+    const Real w2 = fma_r(h, -(omd * b.r.y), b.r.w), y2 = fma_r(h, omd * b.r.w, b.r.y);  // r + h (0, omega) (x) r
+    const Real inv = rsqrt_r(w2 * w2 + y2 * y2);
     b.r.w = w2 * inv; b.r.y = y2 * inv;
     b.v.x = vx; b.v.z = vz; b.w.y = om;
     Lds::put_body(ll.own, b);
@@ -1912,7 +2025,8 @@ static __device__ __forceinline__ void write_ctx_obs(const carl_batch_t& b, cons
 }
 
 // mode 0: reset (mask optional), mode 1: n_steps env steps (1 = per call, T = fused rollout)
-template <int MODE, bool MULTI, bool TASK, bool PLANAR = false>
+// F32 (MODE 1, CARL_FLAG_BRAX_FP32): the n_frames substeps of an env step run their pose algebra in float32.
+template <int MODE, bool MULTI, bool TASK, bool PLANAR = false, bool F32 = false>
 static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_brax_sys_t* __restrict__ sys_dev,
                                            const Prepared& prep, const carl_step_io_t& io,
                                            const uint8_t* __restrict__ mask, float* __restrict__ reset_obs,
@@ -2138,8 +2252,21 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
         Lds ms = m;
         asm volatile("" : "+v"(ms.sub), "+v"(ms.env));
         const LaneLink ll = make_lane_link(pk, jx, K, ms);
-        StepRegs<MULTI> R;
-        R.b = Lds::body_of(ll.own);
+        using Real = std::conditional_t<F32, float, double>;
+        StepRegs<MULTI, Real> R;
+        if constexpr (F32) {
+          // the env's records -> the float32 layout the substeps read and write (Lds::put_body, float form); the world record
+          // likewise (r.w = 1.0f is word 3).  Everything outside the substeps keeps reading float64 records: converted back below.
+          static_assert(!TASK, "CARL_FLAG_BRAX_FP32: the task models' pair contact reads float64 records");
+          const Body b64 = Lds::body_of(ll.own);
+          R.b = narrow_body(b64);
+          phase_sync();  // (every read of the float64 records above is done)
+          if (ll.body) Lds::put_body(ll.own, R.b);
+          if (tid < kWorldRecBytes / 4) reinterpret_cast<uint32_t*>(m.rec + m.world_off())[tid] = (tid == 3) ? 0x3f800000u : 0u;
+          phase_sync();
+        } else {
+          R.b = Lds::body_of(ll.own);
+        }
         {
           const int d = wa_dof(ll.wa) + wa_slides(ll.wa);  // the joint's first hinge dof
 #pragma unroll
@@ -2149,9 +2276,12 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
         R.sig_lim = 0u;
         R.inv_m = __builtin_amdgcn_rcpf(m.at(m.lay.mass + ll.i));  // v_rcp_f32 (1 ulp): the phase is issue-bound
         if constexpr (PLANAR) {
-          for (int f = 0; f < n_frames; ++f) substep_planar<TASK>(s, tp, K, ll, m, R, prof);
+          for (int f = 0; f < n_frames; ++f) substep_planar<TASK, Real>(s, tp, K, ll, m, R, prof);
         } else {
-          for (int f = 0; f < n_frames; ++f) substep<MULTI, TASK>(s, tp, K, ll, m, R, prof);
+          for (int f = 0; f < n_frames; ++f) substep<MULTI, TASK, Real>(s, tp, K, ll, m, R, prof);
+        }
+        if constexpr (F32) {  // the world record back to its float64 form (observe reads it as a planar root's parent)
+          if (tid < kWorldRecBytes / 4) reinterpret_cast<uint32_t*>(m.rec + m.world_off())[tid] = (tid == 7) ? 0x3ff00000u : 0u;
         }
         if (ll.body) {  // this step's branch record, per link
           m.atu(m.lay.sig + 2 * ll.i) = R.sig_hit;
@@ -2160,9 +2290,10 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
           // on the register copy: a fused rollout then continues from exactly the state a per-call step stores and
           // reloads -- rollout == repeated step, bit for bit -- and the step's observation, reward and health checks
           // read the rounded pose in both.
-          R.b.p = D(round48(R.b.p.x), round48(R.b.p.y), round48(R.b.p.z));
-          R.b.r = qtd{round48(R.b.r.w), round48(R.b.r.x), round48(R.b.r.y), round48(R.b.r.z)};
-          Lds::put_body(ll.own, R.b);
+          Body bw = widen_body(R.b);  // (F32: a float is its own float32 head, tail 0 -- nothing to round)
+          bw.p = D(round48(bw.p.x), round48(bw.p.y), round48(bw.p.z));
+          bw.r = qtd{round48(bw.r.w), round48(bw.r.x), round48(bw.r.y), round48(bw.r.z)};
+          Lds::put_body(ll.own, bw);
         }
         phase_sync();
       }
@@ -2322,12 +2453,12 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
 // out, as MULTI = false does for the Euler-angle joints.  Task models always have a hinge-less last link,
 // so TASK implies MULTI.
 // PLANAR: substep_planar (step / rollout of a planar single-hinge model; the host checks the model, carl_brax.hip).
-template <int MODE, bool MULTI, int K, bool TASK = false, bool PLANAR = false>
-__global__ void __launch_bounds__(kLanes * max_waves_per_wg(MULTI)) __attribute__((amdgpu_waves_per_eu(CARL_BRAX_WAVES_PER_EU(MULTI)))) brax_kernel(const carl_batch_t b, const carl_brax_sys_t* __restrict__ sys_dev,
+template <int MODE, bool MULTI, int K, bool TASK = false, bool PLANAR = false, bool F32 = false>
+__global__ void __launch_bounds__(kLanes * max_waves_per_wg(MULTI)) __attribute__((amdgpu_waves_per_eu(F32 ? CARL_BRAX_WAVES_PER_EU_F32(MULTI) : CARL_BRAX_WAVES_PER_EU(MULTI)))) brax_kernel(const carl_batch_t b, const carl_brax_sys_t* __restrict__ sys_dev,
                                                       const Prepared prep, const carl_step_io_t io,
                                                       const uint8_t* __restrict__ mask, float* __restrict__ reset_obs,
                                                       const int n_steps) {
-  Group<K>::template run<MODE, MULTI, TASK, PLANAR>(b, sys_dev, prep, io, mask, reset_obs, n_steps);
+  Group<K>::template run<MODE, MULTI, TASK, PLANAR, F32>(b, sys_dev, prep, io, mask, reset_obs, n_steps);
 }
 
 }  // namespace brax

@@ -231,7 +231,9 @@ int launch_brax(const carl_batch_t* b, const carl_brax_sys_t* sd, const carl_bra
     if (wg > 160 * 1024) break;
     if (w > 1 && (long long)(w - 1) * envs >= b->n_lanes) break;  // a small batch: no empty wavefronts
     int per_cu = (int)((160 * 1024) / wg) * w;                     // resident wavefronts per CU, LDS-wise
-    if (per_cu > 4 * CARL_BRAX_WAVES_PER_EU(multi)) per_cu = 4 * CARL_BRAX_WAVES_PER_EU(multi);
+    const int waves_per_eu = (MODE == 1 && (b->flags & CARL_FLAG_BRAX_FP32)) ? CARL_BRAX_WAVES_PER_EU_F32(multi)
+                                                                              : CARL_BRAX_WAVES_PER_EU(multi);
+    if (per_cu > 4 * waves_per_eu) per_cu = 4 * waves_per_eu;
     per_cu -= per_cu % w;  // whole workgroups
     per_cu_of[w] = per_cu;
     if (per_cu > best) {
@@ -284,6 +286,30 @@ int launch_brax(const carl_batch_t* b, const carl_brax_sys_t* sd, const carl_bra
     CARL_PICK_PLANAR(9);
     CARL_PICK_PLANAR(16);
 #undef CARL_PICK_PLANAR
+    // CARL_FLAG_BRAX_FP32 (opt-in): the same kernels with the substeps' pose algebra in float32
+    if (b->flags & CARL_FLAG_BRAX_FP32) {
+      if (task) return fail(CARL_ERR_UNSUPPORTED, "%s: CARL_FLAG_BRAX_FP32 is not built for the reach / push task models", who);
+      kern = nullptr;
+#define CARL_PICK_F32(KK, MM) \
+  if (!planar && K == KK && multi == MM) kern = static_cast<kern_t>(carl::brax::brax_kernel<1, MM, KK, false, false, true>)
+#define CARL_PICK_F32_PLANAR(KK) \
+  if (planar && K == KK) kern = static_cast<kern_t>(carl::brax::brax_kernel<1, false, KK, false, true, true>)
+      CARL_PICK_F32(2, true);
+      CARL_PICK_F32(11, true);
+      CARL_PICK_F32(16, true);
+      CARL_PICK_F32(4, false);
+      CARL_PICK_F32(7, false);
+      CARL_PICK_F32(8, false);
+      CARL_PICK_F32(9, false);
+      CARL_PICK_F32(16, false);
+      CARL_PICK_F32_PLANAR(4);
+      CARL_PICK_F32_PLANAR(7);
+      CARL_PICK_F32_PLANAR(8);
+      CARL_PICK_F32_PLANAR(9);
+      CARL_PICK_F32_PLANAR(16);
+#undef CARL_PICK_F32
+#undef CARL_PICK_F32_PLANAR
+    }
   }
 #undef CARL_PICK
 #undef CARL_PICK_TASK

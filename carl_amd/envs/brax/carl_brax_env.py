@@ -43,6 +43,13 @@ def check_context(context: dict[str, Any], registered_context_features: list[str
             )
 
 
+
+def _precision_flag(substep_precision: str) -> bool:
+    if substep_precision not in ("float64", "float32"):
+        raise ValueError("substep_precision must be 'float64' or 'float32'")
+    return substep_precision == "float32"
+
+
 class CARLBraxEnv(CARLEnv):
     env_name: str
     backend: str = "spring"
@@ -72,6 +79,7 @@ class CARLBraxEnv(CARLEnv):
         autoreset: str = "redraw",
         mass_check: str = "warn",
         viscosity: str = "observed",
+        substep_precision: str = "float64",
         **kwargs,
     ) -> None:
         """Reference parameters (carl_brax_env.py:119-131) plus the lane-engine ones.
@@ -80,6 +88,11 @@ class CARLBraxEnv(CARLEnv):
         ``viscosity``: "observed" (default: the feature only appears in the context observation, Quirk B2) or
         "reference" (the literal rule of carl_brax_env.py:276-279: the viscosity value is written into ``ang_damping``,
         overwriting the ``ang_damping`` context).
+
+        ``substep_precision``: "float64" (default: the pose algebra of the pipeline substeps in float64, within north_star's
+        1e-5 of the float64 restatement) or "float32" (OPT-IN: brax's own precision under JAX's default -- the reference
+        creates its env without enabling x64, carl_brax_env.py:163-176 -- ~20 % faster, off the restatement by the amounts in
+        profiles/r06_brax_fp32_deviation.txt; ``CARL_FLAG_BRAX_FP32``).
 
         ``mass_check``: what happens to ``mass_<link>`` contexts below the model's stability floor
         (``feature_tables.MASS_RATIO_FLOOR``) -- every value inside the reference's bounds (0.1, inf) constructs:
@@ -125,6 +138,7 @@ class CARLBraxEnv(CARLEnv):
                 auto_reset=n_auto if auto_reset is None else auto_reset,
                 seed=seed, lane_offset=lane_offset, fin_capacity=fin_capacity, context_offset=context_offset,
                 autoreset_mode=autoreset,  # "first_state" = brax's AutoResetWrapper (reference behaviour)
+                pose_float32=_precision_flag(substep_precision),
             )
         self.use_language_goals = use_language_goals
         # the reference stacks BraxLanguageWrapper on the goal wrapper, i.e. only when goals vary (:216-218)

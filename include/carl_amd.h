@@ -96,6 +96,18 @@ enum {
                                        plane (same records, same results to rounding, a third of the instructions).  A
                                        planar model's state must BE planar (what reset produces); a caller that sets
                                        an out-of-plane state itself passes this flag. */
+  ,
+  CARL_FLAG_BRAX_FP32 = 64            /* Brax families, OPT-IN, never a default (ABI 9): carl_brax_step / carl_brax_rollout run the
+                                       n_frames substeps of an env step with their pose algebra (anchor separation, relative
+                                       joint rotation, joint angles, contact depth, integration) in float32 -- the precision
+                                       brax itself runs at under JAX's default (carl/envs/brax/carl_brax_env.py:163-176 creates
+                                       the env without enabling x64).  The product path forms these differences of poses in
+                                       float64 to stay within north_star's 1e-5 of the float64 restatement; this flag tells a
+                                       user what that bar costs: faster, and off the restatement by the amounts reported in
+                                       profiles/r06_brax_fp32_deviation.txt (like CARL_FLAG_ACROBOT_FP32 for the classic
+                                       path).  Between env steps the state record is the same 48-bit pose; reset, observe
+                                       and reward are unchanged.  Not built for the reach / push task models
+                                       (CARL_ERR_UNSUPPORTED). */
 };
 
 /* Storage type of carl_step_io.action.  The reference's discrete action is whatever integer the caller's policy

@@ -5,6 +5,7 @@ Lanes are classified by their DISCRETE decisions (tests/brax_parity_util.py: con
 both sides; `terminated`): prints percentiles and the MAXIMUM of |d| / (1 + |x|) over observation entries and
 reward on the agreeing lanes, the excluded shares, and the all-lanes figures round 2 reported.  Run on the GPU box:
     python tools/brax_parity_percentiles.py [family ...]"""
+import os
 import sys
 
 sys.path.insert(0, ".")
@@ -42,7 +43,11 @@ def measure(fam, n=2048, steps=40, seed=1):
             rows[:, names.index(name)] = rng.uniform(lo, hi, n)
     rows = rows.astype(np.float32).astype(np.float64)
     kw = dict(selector=O.SEL_STATIC, seed=5, ctx_idx0=np.arange(n))
-    eng = BraxVecEngine(s, len(names), rows, n, "cuda", max_episode_steps=10_000, auto_reset=False, branch_record=True, **kw)
+    fp32 = os.environ.get("CARL_BRAX_FP32") == "1" and not (s.target_link > 0 or s.push_link > 0)  # opt-in float32 substeps
+    eng = BraxVecEngine(s, len(names), rows, n, "cuda", max_episode_steps=10_000, auto_reset=False, branch_record=True,
+                        pose_float32=fp32, **kw)
+    if fp32:
+        fam = fam + " [float32 substeps]"
     ora = B.Engine(s, rows, n, max_steps=10_000, autoreset=False, **kw)
     eng.reset()
     ora.reset()
