@@ -608,6 +608,28 @@ def _cpu_worker_brax(job):
     return n * steps, time.perf_counter() - t0
 
 
+_POOL = None
+
+
+def _get_pool():
+    """ONE process pool (one worker per host core, spawn) for every CPU baseline of the run: starting 256 interpreters costs
+    seconds, and round 6 times a baseline beside each BASELINE config."""
+    global _POOL
+    if _POOL is None:
+        import multiprocessing as mp
+
+        _POOL = mp.get_context("spawn").Pool(os.cpu_count() or 1)
+    return _POOL
+
+
+def _close_pool():
+    global _POOL
+    if _POOL is not None:
+        _POOL.terminate()
+        _POOL.join()
+        _POOL = None
+
+
 def cpu_baseline_brax(env, table):
     """Brax families: the fp64 C restatement of the spring pipeline (oracle/brax_spring.c), one
     process per host core, on a bounded sample of the same context set.  kind = "port" (brax /
@@ -620,12 +642,11 @@ def cpu_baseline_brax(env, table):
     names = list(table.names)
     jobs = [(env, names, rows[(c * per) % len(rows):(c * per) % len(rows) + per].tolist(), steps)
             for c in range(cores)]
-    ctx = mp.get_context("spawn")
-    with ctx.Pool(cores) as pool:
-        pool.map_async(_cpu_worker_brax, [(env, names, j[2][:2], 2) for j in jobs]).get(timeout=300)  # warm the workers
-        t0 = time.perf_counter()
-        res = pool.map_async(_cpu_worker_brax, jobs).get(timeout=600)  # (bounded: a stuck worker must not hang the bench)
-        wall = time.perf_counter() - t0
+    pool = _get_pool()
+    pool.map_async(_cpu_worker_brax, [(env, names, j[2][:2], 2) for j in jobs], chunksize=1).get(timeout=180)  # warm the workers
+    t0 = time.perf_counter()
+    res = pool.map_async(_cpu_worker_brax, jobs, chunksize=1).get(timeout=300)  # (bounded: a stuck worker must not hang the bench)
+    wall = time.perf_counter() - t0
     return {
         "value": sum(r[0] for r in res) / wall, "unit": "env-steps/s", "cores": cores, "kind": "port",
         "sample": f"fp64 C restatement of the spring pipeline (oracle/brax_spring.c), {cores} processes x {per} contexts "
@@ -655,12 +676,11 @@ def cpu_baseline(args, env, table, lanes):
     rows = table.values_2d[:, :F]
     jobs = [(fam, rows[(c * per) % len(rows):(c * per) % len(rows) + per].tolist(), names, args.cpu_steps_per_env)
             for c in range(cores)]
-    ctx = mp.get_context("spawn")
-    with ctx.Pool(cores) as pool:
-        pool.map_async(_cpu_worker, [(fam, j[1][:2], names, 10) for j in jobs]).get(timeout=300)  # warm the workers (imports)
-        t0 = time.perf_counter()
-        res = pool.map_async(_cpu_worker, jobs).get(timeout=600)  # (bounded: a stuck worker must not hang the bench)
-        wall = time.perf_counter() - t0
+    pool = _get_pool()
+    pool.map_async(_cpu_worker, [(fam, j[1][:2], names, 10) for j in jobs], chunksize=1).get(timeout=180)  # warm the workers (imports)
+    t0 = time.perf_counter()
+    res = pool.map_async(_cpu_worker, jobs, chunksize=1).get(timeout=300)  # (bounded: a stuck worker must not hang the bench)
+    wall = time.perf_counter() - t0
     total = sum(r[0] for r in res)
     single = res[0][0] / res[0][1]
     # stronger CPU line: the vectorised C oracle (float64), one thread
@@ -774,6 +794,7 @@ def cpu_baseline_beside(args, fams, tables, lanes):
         try:
             recs[f] = cpu_baseline(args, f, tab, lanes)
         except Exception as e:
+            _close_pool()  # (a stuck worker must not stall the next baseline too: the next one starts a fresh pool)
             recs[f] = {"value": None, "unit": "env-steps/s", "cores": os.cpu_count(), "kind": "port", "error": repr(e)[:200]}
     if len(fams) == 1:
         return recs[fams[0]]
@@ -1126,6 +1147,7 @@ def main():
         try:
             cpu = cpu_baseline(args, args.families[0], wl.tables[0], n_fam)
         except Exception as e:  # the CPU line is a reported baseline: its failure must not take the GPU measurement with it
+            _close_pool()
             cpu = {"value": None, "unit": "env-steps/s", "cores": os.cpu_count(), "kind": "port", "error": repr(e)[:200]}
 
     if per_call is not None and rank == 0 and world == 1 and tuple(args.families) == ("cartpole",):
@@ -1277,6 +1299,7 @@ def main():
             "per_rank_avg_launch_ms": per_rank_launch_ms, "uneven_shards": uneven,
         }
         print(json.dumps(line), flush=True)
+    _close_pool()
     if dist is not None:
         dist.destroy_process_group()
 
