@@ -1083,12 +1083,25 @@ static __device__ __forceinline__ LaneLink make_lane_link(const Packed& pk, cons
 // LinkRec of link i from the model table and the host-built records (one lane per link, once per workgroup)
 static __device__ __forceinline__ void expand_link(const carl_brax_sys_t& s, const Packed& pk, int i, LinkRec& out) {
   const LinkA& A = pk.a[i];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    out.ac[k] = (double)A.ac[k];
-    out.ap[k] = (double)A.ap[k];
+  // The float64 block is formed in FLOAT64 from the model table's float32 values -- the numbers the float64 restatement
+  // combines (oracle/brax_spring.c: joint_geometry).  Rounds 1-5 widened the host's float32 results instead
+  // (build_packed_host: ac = a - com, ap = link_pos + link_rot a - com_parent, rpl = link_rot (x) joint_rot, each rounded
+  // to float32): a constant 6e-8 in the parent-side joint frame of every link whose frame is rotated against its
+  // parent's (Humanoid's thighs, shins and arms) = 2e-7 of axis misalignment x k_pos = 1e-5 rad/s of angular velocity PER
+  // SUBSTEP on those links (tools/diag_humanoid_reset_step.py), and 1.5e-8 m in the anchors x k_pos = 1e-6 m/s: the largest
+  // single term of the Humanoid's parity error since round 2 -- found in round 6 when the stiffer humanoid.xml constants
+  // pushed its worst entry from 7e-6 to 1.0e-5.
+  const qtd lrot = tod(f4(s.link_rot[i])), j = tod(f4(s.joint_rot[i]));
+  {
+    const int P = wa_parent(A.word);
+    const v3d a = tod(f3(s.joint_pos[i]));
+    const v3d com_p = (P < 0) ? D(0, 0, 0) : tod(f3(s.com[P]));
+    const v3d ac = a - tod(f3(s.com[i]));
+    const v3d ap = (tod(f3(s.link_pos[i])) + qrot(lrot, a)) - com_p;
+    out.ac[0] = ac.x; out.ac[1] = ac.y; out.ac[2] = ac.z;
+    out.ap[0] = ap.x; out.ap[1] = ap.y; out.ap[2] = ap.z;
   }
-  const qtd j = tod(f4(A.jrot)), cr = qconj(tod(f4(A.rpl)));
+  const qtd cr = qconj(qmul(lrot, j));
   double G[4][4];
 #pragma unroll
   for (int cidx = 0; cidx < 4; ++cidx) {  // column cidx of G: conj(rpl) (x) e_cidx (x) joint_rot
@@ -1794,7 +1807,26 @@ static __device__ CARL_BRAX_RESET_INLINE void forward_kinematics(const carl_brax
       m.put3(m.lay.wrench + 12 * i + 3, vel);
       const v3 c = qrot(rot, f3(s.com[i]));
       Body b;
-      b.r = tod(rot);
+      {
+        // The float32 kinematics leave |rot|^2 = 1 +- 2e-7; the state record keeps 48 bits, so the rotation is made a
+        // unit quaternion in float64 here, once.  Why it matters (round 6, tools/diag_humanoid_reset_step.py): rotation
+        // formulas that agree for unit quaternions differ by (|q|^2 - 1) x the vector for others -- v + 2 w (u x v) +
+        // 2 u x (u x v) keeps an unscaled v, brax's math.rotate (2 (u.v) u + (w^2 - u.u) v + 2 w (u x v)) scales the whole
+        // result -- and the hinge-alignment term turns that 1e-7 into k_pos x 1e-7 = 5e-3 N m on every hinge that is
+        // not parallel to e_x: 1.8e-5 rad/s per substep between this kernel (which forms the misalignment from the
+        // relative rotation: scale-type) and the float64 restatement (which crosses two rotated axes) on the FIRST
+        // steps after every reset -- the Humanoid's worst parity entries (1.0e-5) all sat there.  After the first
+        // substep the integrator's own float64 normalisation has always made the question moot.
+        // (rounded to what the state record holds -- float32 head + tail, 48 bits -- so that a fused launch continues after
+        // an in-kernel reset from exactly the state a per-call step stores and reloads: rollout == repeated step)
+        const qtd r64 = tod(rot);
+        const double inv = 1.0 / sqrt(r64.w * r64.w + r64.x * r64.x + r64.y * r64.y + r64.z * r64.z);
+        auto r48 = [](double d) {
+          const float hi = (float)d;
+          return (double)hi + (double)(float)(d - (double)hi);
+        };
+        b.r = qtd{r48(r64.w * inv), r48(r64.x * inv), r48(r64.y * inv), r48(r64.z * inv)};
+      }
       b.w = ang;
       b.p = tod(o + c);
       b.v = vel + cross(ang, c);

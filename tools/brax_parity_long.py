@@ -62,6 +62,7 @@ def run(fam, n, steps, pool, n_chunks):
     amp = FAMS[fam][2] * float(max(s.act_hi[: s.n_act]))
     cuts = np.linspace(0, n, n_chunks + 1).astype(int)
     worst, n_agree, n_contact, n_flag, total, over = 0.0, 0, 0, 0, 0, 0
+    col_worst, worst_at = np.zeros(s.obs_dim), None
     for t in range(steps):
         state = eng.state_np()
         elapsed = eng.elapsed.cpu().numpy()
@@ -77,13 +78,22 @@ def run(fam, n, steps, pool, n_chunks):
         flag = term_g != (o_term != 0)
         contact = (sig[:, 0] != o_sig[:, 0]) & ~flag
         agree = ~flag & ~contact
-        e = np.maximum((np.abs(got.astype(np.float64) - o_obs) / (1 + np.abs(o_obs))).max(1),
-                       np.abs(rew.cpu().numpy().astype(np.float64) - o_rew) / (1 + np.abs(o_rew)))
+        eo = np.abs(got.astype(np.float64) - o_obs) / (1 + np.abs(o_obs))
+        e = np.maximum(eo.max(1), np.abs(rew.cpu().numpy().astype(np.float64) - o_rew) / (1 + np.abs(o_rew)))
+        col_worst = np.maximum(col_worst, eo[agree].max(0)) if agree.any() else col_worst
+        if agree.any() and float(e[agree].max()) > worst:  # where the run's worst entry sits (column, value, step, env state)
+            k = int(np.argmax(np.where(agree, e, -1.0)))
+            c = int(np.argmax(eo[k]))
+            worst_at = (t, k, c, float(o_obs[k, c]), float(got[k, c]), int(elapsed[k]), bool(done[k]))
         worst = max(worst, float(e[agree].max()))
         over += int((e[agree] > 1e-5).sum())
         n_agree += int(agree.sum()); n_contact += int(contact.sum()); n_flag += int(flag.sum()); total += n
     print(f"{fam:12s} {total:9d} lane-steps ({n} envs x {steps} steps, auto-reset on, {int(eng.episodes_done.sum())} episodes): agreeing lanes max {worst:.2e}, "
           f"above 1e-5: {over}; excluded: contact record differs {n_contact} ({n_contact / total:.2e}), terminated differs {n_flag} ({n_flag / total:.2e})", flush=True)
+    if os.environ.get("CARL_PARITY_DETAIL") == "1":
+        top = np.argsort(-col_worst)[:10]
+        print("   worst entry (step, lane, column, oracle value, engine value, elapsed, done):", worst_at)
+        print("   worst columns:", [(int(c), f"{col_worst[c]:.2e}") for c in top], flush=True)
 
 
 if __name__ == "__main__":
