@@ -233,6 +233,7 @@ class Workload:
         from carl_amd.mixed import MixedVecEngine
 
         self.families, self.T, self.device, self.narrow_actions = tuple(families), T, device, narrow_actions
+        self.brax_fp32 = brax_fp32
         self.envs, self.tables = [], []
         for k, f in enumerate(self.families):
             e, t = make_env(f, lanes_per_gpu, rank, world, device, lane_base=k * lanes_per_gpu * world, brax_fp32=brax_fp32)
@@ -544,7 +545,8 @@ def roofline_of(wl, avg_launch_s):
         "algorithmic_bytes_per_launch": wl.bytes_per_launch,
     }
     part_n = wl.n // len(wl.families)
-    key = f"{'+'.join(wl.families)}{'_narrow' if getattr(wl, 'narrow_actions', False) else ''}:{part_n}:{wl.T}"
+    key = (f"{'+'.join(wl.families)}{'_narrow' if getattr(wl, 'narrow_actions', False) else ''}"
+           f"{'_fp32' if getattr(wl, 'brax_fp32', False) else ''}:{part_n}:{wl.T}")  # (committed records are per kernel variant)
     rec = traffic_record(key)
     if rec:
         r["traffic"] = rec["hbm_bytes_per_launch"]
@@ -1201,7 +1203,7 @@ def main():
             also[name]["bound"] = ("vector-ALU issue (roofline_valu: SQ_INSTS_VALU of the full-size launch x cycles per wavefront-"
                                    "instruction / (1 024 SIMDs x 2.4 GHz) against the launch time); `frac` above is the HBM fraction "
                                    "of the same launch, which the metric asks for")
-            also[name]["roofline_valu"] = roofline_valu_of(f"{'+'.join(fams)}:{lanes}:{Ta}", avg2)
+            also[name]["roofline_valu"] = roofline_valu_of(f"{'+'.join(fams)}{'_fp32' if fp32 else ''}:{lanes}:{Ta}", avg2)
             # double-buffered use: the same contexts as two free-running half-batches (one family: two engines of half
             # the lanes; two families: one engine each), launches overlapping across streams
             w4 = SplitWorkload(fams[0], lanes // 2, Ta, args.buffer_sets, rank, world, device) if len(fams) == 1 else w2

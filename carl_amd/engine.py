@@ -450,6 +450,7 @@ class VecEngine:
             self._out_host = torch.empty(self._out_slab.shape, dtype=torch.uint8).pin_memory()
         self._out_host.copy_(self._out_slab, non_blocking=True)
         torch.cuda.current_stream(self.device).synchronize()
+        self._a_pending = False  # (everything on the stream is done: the staged action upload too)
         h = self._out_host.numpy()
         n, D = self.n, self.D
         o_rew, o_term, o_trunc, _ = self._out_offsets
