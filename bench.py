@@ -590,14 +590,12 @@ def _cpu_worker(job):
 
 
 def _cpu_worker_brax(job):
-    env, names, rows, steps = job
+    sys_t, rows, steps = job  # sys_t: oracle.brax.SysSnapshot (the worker imports neither the product package nor torch)
     import numpy as np
 
-    from carl_amd.envs.brax.models import SYSTEMS
     from oracle import brax as B
     from oracle import oracle as O
 
-    sys_t = SYSTEMS[env](names)
     rows = np.asarray(rows, dtype=np.float64)
     n = len(rows)
     eng = B.Engine(sys_t, rows, n, selector=O.SEL_STATIC, ctx_idx0=np.arange(n), seed=0)
@@ -642,10 +640,13 @@ def cpu_baseline_brax(env, table):
     per, steps = 16, 200
     rows = table.values_2d
     names = list(table.names)
-    jobs = [(env, names, rows[(c * per) % len(rows):(c * per) % len(rows) + per].tolist(), steps)
-            for c in range(cores)]
+    from carl_amd.envs.brax.models import SYSTEMS
+    from oracle import brax as B
+
+    snap = B.SysSnapshot(SYSTEMS[env](names))
+    jobs = [(snap, rows[(c * per) % len(rows):(c * per) % len(rows) + per].tolist(), steps) for c in range(cores)]
     pool = _get_pool()
-    pool.map_async(_cpu_worker_brax, [(env, names, j[2][:2], 2) for j in jobs], chunksize=1).get(timeout=180)  # warm the workers
+    pool.map_async(_cpu_worker_brax, [(snap, j[1][:2], 2) for j in jobs], chunksize=1).get(timeout=180)  # warm the workers
     t0 = time.perf_counter()
     res = pool.map_async(_cpu_worker_brax, jobs, chunksize=1).get(timeout=300)  # (bounded: a stuck worker must not hang the bench)
     wall = time.perf_counter() - t0

@@ -15,11 +15,30 @@ def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
+class SysSnapshot:
+    """The bytes and the handful of ints of a ``carl_brax_sys_t``, picklable: lets a worker PROCESS drive the restatement
+    without importing the product package (whose ctypes binding imports torch -- 256 bench workers doing that cost the
+    round-6 bench four minutes).  Accepted wherever a model table is (``Engine``, ``forward_kinematics`` ...)."""
+
+    _INTS = ("n_links", "n_q", "n_dof", "n_act", "obs_dim", "max_episode_steps", "n_frames")
+
+    def __init__(self, sys_struct):
+        self.raw = bytes(sys_struct)
+        for k in self._INTS:
+            setattr(self, k, int(getattr(sys_struct, k)))
+        self.act_lo = [float(sys_struct.act_lo[i]) for i in range(self.n_act)]
+        self.act_hi = [float(sys_struct.act_hi[i]) for i in range(self.n_act)]
+
+    def __bytes__(self):
+        return self.raw
+
+
 class _Sys:
     """holds the struct bytes and the handful of ints the binding needs"""
 
     def __init__(self, sys_struct):
-        self.buf = C.create_string_buffer(bytes(sys_struct), C.sizeof(sys_struct))
+        size = len(sys_struct.raw) if isinstance(sys_struct, SysSnapshot) else C.sizeof(sys_struct)
+        self.buf = C.create_string_buffer(bytes(sys_struct), size)
         self.n_links, self.n_q, self.n_dof = sys_struct.n_links, sys_struct.n_q, sys_struct.n_dof
         self.n_act, self.obs_dim = sys_struct.n_act, sys_struct.obs_dim
         self.max_episode_steps = sys_struct.max_episode_steps
