@@ -103,7 +103,8 @@ ALSO = {
     # the same two workloads in 100-step launches (round 6): a Brax launch pays its set-up (model table -> LDS, state in /
     # out) and ~one env step per fragment boundary ONCE, so the 20-step figure above carries 5-10 % of per-launch cost that a
     # collector with longer unrolls does not pay.  Reported BESIDE config4 / config5 (whose definition stays: comparable
-    # with rounds 2-5), never instead of them.
+    # with rounds 2-5), never instead of them.  Not in the default `--also` list (they measured: config 4 +-0 %, config 5
+    # +2.8 % -- the 20-step definition hides no per-launch cost -- and cost the default run half a minute): ask with --also.
     "config4_T100": (("ant",), 32768, "strong", 100),
     "config5_T100": (("halfcheetah", "humanoid"), 32768, "strong", 100),
     # OPT-IN, labelled, never the headline and never config4 / config5 themselves (VERDICT r05 "Next" #7): the substeps'
@@ -146,14 +147,14 @@ def parse():
     p.add_argument("--rccl", action="store_true",
                    help="single GPU: build a one-rank RCCL process group and run the reporting all-gather through it")
     p.add_argument("--sustained-seconds", type=float, default=0.3)
-    p.add_argument("--also", default="cartpole_T250,cartpole_u8,pendulum,pendulum_f16,config3,config4,config5,config4_T100,config5_T100,config4_fp32,config5_fp32",
+    p.add_argument("--also", default="cartpole_T250,cartpole_u8,pendulum,pendulum_f16,config3,config4,config5,config4_fp32,config5_fp32",
                    help="comma list of extra workloads reported under 'also' (" + ", ".join(ALSO) + "), or 'none'")
     p.add_argument("--narrow-actions", action="store_true",
                    help="feed the MAIN workload uint8 (discrete) / float16 (Box) actions (ABI 7); profiling runs of "
                         "also.cartpole_u8 / pendulum_f16 -- the default headline reads int32")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-per-call", action="store_true")
-    p.add_argument("--cpu-envs-per-core", type=int, default=256)
+    p.add_argument("--cpu-envs-per-core", type=int, default=128)
     p.add_argument("--cpu-steps-per-env", type=int, default=1000)
     a = p.parse_args()
     a.strong = not a.weak
@@ -673,11 +674,16 @@ def cpu_baseline(args, env, table, lanes):
 
     fam = O.FAMILY_NAMES.index(env)
     cores = os.cpu_count() or 1
-    per = args.cpu_envs_per_core
+    # a BOUNDED sample (about ten seconds per family on the reference-style Python loop): the headline family keeps the
+    # command line's sample; the others are scaled by what their scalar step costs (Acrobot's RK4 in Python: ~15 x CartPole's)
+    scale = {"cartpole": (1, 1), "pendulum": (2, 2), "acrobot": (8, 4), "mountaincar": (2, 1), "mountaincar_cont": (2, 1)}[env]
+    head = env == args.families[0]
+    per = args.cpu_envs_per_core if head else max(8, args.cpu_envs_per_core // scale[0])
+    steps = args.cpu_steps_per_env if head else max(50, args.cpu_steps_per_env // scale[1])
     F = len(O.FEATURES[fam])
     names = O.feature_names(fam)
     rows = table.values_2d[:, :F]
-    jobs = [(fam, rows[(c * per) % len(rows):(c * per) % len(rows) + per].tolist(), names, args.cpu_steps_per_env)
+    jobs = [(fam, rows[(c * per) % len(rows):(c * per) % len(rows) + per].tolist(), names, steps)
             for c in range(cores)]
     pool = _get_pool()
     pool.map_async(_cpu_worker, [(fam, j[1][:2], names, 10) for j in jobs], chunksize=1).get(timeout=180)  # warm the workers (imports)
@@ -700,7 +706,7 @@ def cpu_baseline(args, env, table, lanes):
     return {
         "value": total / wall, "unit": "env-steps/s", "cores": cores, "kind": "port",
         "sample": f"restatement of the reference's scalar Python step() loop (oracle/ref_style.py), {cores} processes x "
-                  f"{per} contexts x {args.cpu_steps_per_env} steps of the same {env} context set, auto-reset on",
+                  f"{per} contexts x {steps} steps of the same {env} context set, auto-reset on",
         "single_core_value": single,
         "c_oracle_f64_1thread_value": c_rate,
     }
@@ -1044,6 +1050,14 @@ def main():
         dist.all_gather(parts, t)
         return [float(v.item()) for v in parts]
 
+    _t_last = [time.perf_counter()]
+
+    def tick(label):  # CARL_BENCH_TIMING=1: where the wall clock of a run goes (stderr)
+        if os.environ.get("CARL_BENCH_TIMING") == "1" and rank == 0:
+            now = time.perf_counter()
+            print(f"[bench timing] {label}: {now - _t_last[0]:.1f} s", file=sys.stderr, flush=True)
+            _t_last[0] = now
+
     K, W = args.steps, args.warmup
     T = args.chunk or DEFAULT_CHUNK[args.families[0]]
     n_fam = args.lanes // world if args.strong else args.lanes
@@ -1145,6 +1159,7 @@ def main():
                 per_call["captured_100_ms_per_step"] = dt / ((Kc // 100) * 100) * 1e3
         gc.enable()
 
+    tick("headline + sustained + per_call")
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
@@ -1159,6 +1174,7 @@ def main():
         except Exception as e:  # a reported side record: its failure must not take the measurement with it
             per_call["dropin"] = {"error": repr(e)[:300]}
 
+    tick("cpu_baseline + dropin")
     # ---- the other BASELINE workloads, same launch train ---------------------------
     also = {}
     names = [] if args.also in ("", "none") else args.also.split(",")
@@ -1231,6 +1247,7 @@ def main():
             also[name]["cpu_baseline"] = cpu_baseline_beside(args, fams, w2.tables, lanes)
         del w2
         torch.cuda.empty_cache()
+        tick(f"also.{name}")
 
     # ---- the 8-GPU shard regime on this ONE GPU ----
     shard8 = None
@@ -1258,6 +1275,7 @@ def main():
             }
             del w5
             torch.cuda.empty_cache()
+            tick(f"shard8.{name}")
         shard8["note"] = ("prediction = 8 x this GPU's rate (lanes are independent, no data-path collective: SURVEY 8e); a shard "
                           "this small is bound by ONE wavefront's dependent-issue latency per env step, not by HBM: DESIGN.md 6")
 
