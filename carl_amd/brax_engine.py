@@ -114,8 +114,12 @@ class BraxVecEngine(VecEngine):
         that does not switches the engine to the general substep (``_check_planar_state``).  Direct writes to
         ``eng.state`` bypass that check: pass ``generic_substep=True`` if you write out-of-plane states yourself."""
         L = self.sys.n_links
-        st = torch.as_tensor(state, dtype=torch.float64, device=self.device).reshape(self.n, L, 13)
+        st = torch.as_tensor(state, dtype=torch.float64, device=self.device).reshape(self.n, L, 13).clone()
         self._check_planar_state(st)
+        # rotations as UNIT quaternions (float64): rotation formulas that agree for unit quaternions differ by (|q|^2 - 1) x
+        # the vector otherwise, and the constraint springs turn 1e-7 of that into 1e-5 rad/s per substep (round 6: the
+        # engine's own reset does the same, brax_kernels.hip.h: forward kinematics)
+        st[:, :, 3:7] /= st[:, :, 3:7].norm(dim=2, keepdim=True).clamp_min(1e-300)
         pose = st[:, :, :7]
         head = pose.to(torch.float32)
         tail = (pose - head.to(torch.float64)).to(torch.float32)

@@ -428,16 +428,18 @@ class VecEngine:
             self._a_host = torch.empty(self.n * self._action_dim, dtype=dt).pin_memory()
             self._a_dev = torch.empty((self.n, self._action_dim) if self._action_dim > 1 or not self.info.action_is_discrete
                                       else (self.n,), dtype=dt, device=self.device)
-            self._a_event = torch.cuda.Event()
+            self._a_host_np = self._a_host.numpy()
             self._a_pending = False
         a = np.asarray(action).reshape(-1)
-        if a.size != self._a_host.numel():  # (NumPy would broadcast one value over every actuator silently)
+        if a.size != self._a_host_np.size:  # (NumPy would broadcast one value over every actuator silently)
             raise ValueError(f"action has {a.size} elements, this engine takes {self.n} x {self._action_dim}")
-        if self._a_pending:  # the previous asynchronous upload still reads the pinned buffer
-            self._a_event.synchronize()
-        self._a_host.numpy()[:] = a
+        if self._a_pending:
+            # the previous asynchronous upload may still be reading the pinned buffer: wait for the stream before rewriting
+            # it.  Never taken by the scalar step path -- ``read_transition`` synchronises the stream after every step and
+            # clears the mark -- so the guard costs a flag test, not an event per call
+            torch.cuda.current_stream(self.device).synchronize()
+        self._a_host_np[:] = a
         self._a_dev.view(-1).copy_(self._a_host, non_blocking=True)
-        self._a_event.record(torch.cuda.current_stream(self.device))
         self._a_pending = True
         return self._a_dev
 
