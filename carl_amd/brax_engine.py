@@ -114,12 +114,11 @@ class BraxVecEngine(VecEngine):
         that does not switches the engine to the general substep (``_check_planar_state``).  Direct writes to
         ``eng.state`` bypass that check: pass ``generic_substep=True`` if you write out-of-plane states yourself."""
         L = self.sys.n_links
-        st = torch.as_tensor(state, dtype=torch.float64, device=self.device).reshape(self.n, L, 13).clone()
+        st = torch.as_tensor(state, dtype=torch.float64, device=self.device).reshape(self.n, L, 13)
         self._check_planar_state(st)
-        # rotations as UNIT quaternions (float64): rotation formulas that agree for unit quaternions differ by (|q|^2 - 1) x
-        # the vector otherwise, and the constraint springs turn 1e-7 of that into 1e-5 rad/s per substep (round 6: the
-        # engine's own reset does the same, brax_kernels.hip.h: forward kinematics)
-        st[:, :, 3:7] /= st[:, :, 3:7].norm(dim=2, keepdim=True).clamp_min(1e-300)
+        # (rotations are taken as given.  The engine's own reset makes its rotations unit quaternions in float64 -- round 6 --
+        # because rotation formulas that agree for unit quaternions differ by (|q|^2 - 1) x the vector otherwise; a caller
+        # who wants the float64 restatement's numbers to 1e-5 on the first substep passes unit quaternions too.)
         pose = st[:, :, :7]
         head = pose.to(torch.float32)
         tail = (pose - head.to(torch.float64)).to(torch.float32)

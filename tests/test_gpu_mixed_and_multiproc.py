@@ -61,13 +61,14 @@ def test_mixed_batch_equals_separate_engines(n, T, device):
 
 
 @pytest.mark.parametrize("other", [O.MOUNTAINCAR, O.CARTPOLE, O.PENDULUM, O.MOUNTAINCAR_CONT], ids=lambda f: O.FAMILY_NAMES[f])
-@pytest.mark.parametrize("n_a,n_b,T,max_steps", [(4112, 1040, 37, 5), (1024, 4096, 64, 0)])
+@pytest.mark.parametrize("n_a,n_b,T,max_steps", [(4112, 1040, 37, 5), (1024, 4096, 64, 0), (1003, 517, 21, 7)])
 def test_pair_launch_equals_two_launches_bit_for_bit(other, n_a, n_b, T, max_steps, device):
     """`carl_rollout_pair`: Acrobot + one other family as ONE heterogeneous launch at 4-step chunks ==
     the two families' own `carl_rollout` launches (8-step chunks), in every output and counter: unequal part sizes,
     ragged last workgroups (4112 = 16 x 256 + 16), a ragged last chunk (37 = 9 x 4 + 1), resets of every lane inside
-    the window (TimeLimit 5), either order of the parts.  Combinations the library declines (int64 actions, terminal
-    observations) fall back to two launches with the same results."""
+    the window (TimeLimit 5), either order of the parts; lane counts that are not multiples of 16 (1 003 + 517: rows at
+    the ABI-9 pitch -- what the uneven shards of a multi-GPU run of BASELINE config 3 look like).  Combinations the
+    library declines (int64 actions, terminal observations) fall back to two launches with the same results."""
     from carl_amd.mixed import MixedVecEngine
 
     rng = np.random.default_rng(T + other)
