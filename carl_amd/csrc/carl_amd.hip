@@ -128,9 +128,26 @@ int row_pitch_of(const carl_batch_t* b, const carl_step_io_t* io) {
   return (io != nullptr && io->row_pitch > 0) ? io->row_pitch : b->n_lanes;
 }
 
+// The staged kernel writes 16-byte pieces of every row: rows must start on 16-byte boundaries (pitch % 16 == 0) and the
+// columns [n_lanes, n_lanes rounded up to 16) must be the caller's to lose -- they are when the lane count is a multiple
+// of 16 (there are none) or when the pitch IS that rounded-up count (the padded layout of carl_rollout_pitch).  A wider
+// pitch with an odd lane count is a view into an array whose neighbouring columns belong to someone else: direct stores.
 int rollout_variant(const carl_batch_t* b, const carl_step_io_t* io = nullptr) {
   if (b->flags & CARL_FLAG_ROLLOUT_DIRECT) return CARL_ROLLOUT_DIRECT_FLAG;
-  return (row_pitch_of(b, io) % 16 == 0) ? CARL_ROLLOUT_STAGED : CARL_ROLLOUT_DIRECT_SHAPE;
+  const int pitch = row_pitch_of(b, io), n16 = (b->n_lanes + 15) / 16 * 16;
+  // ... and every array must START on a 16-byte boundary (fresh allocations do; a column view `array[:, k:]` need not)
+  bool aligned = true;
+  if (io != nullptr) {
+    const uintptr_t bits = reinterpret_cast<uintptr_t>(io->obs) | reinterpret_cast<uintptr_t>(io->reward) |
+                           reinterpret_cast<uintptr_t>(io->terminated) | reinterpret_cast<uintptr_t>(io->truncated) |
+                           reinterpret_cast<uintptr_t>(io->final_obs);
+    // the loader wave reads a lane-row of four actions per load: 16 bytes (int32 / float32; int64: two of them), 4 (uint8), 8
+    const uintptr_t amask = io->action_dtype == CARL_ACTION_U8 ? 3u
+                            : (io->action_dtype == CARL_ACTION_F16 || io->action_dtype == CARL_ACTION_BF16) ? 7u : 15u;
+    aligned = (bits & 15) == 0 && (reinterpret_cast<uintptr_t>(io->action) & amask) == 0;
+  }
+  return (aligned && pitch % 16 == 0 && (b->n_lanes % 16 == 0 || pitch == n16)) ? CARL_ROLLOUT_STAGED
+                                                                                : CARL_ROLLOUT_DIRECT_SHAPE;
 }
 
 // 64-thread workgroups spread a small batch over all 256 CUs x 4 SIMDs (65 536

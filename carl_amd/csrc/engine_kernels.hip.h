@@ -829,7 +829,7 @@ struct ActionPipe {
   // branches (a predicated tail in the same function) made the register allocator spill the in-flight
   // rows and wait for each load before issuing the next.  Lanes past the end of a ragged last
   // workgroup load the batch's last four actions instead (valid memory, valid actions).
-  __device__ __forceinline__ void issue(const AStore* __restrict__ act, size_t n, int lane_base, int l, int t0_,
+  __device__ __forceinline__ void issue(const AStore* __restrict__ act, size_t n, int cols, int lane_base, int l, int t0_,
                                         int n_steps) {
     t0 = t0_;
     fast = t0 + CHUNK <= n_steps;
@@ -838,7 +838,7 @@ struct ActionPipe {
       // let the YOUNGER set stay in flight across the older set's commit if the number of loads issued here is a
       // compile-time fact: always eight, rows past the end of the rollout re-read its last row (valid memory; `fast`
       // still tells commit() whether the registers hold the chunk)
-      const int lane4 = min(lane_base + 4 * l, (int)n - 4);
+      const int lane4 = min(lane_base + 4 * l, cols - 4);
       const int last = n_steps - 1;
       a0 = load_row(act + (size_t)min(t0, last) * n + lane4);
       a1 = load_row(act + (size_t)min(t0 + 1, last) * n + lane4);
@@ -854,7 +854,7 @@ struct ActionPipe {
     }
     if (!fast) return;
     // uniform row base + 32-bit lane offset: the loads take the scalar-base addressing form
-    const int lane4 = min(lane_base + 4 * l, (int)n - 4);
+    const int lane4 = min(lane_base + 4 * l, cols - 4);
     const AStore* row = act + (size_t)t0 * n;
     a0 = load_row(row + lane4);
     row += n;
@@ -874,7 +874,7 @@ struct ActionPipe {
       a7 = load_row(row + lane4);
     }
   }
-  __device__ __forceinline__ void commit(LdsElem* buf, const AStore* __restrict__ act, size_t n, int lane_base, int l,
+  __device__ __forceinline__ void commit(LdsElem* buf, const AStore* __restrict__ act, size_t n, int cols, int lane_base, int l,
                                          int n_steps) const {
     // padding lanes of a ragged last workgroup must see VALID actions too (they run as clones of the
     // last lane; a garbage torque sent the Acrobot's angle to 1e7 rad and its wrap loop with it):
@@ -895,7 +895,7 @@ struct ActionPipe {
       return;
     }
     // last, ragged chunk of the rollout (once per launch): a plain row loop
-    const AStore* src = act + (size_t)t0 * n + min(lane_base + 4 * l, (int)n - 4);
+    const AStore* src = act + (size_t)t0 * n + min(lane_base + 4 * l, cols - 4);
 #pragma unroll 1
     for (int u = 0; u < CHUNK && t0 + u < n_steps; ++u) dst[u * row] = narrow(load_row(src + (size_t)u * n));
   }
@@ -904,13 +904,14 @@ struct ActionPipe {
 // storer wave `which` of kStorers: its share (every kStorers-th step) of the records of steps
 // [t0, t0 + steps) from LDS to HBM; l = lane of the wave (0..63)
 template <class Fam>
-__device__ __forceinline__ void drain_records(char* buf, const carl_step_io_t& io, size_t n, int lane_base, int l,
+__device__ __forceinline__ void drain_records(char* buf, const carl_step_io_t& io, size_t n, int cols, int lane_base, int l,
                                               int which, int t0, int steps) {
   using SK = LdsSink<Fam>;
-  // lanes of this workgroup inside the ROW (n = the row pitch): 256, or a multiple of 16 in the ragged last workgroup
-  // (n % 16 == 0), so every 16-byte piece below is entirely inside or entirely outside; columns [n_lanes, n) of a
-  // padded row receive the records of the padding lanes (clones of the batch's last lane)
-  const int valid = min(kRolloutLanes, (int)n - lane_base);
+  // lanes of this workgroup inside the row's columns (cols = n_lanes rounded up to a multiple of 16, <= the pitch n): 256,
+  // or a multiple of 16 in the ragged last workgroup, so every 16-byte piece below is entirely inside or entirely
+  // outside; columns [n_lanes, cols) of a padded row receive the records of the padding lanes (clones of the batch's
+  // last lane) -- nothing beyond cols is ever written
+  const int valid = min(kRolloutLanes, cols - lane_base);
   typedef float vf4 __attribute__((ext_vector_type(4)));
   // streamed once, never re-read by this kernel: non-temporal stores (temporal ones: +6 %, measured)
   auto put = [](char* dst, const char* src) {
@@ -1004,6 +1005,9 @@ __device__ __forceinline__ void rollout_staged_body(const carl_batch_t& b, const
   const bool active = compute && lane < b.n_lanes;
   const uint64_t glane = (uint64_t)(b.lane_offset + lane);
   const size_t n = (size_t)io.row_pitch;  // lanes per row of the action / output arrays (>= n_lanes; resolved by the host)
+  // columns of a row this launch may touch: the lanes and the padding up to the next multiple of 16 (<= the pitch: host);
+  // a pitch beyond that is a view into a wider array whose other columns belong to someone else
+  const int n_cols = (b.n_lanes + 15) & ~15;
   const int max_steps = b.max_episode_steps;
   const AStore* act = static_cast<const AStore*>(io.action);
   constexpr int kBufActs = kStageChunk * kRolloutLanes;
@@ -1013,10 +1017,10 @@ __device__ __forceinline__ void rollout_staged_body(const carl_batch_t& b, const
   float* const final_base = (io.final_obs != nullptr && active) ? io.final_obs + (size_t)lane * Fam::D : nullptr;
   if (!compute && !loader) zero_flag_rows<Fam, CHUNK>(out_buf, hl, storer);
   if (loader) {
-    pipe.issue(act, n, lane_base, hl, 0, n_steps);
-    pipe.commit(act_buf, act, n, lane_base, hl, n_steps);
-    pipe.issue(act, n, lane_base, hl, kStageChunk, n_steps);  // in flight across the barrier
-    if constexpr (kDeep) pipe_b.issue(act, n, lane_base, hl, 2 * kStageChunk, n_steps);
+    pipe.issue(act, n, n_cols, lane_base, hl, 0, n_steps);
+    pipe.commit(act_buf, act, n, n_cols, lane_base, hl, n_steps);
+    pipe.issue(act, n, n_cols, lane_base, hl, kStageChunk, n_steps);  // in flight across the barrier
+    if constexpr (kDeep) pipe_b.issue(act, n, n_cols, lane_base, hl, 2 * kStageChunk, n_steps);
   } else if (compute) {
     // padding lanes of a ragged last workgroup run as register-only clones of the batch's last lane
     // (valid numbers, so the step loop needs no per-lane predicate and takes no slow math path)
@@ -1047,13 +1051,13 @@ __device__ __forceinline__ void rollout_staged_body(const carl_batch_t& b, const
     // are the younger ones, so its wait is vmcnt(8 + ...), not vmcnt(0))
     int lbuf = 0;
     for (int t0 = 0;;) {  // n_steps >= 1
-      pipe.commit(act_buf + (lbuf ^ 1) * kBufActs, act, n, lane_base, hl, n_steps);
-      pipe.issue(act, n, lane_base, hl, t0 + 3 * kStageChunk, n_steps);
+      pipe.commit(act_buf + (lbuf ^ 1) * kBufActs, act, n, n_cols, lane_base, hl, n_steps);
+      pipe.issue(act, n, n_cols, lane_base, hl, t0 + 3 * kStageChunk, n_steps);
       __syncthreads();
       lbuf ^= 1;
       if (t0 + kStageChunk >= n_steps) break;
-      pipe_b.commit(act_buf + (lbuf ^ 1) * kBufActs, act, n, lane_base, hl, n_steps);
-      pipe_b.issue(act, n, lane_base, hl, t0 + 4 * kStageChunk, n_steps);
+      pipe_b.commit(act_buf + (lbuf ^ 1) * kBufActs, act, n, n_cols, lane_base, hl, n_steps);
+      pipe_b.issue(act, n, n_cols, lane_base, hl, t0 + 4 * kStageChunk, n_steps);
       __syncthreads();
       lbuf ^= 1;
       t0 += 2 * kStageChunk;
@@ -1136,10 +1140,10 @@ __device__ __forceinline__ void rollout_staged_body(const carl_batch_t& b, const
       }
     } else if constexpr (ROLE == 1) {
       // chunk c+1 (loads issued one iteration ago) -> LDS; then start chunk c+2
-      pipe.commit(act_buf + (buf ^ 1) * kBufActs, act, n, lane_base, hl, n_steps);
-      pipe.issue(act, n, lane_base, hl, t0 + 2 * kStageChunk, n_steps);
+      pipe.commit(act_buf + (buf ^ 1) * kBufActs, act, n, n_cols, lane_base, hl, n_steps);
+      pipe.issue(act, n, n_cols, lane_base, hl, t0 + 2 * kStageChunk, n_steps);
     } else if (t0 > 0) {  // storer: the previous chunk's records (always a full chunk)
-      drain_records<Fam>(out_buf + (size_t)(buf ^ 1) * kStageChunk * SK::kStepBytes, io, n, lane_base, hl, storer,
+      drain_records<Fam>(out_buf + (size_t)(buf ^ 1) * kStageChunk * SK::kStepBytes, io, n, n_cols, lane_base, hl, storer,
                          t0 - kStageChunk, kStageChunk);
     }
     __syncthreads();
@@ -1152,7 +1156,7 @@ __device__ __forceinline__ void rollout_staged_body(const carl_batch_t& b, const
     if (active) store_lane<Fam>(b, ctx, lane, r);
   } else if (!loader) {  // records of the last chunk
     const int last_t0 = ((n_steps - 1) / kStageChunk) * kStageChunk;
-    drain_records<Fam>(out_buf + (size_t)(buf ^ 1) * kStageChunk * SK::kStepBytes, io, n, lane_base, hl, storer,
+    drain_records<Fam>(out_buf + (size_t)(buf ^ 1) * kStageChunk * SK::kStepBytes, io, n, n_cols, lane_base, hl, storer,
                        last_t0, n_steps - last_t0);
   }
 }

@@ -525,14 +525,14 @@ class VecEngine:
         if out is None:
             out = self.alloc_rollout(T)
         io = self._rollout_io(a, dt, out, T)
-        if self._has_direct_kernel and not self._warned_direct and (io.row_pitch or self.n) % 16 and \
-                not (self.b.flags & _lib.FLAG_ROLLOUT_DIRECT):
+        if self._has_direct_kernel and not self._warned_direct and self._takes_direct_kernel(io.row_pitch or self.n):
             import warnings
 
             self._warned_direct = True
-            warnings.warn(f"carl_rollout: the output buffers' rows are {io.row_pitch or self.n} lanes long, not a multiple "
-                          "of 16 -- this launch takes the direct-store kernel (~50 % slower than the staged one; same "
-                          "results).  Use alloc_rollout()'s buffers (rows padded to a multiple of 16) for the fast path.",
+            warnings.warn(f"carl_rollout: {self.n} lanes in rows {io.row_pitch or self.n} lanes long (not a multiple of 16, or "
+                          "a view into a wider array) -- this launch takes the direct-store kernel (~50 % slower than the "
+                          "staged one; same results).  Use alloc_rollout()'s buffers (rows padded to a multiple of 16) for "
+                          "the fast path.",
                           RuntimeWarning, stacklevel=2)
         with torch.cuda.device(self.device):
             code = self._c_rollout(io, T)
@@ -545,6 +545,12 @@ class VecEngine:
                 code = self._c_rollout(io, T)
             _lib.check(code)
         return out
+
+    def _takes_direct_kernel(self, pitch: int) -> bool:
+        """carl_amd.hip's rule (rollout_variant) for rows of this pitch, without the A/B flag"""
+        n = self.n
+        staged = pitch % 16 == 0 and (n % 16 == 0 or pitch == (n + 15) // 16 * 16)
+        return not staged and not (self.b.flags & _lib.FLAG_ROLLOUT_DIRECT)
 
     def _rollout_io(self, a: torch.Tensor, dt: int, out: dict, T: int) -> "_lib.StepIO":
         """``carl_step_io_t`` of a fused rollout: validated actions + the caller's ``[T, ...]`` output buffers.  The row

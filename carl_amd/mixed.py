@@ -218,7 +218,7 @@ class MixedVecEngine:
         for k, p in enumerate(self.parts):
             a = actions[k]
             pitch = p._row_pitch() if outs is None else max(p.n, int(outs[k]["reward"].stride(0)))  # (engine.py: _rollout_io)
-            lean = (p.b.selector in (_lib.SEL_STATIC, _lib.SEL_HOST) and pitch % 16 == 0 and p.fin_capacity == 0
+            lean = (p.b.selector in (_lib.SEL_STATIC, _lib.SEL_HOST) and not p._takes_direct_kernel(pitch) and p.fin_capacity == 0
                     and not (p.b.flags & _lib.FLAG_ROLLOUT_DIRECT)
                     and not (torch.is_tensor(a) and a.dtype == torch.int64)
                     and not (outs is not None and outs[k].get("final_obs") is not None))

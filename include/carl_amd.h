@@ -202,10 +202,12 @@ typedef struct carl_step_io {
                            also F16 / BF16) */
   int32_t row_pitch;    /* carl_rollout / carl_rollout_pair (classic-control families; ABI 9): lanes per ROW of `action` and of
                            every [T][...] output -- row t of an array starts row_pitch lanes after row t - 1; 0 = n_lanes (dense
-                           rows).  A pitch that is a multiple of 16 keeps every row's 16-byte pieces aligned whatever
-                           n_lanes is, so ANY lane count takes the staged kernel: columns [n_lanes, row_pitch) of the action
-                           rows must hold valid actions (the engine repeats the last lane's) and the same columns of the outputs
-                           receive the records of the padding lanes.  Must be 0 or >= n_lanes; ignored by carl_step; the Brax
+                           rows).  Must be 0 or >= n_lanes.  The staged kernel (16-byte stores) runs when the pitch is a multiple
+                           of 16 AND either n_lanes is one too or the pitch is exactly carl_rollout_pitch(n_lanes): it then also
+                           WRITES columns [n_lanes, carl_rollout_pitch(n_lanes)) of every output row (the records of the padding
+                           lanes) and reads the same columns of the action rows, which must hold valid actions (the engine
+                           repeats the last lane's) -- never anything beyond.  Any other pitch (a view into a wider array) takes
+                           the direct-store kernel, which touches columns [0, n_lanes) only.  Ignored by carl_step; the Brax
                            entry points take 0 only.  (this field was `reserved`, always 0, in ABI <= 8) */
   float* obs;           /* [n_lanes][D]; with AUTORESET the post-reset observation
                            for done lanes (gymnasium vector-env convention) */

@@ -173,6 +173,13 @@ def test_brax_and_sampler_entry_points_validate_arguments():
     assert lib.carl_rollout_variant_io(C.byref(cb), C.byref(io)) == _lib.ROLLOUT_STAGED
     io.row_pitch = 65536
     assert lib.carl_rollout_variant_io(C.byref(cb), C.byref(io)) == _lib.ERR_INVALID_ARGUMENT  # pitch < n_lanes
+    # a pitch beyond the padded one is a view into a wider array: the columns next to the lanes belong to someone else, so
+    # the staged kernel (which writes whole 16-byte pieces) only runs when there is no padding to write
+    cb.n_lanes, io.row_pitch = 1000, 2080
+    assert lib.carl_rollout_variant_io(C.byref(cb), C.byref(io)) == _lib.ROLLOUT_DIRECT_SHAPE
+    cb.n_lanes, io.row_pitch = 1024, 2048
+    assert lib.carl_rollout_variant_io(C.byref(cb), C.byref(io)) == _lib.ROLLOUT_STAGED
+    cb.n_lanes = 65537
     cb.flags = _lib.FLAG_ROLLOUT_DIRECT
     io.row_pitch = 65552
     assert lib.carl_rollout_variant_io(C.byref(cb), C.byref(io)) == _lib.ROLLOUT_DIRECT_FLAG

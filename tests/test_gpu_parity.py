@@ -839,6 +839,34 @@ def test_rollout_variant_is_visible_and_odd_lane_counts_take_the_staged_kernel(d
         for name in ("state", "elapsed", "ctx_idx", "episode", "n_calls", "ep_return", "last_return", "episodes_done"):
             assert torch.equal(getattr(e, name), getattr(d, name)) and torch.equal(getattr(e, name), getattr(c, name)), name
         assert int(e.episodes_done.sum()) > 0
+    # two engines writing side by side into column views of ONE wider array (rows 2 080 lanes long): neither launch may
+    # touch the other's columns -- an odd lane count there takes the direct-store kernel (the staged one would write the
+    # padding columns, which are the neighbour's), a multiple of 16 keeps the staged kernel
+    for n_a, n_b in ((1000, 1080), (1040, 1040)):
+        fam = O.PENDULUM
+        tab_a, tab_b = random_table(fam, rng, n_a), random_table(fam, rng, n_b)
+        acts_a = torch.as_tensor(random_actions(fam, rng, (T, n_a)), device=device)
+        acts_b = torch.as_tensor(random_actions(fam, rng, (T, n_b)), device=device)
+        P = n_a + n_b
+        wide = {"obs": torch.full((T, P, 3), -7.0, device=device), "reward": torch.full((T, P), -7.0, device=device),
+                "terminated": torch.full((T, P), 9, dtype=torch.uint8, device=device),
+                "truncated": torch.full((T, P), 9, dtype=torch.uint8, device=device)}
+        ea = _engine(fam, tab_a, n_a, device, selector=O.SEL_STATIC, seed=2, ctx_idx0=np.arange(n_a))
+        eb = _engine(fam, tab_b, n_b, device, selector=O.SEL_STATIC, seed=3, ctx_idx0=np.arange(n_b))
+        ra = _engine(fam, tab_a, n_a, device, selector=O.SEL_STATIC, seed=2, ctx_idx0=np.arange(n_a))
+        rb = _engine(fam, tab_b, n_b, device, selector=O.SEL_STATIC, seed=3, ctx_idx0=np.arange(n_b))
+        for x in (ea, eb, ra, rb):
+            x.reset()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)
+            ea.rollout(acts_a, {k: v[:, :n_a] for k, v in wide.items()})
+            torch.cuda.synchronize()
+            assert bool((wide["reward"][:, n_a:] == -7.0).all()) and bool((wide["terminated"][:, n_a:] == 9).all())
+            assert bool((wide["obs"][:, n_a:] == -7.0).all())
+            eb.rollout(acts_b, {k: v[:, n_a:] for k, v in wide.items()})
+        want_a, want_b = ra.rollout(acts_a), rb.rollout(acts_b)
+        for k in ("obs", "reward", "terminated", "truncated"):
+            assert torch.equal(wide[k][:, :n_a], want_a[k]) and torch.equal(wide[k][:, n_a:], want_b[k]), (n_a, k)
     # buffers whose arrays disagree about the pitch are refused
     bad = e.alloc_rollout(T)
     bad["reward"] = torch.empty((T, n), device=device)
