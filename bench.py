@@ -1114,7 +1114,10 @@ def main():
     # and the return all-gather runs in its uneven-counts form (VERDICT r05 "Next" #5 / #6)
     uneven = None
     if dist is not None and world > 1:
-        uneven = uneven_shard_record(args.families[0], args.lanes + 5, rank, world, device, backend, barrier, gather_over_ranks)
+        try:
+            uneven = uneven_shard_record(args.families[0], args.lanes + 5, rank, world, device, backend, barrier, gather_over_ranks)
+        except Exception as e:  # a plumbing side record: it must not take the scaling measurement with it
+            uneven = {"error": repr(e)[:300]}
 
     # ---- per-call path (one launch per env step) -----------------------------------
     per_call = None
