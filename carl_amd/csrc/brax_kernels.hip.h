@@ -937,12 +937,13 @@ static __device__ __forceinline__ ObsGeom obs_geometry(const LinkA& rec, const f
 // difference: float64.
 struct PairOut {
   v3 on_obj, on_a, t_a;
+  uint32_t fired;  // bit 16 + k: pair contact k pushed (a discrete decision: part of the object's contact hash)
 };
 static __device__ __forceinline__ PairOut pair_contact(const carl_brax_sys_t& s, const Lds& m, const float friction) {
   const int a = s.pair_link;
   const Body ba = m.body(a), bo = m.body(s.push_link);
   const v3d o = bo.p - qrot(bo.r, tod(f3(s.com[s.push_link])));
-  PairOut r{V(0, 0, 0), V(0, 0, 0), V(0, 0, 0)};
+  PairOut r{V(0, 0, 0), V(0, 0, 0), V(0, 0, 0), 0u};
   for (int k = 0; k < s.n_pair; ++k) {
     const v3d reld = qrot(ba.r, tod(f3(s.pair_pos[k]) - f3(s.com[a])));
     const v3d cs = ba.p + reld;
@@ -960,6 +961,7 @@ static __device__ __forceinline__ PairOut pair_contact(const carl_brax_sys_t& s,
     const float closing = dot(vr, n);
     const float fm = s.pair_k * depth + s.pair_c * closing;
     if (!(fm > 0.0f)) continue;
+    r.fired |= 1u << (16 + (k & 15));
     v3 fc = n * fm;
     if (s.pair_ct > 0.0f) {  // Coulomb friction, regularised (carl_amd.h: pair_ct): min(pair_ct |vt|, friction fm) along vt
       v3 vt = vr - n * closing;
@@ -1180,6 +1182,7 @@ static __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const T
   // phase A -- spring.joints.resolve, the lane's own joint.  The wrench on the child stays in registers (the same lane
   // applies it in the body phase); only the reaction on the parent goes through LDS.
   v3 f = V(0, 0, 0), tc = V(0, 0, 0);
+  [[maybe_unused]] uint32_t pair_fired = 0u;  // (task models: the object's lane carries it to its contact hash)
   if (ll.joint) {
     const uint32_t wa = ll.wa;
     const int ns = MULTI ? wa_slides(wa) : 0;
@@ -1250,6 +1253,7 @@ static __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const T
     v3 pf = f * -1.0f, pt = (cross(g.rp_off, f) + t) * -1.0f;  // on the parent
     if (TASK && s.n_pair > 0 && ll.i == s.push_link) {
       const PairOut po = pair_contact(s, m, ll.ctx[1]);
+      pair_fired = po.fired;
       f = f + po.on_obj;
       pf = po.on_a;
       pt = po.t_a;
@@ -1382,6 +1386,7 @@ static __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const T
       }
     }
     prof.mark(kProfContacts);
+    if constexpr (TASK) hit |= pair_fired;
     R.sig_hit = R.sig_hit * 33u + hit;
     // spring.integrator.integrate
     b.v = b.v * dl;

@@ -220,7 +220,8 @@ typedef struct carl_step_io {
                            only, ignored by the rollout entry points */
   uint32_t* branch_sig; /* Brax families: [n_lanes][2] or NULL.  Hash of the DISCRETE decisions the physics took in
                            this env step: [0] which collision spheres delivered an impulse in which substep
-                           (discontinuous: an impulse appears when a point starts to approach), [1] which joint
+                           (discontinuous: an impulse appears when a point starts to approach; push task: also which
+                           gripper / object contacts pushed -- round 6), [1] which joint
                            range limits were active (continuous: the limit spring starts at zero).  Two
                            implementations of the same arithmetic can only be compared to rounding on lanes
                            whose word [0] agrees; tests/test_gpu_brax.py uses it for exactly that.  Ignored by

@@ -313,8 +313,9 @@ static v3 apply_inv_inertia(const carl_brax_sys_t* s, int i, qt r, v3 t) {
 /* spring.joints.resolve: net force F[i] and torque T[i] (about the COM, world frame) on every link from the joint
  * springs, dampers, limits, actuators (and the push task's pair contacts) */
 static void joint_wrenches(const carl_brax_sys_t* s, const lane_ctx* c, const double* tau, const body* b, v3* F, v3* T,
-                           uint32_t* hl) {
+                           uint32_t* hl, uint32_t* pair_fired) {
   const int L = s->n_links;
+  if (pair_fired) *pair_fired = 0;
   for (int i = 0; i < L; ++i) { F[i] = V(0, 0, 0); T[i] = V(0, 0, 0); }
   for (int i = 0; i < L; ++i) {
     const int P = s->parent[i];
@@ -387,6 +388,9 @@ static void joint_wrenches(const carl_brax_sys_t* s, const lane_ctx* c, const do
         const double closing = vdot(vsub(vs, b[i].v), n);
         const double fm = s->pair_k * depth + s->pair_c * closing;
         if (!(fm > 0.0)) continue;
+        /* a DISCRETE decision (the damper term makes the force jump where the contact opens or closes): recorded in the
+         * object's contact hash (bits 16 + k), so that a parity check can set lanes aside where it flipped within rounding */
+        if (pair_fired) *pair_fired |= 1u << (16 + (k & 15));
         v3 fc = vscale(n, fm);
         if (s->pair_ct > 0.0f) { /* Coulomb friction, regularised (carl_amd.h: pair_ct): the object is dragged along the
                                   * sphere's tangential velocity, never harder than friction x the normal force --
@@ -414,7 +418,8 @@ static void joint_wrenches(const carl_brax_sys_t* s, const lane_ctx* c, const do
 static void substep(const carl_brax_sys_t* s, const lane_ctx* c, const double* tau, body* b, uint32_t* hc, uint32_t* hl) {
   v3 F[L_MAX], T[L_MAX];
   const int L = s->n_links;
-  joint_wrenches(s, c, tau, b, F, T, hl);
+  uint32_t pair_fired = 0;
+  joint_wrenches(s, c, tau, b, F, T, hl, &pair_fired);
   /* --- semi-implicit Euler: velocity update before the collision pass -------------- */
   for (int i = 0; i < L; ++i) {
     b[i].v = vadd(b[i].v, vscale(vadd(vscale(F[i], 1.0 / c->mass[i]), V(0, 0, c->gravity_z)), s->dt));
@@ -441,6 +446,7 @@ static void substep(const carl_brax_sys_t* s, const lane_ctx* c, const double* t
   int cnt[L_MAX], seen[L_MAX];
   uint32_t hit[L_MAX];
   for (int i = 0; i < L; ++i) { dv[i] = V(0, 0, 0); dw[i] = V(0, 0, 0); cnt[i] = 0; seen[i] = 0; hit[i] = 0; }
+  if (s->n_pair > 0 && s->push_link > 0) hit[s->push_link] |= pair_fired; /* the gripper / object contacts that pushed */
   const v3 n = V(0, 0, 1);
   for (int k = 0; k < s->n_coll; ++k) {
     const int i = s->coll_link[k];
@@ -699,7 +705,7 @@ void obx_joint_wrenches(const carl_brax_sys_t* s, const double* ctx_row, const d
   v3 F[L_MAX], T[L_MAX];
   const lane_ctx c = make_ctx(s, ctx_row);
   load_bodies(s, state, b);
-  joint_wrenches(s, &c, tau, b, F, T, NULL);
+  joint_wrenches(s, &c, tau, b, F, T, NULL, NULL);
   for (int i = 0; i < s->n_links; ++i) {
     F_out[3 * i] = F[i].x; F_out[3 * i + 1] = F[i].y; F_out[3 * i + 2] = F[i].z;
     T_out[3 * i] = T[i].x; T_out[3 * i + 1] = T[i].y; T_out[3 * i + 2] = T[i].z;
