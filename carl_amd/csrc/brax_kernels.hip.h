@@ -1271,6 +1271,10 @@ static __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const T
     const vf4 qb = ld4(&lr->inv_i[0]);  // .x inv_inertia[0], .w reach
     const float inv_i0 = qb.x;
     const bool iso = (wb & kWbIso) != 0u;
+    // Anisotropic effective inertia only exists in the GENERAL kernels (TASK: the host sends every model with a link whose
+    // principal moments differ there, carl_brax.hip: brax_is_general); everywhere else isotropy is a compile-time fact and
+    // the rotated-inertia code is not in the instruction stream at all.
+    const bool all_iso = !TASK || K.all_iso;
     const qt rf = tof(b.r);
     v3 F = f, T = tc;  // own joint's wrench (a free root has none)
     {  // children's reactions, ascending: a wavefront-uniform trip count and loads whose addresses come from registers
@@ -1298,7 +1302,7 @@ static __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const T
     }
     const float inv_m = R.inv_m;
     b.v = b.v + (F * inv_m + V(0, 0, cx.x)) * dt;
-    b.w = b.w + (K.all_iso ? T * inv_i0 : apply_inv_inertia(lr, rf, T, iso, inv_i0)) * dt;
+    b.w = b.w + (all_iso ? T * inv_i0 : apply_inv_inertia(lr, rf, T, iso, inv_i0)) * dt;
     if (TASK && s.obj_support != 0 && ll.i == s.push_link) {
       // the push task's object on the table (carl_amd.h: obj_support): Coulomb friction under the normal load m |g| as an
       // impulse -- the horizontal velocity shrinks by friction |g| dt, at most to zero
@@ -1315,6 +1319,9 @@ static __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const T
     v3 cdv = V(0, 0, 0), cdw = V(0, 0, 0);
     float cnt = 0.0f;
     uint32_t hit = 0u;
+    // (ONE definition of the eight accumulators: as plain constants the compiler re-materialised their zeros on every path
+    //  into and around the sphere loop -- three sets of eight v_mov per substep)
+    asm volatile("" : "+v"(cdv.x), "+v"(cdv.y), "+v"(cdv.z), "+v"(cdw.x), "+v"(cdw.y), "+v"(cdw.z), "+v"(cnt), "+v"(hit));
     // no sphere of this link can reach the plane while its COM is higher than the farthest sphere surface
     const Real pz = b.p.z - (Real)K.plane_z;  // height above the collision plane (the ground; the push task's table)
     const int n_sph = ((float)pz < qb.w) ? wb_spheres(wb) : 0;
@@ -1374,14 +1381,48 @@ static __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const T
         }
         cnt += 1.0f;
       };
+      // The same impulse for isotropic models (every shipped one) as STRAIGHT-LINE code: every lane of the loop evaluates
+      // it and the discrete decisions (penetrating, delivering an impulse, sliding) become selects on the impulse's
+      // components -- a lane that does not fire adds exact zeros.  The nested per-lane branches of `respond` cost the
+      // wavefront more than the arithmetic they skip: some foot of some env of a wavefront is on the ground in nearly
+      // every substep, so the blocks ran anyway, with ~10 exec-mask / branch instructions and ~24 register copies at the
+      // joins of the eight accumulators around ~60 of arithmetic (ISA of round 6).  The tangential speed's square root is
+      // v_sqrt_f32 (1 ulp; sqrtf's correctly rounded finish is 14 instructions).  One wavefront-uniform branch remains:
+      // nothing is evaluated while no sphere of the wavefront penetrates.
+      auto respond_iso = [&](const vf4 sp, const float depth, const int j) {
+        const float radius = sp.w;
+        const v3 ro = qrot(rf, V(sp.x, sp.y, sp.z));
+        const v3 r = V(ro.x, ro.y, ro.z - radius);
+        const v3 rel = b.v + cross(b.w, r);
+        const float vn = rel.z;
+        const float ang = inv_i0 * (r.x * r.x + r.y * r.y);
+        const float imp = div_fast(-(1.0f + cx.z) * vn + K.erp * depth * inv_dt, inv_m + ang);
+        const bool fire = depth > 0.0f && imp > 0.0f && vn < 0.0f;
+        const float vt_len = __builtin_amdgcn_sqrtf(rel.x * rel.x + rel.y * rel.y);
+        const bool slip = fire && vt_len > 1e-9f;
+        const float il = __builtin_amdgcn_rcpf(vt_len), dx = rel.x * il, dy = rel.y * il;
+        const v3 rxd = V(-r.z * dy, r.z * dx, r.x * dy - r.y * dx);  // r x dir
+        const float imp_d = fminf(div_fast(vt_len, inv_m + inv_i0 * dot(rxd, rxd)), cx.y * imp);
+        const v3 J = V(slip ? -dx * imp_d : 0.0f, slip ? -dy * imp_d : 0.0f, fire ? imp : 0.0f);
+        hit |= fire ? (1u << j) : 0u;
+        cnt += fire ? 1.0f : 0.0f;
+        cdv = cdv + J * inv_m;
+        cdw = cdw + cross(r, J) * inv_i0;
+      };
       vf4 nxt = ld4(&ll.sph[0]);
-      for (int j = 0; j < n_sph; ++j) {  // the next sphere's record is in flight while this one is evaluated
-        const vf4 sp = nxt;
-        nxt = ld4(&ll.sph[j + 1]);
-        const float depth = depth_of(sp);
-        if (depth > 0.0f) {
-          if (K.all_iso) respond(sp, depth, j, std::true_type{});
-          else respond(sp, depth, j, std::false_type{});
+      if (all_iso) {  // (wavefront-uniform; two loops: one loop with both bodies copied the accumulators at its joins)
+        for (int j = 0; j < n_sph; ++j) {  // the next sphere's record is in flight while this one is evaluated
+          const vf4 sp = nxt;
+          nxt = ld4(&ll.sph[j + 1]);
+          const float depth = depth_of(sp);
+          if (ballot(depth > 0.0f) != 0ull) respond_iso(sp, depth, j);
+        }
+      } else {
+        for (int j = 0; j < n_sph; ++j) {
+          const vf4 sp = nxt;
+          nxt = ld4(&ll.sph[j + 1]);
+          const float depth = depth_of(sp);
+          if (depth > 0.0f) respond(sp, depth, j, std::false_type{});
         }
       }
     }

@@ -113,7 +113,18 @@ constexpr bool brax_instantiated(int k, bool multi, bool task) {
   if (task) return k == 4 || k == 8 || k == 16;  // reacher: 3 links, pusher: 8
   return multi ? (k == 2 || k == 11 || k == 16) : (k == 4 || k == 7 || k == 8 || k == 9 || k == 16);
 }
-bool brax_is_task(const carl_brax_sys_t* sh) { return sh->target_link > 0 || sh->push_link > 0; }
+// The GENERAL kernels (template parameter TASK of brax_kernel): the reach / push task models -- and every model with a link
+// whose principal moments of inertia differ.  Every shipped locomotion model has isotropic effective inertia
+// (spring_inertia_scale = 1), so the rotated-inertia code R diag(1 / I) R^T lives in the general kernels only: the lean and
+// multi-hinge kernels compile isotropy in (brax_kernels.hip.h: substep, all_iso) and carry neither its instructions nor its
+// registers through the substep loop.  A general kernel runs a non-task model unchanged (its task epilogues are guarded by
+// the model's own target_link / push_link / n_pair).
+bool brax_is_task(const carl_brax_sys_t* sh) {
+  if (sh->target_link > 0 || sh->push_link > 0) return true;
+  for (int i = 0; i < sh->n_links; ++i)
+    if (!(sh->inv_inertia[i][0] == sh->inv_inertia[i][1] && sh->inv_inertia[i][1] == sh->inv_inertia[i][2])) return true;
+  return false;
+}
 bool brax_is_planar(const carl_brax_sys_t* sh);
 // The general kernels (MULTI): any link with 0, 2 or 3 hinges (Euler-angle path), a link frame that is rotated against
 // its parent's (link_rot != identity: the relative rotation of the joint frames then needs the full 4 x 4 map,
@@ -288,7 +299,7 @@ int launch_brax(const carl_batch_t* b, const carl_brax_sys_t* sd, const carl_bra
 #undef CARL_PICK_PLANAR
     // CARL_FLAG_BRAX_FP32 (opt-in): the same kernels with the substeps' pose algebra in float32
     if (b->flags & CARL_FLAG_BRAX_FP32) {
-      if (task) return fail(CARL_ERR_UNSUPPORTED, "%s: CARL_FLAG_BRAX_FP32 is not built for the reach / push task models", who);
+      if (task) return fail(CARL_ERR_UNSUPPORTED, "%s: CARL_FLAG_BRAX_FP32 is not built for the reach / push task models or anisotropic inertia", who);
       kern = nullptr;
 #define CARL_PICK_F32(KK, MM) \
   if (!planar && K == KK && multi == MM) kern = static_cast<kern_t>(carl::brax::brax_kernel<1, MM, KK, false, false, true>)
