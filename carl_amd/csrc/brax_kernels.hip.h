@@ -431,6 +431,16 @@ struct alignas(16) Sphere {  // a link's spheres are consecutive, in Topo::coll_
   float off[3];              // centre - COM of its link (link frame)
   float radius;
 };
+// What the body phase reads per sphere (static LDS, widened on the device once per workgroup from Packed::sph): the
+// offset and radius as DOUBLES -- the operands of the float64 depth, which is evaluated for every sphere of every link near
+// the plane in every substep (four v_cvt_f64_f32 per sphere and substep until round 6) -- and the float32 record the
+// impulse reads.  One record = one base address.
+struct alignas(16) SphRec {
+  double off[3], radius;  //  0
+  float f[4];             // 32: off x y z, radius
+};
+constexpr int kSphRecBytes = 48;
+static_assert(sizeof(SphRec) == kSphRecBytes, "SphRec is read in 16-byte pieces at fixed offsets");
 struct Packed {
   LinkA a[CARL_BRAX_MAX_LINKS];
   LinkB b[CARL_BRAX_MAX_LINKS];
@@ -1037,7 +1047,7 @@ struct LaneLink {
   uint32_t wa, wb;        // the index words of LinkA / LinkB
   uint32_t wch;           // LinkB::children: the first four children's links, a byte each (none: L, the env's zero record)
   const LinkRec* lr;      // the link's constants
-  const Sphere* sph;      // the link's first sphere
+  const SphRec* sph;      // the link's first sphere (widened records)
   char* own;              // the own body record
   const char* par;        // the parent's (the world record)
   char* react;            // the own joint's reaction record
@@ -1060,7 +1070,8 @@ struct StepRegs {
   float inv_m;
 };
 
-static __device__ __forceinline__ LaneLink make_lane_link(const Packed& pk, const LinkRec* lrec, const SubK& K, const Lds& m) {
+static __device__ __forceinline__ LaneLink make_lane_link(const Packed& pk, const LinkRec* lrec, const SphRec* sph_rec, const SubK& K,
+                                                          const Lds& m) {
   LaneLink ll;
   const bool body = m.sub < K.L;
   const int i = body ? m.sub : K.L - 1;
@@ -1072,7 +1083,7 @@ static __device__ __forceinline__ LaneLink make_lane_link(const Packed& pk, cons
   ll.joint = body && (ll.wa & kWaFree) == 0u;
   const int P = wa_parent(ll.wa);
   ll.lr = lrec + i;
-  ll.sph = pk.sph + wb_first_sphere(ll.wb);
+  ll.sph = sph_rec + wb_first_sphere(ll.wb);
   ll.own = m.rec + m.body_off(i);
   ll.par = m.rec + (P < 0 ? m.world_off() : m.body_off(P));
   ll.react = reinterpret_cast<char*>(m.base) + m.react_off(i);
@@ -1330,9 +1341,19 @@ static __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const T
       // term multiplies by erp / dt -- is a pose difference
       const Real R20 = (Real)2.0 * (b.r.x * b.r.z - b.r.w * b.r.y), R21 = (Real)2.0 * (b.r.y * b.r.z + b.r.w * b.r.x),
                  R22 = (Real)1.0 - (Real)2.0 * (b.r.x * b.r.x + b.r.y * b.r.y);
-      auto depth_of = [&](const vf4 sp) {
-        return (float)((Real)sp.w - (pz + (R20 * (Real)sp.x + R21 * (Real)sp.y + R22 * (Real)sp.z)));
+      // a sphere's operands in the substep's pose type: the widened record's doubles (float32 launches: its float part)
+      struct SphOp { Real x, y, z, r; };
+      auto ld_sph = [&](const SphRec* q) {
+        if constexpr (std::is_same_v<Real, double>) {
+          typedef double vd2 __attribute__((ext_vector_type(2)));
+          const vd2 a = *reinterpret_cast<const vd2*>(q), c = *(reinterpret_cast<const vd2*>(q) + 1);
+          return SphOp{a.x, a.y, c.x, c.y};
+        } else {
+          const vf4 a = ld4(&q->f[0]);
+          return SphOp{a.x, a.y, a.z, a.w};
+        }
       };
+      auto depth_of = [&](const SphOp sp) { return (float)(sp.r - (pz + (R20 * sp.x + R21 * sp.y + R22 * sp.z))); };
       // the impulse of sphere j (ordinal on its link) at penetration `depth`.  ISO (wavefront-uniform: every link of the
       // model has isotropic effective inertia c) folds R diag(c) R^T = c into the formulas:
       //   n . (I^-1 (r x n) x r) = c (r.x^2 + r.y^2),   dir . (I^-1 (r x dir) x r) = c |r x dir|^2
@@ -1409,20 +1430,23 @@ static __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const T
         cdv = cdv + J * inv_m;
         cdw = cdw + cross(r, J) * inv_i0;
       };
-      vf4 nxt = ld4(&ll.sph[0]);
+      // (no software prefetch of the next record: the kernel is bound by instruction issue, not by this load's latency -- the
+      //  other wavefronts of the SIMD fill the wait -- and rotating a prefetched record costs four 64-bit moves per sphere)
       if (all_iso) {  // (wavefront-uniform; two loops: one loop with both bodies copied the accumulators at its joins)
-        for (int j = 0; j < n_sph; ++j) {  // the next sphere's record is in flight while this one is evaluated
-          const vf4 sp = nxt;
-          nxt = ld4(&ll.sph[j + 1]);
+        // the record's doubles -- no conversions -- and the next record loaded into the registers the depth has just released:
+        // no copies (Ant -1.7 % against the float32 record with a rotating prefetch; Humanoid unchanged within its +-0.4 %
+        // run-to-run spread)
+        SphOp sp = ld_sph(&ll.sph[0]);
+        for (int j = 0; j < n_sph; ++j) {
           const float depth = depth_of(sp);
-          if (ballot(depth > 0.0f) != 0ull) respond_iso(sp, depth, j);
+          __builtin_amdgcn_sched_barrier(0);
+          sp = ld_sph(&ll.sph[j + 1]);
+          if (ballot(depth > 0.0f) != 0ull) respond_iso(ld4(&ll.sph[j].f[0]), depth, j);
         }
       } else {
         for (int j = 0; j < n_sph; ++j) {
-          const vf4 sp = nxt;
-          nxt = ld4(&ll.sph[j + 1]);
-          const float depth = depth_of(sp);
-          if (depth > 0.0f) respond(sp, depth, j, std::false_type{});
+          const float depth = depth_of(ld_sph(&ll.sph[j]));
+          if (depth > 0.0f) respond(ld4(&ll.sph[j].f[0]), depth, j, std::false_type{});
         }
       }
     }
@@ -1560,6 +1584,7 @@ static __device__ __forceinline__ void substep_planar(const carl_brax_sys_t& s, 
     // spring.collisions.resolve: this body's spheres vs the plane z = 0
     float cdvx = 0.0f, cdvz = 0.0f, cdw = 0.0f, cnt = 0.0f;
     uint32_t hit = 0u;
+    asm volatile("" : "+v"(cdvx), "+v"(cdvz), "+v"(cdw), "+v"(cnt), "+v"(hit));  // (one definition: substep's note)
     const Real pz = b.p.z - (Real)K.plane_z;
     // Which links can touch the plane at all: the COM lower than the ball that holds every sphere (reach), and lower
     // than the link's box at its present pitch -- |sin| ext.x + |cos| ext.z: a level torso (Halfcheetah's: four
@@ -1575,32 +1600,34 @@ static __device__ __forceinline__ void substep_planar(const carl_brax_sys_t& s, 
       auto depth_of = [&](const vf4 sp) {
         return (float)((Real)sp.w - (pz + (cth * (Real)sp.z - sth * (Real)sp.x)));
       };
+      // straight-line like the general substep's respond_iso: the decisions are selects on the impulse's components, the one
+      // branch left is wavefront-uniform (no sphere of the wavefront penetrates)
       auto respond = [&](const vf4 sp, const float depth, const int j) {
         const float radius = sp.w;
         const float rx = cf * sp.x + sf * sp.z, rz = (cf * sp.z - sf * sp.x) - radius;  // sphere's lowest point - COM
         const float relx = vx + om * rz, relz = vz - om * rx;
         const float vn = relz;
         const float imp = div_fast(-(1.0f + cx.z) * vn + K.erp * depth * inv_dt, inv_m + inv_i * (rx * rx));
-        if (!(imp > 0.0f) || !(vn < 0.0f)) return;
-        hit |= 1u << j;
-        float Jx = 0.0f;
+        const bool fire = depth > 0.0f && imp > 0.0f && vn < 0.0f;
         const float vt_len = fabsf(relx);
-        if (vt_len > 1e-9f) {
-          const float dx = relx > 0.0f ? 1.0f : -1.0f;
-          const float imp_d = fminf(div_fast(vt_len, inv_m + inv_i * (rz * rz)), cx.y * imp);
-          Jx = -dx * imp_d;
-        }
+        const bool slip = fire && vt_len > 1e-9f;
+        const float dx = relx > 0.0f ? 1.0f : -1.0f;
+        const float imp_d = fminf(div_fast(vt_len, inv_m + inv_i * (rz * rz)), cx.y * imp);
+        const float Jx = slip ? -dx * imp_d : 0.0f, Jz = fire ? imp : 0.0f;
+        hit |= fire ? (1u << j) : 0u;
+        cnt += fire ? 1.0f : 0.0f;
         cdvx += Jx * inv_m;
-        cdvz += imp * inv_m;
-        cdw += inv_i * (rz * Jx - rx * imp);  // (r x J).y
-        cnt += 1.0f;
+        cdvz += Jz * inv_m;
+        cdw += inv_i * (rz * Jx - rx * Jz);  // (r x J).y
       };
-      vf4 nxt = ld4(&ll.sph[0]);
-      for (int j = 0; j < n_sph; ++j) {  // the next sphere's record is in flight while this one is evaluated
+      // (the float32 part of the widened record, the next one in flight while this one is evaluated: this short substep is
+      //  not purely issue-bound -- without the prefetch Halfcheetah lost 2 %, measured; the general substep gained 1 %)
+      vf4 nxt = ld4(&ll.sph[0].f[0]);
+      for (int j = 0; j < n_sph; ++j) {
         const vf4 sp = nxt;
-        nxt = ld4(&ll.sph[j + 1]);
+        nxt = ld4(&ll.sph[j + 1].f[0]);
         const float depth = depth_of(sp);
-        if (depth > 0.0f) respond(sp, depth, j);
+        if (ballot(depth > 0.0f) != 0ull) respond(sp, depth, j);
       }
     }
     prof.mark(kProfContacts);
@@ -1641,7 +1668,10 @@ static __device__ __forceinline__ v3d system_com(const carl_brax_sys_t& s, const
 // link per lane; obs_extended (humanoid) appends com inertia (L x 10), com velocity (L x 6) and
 // qfrc_actuator (the tau rows; `zero_frc`: reset observations see a zero action).  `go`: envs
 // that take part (the calls are wavefront-uniform).  Ends with a phase_sync.
-template <bool MULTI, bool TASK>
+// SLIDES: the model may have prismatic dofs.  False for the step kernels of the lean non-planar models (the host sends a
+// model with slides to the multi-hinge or the planar kernels, carl_brax.hip: brax_is_multi): the slide rows and the anchor
+// separation / anchor velocities they alone read are then not in the instruction stream.
+template <bool MULTI, bool TASK, bool SLIDES = true>
 // `com_in` / `mass_in`: the whole-body centre of mass and total mass when the caller has just formed them at this very
 // state (the step's forward reward of reward_on_com models: one 11-link pass less per Humanoid env step).
 static __device__ __forceinline__ void observe(const carl_brax_sys_t& s, const Packed& pk, const Lds& m, bool go,
@@ -1687,7 +1717,7 @@ static __device__ __forceinline__ void observe(const carl_brax_sys_t& s, const P
     } else {
       const Body bp = (P < 0) ? world_body() : m.body(P);
       const ObsGeom g = obs_geometry<MULTI>(pk.a[i], s.dof_sign3[i], b, bp);
-      const int ns = s.n_slide[i];
+      const int ns = SLIDES ? s.n_slide[i] : 0;
       for (int k = 0; k < ns; ++k) {
         const v3 ax = qrot(tof(bp.r), f3(s.slide_axis[i][k]));
         if (s.q_start[i] + k >= skip) m.at(m.lay.io + s.q_start[i] + k - skip) = -dot(g.ed, ax);
@@ -2113,6 +2143,8 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
   __shared__ Topo tp;
   __shared__ Packed pk;
   __shared__ LinkRec jx_lds[CARL_BRAX_MAX_LINKS];
+  __shared__ vf4 dof_act_lds[CARL_BRAX_MAX_DOF];
+  __shared__ SphRec sph_lds[CARL_BRAX_MAX_COLL + 1];
   __shared__ int head_done[kMaxWavesPerWg3];  // fragment hand-over flags (MODE 1, see below)
   if (threadIdx.x < kMaxWavesPerWg3) head_done[threadIdx.x] = 0;
   extern __shared__ vf4 lds_dyn[];  // per wavefront: body records, then the float rows (16-byte aligned slices)
@@ -2148,8 +2180,24 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
   }
   __syncthreads();
   if ((int)threadIdx.x < s.n_links) expand_link(s, pk, (int)threadIdx.x, jx_lds[threadIdx.x]);
+  for (int k = (int)threadIdx.x; k < CARL_BRAX_MAX_COLL + 1; k += (int)blockDim.x) {
+    const int kk = k < CARL_BRAX_MAX_COLL ? k : CARL_BRAX_MAX_COLL - 1;
+    const Sphere sp = pk.sph[kk];
+    SphRec r;
+    r.off[0] = sp.off[0]; r.off[1] = sp.off[1]; r.off[2] = sp.off[2]; r.radius = sp.radius;
+    r.f[0] = sp.off[0]; r.f[1] = sp.off[1]; r.f[2] = sp.off[2]; r.f[3] = sp.radius;
+    sph_lds[k] = r;
+  }
+  if ((int)threadIdx.x < CARL_BRAX_MAX_DOF) {  // dof -> its actuator (gear, control range, index; -1: none), for the step's torque pass
+    const int d = (int)threadIdx.x;
+    int a = -1;
+    for (int k = 0; k < s.n_act; ++k) a = (s.act_dof[k] == d) ? k : a;
+    const int ac = a < 0 ? 0 : a;
+    dof_act_lds[d] = vf4{s.act_gear[ac], s.act_lo[ac], s.act_hi[ac], __int_as_float(a)};
+  }
   __syncthreads();
   const LinkRec* const jx = jx_lds;
+  [[maybe_unused]] const vf4* const dof_act = dof_act_lds;
   // kSub need not divide 64 (one lane per link: 7, 9, 11): the wavefront's spare lanes idle -- they
   // point at the last env's column, own no link (sub beyond every loop bound) and are never active
   const int tid = (int)threadIdx.x & (kLanes - 1), wave = (int)threadIdx.x >> 6;
@@ -2218,6 +2266,7 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
     // boundary is what a launch boundary is -- state record and episode scalars through HBM, pose rounded at every
     // env step -- so results are bit-identical to one launch per group; both wavefronts are in one workgroup,
     // i.e. co-resident on one CU, so the wait cannot deadlock.
+    constexpr bool kSlides = MULTI || PLANAR;  // (observe: a lean non-planar step kernel never sees a prismatic dof)
     const int T = n_steps;
     const int n_groups = ((int)b.n_lanes + kEnvs - 1) / kEnvs;
     const WgShare share = wg_share(n_groups, (int)gridDim.x, (int)blockIdx.x);
@@ -2304,16 +2353,25 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
       } else {
         record_in(static_cast<const float*>(io.action) + step_off * s.n_act, (size_t)env, s.n_act, m, active);
       }
-      // actuator.to_tau: tau = 0, then every actuator adds gear * clip(action) to its dof
+      // the control cost's sum of squares, four actions per round trip (rows past n_act are read -- they exist: the staging
+      // holds at least n_act rows, the index is clamped -- and masked; one LDS round trip per action made this loop
+      // eight dependent waits per Ant env step)
       float ctrl = 0.0f;
-      for (int k = 0; k < s.n_act; ++k) {
-        const float u = m.at(m.lay.io + k);
-        ctrl += u * u;
+      for (int k = 0; k < n_act; k += 4) {
+        float u[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) u[j] = m.at(m.lay.io + min(k + j, n_act - 1));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ctrl += (k + j < n_act) ? u[j] * u[j] : 0.0f;
       }
-      for (int d = m.sub; d < s.n_dof; d += kSub) m.at(m.lay.tau + d) = 0.0f;
-      phase_sync();
-      for (int k = m.sub; k < s.n_act; k += kSub)  // act_dof entries are distinct (checked by the host)
-        m.at(m.lay.tau + s.act_dof[k]) += s.act_gear[k] * fminf(fmaxf(m.at(m.lay.io + k), s.act_lo[k]), s.act_hi[k]);
+      // actuator.to_tau: every dof's torque in ONE pass from the dof -> actuator table (act_dof entries are distinct, checked
+      // by the host: a dof has at most one actuator) -- tau = gear * clip(action), 0 for a dof without an actuator.  (Until
+      // round 6: zero the rows, hand over, every actuator adds to its dof, hand over.)
+      for (int d = m.sub; d < s.n_dof; d += kSub) {
+        const vf4 da = dof_act[d];  // gear, lo, hi, actuator (int bits; -1: none)
+        const int a = __float_as_int(da.w);
+        m.at(m.lay.tau + d) = a >= 0 ? da.x * fminf(fmaxf(m.at(m.lay.io + max(a, 0)), da.y), da.z) : 0.0f;
+      }
       phase_sync();
       float msum;
       // forward progress and root height: pose differences, float64
@@ -2329,7 +2387,7 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
         // have none to spare (a scratch reload there waits for every store of the step before it).
         Lds ms = m;
         asm volatile("" : "+v"(ms.sub), "+v"(ms.env));
-        const LaneLink ll = make_lane_link(pk, jx, K, ms);
+        const LaneLink ll = make_lane_link(pk, jx, sph_lds, K, ms);
         using Real = std::conditional_t<F32, float, double>;
         StepRegs<MULTI, Real> R;
         if constexpr (F32) {
@@ -2391,7 +2449,7 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
         io.branch_sig[(step_off + env) * 2 + 1] = hl;
       }
       prof.mark(kProfEpilogue);
-      observe<MULTI, TASK>(s, pk, m, active, false, s.reward_on_com ? &com1 : nullptr, msum);
+      observe<MULTI, TASK, kSlides>(s, pk, m, active, false, s.reward_on_com ? &com1 : nullptr, msum);
       prof.mark(kProfObserve);
       stash_get(m, r);
       r.elapsed += 1;
@@ -2489,7 +2547,7 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
             write_ctx_obs(b, m, n, env, r.cidx);
           }
           }
-          observe<MULTI, TASK>(s, pk, m, done, true);
+          observe<MULTI, TASK, kSlides>(s, pk, m, done, true);
         }
       }
       prof.mark(kProfDone);

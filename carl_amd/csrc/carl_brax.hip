@@ -214,7 +214,9 @@ int launch_brax(const carl_batch_t* b, const carl_brax_sys_t* sd, const carl_bra
   // independent wavefronts per workgroup, sharing the LDS copy of the static tables: as many (<= kMaxWavesPerWg) as fit
   // (the kernel's static LDS: model table, prepared topology / records, the fragment hand-over flags)
   const size_t static_lds = sizeof(carl_brax_sys_t) + sizeof(carl::brax::Prepared) +
-                            (size_t)carl::brax::kLinkRecBytes * CARL_BRAX_MAX_LINKS + sizeof(int) * carl::brax::kMaxWavesPerWg3;
+                            (size_t)carl::brax::kLinkRecBytes * CARL_BRAX_MAX_LINKS + 16 * CARL_BRAX_MAX_DOF +
+                            (size_t)carl::brax::kSphRecBytes * (CARL_BRAX_MAX_COLL + 1) +
+                            sizeof(int) * carl::brax::kMaxWavesPerWg3;
   const size_t wave_bytes = lay.bytes(envs);
   if (wave_bytes + static_lds > 160 * 1024)
     return fail(CARL_ERR_UNSUPPORTED, "%s: model needs %zu B of LDS per wavefront", who, wave_bytes);
