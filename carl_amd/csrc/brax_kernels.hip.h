@@ -59,7 +59,7 @@ constexpr int kMaxThreads = kLanes * kMaxWavesPerWg;
 // 12 wavefronts -- what the balanced fragment schedule of a large batch wants (run(): the fewer, larger workgroups
 // the groups are dealt to, the smaller the rounding loss between workgroups).
 constexpr int kMaxWavesPerWg3 = 12;
-__host__ __device__ constexpr int max_waves_per_wg(bool multi) { return multi ? kMaxWavesPerWg : kMaxWavesPerWg3; }
+__host__ __device__ constexpr int max_waves_per_wg(bool task) { return task ? kMaxWavesPerWg : kMaxWavesPerWg3; }
 // Register budget.  Single-hinge models (MULTI = false: Ant, Halfcheetah, Hopper, Walker2d): THREE wavefronts per SIMD
 // (168 VGPRs) -- the kernel is bound by the latency of its own dependent chains (one -> two wavefronts per SIMD: 1.7 x),
 // the hot substep loop fits 168 registers without a spill (ISA checked) and what spills (62 dwords) sits in observe and
@@ -67,11 +67,17 @@ __host__ __device__ constexpr int max_waves_per_wg(bool multi) { return multi ? 
 // reset_state / forward_kinematics as non-inlined calls the 168-register Ant build faulted on the device
 // (HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION in the spilled call path).  Multi-hinge / task models (Humanoid, ...):
 // two wavefronts (256 VGPRs; they are LDS-bound at 2.5 and lose 4-28 % at 168 / 128).  profiles/r03_brax_occupancy.txt.
-#ifndef CARL_BRAX_WAVES_PER_EU_F32  // the float32-substep kernels (CARL_FLAG_BRAX_FP32) need fewer registers
-#define CARL_BRAX_WAVES_PER_EU_F32(MULTI) ((MULTI) ? 2 : 3)
+// Since late round 6 the multi-hinge kernels run three wavefronts per SIMD too: with the anisotropic-inertia code gone from
+// them (general kernels only) their substep loop fits 168 registers without a spill (ISA checked: 336 B of scratch, all of
+// it in the per-step code), and with the reaction records overlaying the observation staging (Layout::make) twelve
+// Humanoid wavefronts fit a compute unit's LDS: Humanoid 2.565 -> see DESIGN 5.2.  NINE wavefronts per compute unit (what
+// the LDS allowed before the overlay) were 8 % SLOWER than eight: the SIMD that holds three of them finishes its equal
+// share of the groups last.  The general (TASK) kernels keep two wavefronts per SIMD (256 registers).
+#ifndef CARL_BRAX_WAVES_PER_EU_F32  // the float32-substep kernels (CARL_FLAG_BRAX_FP32; never a general kernel)
+#define CARL_BRAX_WAVES_PER_EU_F32(TASK) 3
 #endif
 #ifndef CARL_BRAX_WAVES_PER_EU
-#define CARL_BRAX_WAVES_PER_EU(MULTI) ((MULTI) ? 2 : 3)
+#define CARL_BRAX_WAVES_PER_EU(TASK) ((TASK) ? 2 : 3)
 #endif
 #ifndef CARL_BRAX_RESET_INLINE
 #define CARL_BRAX_RESET_INLINE __forceinline__
@@ -324,17 +330,38 @@ struct Layout {
   int tau;     // n_dof rows
   int io;      // staging of the env's action / observation record, and of (q, qd) in reset
   int total;   // float rows
-  __host__ __device__ static Layout make(int L, int n_dof, int io_rows) {
+  // `overlay_at` >= 0: the reaction records OVERLAY the staging rows from row `overlay_at` (rounded up to a multiple of 4: the
+  // records are read in 16-byte pieces) instead of having rows of their own.  The two are never alive together where the
+  // caller allows it (layout_of below): the staging holds the actions before the substeps (rows [0, n_act)), (q, qd) during
+  // a reset's kinematics (rows [0, n_q + n_dof)) and the observation after the substeps; the records live through the
+  // substeps, and as the kinematics' scratch during a reset.  For the extended observation of the Humanoid models (244 rows
+  // against 47 of (q, qd)) that is 144 rows = 2.9 KB less per wavefront: twelve wavefronts fit a compute unit's LDS instead
+  // of eight.
+  __host__ __device__ static Layout make(int L, int n_dof, int io_rows, int overlay_at = -1) {
     Layout l;
     l.L = L;
-    l.wrench = 0;
-    l.mass = l.wrench + 12 * (L + 1);
-    l.sig = l.mass + L;
-    l.goal = l.sig + 2 * L;
-    l.stash = l.goal + 3;
-    l.tau = l.stash + kStashRows;
-    l.io = l.tau + n_dof;
-    l.total = l.io + io_rows;
+    const int wr = 12 * (L + 1);
+    int shared;  // rows of the staging / record region
+    if (overlay_at >= 0) {
+      l.io = 0;
+      l.wrench = (overlay_at + 3) & ~3;
+      shared = io_rows > l.wrench + wr ? io_rows : l.wrench + wr;
+      l.mass = shared;
+      l.sig = l.mass + L;
+      l.goal = l.sig + 2 * L;
+      l.stash = l.goal + 3;
+      l.tau = l.stash + kStashRows;
+      l.total = l.tau + n_dof;
+    } else {
+      l.wrench = 0;
+      l.mass = l.wrench + wr;
+      l.sig = l.mass + L;
+      l.goal = l.sig + 2 * L;
+      l.stash = l.goal + 3;
+      l.tau = l.stash + kStashRows;
+      l.io = l.tau + n_dof;
+      l.total = l.io + io_rows;
+    }
     return l;
   }
   // bytes of dynamic LDS for `envs` envs per workgroup
@@ -356,6 +383,15 @@ __host__ __device__ inline int io_rows_of(const carl_brax_sys_t& s) {
   const int qrows = s.n_q + s.n_dof;
   int r = s.obs_dim > qrows ? s.obs_dim : qrows;
   return r > s.n_act ? r : s.n_act;
+}
+
+// The LDS layout of a model's wavefront slice (kernel and host).  The records overlay the staging rows where nothing else
+// uses the record rows as scratch while the observation is being laid out: not the tip models (observe parks the unclipped
+// rates there), not the reach / push task models (they park and re-order rows there) -- i.e. for the extended observation
+// (the only staging much larger than (q, qd) anyway).
+__host__ __device__ inline Layout layout_of(const carl_brax_sys_t& s) {
+  const bool overlay = s.obs_extended != 0 && s.tip_link <= 0 && s.target_link <= 0 && s.push_link <= 0;
+  return Layout::make(s.n_links, s.n_dof, io_rows_of(s), overlay ? s.n_q + s.n_dof : -1);
 }
 
 // tree topology derived from the model table once per workgroup
@@ -632,7 +668,9 @@ struct Lds {
     *reinterpret_cast<vf4*>(q + 64) = vf4{b.v.z, b.w.x, b.w.y, b.w.z};
   }
   // reaction records (kReactBytes; byte offsets from the float rows)
-  __device__ __forceinline__ int react_off(int i) const { return (env * (lay.L + 1) + i) * kReactBytes; }
+  __device__ __forceinline__ int react_off(int i) const {
+    return (env * (lay.L + 1) + i) * kReactBytes + lay.wrench * kEnvs * 4;  // (the record region starts at row lay.wrench)
+  }
   // the env's context record (Layout): just below the float rows
   __device__ __forceinline__ const float* ctx_rec() const {
     return reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) - (kEnvs - env) * kCtxRecBytes);
@@ -2202,7 +2240,7 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
   // point at the last env's column, own no link (sub beyond every loop bound) and are never active
   const int tid = (int)threadIdx.x & (kLanes - 1), wave = (int)threadIdx.x >> 6;
   const bool lane_ok = tid < kEnvs * kSub;
-  const Layout lay = Layout::make(s.n_links, s.n_dof, io_rows_of(s));
+  const Layout lay = layout_of(s);
   char* const my_lds = reinterpret_cast<char*>(lds_dyn) + (size_t)wave * lay.bytes(kEnvs);  // this wavefront's slice
   const Lds m{my_lds, reinterpret_cast<float*>(my_lds + lay.rows_offset(kEnvs)), lay,
               lane_ok ? tid / kSub : kEnvs - 1, lane_ok ? tid % kSub : kLanes};
@@ -2590,7 +2628,7 @@ static __device__ __forceinline__ void run(const carl_batch_t& b, const carl_bra
 // so TASK implies MULTI.
 // PLANAR: substep_planar (step / rollout of a planar single-hinge model; the host checks the model, carl_brax.hip).
 template <int MODE, bool MULTI, int K, bool TASK = false, bool PLANAR = false, bool F32 = false>
-__global__ void __launch_bounds__(kLanes * max_waves_per_wg(MULTI)) __attribute__((amdgpu_waves_per_eu(F32 ? CARL_BRAX_WAVES_PER_EU_F32(MULTI) : CARL_BRAX_WAVES_PER_EU(MULTI)))) brax_kernel(const carl_batch_t b, const carl_brax_sys_t* __restrict__ sys_dev,
+__global__ void __launch_bounds__(kLanes * max_waves_per_wg(TASK)) __attribute__((amdgpu_waves_per_eu(F32 ? CARL_BRAX_WAVES_PER_EU_F32(TASK) : CARL_BRAX_WAVES_PER_EU(TASK)))) brax_kernel(const carl_batch_t b, const carl_brax_sys_t* __restrict__ sys_dev,
                                                       const Prepared prep, const carl_step_io_t io,
                                                       const uint8_t* __restrict__ mask, float* __restrict__ reset_obs,
                                                       const int n_steps) {

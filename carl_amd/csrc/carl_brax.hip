@@ -210,7 +210,7 @@ int launch_brax(const carl_batch_t* b, const carl_brax_sys_t* sd, const carl_bra
   const bool multi = brax_is_multi(sh) || (MODE == 1 && planar_model && !planar);
   const int K = brax_lanes_per_env(sh->n_links, multi, task, b->n_lanes, sh->lanes_per_env);
   const int envs = carl::brax::kLanes / K;  // one wavefront = envs x K lanes; LDS rows are `envs` floats wide
-  const carl::brax::Layout lay = carl::brax::Layout::make(sh->n_links, sh->n_dof, carl::brax::io_rows_of(*sh));
+  const carl::brax::Layout lay = carl::brax::layout_of(*sh);
   // independent wavefronts per workgroup, sharing the LDS copy of the static tables: as many (<= kMaxWavesPerWg) as fit
   // (the kernel's static LDS: model table, prepared topology / records, the fragment hand-over flags)
   const size_t static_lds = sizeof(carl_brax_sys_t) + sizeof(carl::brax::Prepared) +
@@ -235,7 +235,7 @@ int launch_brax(const carl_batch_t* b, const carl_brax_sys_t* sd, const carl_bra
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
       n_cu = v;
   }
-  const int max_w = carl::brax::max_waves_per_wg(multi);
+  const int max_w = carl::brax::max_waves_per_wg(task);
   const int n_groups = (b->n_lanes + envs - 1) / envs;
   int per_cu_of[16] = {0};
   int W = 1, best = 0;
@@ -244,8 +244,8 @@ int launch_brax(const carl_batch_t* b, const carl_brax_sys_t* sd, const carl_bra
     if (wg > 160 * 1024) break;
     if (w > 1 && (long long)(w - 1) * envs >= b->n_lanes) break;  // a small batch: no empty wavefronts
     int per_cu = (int)((160 * 1024) / wg) * w;                     // resident wavefronts per CU, LDS-wise
-    const int waves_per_eu = (MODE == 1 && (b->flags & CARL_FLAG_BRAX_FP32)) ? CARL_BRAX_WAVES_PER_EU_F32(multi)
-                                                                              : CARL_BRAX_WAVES_PER_EU(multi);
+    const int waves_per_eu = (MODE == 1 && (b->flags & CARL_FLAG_BRAX_FP32)) ? CARL_BRAX_WAVES_PER_EU_F32(task)
+                                                                              : CARL_BRAX_WAVES_PER_EU(task);
     if (per_cu > 4 * waves_per_eu) per_cu = 4 * waves_per_eu;
     per_cu -= per_cu % w;  // whole workgroups
     per_cu_of[w] = per_cu;
