@@ -1459,14 +1459,19 @@ static __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const T
         const bool fire = depth > 0.0f && imp > 0.0f && vn < 0.0f;
         const float vt_len = __builtin_amdgcn_sqrtf(rel.x * rel.x + rel.y * rel.y);
         const bool slip = fire && vt_len > 1e-9f;
-        const float il = __builtin_amdgcn_rcpf(vt_len), dx = rel.x * il, dy = rel.y * il;
+        // (a lane that does not slide gets the zero direction: its tangential impulse is then an exact zero without a select
+        //  per component; every other factor below is finite)
+        const float il = slip ? __builtin_amdgcn_rcpf(vt_len) : 0.0f, dx = rel.x * il, dy = rel.y * il;
         const v3 rxd = V(-r.z * dy, r.z * dx, r.x * dy - r.y * dx);  // r x dir
         const float imp_d = fminf(div_fast(vt_len, inv_m + inv_i0 * dot(rxd, rxd)), cx.y * imp);
-        const v3 J = V(slip ? -dx * imp_d : 0.0f, slip ? -dy * imp_d : 0.0f, fire ? imp : 0.0f);
-        hit |= fire ? (1u << j) : 0u;
-        cnt += fire ? 1.0f : 0.0f;
+        const v3 J = V(-dx * imp_d, -dy * imp_d, fire ? imp : 0.0f);
+        hit |= (uint32_t)fire << j;  // (the count of the impulses is the population count of these bits: below the loop)
         cdv = cdv + J * inv_m;
-        cdw = cdw + cross(r, J) * inv_i0;
+        // r x J accumulated as is, scaled by 1 / I once below the loop (the impulse runs ~2.5 times per Ant substep: every
+        // instruction in it is 0.4 % of the launch)
+        cdw.x = fmaf(r.y, J.z, cdw.x); cdw.x = fmaf(-r.z, J.y, cdw.x);
+        cdw.y = fmaf(r.z, J.x, cdw.y); cdw.y = fmaf(-r.x, J.z, cdw.y);
+        cdw.z = fmaf(r.x, J.y, cdw.z); cdw.z = fmaf(-r.y, J.x, cdw.z);
       };
       // (no software prefetch of the next record: the kernel is bound by instruction issue, not by this load's latency -- the
       //  other wavefronts of the SIMD fill the wait -- and rotating a prefetched record costs four 64-bit moves per sphere)
@@ -1481,6 +1486,8 @@ static __device__ __forceinline__ void substep(const carl_brax_sys_t& s, const T
           sp = ld_sph(&ll.sph[j + 1]);
           if (ballot(depth > 0.0f) != 0ull) respond_iso(ld4(&ll.sph[j].f[0]), depth, j);
         }
+        cnt = (float)__popc(hit);
+        cdw = cdw * inv_i0;
       } else {
         for (int j = 0; j < n_sph; ++j) {
           const float depth = depth_of(ld_sph(&ll.sph[j]));

@@ -364,7 +364,11 @@ typedef struct carl_brax_sys {
   float joint_pos[CARL_BRAX_MAX_LINKS][3], joint_rot[CARL_BRAX_MAX_LINKS][4]; /* anchor / joint frame in the child frame */
   float com[CARL_BRAX_MAX_LINKS][3];        /* centre of mass in the link frame */
   float mass[CARL_BRAX_MAX_LINKS];          /* effective (spring_mass_scale applied) */
-  float inv_inertia[CARL_BRAX_MAX_LINKS][3];/* effective inverse principal moments, link frame */
+  float inv_inertia[CARL_BRAX_MAX_LINKS][3];/* effective inverse principal moments, link frame.  Every shipped model is
+                                             * isotropic ([0] == [1] == [2]: brax's spring_inertia_scale = 1); a model with a
+                                             * link whose three moments differ is stepped by the general kernels (the ones
+                                             * the reach / push task models take: 4, 8 or 16 lanes per env), the only ones
+                                             * that carry R diag(inv_inertia) R^T -- same results, lower throughput */
   float k_pos[CARL_BRAX_MAX_LINKS], k_vel[CARL_BRAX_MAX_LINKS];        /* constraint_stiffness / _vel_damping */
   float k_limit[CARL_BRAX_MAX_LINKS], k_ang_damp[CARL_BRAX_MAX_LINKS]; /* constraint_limit_stiffness / _ang_damping */
   float dof_lo[CARL_BRAX_MAX_DOF], dof_hi[CARL_BRAX_MAX_DOF];
