@@ -8,10 +8,11 @@
 Workload: north_star's target -- CARLCartPole with 65 536 sampled contexts (gravity, length, masspole;
 carl/envs/gymnasium/classic_control/carl_cartpole.py:11-66), lane i <-> context i (StaticSelector), auto-reset on,
 synthetic actions resident in HBM.  BASELINE.json configs[1] (CARLPendulum x 65 536 over g / l) and configs 3-5
-follow under `also`.  With N GPUs every GPU steps its own 65 536 contexts (weak scaling: lanes are independent units
-sharded over the ranks with no data-path collective -- `value` is the whole-node aggregate); the same JSON line
-carries the strong-scaling run (the letter of "at 65k parallel contexts": 65 536 contexts SPLIT over the node) under
-`strong`.  `--strong` swaps the two.
+follow under `also`.  With N GPUs the 65 536 contexts are SPLIT over the node (strong scaling -- the letter of "at 65k
+parallel contexts (whole node)"): lanes are independent units sharded over the ranks by contiguous global-id
+ranges with no data-path collective, `value` is the whole-node aggregate; the same JSON line carries the weak-scaling
+run (every GPU steps its own 65 536 contexts -- the operating point the engine is built for) under `weak`.  `--weak`
+swaps the two.
 
 One "step" of this benchmark = ONE PASS of the hot path over one batch of synthetic input:
 one fused `carl_rollout` launch that advances every lane by `--chunk` (1 000: SURVEY.md 8d's K) env steps and
