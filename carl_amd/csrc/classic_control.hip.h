@@ -246,6 +246,37 @@ struct SinCosTab {
     const vd2* g = reinterpret_cast<const vd2*>(kSinCosTab);
     for (int i = threadIdx.x; i < CARL_SINCOS_TAB_N; i += blockDim.x) t[i] = g[i];
   }
+  // The same evaluation in two halves (Acrobot's RK4: the lookups of stage n + 1 are issued BEFORE stage n's algebra, the
+  // polynomials and the combination follow it -- same operations, same values as sincos2).
+  struct Pending {
+    vd2 ea, eb;
+    double ra, rb;
+  };
+  __device__ static __forceinline__ Pending lookup2(double xa, double xb) {
+    const vd2* t = lds();
+    const double inv = CARL_SINCOS_TAB_INV_STEP, hi = CARL_SINCOS_TAB_STEP_HI;
+    const double magic = 0x1.8p52;
+    const double ta = fma(xa, inv, magic), tb = fma(xb, inv, magic);
+    const double ka = ta - magic, kb = tb - magic;
+    Pending q;
+    q.ea = t[__double2loint(ta) & (CARL_SINCOS_TAB_N - 1)];
+    q.eb = t[__double2loint(tb) & (CARL_SINCOS_TAB_N - 1)];
+    q.ra = fma(ka, -hi, xa);
+    q.rb = fma(kb, -hi, xb);
+    return q;
+  }
+  __device__ static __forceinline__ void finish2(const Pending& q, double& sna, double& csa, double& snb, double& csb) {
+    const double ra = q.ra, rb = q.rb;
+    const double za = ra * ra, zb = rb * rb;
+    const double sra = fma(ra * za, -1.0 / 6.0, ra);
+    const double srb = fma(rb * zb, -1.0 / 6.0, rb);
+    const double cra = fma(za, -0.5, 1.0);
+    const double crb = fma(zb, -0.5, 1.0);
+    sna = fma(q.ea.x, cra, q.ea.y * sra);
+    csa = fma(q.ea.y, cra, -(q.ea.x * sra));
+    snb = fma(q.eb.x, crb, q.eb.y * srb);
+    csb = fma(q.eb.y, crb, -(q.eb.x * srb));
+  }
   // two angles at once (an RK4 stage): both table reads are issued before the polynomials
   __device__ static __forceinline__ void sincos2(double xa, double xb, double& sna, double& csa, double& snb,
                                                  double& csb) {
@@ -453,24 +484,55 @@ struct AcrobotT {
     const Real dt = (Real)0.2, dt2 = dt / (Real)2.0;
     const Real a = (Real)((float)(action - 1) + noise);
     const Real y0 = s[0], y1 = s[1], y2 = s[2], y3 = s[3];
-    // first stage at the stored state: its trig was carried over from the previous step / reset
-    const Deriv k1 = dsdt_trig(p, aux.ks0, aux.kc0, aux.ks1, aux.kc1, y2, y3, a);
-    const Deriv k2 = dsdt(p, y0 + dt2 * k1.d0, y1 + dt2 * k1.d1, y2 + dt2 * k1.d2, y3 + dt2 * k1.d3, a);
-    const Deriv k3 = dsdt(p, y0 + dt2 * k2.d0, y1 + dt2 * k2.d1, y2 + dt2 * k2.d2, y3 + dt2 * k2.d3, a);
-    const Deriv k4 = dsdt(p, y0 + dt * k3.d0, y1 + dt * k3.d1, y2 + dt * k3.d2, y3 + dt * k3.d3, a);
+    // first stage at the stored state: its trig was carried over from the previous step / reset.
+    // A stage's ANGLES are the previous stage's velocities integrated -- (d0, d1) of a Deriv are its input velocities, not
+    // its accelerations -- so the angles of stage n + 1 are known as soon as stage n - 1's accelerations are: stage 2's at
+    // the step's start, stage 3's after stage 1's algebra, stage 4's after stage 2's.  Each stage's table lookups and
+    // sin / cos are therefore written BEFORE the preceding stage's algebra (same expressions, same values): the LDS reads
+    // are in flight and the independent float64 chain is there to issue while v_rcp_f64 and the reads complete -- a
+    // lone wavefront per SIMD (65 536 lanes) has nothing else to hide them behind.
+    Real s1b, c1b, s2b, c2b, s1c, c1c, s2c, c2c, s1d, c1d, s2d, c2d;
+    Deriv k1, k2, k3;
+    if constexpr (std::is_same_v<Real, double>) {
+      // (the table form in its two halves: lookups, THEN the preceding stage's algebra, then polynomials + combination)
+      const SinCosTab::Pending qb = SinCosTab::lookup2(y0 + dt2 * y2, y1 + dt2 * y3);  // stage 2: k1.d0 = y2, k1.d1 = y3
+      __builtin_amdgcn_sched_barrier(0);
+      k1 = dsdt_trig(p, aux.ks0, aux.kc0, aux.ks1, aux.kc1, y2, y3, a);
+      SinCosTab::finish2(qb, s1b, c1b, s2b, c2b);
+    } else {
+      sincos_pair(y0 + dt2 * y2, y1 + dt2 * y3, s1b, c1b, s2b, c2b);
+      k1 = dsdt_trig(p, aux.ks0, aux.kc0, aux.ks1, aux.kc1, y2, y3, a);
+    }
+    const Real w1b = y2 + dt2 * k1.d2, w2b = y3 + dt2 * k1.d3;  // stage 2's velocities = k2.d0, k2.d1
+    if constexpr (std::is_same_v<Real, double>) {
+      const SinCosTab::Pending qc = SinCosTab::lookup2(y0 + dt2 * w1b, y1 + dt2 * w2b);  // stage 3
+      __builtin_amdgcn_sched_barrier(0);
+      k2 = dsdt_trig(p, s1b, c1b, s2b, c2b, w1b, w2b, a);
+      SinCosTab::finish2(qc, s1c, c1c, s2c, c2c);
+    } else {
+      sincos_pair(y0 + dt2 * w1b, y1 + dt2 * w2b, s1c, c1c, s2c, c2c);
+      k2 = dsdt_trig(p, s1b, c1b, s2b, c2b, w1b, w2b, a);
+    }
+    const Real w1c = y2 + dt2 * k2.d2, w2c = y3 + dt2 * k2.d3;  // = k3.d0, k3.d1
+    if constexpr (std::is_same_v<Real, double>) {
+      const SinCosTab::Pending qd = SinCosTab::lookup2(y0 + dt * w1c, y1 + dt * w2c);  // stage 4
+      __builtin_amdgcn_sched_barrier(0);
+      k3 = dsdt_trig(p, s1c, c1c, s2c, c2c, w1c, w2c, a);
+      SinCosTab::finish2(qd, s1d, c1d, s2d, c2d);
+    } else {
+      sincos_pair(y0 + dt * w1c, y1 + dt * w2c, s1d, c1d, s2d, c2d);
+      k3 = dsdt_trig(p, s1c, c1c, s2c, c2c, w1c, w2c, a);
+    }
+    const Real w1d = y2 + dt * k3.d2, w2d = y3 + dt * k3.d3;  // stage 4's velocities = k4.d0, k4.d1
+    // The NEW ANGLES need stage 4's velocities only (k4.d0 = w1d, k4.d1 = w2d), not its accelerations: they are formed,
+    // wrapped and rounded BEFORE stage 4's algebra, and the step's one trig evaluation at the stored angles (below) has its
+    // lookups in flight through that algebra.
     const Real two = (Real)2.0, six = (Real)6.0;
-    Real n0 = y0 + dt / six * (k1.d0 + two * k2.d0 + two * k3.d0 + k4.d0);
-    Real n1 = y1 + dt / six * (k1.d1 + two * k2.d1 + two * k3.d1 + k4.d1);
-    Real n2 = y2 + dt / six * (k1.d2 + two * k2.d2 + two * k3.d2 + k4.d2);
-    Real n3 = y3 + dt / six * (k1.d3 + two * k2.d3 + two * k3.d3 + k4.d3);
+    Real n0 = y0 + dt / six * (k1.d0 + two * k2.d0 + two * k3.d0 + w1d);
+    Real n1 = y1 + dt / six * (k1.d1 + two * k2.d1 + two * k3.d1 + w2d);
     wrap_pair(n0, n1);
-    // bound(x, m, M) = min(max(x, m), M)
-    n2 = fmin(fmax(n2, -p.max_vel_1), p.max_vel_1);
-    n3 = fmin(fmax(n3, -p.max_vel_2), p.max_vel_2);
     s[0] = (float)n0;
     s[1] = (float)n1;
-    s[2] = (float)n2;
-    s[3] = (float)n3;
     // One trig evaluation per step, at the STORED (float32) angles: it is exactly what the next step's first RK4 stage
     // needs, and it serves _terminal (-cos t1 - cos(t1 + t2) > 1, cos(t1 + t2) = c0 c1 - s0 s1) and the observation
     // as well -- the reference takes those from its unrounded float64 state, 2e-7 away at most (the float32 rounding
@@ -478,7 +540,23 @@ struct AcrobotT {
     // within 2e-7 of the threshold.  (Round 4 evaluated the unrounded angles and corrected to the stored ones with
     // sin(x + d) = sin x + d cos x: ten float64 instructions more per step on a vector-ALU-bound kernel.)
     Real s0r, c0r, s1r, c1r;
-    sincos_pair((Real)s[0], (Real)s[1], s0r, c0r, s1r, c1r);
+    Deriv k4;
+    if constexpr (std::is_same_v<Real, double>) {
+      const SinCosTab::Pending qe = SinCosTab::lookup2((Real)s[0], (Real)s[1]);
+      __builtin_amdgcn_sched_barrier(0);
+      k4 = dsdt_trig(p, s1d, c1d, s2d, c2d, w1d, w2d, a);
+      SinCosTab::finish2(qe, s0r, c0r, s1r, c1r);
+    } else {
+      k4 = dsdt_trig(p, s1d, c1d, s2d, c2d, w1d, w2d, a);
+      sincos_pair((Real)s[0], (Real)s[1], s0r, c0r, s1r, c1r);
+    }
+    Real n2 = y2 + dt / six * (k1.d2 + two * k2.d2 + two * k3.d2 + k4.d2);
+    Real n3 = y3 + dt / six * (k1.d3 + two * k2.d3 + two * k3.d3 + k4.d3);
+    // bound(x, m, M) = min(max(x, m), M)
+    n2 = fmin(fmax(n2, -p.max_vel_1), p.max_vel_1);
+    n3 = fmin(fmax(n3, -p.max_vel_2), p.max_vel_2);
+    s[2] = (float)n2;
+    s[3] = (float)n3;
     const bool terminated = (-c0r - (c0r * c1r - s0r * s1r)) > (Real)1.0;
     aux = Aux{(float)c0r, (float)s0r, (float)c1r, (float)s1r, s0r, c0r, s1r, c1r};
     reward = terminated ? 0.0f : -1.0f;
