@@ -226,11 +226,14 @@ struct Pendulum {
 // 512-entry table of correctly rounded doubles (8 KiB of LDS, staged once per workgroup from a constant array;
 // generated by tools/gen_sincos_table.py), sin r and cos r need two terms each, and
 //   sin x = S cos r + C sin r,   cos x = C cos r - S sin r
-// -- 12 vector instructions + the table read, no quadrant logic; max error < 6e-11 (tests/test_sincos_table.py: table
-// entries against mpmath, the formula against long-double libm over +-40 rad).  Round 4 traded 3e-16 for 6e-11 -- five
-// orders below the 1e-5 parity bar; the float32 state the step ends in is rounded at 6e-8 -- to take 5 of the 19
-// instructions out of each of the step's eight evaluations (magic-number rounding, one-term reduction, sin r without its
-// r^5 term, cos r without its r^4 term): Acrobot is vector-ALU-bound.
+// -- 13 vector instructions + the table read, no quadrant logic; max error < 1e-13 (tests/test_sincos_table.py: table
+// entries against mpmath, the formula against long-double libm over +-40 rad).  Round 4 shortened the evaluation (magic-number
+// rounding, one-term reduction, sin r without its r^5 term, cos r without its r^4 term: 6e-11) because Acrobot is
+// vector-ALU-bound.  Round 6 took the cosine's r^4 / 24 term BACK (one fma per angle): inside the reference's
+// declared context bounds (link masses / lengths / MOI x 3, MAX_VEL x 3, velocities up to those bounds) a transition
+// amplifies an error of its stage trig by up to 1e8, and 6e-11 put 265 of 131 072 such rows outside the 1e-5 bar (worst
+// 0.11; tools/fuzz_wide_contexts.py); with 7e-14 (the sine's dropped r^5 / 120) 5 are left, 4 of them rows
+// whose float64 ORACLE moves by more than 1e-7 when its input moves by 1e-15.
 #include "sincos_table.inc"
 __device__ const double kSinCosTab[2 * CARL_SINCOS_TAB_N] = {CARL_SINCOS_TAB_VALUES};
 
@@ -270,8 +273,8 @@ struct SinCosTab {
     const double za = ra * ra, zb = rb * rb;
     const double sra = fma(ra * za, -1.0 / 6.0, ra);
     const double srb = fma(rb * zb, -1.0 / 6.0, rb);
-    const double cra = fma(za, -0.5, 1.0);
-    const double crb = fma(zb, -0.5, 1.0);
+    const double cra = fma(za, fma(za, 1.0 / 24.0, -0.5), 1.0);
+    const double crb = fma(zb, fma(zb, 1.0 / 24.0, -0.5), 1.0);
     sna = fma(q.ea.x, cra, q.ea.y * sra);
     csa = fma(q.ea.y, cra, -(q.ea.x * sra));
     snb = fma(q.eb.x, crb, q.eb.y * srb);
@@ -291,11 +294,11 @@ struct SinCosTab {
     // r = x - k * step with step = hi alone: the dropped k * lo is < 2e-15 for |x| <= 40 rad (lo = 4.8e-19)
     const double ra = fma(ka, -hi, xa), rb = fma(kb, -hi, xb);
     const double za = ra * ra, zb = rb * rb;
-    // sin r = r - r z / 6 (dropped r^5 / 120 <= 7.3e-14 at |r| <= pi / 512), cos r = 1 - z / 2 (dropped z^2 / 24 <= 5.9e-11)
+    // sin r = r - r z / 6 (dropped r^5 / 120 <= 7.3e-14 at |r| <= pi / 512), cos r = 1 - z / 2 + z^2 / 24 (dropped z^3 / 720 <= 7e-17)
     const double sra = fma(ra * za, -1.0 / 6.0, ra);
     const double srb = fma(rb * zb, -1.0 / 6.0, rb);
-    const double cra = fma(za, -0.5, 1.0);
-    const double crb = fma(zb, -0.5, 1.0);
+    const double cra = fma(za, fma(za, 1.0 / 24.0, -0.5), 1.0);
+    const double crb = fma(zb, fma(zb, 1.0 / 24.0, -0.5), 1.0);
     sna = fma(ea.x, cra, ea.y * sra);
     csa = fma(ea.y, cra, -(ea.x * sra));
     snb = fma(eb.x, crb, eb.y * srb);

@@ -75,7 +75,7 @@ enum {
                                        fp64 (faster; up to ~1e-3 relative error on
                                        states near the velocity bounds).  Without the flag the step is float64
                                        ARITHMETIC, not a float64 reference: sin / cos come from a 512-entry table with a
-                                       short correction (6e-11), 1 / det from v_rcp_f64 + one Newton step (4e-15), the
+                                       short correction (7e-14), 1 / det from v_rcp_f64 + one Newton step (4e-15), the
                                        angle wrap is x - rint(x / 2 pi) 2 pi (the reference's strict > pi / < -pi
                                        compares differ for the doubles within one ulp of +-pi), the state is stored as
                                        float32 and the observation / _terminal trig is taken at the STORED angles

@@ -1,0 +1,62 @@
+"""Classic-control parity far outside the usual context ranges (run on the GPU box): every physics feature of a context row is
+scaled by an independent log-uniform factor in [1 / S, S] around the reference's default (S = 10 unless --span=S), 131 072
+random (context, state, action) triples per family, ONE engine step each through the C ABI against the float64 oracle.
+
+    python tools/fuzz_wide_contexts.py [--span=10] [--n=131072]
+
+Prints, per family: the worst |d| / (1 + |x|) of next state / observation / reward, the number of rows above 1e-5 and where the
+worst row sits (its context), the done flags that differ and their float64 margin.  A checker's tool (imports oracle/)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from oracle import oracle as O  # noqa: E402
+from tests.test_gpu_parity import flag_margin, random_actions, rel_err, run_transitions, wide_context_rows  # noqa: E402
+
+def main():
+    span, n = 10.0, 131072
+    for a in sys.argv[1:]:
+        if a.startswith("--span="):
+            span = float(a.split("=")[1])
+        if a.startswith("--n="):
+            n = int(a.split("=")[1])
+    dev = torch.device("cuda", 0)
+    span_all = span
+    for fam in range(5):
+        # Acrobot: at most x 3 -- beyond that some rows have a near-singular mass matrix, the new angle is ~1e9 rad and the
+        # reference's `while x > pi: x -= 2 pi` (restated faithfully in the oracle) spins for minutes (the kernel reduces it in one go)
+        span = min(span_all, 3.0) if fam == O.ACROBOT else span_all
+        rng = np.random.default_rng(1000 + fam)
+        ctx, s = wide_context_rows(fam, rng, n, span)
+        a = random_actions(fam, rng, n)
+        s2, obs, rew, term, _ = run_transitions(fam, ctx, s, a, dev)
+        w_s2, w_obs, w_rew, w_term = O.transitions(fam, ctx, s.astype(np.float64), a, precision="f64")
+        e = np.maximum(rel_err(s2, w_s2).max(1), np.maximum(rel_err(obs, w_obs).max(1), rel_err(rew, w_rew)))
+        fin = np.isfinite(np.asarray(w_s2)).all(1)
+        bad = (e > 1e-5) & fin
+        k = int(np.nanargmax(np.where(fin, e, -1)))
+        diff = term != w_term
+        margin = flag_margin(fam, ctx, np.asarray(w_s2))
+        print(f"{O.FAMILY_NAMES[fam]:18s} span x{span:g}: worst {e[k]:.2e} (rows above 1e-5: {int(bad.sum())} of {n}; oracle non-finite rows: "
+              f"{int((~fin).sum())}); flags differing {int(diff.sum())}" + (f", largest margin {margin[diff].max():.1e}" if diff.any() else ""))
+        if bad.any():
+            # Is the ROW ill-conditioned?  Move the float64 input state by 1e-15 relative and see how far the oracle itself moves:
+            # where that is already more than the tolerance the transition has no digits to compare (Acrobot with unphysical
+            # contexts at the velocity bounds: stage accelerations of 1e6+ rad/s^2, a new angle of 1e4+ rad before the wrap).
+            idx = np.nonzero(bad)[0]
+            sp = s[idx].astype(np.float64) * (1.0 + 1e-15)
+            p_s2, p_obs, p_rew, _ = O.transitions(fam, ctx[idx], sp, a[idx], precision="f64")
+            moved = np.maximum(rel_err(p_s2, np.asarray(w_s2)[idx]).max(1), rel_err(p_obs, np.asarray(w_obs)[idx]).max(1))
+            ill = moved > 1e-7
+            print(f"    of the {idx.size} rows above 1e-5: {int(ill.sum())} are ill-conditioned (the float64 oracle moves by > 1e-7 -- median "
+                  f"{np.median(moved[ill]) if ill.any() else 0:.1e} -- when its input moves by 1e-15 relative); well-conditioned rows above 1e-5: "
+                  f"{int((~ill).sum())}" + (f", worst {e[idx][~ill].max():.2e}" if (~ill).any() else ""))
+            print("    worst row: ctx", np.array2string(ctx[k], precision=4), "state", s[k], "action", a[k])
+            print("               got", s2[k], "want", np.asarray(w_s2)[k])
+
+
+if __name__ == "__main__":
+    main()
