@@ -185,6 +185,7 @@ class CARLBraxEnv(CARLEnv):
             floor = floors.get(name, DEFAULT_MASS_RATIO_FLOOR) * float(feats[name].default_value)
             if lowest < floor:
                 low.append(f"{name} = {lowest:g} < {floor:g}")
+        self._check_stiffness_stability(names)
         if not low:
             return
         msg = (f"{type(self).__name__}: context values below the smallest effective mass for which this model's explicit "
@@ -194,6 +195,31 @@ class CARLBraxEnv(CARLEnv):
                              "to ignore physics contexts as the reference effectively does")
         warnings.warn(msg + " -- the physics runs these envs at the floor (the context observation keeps the sampled "
                       "value); mass_check='error' refuses instead", RuntimeWarning, stacklevel=3)
+
+    def _check_stiffness_stability(self, names) -> None:
+        """``joint_stiffness`` (extension feature of the ``...Stiffness`` classes; declared bounds (0.01, 100)) above the measured
+        ceiling of the model (``feature_tables.JOINT_STIFFNESS_CEILING``): every env there leaves the finite range within a few
+        hundred steps.  The physics is not clamped (a stiffer joint is what was asked for): one RuntimeWarning with
+        ``mass_check="warn"``, a ValueError with ``"error"``."""
+        import warnings
+
+        from carl_amd.envs.brax.feature_tables import JOINT_STIFFNESS_CEILING
+
+        ceiling = JOINT_STIFFNESS_CEILING.get(self.env_name)
+        if ceiling is None or "joint_stiffness" not in names:
+            return
+        j = names.index("joint_stiffness")
+        col = self._table.tensor[j] if hasattr(self._table, "tensor") else self._table.values_2d[:, j]
+        highest = float(col.max())
+        if highest <= ceiling:
+            return
+        msg = (f"{type(self).__name__}: joint_stiffness = {highest:g} > {ceiling:g}, the largest scale of the constraint stiffness "
+               f"for which this model's explicit spring integration stays stable at default masses (measured: "
+               f"tools/stiffness_stability_sweep.py)")
+        if getattr(self, "_mass_check", "warn") == "error":
+            raise ValueError(msg + "; pass mass_check='warn' to run such envs anyway (they leave the finite range)")
+        warnings.warn(msg + " -- envs above it leave the finite range within a few hundred steps (the physics is not clamped); "
+                      "mass_check='error' refuses instead", RuntimeWarning, stacklevel=4)
 
     def effective_mass_context(self) -> dict[str, torch.Tensor]:
         """The ``mass_<link>`` context values the PHYSICS runs each env at: ``{feature: [N] float32}`` in the

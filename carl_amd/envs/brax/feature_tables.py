@@ -110,6 +110,13 @@ MASS_RATIO_FLOOR = {
     "reacher": {"mass_body0": 0.42, "mass_body1": 0.22},
     "pusher": {"mass_r_wrist_flex_link": 0.88, "mass_object": 0.22},
 }
+# ``joint_stiffness`` (this build's extension feature, BASELINE config 5) scales the constraint stiffness k of the spring backend;
+# the explicit integration needs k dt^2 / m below its bound just as it does for a light link.  Measured ceilings of the
+# SCALE at default masses (tools/stiffness_stability_sweep.py on an MI355X, round 6: 1 024 envs x 300 steps per cell under
+# random actions -- Halfcheetah: none of 1 024 blows up at x 2.0 with mass_torso >= 0.8 x default, all at x 2.5 / 0.8 and
+# x 3.0 / 1.0, all at x 4 whatever the torso; Humanoid: none at x 6, all at x 10 / 0.8).  BASELINE config 5 samples
+# U(0.5, 2): inside.  ``CARLBraxEnv`` warns (mass_check="warn") or refuses ("error") above them; the physics is NOT clamped.
+JOINT_STIFFNESS_CEILING = {"halfcheetah": 2.0, "humanoid": 6.0, "humanoidstandup": 6.0}
 DEFAULT_MASS_RATIO_FLOOR = 0.1  # nothing below was measured
 # Several light links at once are less stable than each alone: with EVERY mass feature at alpha x its floor the
 # envs still blew up to the alpha below (tools/mass_combo_sweep.py on an MI355X, round 3: profiles/

@@ -905,6 +905,39 @@ def test_every_mass_feature_at_the_reference_lower_bound_constructs_and_stays_fi
     assert n_classes >= 10
 
 
+def test_joint_stiffness_above_the_measured_ceiling_warns_or_refuses(device):
+    """``joint_stiffness`` (this build's extension feature, declared bounds (0.01, 100)) scales the constraint stiffness; above
+    a model-specific scale the explicit spring integration leaves the finite range (tools/stiffness_stability_sweep.py:
+    Halfcheetah all envs at x 2.5 with a torso at 0.8 x default and at x 3.0 with the default torso, none at x 2.0; Humanoid
+    none at x 6, all at x 10 / 0.8).  BASELINE config 5's U(0.5, 2) constructs silently; above the ceiling the constructor
+    warns once (the physics is not clamped) or, with mass_check="error", refuses."""
+    import warnings
+
+    from carl_amd.envs import CARLBraxHalfcheetahStiffness, CARLBraxHumanoidStiffness
+    from carl_amd.envs.brax.feature_tables import JOINT_STIFFNESS_CEILING
+
+    for cls, fam in ((CARLBraxHalfcheetahStiffness, "halfcheetah"), (CARLBraxHumanoidStiffness, "humanoid")):
+        feats = cls.get_context_features()
+        default = {k: float(f.default_value) for k, f in feats.items() if k not in ("target_distance", "target_direction", "target_radius")}
+        top = JOINT_STIFFNESS_CEILING[fam]
+        inside = {0: dict(default, joint_stiffness=0.5), 1: dict(default, joint_stiffness=top)}
+        above = {0: dict(default), 1: dict(default, joint_stiffness=top * 1.5)}
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")
+            env = cls(contexts=inside, batch_size=2, device=device, seed=0)
+        with pytest.warns(RuntimeWarning, match="joint_stiffness"):
+            cls(contexts=above, batch_size=2, device=device, seed=0)
+        with pytest.raises(ValueError, match="joint_stiffness"):
+            cls(contexts=above, batch_size=2, device=device, seed=0, mass_check="error")
+        env.reset(seed=0)
+        g = torch.Generator(device="cpu").manual_seed(2)
+        lo, hi = env.action_space.low[0], env.action_space.high[0]
+        for _ in range(100):  # at the ceiling the envs stay finite
+            a = torch.rand((2, env.action_space.shape[1]), generator=g) * float(hi[0] - lo[0]) + float(lo[0])
+            o, r, *_ = env.step(a.to(device))
+            assert bool(torch.isfinite(o["obs"]).all()) and bool(torch.isfinite(r).all())
+
+
 def test_config4_and_config5_full_size_step_parity(device):
     """BASELINE configs 4 and 5 at their full sizes (Ant x 32 768; Halfcheetah + Humanoid x 32 768 each with the
     joint_stiffness classes): the engines run the whole batch; the fp64 oracle re-computes every lane (Ant) or every
