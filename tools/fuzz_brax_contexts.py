@@ -17,29 +17,38 @@ import torch  # noqa: E402
 
 from oracle import brax as B  # noqa: E402
 from oracle import oracle as O  # noqa: E402
-from tests.test_gpu_brax import DEFAULT, NAMES, _cheetah, _humanoid, ant_sys, rel_err  # noqa: E402
+from tests.test_gpu_brax import rel_err  # noqa: E402
 
 
 def logu(rng, lo, hi, n):
     return np.exp(rng.uniform(np.log(lo), np.log(hi), n))
 
 
-def widen(rng, n, default, names):
+def widen(rng, n, default, names, fam, heavy_only):
+    from carl_amd.envs.brax.feature_tables import JOINT_STIFFNESS_CEILING
+
     rows = np.tile(default, (n, 1))
     rows[:, names.index("gravity")] = -logu(rng, 2.0, 50.0, n)
     rows[:, names.index("friction")] = logu(rng, 0.1, 10.0, n)
     rows[:, names.index("elasticity")] = rng.uniform(0.0, 0.8, n)
-    k = names.index("mass_torso")
-    rows[:, k] = default[k] * logu(rng, 0.5, 3.0, n)
+    if "ang_damping" in names:
+        rows[:, names.index("ang_damping")] = -rng.uniform(0.0, 0.5, n)
+    for k, nm in enumerate(names):  # every link mass from its default upwards (lighter links: the documented stability floors)
+        if nm.startswith("mass_"):
+            rows[:, k] = default[k] * logu(rng, 1.0 if heavy_only else 0.5, 3.0, n)
     if "joint_stiffness" in names:
-        rows[:, names.index("joint_stiffness")] = logu(rng, 0.3, 3.0, n)
+        rows[:, names.index("joint_stiffness")] = logu(rng, 0.3, JOINT_STIFFNESS_CEILING.get(fam, 2.0), n)
     return rows.astype(np.float32).astype(np.float64)
 
 
 def main():
-    from carl_amd.brax_engine import BraxVecEngine
+    import inspect
 
-    n, steps = 16384, 30
+    import carl_amd.envs.brax as brax_envs
+    from carl_amd.brax_engine import BraxVecEngine
+    from carl_amd.envs.brax.models import SYSTEMS
+
+    n, steps = 8192, 60
     for a in sys.argv[1:]:
         if a.startswith("--n="):
             n = int(a.split("=")[1])
@@ -47,13 +56,16 @@ def main():
             steps = int(a.split("=")[1])
     dev = torch.device("cuda", 0)
     rng = np.random.default_rng(2026)
-    cases = [("ant", ant_sys(NAMES), NAMES, DEFAULT, 1.0)]
-    s, names, default = _cheetah()
-    cases.append(("halfcheetah", s, names, default, 1.0))
-    s, names, default = _humanoid()
-    cases.append(("humanoid", s, names, default, 0.4))
-    for label, s, names, default, amp in cases:
-        rows = widen(rng, n, default, list(names))
+    for cname, cls in inspect.getmembers(brax_envs):
+        if not (inspect.isclass(cls) and cname.startswith("CARLBrax") and cname != "CARLBraxEnv"):
+            continue
+        feats = cls.get_context_features()
+        names = list(feats)
+        default = np.array([float(f.default_value) for f in feats.values()])
+        fam = cls.env_name
+        s = SYSTEMS[fam](names)
+        amp = 0.4 if "humanoid" in fam else 1.0
+        rows = widen(rng, n, default, names, fam, heavy_only=True)
         eng = BraxVecEngine(s, len(names), rows, n, dev, selector=O.SEL_STATIC, seed=1, ctx_idx0=np.arange(n), auto_reset=False,
                             max_episode_steps=10_000, branch_record=True)
         eng.reset()
@@ -71,21 +83,22 @@ def main():
         out = ora.step(a)
         sig = eng.branch_sig.cpu().numpy().view(np.uint32)
         o = obs.cpu().numpy()
-        fin = fin0 & np.isfinite(o).all(1) & np.isfinite(out.obs).all(1)
+        fin = fin0 & np.isfinite(o).all(1) & np.isfinite(out.obs).all(1) & (np.abs(o).max(1) < 1e4)
         flag = (term.cpu().numpy() != 0) != (out.terminated != 0)
         agree = (sig[:, 0] == ora.branch_sig[:, 0]) & ~flag & fin
         e = np.where(fin, np.maximum(rel_err(o, out.obs).max(1), rel_err(rew.cpu().numpy(), out.reward)), 0.0)
         k = int(np.argmax(np.where(agree, e, -1)))
         above = agree & (e > 1e-5)
-        print(f"{label:12s} {n} lanes after {steps} free-running steps: agreeing lanes {int(agree.sum())} worst {e[k]:.2e}, above 1e-5: {int(above.sum())}; "
-              f"excluded (contact record / flag differs) {int((~agree & fin).sum())}; non-finite lanes {int((~fin).sum())}")
+        print(f"{cname:32s} {n} lanes after {steps} free-running steps: agreeing {int(agree.sum())} worst {e[k]:.2e}, above 1e-5: {int(above.sum())}; "
+              f"excluded (contact record / flag differs) {int((~agree & fin).sum())}; blown up (non-finite or |obs| > 1e4) {int((~fin).sum())}")
         badl = above | ~fin
         if badl.any():  # which feature separates the lanes that left the bar (or blew up) from the rest?
-            for nm in ("gravity", "friction", "elasticity", "mass_torso", "joint_stiffness"):
-                if nm in names:
-                    c = rows[:, list(names).index(nm)]
-                    q = lambda v: np.array2string(np.quantile(v, [0, 0.1, 0.5, 0.9, 1]), precision=3)
-                    print(f"    {nm:16s} bad lanes quantiles {q(c[badl])}   good lanes {q(c[~badl])}")
+            for nm in names:
+                c = rows[:, names.index(nm)]
+                if np.ptp(c) == 0:
+                    continue
+                q = lambda v: np.array2string(np.quantile(v, [0, 0.1, 0.5, 0.9, 1]), precision=3)
+                print(f"    {nm:28s} bad lanes quantiles {q(c[badl])}   good lanes {q(c[~badl])}")
 
 
 if __name__ == "__main__":
