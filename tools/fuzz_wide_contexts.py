@@ -26,9 +26,10 @@ def main():
     dev = torch.device("cuda", 0)
     span_all = span
     for fam in range(5):
-        # Acrobot: at most x 3 -- beyond that some rows have a near-singular mass matrix, the new angle is ~1e9 rad and the
-        # reference's `while x > pi: x -= 2 pi` (restated faithfully in the oracle) spins for minutes (the kernel reduces it in one go)
-        span = min(span_all, 3.0) if fam == O.ACROBOT else span_all
+        # Acrobot: the declared bounds are x 10 (carl_acrobot.py:15-69); beyond x 3 some rows have a near-singular mass matrix and a
+        # new angle of ~1e9 rad -- the oracle's wrap() reduces such an angle in one step since round 6 (the reference's loop would
+        # spin for minutes), and the conditioning filter below sets those rows aside
+        span = min(span_all, 10.0) if fam == O.ACROBOT else span_all
         rng = np.random.default_rng(1000 + fam)
         ctx, s = wide_context_rows(fam, rng, n, span)
         a = random_actions(fam, rng, n)
