@@ -905,6 +905,96 @@ def test_every_mass_feature_at_the_reference_lower_bound_constructs_and_stays_fi
     assert n_classes >= 10
 
 
+def wide_brax_rows(rng, n, default, names, fam):
+    """context rows far outside BASELINE's distributions but inside the reference's declared bounds (carl_ant.py:21-49 and the
+    like): gravity log-uniform in [-50, -2], friction in [0.1, 10], elasticity U(0, 0.8), ang_damping U(-0.5, 0), every link mass
+    x [1, 3] (lighter links: the documented stability floors), joint_stiffness up to the model's measured ceiling"""
+    from carl_amd.envs.brax.feature_tables import JOINT_STIFFNESS_CEILING
+
+    def logu(lo, hi):
+        return np.exp(rng.uniform(np.log(lo), np.log(hi), n))
+
+    rows = np.tile(default, (n, 1))
+    rows[:, names.index("gravity")] = -logu(2.0, 50.0)
+    rows[:, names.index("friction")] = logu(0.1, 10.0)
+    rows[:, names.index("elasticity")] = rng.uniform(0.0, 0.8, n)
+    if "ang_damping" in names:
+        rows[:, names.index("ang_damping")] = -rng.uniform(0.0, 0.5, n)
+    for k, nm in enumerate(names):
+        if nm.startswith("mass_"):
+            rows[:, k] = default[k] * logu(1.0, 3.0)
+    if "joint_stiffness" in names:
+        rows[:, names.index("joint_stiffness")] = logu(0.3, JOINT_STIFFNESS_CEILING.get(fam, 2.0))
+    return rows.astype(np.float32).astype(np.float64)
+
+
+def brax_wide_context_case(cls, n, steps, rng, device):
+    """free-run `steps` env steps from reset under random actions, then re-compute ONE env step of every lane with the float64
+    restatement from the engine's own state: (error per lane, agreeing-lane mask, blown-up mask)"""
+    from carl_amd.brax_engine import BraxVecEngine
+    from carl_amd.envs.brax.models import SYSTEMS
+
+    feats = cls.get_context_features()
+    names = list(feats)
+    default = np.array([float(f.default_value) for f in feats.values()])
+    fam = cls.env_name
+    s = SYSTEMS[fam](names)
+    amp = 0.4 if "humanoid" in fam else 1.0
+    rows = wide_brax_rows(rng, n, default, names, fam)
+    eng = BraxVecEngine(s, len(names), rows, n, device, selector=O.SEL_STATIC, seed=1, ctx_idx0=np.arange(n), auto_reset=False,
+                        max_episode_steps=10_000, branch_record=True)
+    eng.reset()
+    g = torch.Generator(device=device).manual_seed(3)
+    for _ in range(steps):
+        eng.step((torch.rand((n, s.n_act), generator=g, device=device) * 2 - 1) * amp)
+    st = eng.state_np()
+    fin0 = np.isfinite(st.reshape(n, -1)).all(1)
+    ora = B.Engine(s, rows, n, selector=O.SEL_STATIC, ctx_idx0=np.arange(n), autoreset=False, max_steps=10_000)
+    ora.reset()
+    ora.state[:] = np.where(fin0.reshape((n,) + (1,) * (st.ndim - 1)), st, ora.state)
+    ora.elapsed[:] = eng.elapsed.cpu().numpy()
+    a = (rng.uniform(-1, 1, (n, s.n_act)) * amp).astype(np.float32)
+    obs, rew, term, trunc = eng.step(torch.as_tensor(a))
+    out = ora.step(a)
+    sig = eng.branch_sig.cpu().numpy().view(np.uint32)
+    o = obs.cpu().numpy()
+    fin = fin0 & np.isfinite(o).all(1) & np.isfinite(out.obs).all(1) & (np.abs(o).max(1) < 1e4)
+    flag = (term.cpu().numpy() != 0) != (out.terminated != 0)
+    agree = (sig[:, 0] == ora.branch_sig[:, 0]) & ~flag & fin
+    e = np.where(fin, np.maximum(rel_err(o, out.obs).max(1), rel_err(rew.cpu().numpy(), out.reward)), 0.0)
+    return e, agree, ~fin, rows, names
+
+
+def test_every_brax_class_over_wide_contexts(device):
+    """All twelve classes (the ten reference classes + the two ...Stiffness variants) far outside BASELINE's context distributions (`wide_brax_rows`): no env leaves the finite range,
+    the excluded share (contact record / flag differs) stays below 1e-3, and north_star's 1e-5 holds as a MAXIMUM on the
+    agreeing lanes -- with ONE recorded exception: a Humanoid under 2.5-5 g whose joints are stiffened x 3-6
+    (`CARLBraxHumanoidStiffness`: gravity <= -24 AND joint_stiffness >= 2.7; measured 16 of 8 192 lanes up to 2.6e-4,
+    DESIGN 7), bounded here at 1 % of the lanes and 2e-3."""
+    import inspect
+
+    import carl_amd.envs.brax as brax_envs
+
+    rng = np.random.default_rng(2026)
+    n_classes = 0
+    for cname, cls in inspect.getmembers(brax_envs):
+        if not (inspect.isclass(cls) and cname.startswith("CARLBrax") and cname != "CARLBraxEnv"):
+            continue
+        n_classes += 1
+        n = 2048
+        e, agree, blown, rows, names = brax_wide_context_case(cls, n, 40, rng, device)
+        assert not blown.any(), (cname, int(blown.sum()))
+        assert agree.mean() >= 0.999, (cname, agree.mean())
+        above = agree & (e > 1e-5)
+        if cname == "CARLBraxHumanoidStiffness":
+            assert above.sum() <= n // 100 and e[agree].max() <= 2e-3, (cname, int(above.sum()), e[agree].max())
+            corner = (rows[:, names.index("gravity")] <= -20.0) & (rows[:, names.index("joint_stiffness")] >= 2.0)
+            assert corner[above].all(), "a lane above the bar outside the recorded corner"
+        else:
+            assert not above.any(), (cname, int(above.sum()), e[agree].max())
+    assert n_classes == 12
+
+
 def test_joint_stiffness_above_the_measured_ceiling_warns_or_refuses(device):
     """``joint_stiffness`` (this build's extension feature, declared bounds (0.01, 100)) scales the constraint stiffness; above
     a model-specific scale the explicit spring integration leaves the finite range (tools/stiffness_stability_sweep.py:
